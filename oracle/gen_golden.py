@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+Runs only where /root/reference exists (never on the GPU box, never from tests).
+It imports the reference's own model classes (baselines/learned_models.py) and
+metric class (baselines/tracking_utils.py:ResultsAnalyzer) under the container's
+torch 2.10 CPU, feeds them the deterministic synthetic weights / clips of
+oracle/synth.py, and stores inputs-free, outputs-only fixtures (inputs are
+regenerated from seeds by the tests).
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("OPNET_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+
+sys.path.insert(0, REPO)
+from oracle import synth  # noqa: E402
+
+
+def _import_reference():
+    # the reference imports cv2 / torchvision at module top (tracking_utils.py:7, detector.py:6-8);
+    # neither is installed here and neither is on the reasoner path -> stub modules.
+    for name in ("cv2", "torchvision", "torchvision.models", "torchvision.models.detection",
+                 "torchvision.models.detection.faster_rcnn"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.models.detection.faster_rcnn"].FastRCNNPredictor = object
+    if not hasattr(np, "int"):
+        np.int = int  # removed numpy aliases used at tracking_utils.py:270,272
+    if not hasattr(np, "bool"):
+        np.bool = bool
+    sys.path.insert(0, REF)
+    from baselines import learned_models  # noqa
+    from baselines import tracking_utils  # noqa
+    return learned_models, tracking_utils
+
+
+def _load_params(model: torch.nn.Module, params):
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(params.keys()), (sorted(sd.keys()), sorted(params.keys()))
+    for k, v in params.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+
+
+def gen_opnet(lm, cfg, n_clips, t_frames, tag, keep_intermediates):
+    params = synth.opnet_synth_params(cfg)
+    model = lm.OPNet(cfg)
+    _load_params(model, params)
+    model.eval()
+    boxes, labels = synth.make_batch(0, n_clips, t_frames)
+    with torch.no_grad():
+        y, logits = model(torch.from_numpy(boxes))
+    out = {"y": y.numpy(), "logits": logits.numpy(),
+           "cfg": np.array(json.dumps(cfg)), "n_clips": n_clips, "t_frames": t_frames}
+    if keep_intermediates:
+        with torch.no_grad():
+            scene = torch.from_numpy(boxes).view(n_clips, t_frames, -1)
+            h1, _ = model.object_to_track_LSTM(scene)
+            probs = torch.softmax(model.object_to_track_prediction(h1), dim=-1)
+            fb = torch.einsum("bfot,bfo->bft", torch.from_numpy(boxes), probs)
+            h2, _ = model.video_LSTM(fb)
+        out.update(h1=h1.numpy(), probs=probs.numpy(), frames_boxes=fb.numpy(), h2=h2.numpy())
+    else:
+        # a few checksums of intermediates at the real size
+        with torch.no_grad():
+            scene = torch.from_numpy(boxes).view(n_clips, t_frames, -1)
+            h1, _ = model.object_to_track_LSTM(scene)
+        out["h1_last"] = h1[:, -1].numpy()
+    # batch independence: clip 0 alone == clip 0 in the batch
+    with torch.no_grad():
+        y0, _ = model(torch.from_numpy(boxes[:1]))
+    out["y_clip0_alone"] = y0.numpy()
+    np.savez_compressed(os.path.join(OUT, f"opnet_{tag}.npz"), **out)
+    print(f"opnet_{tag}: y range [{y.min():.3f}, {y.max():.3f}] logits range "
+          f"[{logits.min():.2f}, {logits.max():.2f}]")
+    return y.numpy(), labels
+
+
+def gen_metric(tu, y, labels):
+    """ResultsAnalyzer goldens on integer boxes (tracking_utils.py:137-159, 251-256, 278-288)."""
+    frame_shapes = np.array([320, 240, 320, 240])
+    n = y.shape[0]
+    # exactly the reference's post-processing expression (inference_main.py:219)
+    pred_px = (np.array(list(y.reshape(-1, 4))) * frame_shapes).reshape((n, 300, 4)).astype(np.int32)
+    gt_px = (np.array(list(labels.reshape(-1, 4))) * frame_shapes).reshape((n, 300, 4)).astype(np.int32)
+    # a second prediction set with non-trivial overlap: ground truth jittered by a few pixels
+    rng = np.random.default_rng(7)
+    jit_px = gt_px + rng.integers(-12, 13, size=gt_px.shape).astype(np.int32)
+    res = {"pred_px": pred_px, "gt_px": gt_px, "jit_px": jit_px}
+    for tag, p in (("pred", pred_px), ("jit", jit_px)):
+        names = [str(i) for i in range(n)]
+        an = tu.ResultsAnalyzer(names, p, gt_px, iou_thresh=[0.5])
+        an.compute_aggregated_metric("video_mean", np.mean)
+        an.compute_aggregated_metric("video_mean", np.mean, metric="map")
+        # the analyzer drops any video whose prediction array contains the value -100
+        # ("defected videos", tracking_utils.py:234-235) - record which ones survived
+        kept = list(an.get_videos_names())
+        res[f"kept_{tag}"] = np.array([int(k) for k in kept])
+        res[f"iou_{tag}"] = np.stack([an.iou_results[k] for k in kept])
+        res[f"video_mean_iou_{tag}"] = np.array([an.videos_metrics["video_mean_iou"][k] for k in kept])
+        res[f"video_map50_{tag}"] = np.array([an.videos_metrics["video_mean_map_0.5"][k] for k in kept])
+    np.savez_compressed(os.path.join(OUT, "metric.npz"), **res)
+    print("metric: mean IoU jit =", res["video_mean_iou_jit"].mean(), " mAP50 jit =", res["video_map50_jit"].mean())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    lm, tu = _import_reference()
+    tiny = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 16, "videos_hidden_dim": 32}
+    gen_opnet(lm, tiny, n_clips=2, t_frames=12, tag="tiny", keep_intermediates=True)
+    with open(os.path.join(REF, "configs", "opnet_model_config.json")) as f:
+        real = json.load(f)
+    y, labels = gen_opnet(lm, real, n_clips=4, t_frames=300, tag="real", keep_intermediates=False)
+    gen_metric(tu, y, labels)
+
+
+if __name__ == "__main__":
+    main()

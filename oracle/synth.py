@@ -1,0 +1,168 @@
+"""Deterministic synthetic weights and CATER-shaped clips.
+
+TEST INFRASTRUCTURE ONLY (see oracle/README.md): imported by tests/, by
+__graft_entry__.smoke() and by bench.py; never by the product package.
+
+Two generators live here:
+
+* ``counter_uniform`` - a counter-based RNG (splitmix64 finaliser over
+  ``seed * GOLDEN + index``) so that full-size weight tensors never need to
+  be committed: the golden generator (oracle/gen_golden.py, which imports the
+  reference) and the GPU-box tests regenerate bit-identical fp32 weights from
+  a tensor name.
+
+* ``make_clip`` - one synthetic CATER clip in the on-the-wire tensor format the
+  reference's dataset hands to the model:
+  ``boxes float32 [300, 15, 6]`` = per slot ``[x1/320, y1/240, x2/320, y2/240,
+  visible, is_cone]`` (reference baselines/datasets.py:265-336 - invisible
+  object -> all-zero row, invisible cone -> ``[0,0,0,0,0,1]``, slots beyond the
+  video's objects all-zero, slot 0 = snitch) and ``labels float32 [300, 4]`` =
+  snitch ground-truth ``xyxy / [320,240,320,240]`` (datasets.py:33-45).
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Tuple
+
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLDEN = 0x9E3779B97F4A7C15
+
+T_FRAMES = 300
+MAX_OBJECTS = 15
+FRAME_SHAPES = np.array([320, 240, 320, 240], dtype=np.float64)
+
+
+def _splitmix64(z: np.ndarray) -> np.ndarray:
+    z = z.astype(np.uint64, copy=True)
+    with np.errstate(over="ignore"):
+        z = (z + np.uint64(_GOLDEN)) & _MASK
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def counter_uniform(seed: int, n: int) -> np.ndarray:
+    """n doubles in [0, 1), element i a pure function of (seed, i)."""
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        base = (np.uint64(seed & 0xFFFFFFFFFFFFFFFF) * np.uint64(_GOLDEN)) & _MASK
+        z = _splitmix64((idx + base) & _MASK)
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def name_seed(name: str, salt: int = 0) -> int:
+    return (zlib.crc32(name.encode()) << 8) ^ (salt & 0xFF)
+
+
+def synth_tensor(name: str, shape: Tuple[int, ...], bound: float, salt: int = 0) -> np.ndarray:
+    """fp32 tensor ~ U(-bound, bound), keyed by its state_dict name."""
+    n = int(np.prod(shape))
+    u = counter_uniform(name_seed(name, salt), n)
+    return ((2.0 * u - 1.0) * bound).astype(np.float32).reshape(shape)
+
+
+# --------------------------------------------------------------------------------------
+# model parameter sets (names/shapes: SURVEY.md section 8-a1 and section 11, verified against the
+# reference's state_dict() in oracle/gen_golden.py)
+# --------------------------------------------------------------------------------------
+
+def opnet_shapes(cfg: Dict[str, int]) -> Dict[str, Tuple[int, ...]]:
+    h1 = cfg["object_to_track_hidden_dim"]
+    h2 = cfg["videos_hidden_dim"]
+    nsel = cfg["object_to_track_pred_dim"]
+    return {
+        "object_to_track_LSTM.weight_ih_l0": (4 * h1, 6 * 15),
+        "object_to_track_LSTM.weight_hh_l0": (4 * h1, h1),
+        "object_to_track_prediction.weight": (nsel, h1),
+        "video_LSTM.weight_ih_l0": (4 * h2, 6),
+        "video_LSTM.weight_hh_l0": (4 * h2, h2),
+        "prediction_layer.weight": (4, h2),
+    }
+
+
+def opnet_synth_params(cfg: Dict[str, int], salt: int = 0) -> Dict[str, np.ndarray]:
+    """'Trained-like' synthetic OPNet weights.
+
+    torch's default U(-1/sqrt(H), 1/sqrt(H)) init gives outputs of +-0.006 ->
+    int-pixel boxes all zero and a near-uniform selection softmax, i.e. vacuous parity tests. The
+    gains below were picked (oracle fp64 run, 4 clips) so that y spans about (-1.1, 2.0) with
+    std 0.84, the slot softmax is peaked (mean max-prob 0.43) and the recurrences are
+    moderate-gain, non-chaotic (fp32-vs-fp64 drift 2e-6 on y over 300 steps)."""
+    h1 = cfg["object_to_track_hidden_dim"]
+    h2 = cfg["videos_hidden_dim"]
+    bounds = {
+        "object_to_track_LSTM.weight_ih_l0": 2.0 / np.sqrt(h1),
+        "object_to_track_LSTM.weight_hh_l0": 2.0 / np.sqrt(h1),
+        "object_to_track_prediction.weight": 30.0 / np.sqrt(h1),
+        "video_LSTM.weight_ih_l0": 1.0,
+        "video_LSTM.weight_hh_l0": 2.0 / np.sqrt(h2),
+        "prediction_layer.weight": 8.0 / np.sqrt(h2),
+    }
+    return {name: synth_tensor(name, shape, float(bounds[name]), salt)
+            for name, shape in opnet_shapes(cfg).items()}
+
+
+# --------------------------------------------------------------------------------------
+# synthetic clips
+# --------------------------------------------------------------------------------------
+
+SNITCH_ID = 140
+# two cone ids and seven non-cone ids from the reference class table (object_indices.py:
+# "*_cone_*" names are cones; ids 0 and 4 are large cones). Sorted snitch-first then ascending
+# (datasets.py:47-54).
+CONE_IDS = (0, 4)
+OTHER_IDS = (65, 70, 98, 101, 133, 150, 171)
+
+
+def make_clip(c: int, t_frames: int = T_FRAMES) -> Tuple[np.ndarray, np.ndarray]:
+    """Synthetic clip c (seed 1000 + c). Returns (boxes [T,15,6] f32, labels [T,4] f32)."""
+    rng = np.random.default_rng(1000 + c)
+    ids = [SNITCH_ID] + sorted(CONE_IDS + OTHER_IDS)
+    n_obj = len(ids)
+    is_cone = np.array([1.0 if i in CONE_IDS else 0.0 for i in ids])
+
+    # smooth integer random walks in pixels
+    w = rng.integers(8, 65, size=n_obj)
+    h = rng.integers(8, 65, size=n_obj)
+    x1 = np.empty((t_frames, n_obj), dtype=np.int64)
+    y1 = np.empty((t_frames, n_obj), dtype=np.int64)
+    px = rng.uniform(0, 300 - 64, size=n_obj)
+    py = rng.uniform(0, 220 - 64, size=n_obj)
+    vx = rng.normal(0, 1.0, size=n_obj)
+    vy = rng.normal(0, 1.0, size=n_obj)
+    for t in range(t_frames):
+        vx = 0.9 * vx + rng.normal(0, 0.6, size=n_obj)
+        vy = 0.9 * vy + rng.normal(0, 0.6, size=n_obj)
+        px = np.clip(px + vx, 0, 299 - 64)
+        py = np.clip(py + vy, 0, 219 - 64)
+        x1[t] = px.astype(np.int64)
+        y1[t] = py.astype(np.int64)
+    x2 = x1 + w[None, :]
+    y2 = y1 + h[None, :]
+
+    visible = rng.random((t_frames, n_obj)) < 0.9
+    # the snitch disappears in 15-frame runs (containment / occlusion episodes)
+    visible[:, 0] = True
+    n_runs = int(rng.integers(2, 6))
+    for _ in range(n_runs):
+        s = int(rng.integers(5, max(6, t_frames - 20)))
+        visible[s:s + 15, 0] = False
+
+    boxes = np.zeros((t_frames, MAX_OBJECTS, 6), dtype=np.float64)
+    raw = np.stack([x1, y1, x2, y2], axis=-1).astype(np.float64)  # [T, n, 4]
+    norm = raw / FRAME_SHAPES
+    vis_f = visible.astype(np.float64)
+    boxes[:, :n_obj, :4] = norm * vis_f[..., None]
+    boxes[:, :n_obj, 4] = vis_f
+    boxes[:, :n_obj, 5] = is_cone[None, :]  # cone padding row keeps its cone bit (datasets.py:315-316)
+
+    labels = raw[:, 0, :] / FRAME_SHAPES  # ground truth is known even when hidden
+    return boxes.astype(np.float32), labels.astype(np.float32)
+
+
+def make_batch(first_clip: int, n_clips: int, t_frames: int = T_FRAMES) -> Tuple[np.ndarray, np.ndarray]:
+    bs, ls = zip(*(make_clip(first_clip + i, t_frames) for i in range(n_clips)))
+    return np.stack(bs), np.stack(ls)
