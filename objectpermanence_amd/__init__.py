@@ -1,0 +1,3 @@
+"""objectpermanence_amd - MI355X-native OPNet reasoner hot path of ofrikleinfeld/ObjectPermanence."""
+from .learned_models import AbstractCaterModel, OPNet  # noqa: F401
+from .models_factory import ModelsFactory  # noqa: F401

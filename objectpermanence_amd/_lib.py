@@ -1,0 +1,75 @@
+"""ctypes binding of libopnet_hip.so (the C ABI in include/opnet_hip.h).
+
+There is no CPU or eager-PyTorch fallback: if the shared library is missing, loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+
+from . import build as _build
+
+_LIB = None
+
+OPNET_OK = 0
+
+
+class OpnetHipError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    fp = c_void_p  # device pointers travel as integers (tensor.data_ptr())
+    lib.opnet_hip_abi_version.restype = c_int
+    lib.opnet_hip_abi_version.argtypes = []
+    lib.opnet_last_error.restype = c_char_p
+    lib.opnet_last_error.argtypes = []
+    lib.opnet_packed_weights_bytes.restype = c_size_t
+    lib.opnet_packed_weights_bytes.argtypes = [c_int, c_int]
+    lib.opnet_pack_weights_f32.restype = c_int
+    lib.opnet_pack_weights_f32.argtypes = [fp, fp, fp, fp, fp, fp, fp, c_size_t, c_int, c_int, c_void_p]
+    lib.opnet_workspace_bytes.restype = c_size_t
+    lib.opnet_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    lib.opnet_forward_f32.restype = c_int
+    lib.opnet_forward_f32.argtypes = [fp, fp, fp, fp, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]
+    lib.opnet_plan_create.restype = c_int
+    lib.opnet_plan_create.argtypes = [POINTER(c_void_p), c_int, c_int, c_int, c_int]
+    lib.opnet_plan_forward.restype = c_int
+    lib.opnet_plan_forward.argtypes = [c_void_p, fp, fp, fp, fp, c_void_p, c_size_t, c_void_p]
+    lib.opnet_plan_destroy.restype = None
+    lib.opnet_plan_destroy.argtypes = [c_void_p]
+    lib.opnet_postprocess_iou.restype = c_int
+    lib.opnet_postprocess_iou.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_void_p]
+
+
+EXPORTS = [
+    "opnet_hip_abi_version", "opnet_last_error", "opnet_packed_weights_bytes", "opnet_pack_weights_f32",
+    "opnet_workspace_bytes", "opnet_forward_f32", "opnet_plan_create", "opnet_plan_forward",
+    "opnet_plan_destroy", "opnet_postprocess_iou",
+]
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Load (once) and return the ctypes handle. Raises OpnetHipError if the library is absent."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise OpnetHipError(
+                f"{path} not found: build it with `python -m objectpermanence_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
+        lib = ctypes.CDLL(path)
+        _declare(lib)
+        _LIB = lib
+    return _LIB
+
+
+def check(rc: int, what: str) -> None:
+    if rc != OPNET_OK:
+        msg = load().opnet_last_error().decode(errors="replace")
+        raise OpnetHipError(f"{what} failed (code {rc}): {msg}")
