@@ -65,7 +65,7 @@ static PackedLayout packed_layout(int H1, int H2)
 }
 
 struct WorkspaceLayout {  // offsets in bytes
-    size_t ctx, xp, state, h1buf, c1, h2buf, c2, x2buf, state_end, total;
+    size_t io, xp, state, h1buf, c1, h2buf, c2, x2buf, state_end, ystage, lgstage, total;
 };
 
 static WorkspaceLayout workspace_layout(int B, int T, int H1, int H2)
@@ -73,7 +73,7 @@ static WorkspaceLayout workspace_layout(int B, int T, int H1, int H2)
     const size_t RB = (B + 31) / 32;
     WorkspaceLayout L;
     size_t o = 0;
-    L.ctx = o;   o += align_up(sizeof(OpnetCtx), 256);
+    L.io = o;    o += align_up(sizeof(OpnetIO), 256);
     L.xp = o;    o += (size_t)T * RB * OPNET_KXQ * 32 * 16;
     L.state = o;
     L.h1buf = o; o += 2 * RB * (size_t)H1 * 32 * 4;
@@ -82,6 +82,8 @@ static WorkspaceLayout workspace_layout(int B, int T, int H1, int H2)
     L.c2 = o;    o += RB * (size_t)H2 * 32 * 4;
     L.x2buf = o; o += 2 * RB * 32 * 8 * 4;
     L.state_end = o;
+    L.ystage = o;  o += RB * 32 * (size_t)T * 16;
+    L.lgstage = o; o += RB * 32 * (size_t)T * OPNET_SLOTS * 4;
     L.total = align_up(o, 256);
     return L;
 }
@@ -133,8 +135,8 @@ extern "C" int opnet_pack_weights_f32(const float *w_ih1, const float *w_hh1, co
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-static int make_ctx(OpnetCtx *c, const float *boxes, const float *packed, float *y, float *logits,
-                    void *ws, size_t ws_bytes, int B, int T, int H1, int H2)
+static int make_args(StepArgs *a, OpnetIO *io, const float *boxes, const float *packed, float *y,
+                     float *logits, void *ws, size_t ws_bytes, int B, int T, int H1, int H2)
 {
     if (int rc = check_dims(B, T, H1, H2)) return rc;
     if (!boxes || !packed || !y || !logits || !ws) return fail(OPNET_EINVAL, "null pointer");
@@ -144,41 +146,60 @@ static int make_ctx(OpnetCtx *c, const float *boxes, const float *packed, float 
     if (ws_bytes < W.total) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", ws_bytes, W.total);
     const PackedLayout P = packed_layout(H1, H2);
     char *w = (char *)ws;
-    memset(c, 0, sizeof(*c));
-    c->B = B; c->T = T; c->RB = (B + 31) / 32; c->H1 = H1; c->H2 = H2;
-    c->boxes = boxes;
-    c->xp = (float4 *)(w + W.xp);
-    c->w1p = (const float4 *)(packed + P.w1p);
-    c->w2p = (const float4 *)(packed + P.w2p);
-    c->wih2p = (const float4 *)(packed + P.wih2p);
-    c->wselp = (const float4 *)(packed + P.wselp);
-    c->woutp = (const float4 *)(packed + P.woutp);
-    c->h1buf = (float4 *)(w + W.h1buf);
-    c->c1 = (float *)(w + W.c1);
-    c->h2buf = (float4 *)(w + W.h2buf);
-    c->c2 = (float *)(w + W.c2);
-    c->x2buf = (float4 *)(w + W.x2buf);
-    c->y = y;
-    c->logits = logits;
+    memset(a, 0, sizeof(*a));
+    a->B = B; a->T = T; a->RB = (B + 31) / 32; a->H1 = H1; a->H2 = H2;
+    a->xp = (const float4 *)(w + W.xp);
+    a->w1p = (const float4 *)(packed + P.w1p);
+    a->w2p = (const float4 *)(packed + P.w2p);
+    a->wih2p = (const float4 *)(packed + P.wih2p);
+    a->wselp = (const float4 *)(packed + P.wselp);
+    a->woutp = (const float4 *)(packed + P.woutp);
+    a->h1buf = (float4 *)(w + W.h1buf);
+    a->c1 = (float *)(w + W.c1);
+    a->h2buf = (float4 *)(w + W.h2buf);
+    a->c2 = (float *)(w + W.c2);
+    a->x2buf = (float4 *)(w + W.x2buf);
+    a->ystage = (float4 *)(w + W.ystage);
+    a->lgstage = (float *)(w + W.lgstage);
+    memset(io, 0, sizeof(*io));
+    io->B = B; io->T = T; io->RB = a->RB;
+    io->boxes = boxes; io->y = y; io->logits = logits;
+    io->xp = (float4 *)(w + W.xp);
+    io->ystage = a->ystage;
+    io->lgstage = a->lgstage;
     return OPNET_OK;
 }
 
-static dim3 step_grid(int RB, int H1, int H2) { return dim3(H2 / 4 + H1 / 4 + 2, RB, 1); }
+// grid.y: up to OPNET_MAX_GY row blocks side by side (about 3 workgroups a CU at H1=256/H2=512);
+// beyond that a workgroup walks its row blocks with the weights held in registers
+#define OPNET_MAX_GY 4
+static dim3 step_grid(int RB, int H1, int H2)
+{
+    return dim3(H2 / 4 + H1 / 4 + 2, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
+}
+static dim3 copy_grid(int B, int T)
+{
+    const long n = (long)B * T * OPNET_SLOTS;
+    return dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 1, 1);
+}
 
 extern "C" int opnet_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
                                  void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
                                  void *stream)
 {
-    OpnetCtx c;
-    if (int rc = make_ctx(&c, boxes, packed, y, logits, workspace, workspace_bytes, B, T, H1, H2)) return rc;
+    StepArgs a;
+    OpnetIO io;
+    if (int rc = make_args(&a, &io, boxes, packed, y, logits, workspace, workspace_bytes, B, T, H1, H2))
+        return rc;
     const WorkspaceLayout W = workspace_layout(B, T, H1, H2);
     hipStream_t st = (hipStream_t)stream;
-    OpnetCtx *dctx = (OpnetCtx *)((char *)workspace + W.ctx);
-    opnet_set_ctx<<<1, 1, 0, st>>>(dctx, c);
+    OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
+    opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     HIP_TRY(hipMemsetAsync((char *)workspace + W.state, 0, W.state_end - W.state, st));
-    opnet_pack_input<<<dim3(T, c.RB), 256, 0, st>>>(dctx);
-    const dim3 grid = step_grid(c.RB, H1, H2);
-    for (int s = 0; s < T + 3; ++s) opnet_step<<<grid, OPNET_THREADS, 0, st>>>(dctx, s);
+    opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
+    const dim3 grid = step_grid(a.RB, H1, H2);
+    for (int s = 0; s < T + 3; ++s) opnet_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }
@@ -188,7 +209,8 @@ extern "C" int opnet_forward_f32(const float *boxes, const float *packed, float 
 // ------------------------------------------------------------------------------------------------
 struct opnet_plan {
     int B, T, H1, H2;
-    void *ws;           // workspace the graph was built for
+    void *ws;             // workspace and packed weights the graph was built for
+    const float *packed;
     hipGraph_t graph;
     hipGraphExec_t exec;
 };
@@ -200,7 +222,7 @@ extern "C" int opnet_plan_create(opnet_plan **plan, int B, int T, int H1, int H2
     opnet_plan *p = new (std::nothrow) opnet_plan();
     if (!p) return fail(OPNET_EINVAL, "out of host memory");
     p->B = B; p->T = T; p->H1 = H1; p->H2 = H2;
-    p->ws = nullptr; p->graph = nullptr; p->exec = nullptr;
+    p->ws = nullptr; p->packed = nullptr; p->graph = nullptr; p->exec = nullptr;
     *plan = p;
     return OPNET_OK;
 }
@@ -210,6 +232,7 @@ static void plan_drop_graph(opnet_plan *p)
     if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }
     if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
     p->ws = nullptr;
+    p->packed = nullptr;
 }
 
 extern "C" void opnet_plan_destroy(opnet_plan *p)
@@ -219,13 +242,12 @@ extern "C" void opnet_plan_destroy(opnet_plan *p)
     delete p;
 }
 
-// memset(state) -> pack_input -> step 0 -> ... -> step T+2, one linear dependency chain
-static int plan_build(opnet_plan *p, void *ws)
+// memset(state) -> pack_input -> step 0 -> ... -> step T+2 -> copy_out, one linear dependency chain
+static int plan_build(opnet_plan *p, const StepArgs &a, void *ws)
 {
     plan_drop_graph(p);
     const WorkspaceLayout W = workspace_layout(p->B, p->T, p->H1, p->H2);
-    const int RB = (p->B + 31) / 32;
-    OpnetCtx *dctx = (OpnetCtx *)((char *)ws + W.ctx);
+    OpnetIO *dio = (OpnetIO *)((char *)ws + W.io);
     HIP_TRY(hipGraphCreate(&p->graph, 0));
     hipGraphNode_t prev = nullptr, node = nullptr;
 
@@ -240,31 +262,36 @@ static int plan_build(opnet_plan *p, void *ws)
     HIP_TRY(hipGraphAddMemsetNode(&node, p->graph, nullptr, 0, &ms));
     prev = node;
 
-    {
-        void *args[] = {(void *)&dctx};
+    auto add_io_kernel = [&](void *func, dim3 grid) -> hipError_t {
+        void *args[] = {(void *)&dio};
         hipKernelNodeParams kp;
         memset(&kp, 0, sizeof(kp));
-        kp.func = (void *)opnet_pack_input;
-        kp.gridDim = dim3(p->T, RB, 1);
+        kp.func = func;
+        kp.gridDim = grid;
         kp.blockDim = dim3(256, 1, 1);
         kp.kernelParams = args;
-        HIP_TRY(hipGraphAddKernelNode(&node, p->graph, &prev, 1, &kp));
+        hipError_t e = hipGraphAddKernelNode(&node, p->graph, &prev, 1, &kp);
         prev = node;
-    }
+        return e;
+    };
+    HIP_TRY(add_io_kernel((void *)opnet_pack_input, dim3(p->T, a.RB, 1)));
     for (int s = 0; s < p->T + 3; ++s) {
+        StepArgs av = a;
         int step = s;
-        void *args[] = {(void *)&dctx, (void *)&step};
+        void *args[] = {(void *)&av, (void *)&step};
         hipKernelNodeParams kp;
         memset(&kp, 0, sizeof(kp));
         kp.func = (void *)opnet_step;
-        kp.gridDim = step_grid(RB, p->H1, p->H2);
+        kp.gridDim = step_grid(a.RB, p->H1, p->H2);
         kp.blockDim = dim3(OPNET_THREADS, 1, 1);
         kp.kernelParams = args;
         HIP_TRY(hipGraphAddKernelNode(&node, p->graph, &prev, 1, &kp));
         prev = node;
     }
+    HIP_TRY(add_io_kernel((void *)opnet_copy_out, copy_grid(p->B, p->T)));
     HIP_TRY(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
     p->ws = ws;
+    p->packed = (const float *)a.w1p - packed_layout(p->H1, p->H2).w1p;
     return OPNET_OK;
 }
 
@@ -272,15 +299,17 @@ extern "C" int opnet_plan_forward(opnet_plan *p, const float *boxes, const float
                                   float *logits, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!p) return fail(OPNET_EINVAL, "null plan");
-    OpnetCtx c;
-    if (int rc = make_ctx(&c, boxes, packed, y, logits, workspace, workspace_bytes, p->B, p->T, p->H1, p->H2))
+    StepArgs a;
+    OpnetIO io;
+    if (int rc = make_args(&a, &io, boxes, packed, y, logits, workspace, workspace_bytes, p->B, p->T,
+                           p->H1, p->H2))
         return rc;
-    if (p->ws != workspace || !p->exec) {
-        if (int rc = plan_build(p, workspace)) { plan_drop_graph(p); return rc; }
+    if (p->ws != workspace || p->packed != packed || !p->exec) {
+        if (int rc = plan_build(p, a, workspace)) { plan_drop_graph(p); return rc; }
     }
     const WorkspaceLayout W = workspace_layout(p->B, p->T, p->H1, p->H2);
     hipStream_t st = (hipStream_t)stream;
-    opnet_set_ctx<<<1, 1, 0, st>>>((OpnetCtx *)((char *)workspace + W.ctx), c);
+    opnet_set_io<<<1, 1, 0, st>>>((OpnetIO *)((char *)workspace + W.io), io);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipGraphLaunch(p->exec, st));
     return OPNET_OK;

@@ -1,9 +1,11 @@
-// opnet_ctx.h - device-resident launch context shared by the OPNet kernels and the C-ABI host code.
+// opnet_ctx.h - launch arguments shared by the OPNet kernels and the C-ABI host code.
 //
-// The T+3 step launches of one forward are replayed from a hipGraph whose kernel nodes carry only
-// (ctx pointer, step index); everything that can change between calls (tensor pointers) lives in
-// this struct, which sits at the head of the caller's workspace and is rewritten by a by-value
-// kernel argument (opnet_set_ctx) before each replay.
+// The T+3 step launches of one forward are replayed from a hipGraph.  Everything the step kernel
+// needs is fixed for a (plan, workspace, packed-weights) triple and travels BY VALUE in the kernarg
+// segment (StepArgs: one scalar-load round trip, no pointer chasing on the per-step critical
+// path).  What changes between calls - the caller's boxes / y / logits pointers - lives in
+// OpnetIO at the head of the workspace, is rewritten by a by-value kernel argument before each
+// replay, and is only touched by the two boundary kernels (pack_input, copy_out).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -12,11 +14,9 @@
 #define OPNET_KX 90    // LSTM1 input width = 15 slots x 6 features (learned_models.py:24)
 #define OPNET_KXQ 24   // ... padded to 96 = 24 float4 k-quads = 6 MFMA hexadecets
 
-struct OpnetCtx {
+struct StepArgs {
     int B, T, RB, H1, H2;
-    int pad_[3];
-    const float *boxes;    // [B][T][90]   caller's input
-    float4 *xp;            // [T][RB][24][32]        packed LSTM1 input
+    const float4 *xp;      // [T][RB][24][32]        packed LSTM1 input (also read by the selection head)
     const float4 *w1p;     // [H1/4][(96+H1)/16][64] LSTM1 A tiles  (x part | h part)
     const float4 *w2p;     // [H2/4][H2/16][64]      LSTM2 A tiles  (h part)
     const float4 *wih2p;   // [H2][4 gates][2]       LSTM2 x part (6 -> 8 floats)
@@ -27,6 +27,16 @@ struct OpnetCtx {
     float4 *h2buf;         // [2 parity][RB][H2/4][32]
     float *c2;             // [RB][H2][32]
     float4 *x2buf;         // [2 parity][RB][32][2]  frames_boxes (6 -> 8 floats)
-    float *y;              // [B][T][4]
+    float4 *ystage;        // [RB*32][T]             y_boxes staging
+    float *lgstage;        // [RB*32][15][T]         logits staging
+};
+
+struct OpnetIO {
+    int B, T, RB, pad_;
+    const float *boxes;    // [B][T][90]   caller's input
+    float *y;              // [B][T][4]    caller's outputs
     float *logits;         // [B][15][T]
+    float4 *xp;
+    const float4 *ystage;
+    const float *lgstage;
 };

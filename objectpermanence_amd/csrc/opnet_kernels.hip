@@ -30,7 +30,32 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Optional in-kernel timeline (tools/step_probe.hip builds with -DOPNET_TRACE): wave 0 of every
+// workgroup stamps s_memtime at fixed points of each step.  Compiled out of the product library.
+#ifdef OPNET_TRACE
+__device__ unsigned long long *g_trace = nullptr;  // [step][wg][8]
+#define TRACE_STAMP(slot)                                                                         \
+    do {                                                                                          \
+        if (g_trace && threadIdx.x == 0)                                                          \
+            g_trace[(((long)s * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * 8 + (slot)] = \
+                (slot) == 0 ? wall_clock64() : clock64();                                         \
+    } while (0)
+#ifndef OPNET_VARIANT
+#define OPNET_VARIANT 0
+#endif
+#if OPNET_VARIANT == 3   /* stamps only: do not perturb the load/MFMA overlap */
+#define TRACE_WAIT_LOADS() do { } while (0)
+#else
+#define TRACE_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+#else
+#define TRACE_STAMP(slot) do { } while (0)
+#define TRACE_WAIT_LOADS() do { } while (0)
+#endif
+
+#ifndef OPNET_NW
 #define OPNET_NW 4                 // waves per workgroup (K split)
+#endif
 #define OPNET_THREADS (OPNET_NW * 64)
 
 // ------------------------------------------------------------------------------------------------
@@ -87,19 +112,19 @@ __global__ void opnet_pack_wih2(float *__restrict__ out, const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// context + input packing
+// boundary kernels: caller's tensors <-> workspace
 // ------------------------------------------------------------------------------------------------
-__global__ void opnet_set_ctx(OpnetCtx *dst, OpnetCtx src) { *dst = src; }
+__global__ void opnet_set_io(OpnetIO *dst, OpnetIO src) { *dst = src; }
 
 // boxes [B][T][90] -> xp [t][rb][kq 0..23][clip 0..31][4]  (K padded 90 -> 96 with zeros, clips
 // beyond B zero).  One workgroup per (t, rb).
-__global__ void __launch_bounds__(256) opnet_pack_input(const OpnetCtx *__restrict__ ctx)
+__global__ void __launch_bounds__(256) opnet_pack_input(const OpnetIO *__restrict__ io)
 {
     const int t = blockIdx.x;
     const int rb = blockIdx.y;
-    const int B = ctx->B, T = ctx->T, RB = ctx->RB;
-    const float *__restrict__ boxes = ctx->boxes;
-    float4 *__restrict__ xp = ctx->xp + ((long)t * RB + rb) * (OPNET_KXQ * 32);
+    const int B = io->B, T = io->T, RB = io->RB;
+    const float *__restrict__ boxes = io->boxes;
+    float4 *__restrict__ xp = io->xp + ((long)t * RB + rb) * (OPNET_KXQ * 32);
     for (int idx = threadIdx.x; idx < OPNET_KXQ * 32; idx += 256) {
         // read-coalesced mapping: consecutive threads walk k within a clip row
         const int kq = idx % OPNET_KXQ;
@@ -117,43 +142,120 @@ __global__ void __launch_bounds__(256) opnet_pack_input(const OpnetCtx *__restri
     }
 }
 
+// staging -> caller's y [B][T][4] and logits [B][15][T] (both staging buffers use the same layouts
+// with the clip count padded to whole row blocks, so this is two straight copies)
+__global__ void __launch_bounds__(256) opnet_copy_out(const OpnetIO *__restrict__ io)
+{
+    const long ny = (long)io->B * io->T;               // float4 units
+    const long nl = (long)io->B * OPNET_SLOTS_ * io->T;  // floats
+    float4 *__restrict__ y = (float4 *)io->y;
+    float *__restrict__ lg = io->logits;
+    const float4 *__restrict__ ys = io->ystage;
+    const float *__restrict__ ls = io->lgstage;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < ny; i += stride) y[i] = ys[i];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nl; i += stride) lg[i] = ls[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // the MFMA core shared by all four roles
 // ------------------------------------------------------------------------------------------------
 // D[16 x 32] = A[16 x K] * Hsrc^T, K = 16*(nh0+nh1) taken from up to two activation segments (each
-// [k/4][32][4] float4 for this row block).  Wave w reduces hexadecets [w*nhex/NW, (w+1)*nhex/NW).
+// [k/4][32][4] float4 for one row block).  Wave w reduces hexadecets [q0, q1) = its quarter of K.
+// All fragment loads of a chunk (up to CH hexadecets = 3*CH wave-wide 1-KiB loads) are issued
+// before the first MFMA so the memory round trips overlap instead of serialising per hexadecet.
+// A workgroup that serves several row blocks keeps its A fragments (the weights) in registers
+// across them when its K slice fits one chunk (true for H1=256/H2=512: 4..8 hexadecets a wave).
 // part layout in LDS: [wave][acc reg 0..7][lane]; acc regs 0..3 = clips 0..15, 4..7 = clips 16..31.
-__device__ __forceinline__ void gemm16_core(const float4 *__restrict__ A,
-                                            const float4 *__restrict__ seg0, int nh0,
-                                            const float4 *__restrict__ seg1, int nh1,
-                                            float *__restrict__ part)
+#define OPNET_CH 8
+
+struct KSlice {
+    int q0, q1;  // this wave's hexadecet range (wave-uniform)
+};
+
+__device__ __forceinline__ KSlice wave_slice(int nhex)
+{
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    KSlice k;
+    k.q0 = (w * nhex) / OPNET_NW;
+    k.q1 = ((w + 1) * nhex) / OPNET_NW;
+    return k;
+}
+
+__device__ __forceinline__ void load_a_chunk(float4 (&a)[OPNET_CH], const float4 *__restrict__ A, int qb, int q1)
 {
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nhex = nh0 + nh1;
-    const int q0 = (w * nhex) / OPNET_NW;
-    const int q1 = ((w + 1) * nhex) / OPNET_NW;
+#pragma unroll
+    for (int j = 0; j < OPNET_CH; ++j) {
+        if (qb + j < q1) {
+#if defined(OPNET_TRACE) && OPNET_VARIANT == 2   /* probe: no weight loads */
+            a[j] = make_float4(1.f, 2.f, 3.f, (float)(qb + j));
+#else
+            a[j] = A[(qb + j) * 64 + lane];
+#endif
+        }
+    }
+}
+
+__device__ __forceinline__ void mma_chunk(const float4 (&a)[OPNET_CH], const float4 *__restrict__ seg0, int nh0,
+                                          const float4 *__restrict__ seg1, int qb, int q1,
+                                          f32x4 &acc0, f32x4 &acc1, const int s)
+{
+    const int lane = threadIdx.x & 63;
     const int boff = (lane >> 4) * 32 + (lane & 15);
+    float4 b0[OPNET_CH], b1[OPNET_CH];
+#pragma unroll
+    for (int j = 0; j < OPNET_CH; ++j) {
+        const int q = qb + j;
+        if (q < q1) {  // wave-uniform
+            const float4 *src = (q < nh0) ? (seg0 + q * 128) : (seg1 + (q - nh0) * 128);
+#if defined(OPNET_TRACE) && OPNET_VARIANT == 1   /* probe: no activation loads */
+            b0[j] = make_float4(1.f, 2.f, 3.f, (float)q);
+            b1[j] = make_float4(1.f, 2.f, 3.f, (float)lane);
+#else
+            b0[j] = src[boff];
+            b1[j] = src[boff + 16];
+#endif
+        }
+    }
+    TRACE_WAIT_LOADS();
+    TRACE_STAMP(2);
+#pragma unroll
+    for (int j = 0; j < OPNET_CH; ++j) {
+        if (qb + j < q1) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0[j].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b1[j].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b0[j].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b1[j].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b0[j].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b1[j].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b0[j].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b1[j].w, acc1, 0, 0, 0);
+        }
+    }
+}
+
+// One row block.  `a0` holds the wave's first A chunk already (loaded by the caller, possibly for
+// an earlier row block); further chunks - only when the K slice exceeds CH - are reloaded here.
+__device__ __forceinline__ void gemm16_rb(const float4 (&a0)[OPNET_CH], const float4 *__restrict__ A,
+                                          const float4 *__restrict__ seg0, int nh0,
+                                          const float4 *__restrict__ seg1, const KSlice ks,
+                                          float *__restrict__ part, const int s)
+{
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int q = q0; q < q1; ++q) {
-        const float4 a = A[q * 64 + lane];
-        const float4 *src = (q < nh0) ? (seg0 + q * 128) : (seg1 + (q - nh0) * 128);
-        const float4 b0 = src[boff];
-        const float4 b1 = src[boff + 16];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+    mma_chunk(a0, seg0, nh0, seg1, ks.q0, ks.q1, acc0, acc1, s);
+    for (int qb = ks.q0 + OPNET_CH; qb < ks.q1; qb += OPNET_CH) {
+        float4 an[OPNET_CH];
+        load_a_chunk(an, A, qb, ks.q1);
+        mma_chunk(an, seg0, nh0, seg1, qb, ks.q1, acc0, acc1, s);
     }
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *p = part + (w * 8) * 64 + lane;
     p[0 * 64] = acc0[0]; p[1 * 64] = acc0[1]; p[2 * 64] = acc0[2]; p[3 * 64] = acc0[3];
     p[4 * 64] = acc1[0]; p[5 * 64] = acc1[1]; p[6 * 64] = acc1[2]; p[7 * 64] = acc1[3];
+    TRACE_STAMP(3);
 }
 
 // fixed-order cross-wave reduction of D element (reg, lane)
@@ -165,42 +267,58 @@ __device__ __forceinline__ float part_sum(const float *__restrict__ part, int re
     return s;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware transcendental path: v_exp_f32 / v_rcp_f32 are 1-ulp
+// class, giving |error| ~1e-7 on values in (-1, 1) - the same order as the fp32 rounding of the
+// recurrence itself (measured drift vs the fp64 oracle is unchanged to the digit).
+#ifndef OPNET_FAST_GATES
+#define OPNET_FAST_GATES 1
+#endif
+#if OPNET_FAST_GATES
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+#else
+__device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return tanhf(x); }
+#endif
 
 // LSTM cell update for one (clip, unit): gates i,f,g,o -> (c, h)
 __device__ __forceinline__ float lstm_cell(float gi, float gf, float gg, float go, float *c_io)
 {
-    const float i = sigmoidf_(gi);
-    const float f = sigmoidf_(gf);
-    const float g = tanhf(gg);
-    const float o = sigmoidf_(go);
+    const float i = fast_sigmoid(gi);
+    const float f = fast_sigmoid(gf);
+    const float g = fast_tanh(gg);
+    const float o = fast_sigmoid(go);
     const float c = f * (*c_io) + i * g;
     *c_io = c;
-    return o * tanhf(c);
+    return o * fast_tanh(c);
 }
 
 // ------------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------------
-// grid.x = n2 (LSTM2 tiles, longest K first) + n1 (LSTM1 tiles) + 2 heads ; grid.y = row blocks.
-__global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const OpnetCtx *__restrict__ ctx, int s)
+// grid.x = n2 (LSTM2 tiles, longest K first) + n1 (LSTM1 tiles) + 2 heads ; grid.y <= row blocks
+// (a workgroup walks row blocks rb = blockIdx.y, blockIdx.y + gridDim.y, ... with its weights held
+// in registers).
+__global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, const int s)
 {
     __shared__ __attribute__((aligned(16))) float lds[OPNET_NW * 8 * 64 + 32 * 16];
     float *part = lds;
-    float *lg = lds + OPNET_NW * 8 * 64;  // [clip][16] logits / probabilities (selection head)
+    float *lg = lds + OPNET_NW * 8 * 64;  // [clip][16] slot probabilities (selection head)
 
     const int bx = blockIdx.x;
-    const int rb = blockIdx.y;
-    const int T = ctx->T, B = ctx->B;
-    const int H1 = ctx->H1, H2 = ctx->H2;
+    const int T = a.T;
+    const int H1 = a.H1, H2 = a.H2;
     const int n1 = H1 >> 2, n2 = H2 >> 2;
     const int tid = threadIdx.x;
+    TRACE_STAMP(0);
+    TRACE_STAMP(1);
 
     // epilogue coordinates (threads 0..127): D column = clip, D rows 4*(lane>>4)+r in regs r
     const int el = tid & 63;
     const int half = tid >> 6;
     const int clip = half * 16 + (el & 15);
     const int quarter = el >> 4;
+    float4 a0[OPNET_CH];
 
     if (bx < n2) {
         // ---------------- LSTM2 (video_LSTM, learned_models.py:32,46), step t = s-2 -------------
@@ -208,40 +326,50 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const OpnetCtx *__re
         if (t < 0 || t >= T) return;
         const int tile = bx;
         const int nh = H2 >> 4;
-        const float4 *hprev = ctx->h2buf + ((long)((t + 1) & 1) * ctx->RB + rb) * (H2 * 8);
-        // epilogue operands are fetched before the MFMA phase so their latency hides under it
+        const KSlice ks = wave_slice(nh);
+        const float4 *A = a.w2p + (long)tile * nh * 64;
+        load_a_chunk(a0, A, ks.q0, ks.q1);
         const int unit = tile * 4 + quarter;
-        float4 xa, xb, wv[8];
-        float c_old = 0.f;
+        float4 wv[8];
         if (tid < 128) {
-            const float4 *x2 = ctx->x2buf + ((long)(t & 1) * ctx->RB + rb) * 64 + clip * 2;
-            xa = x2[0];
-            xb = x2[1];
-            const float4 *wi = ctx->wih2p + (long)unit * 8;
+            const float4 *wi = a.wih2p + (long)unit * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) wv[j] = wi[j];
-            c_old = ctx->c2[((long)rb * H2 + unit) * 32 + clip];
         }
-        gemm16_core(ctx->w2p + (long)tile * nh * 64, hprev, nh, hprev, 0, part);
-        __syncthreads();
-        if (tid < 128) {
-            float g[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // x part: W_ih2[gate r, unit][0..5] . frames_boxes[clip][0..5]
-                float xs = wv[2 * r].x * xa.x;
-                xs = fmaf(wv[2 * r].y, xa.y, xs);
-                xs = fmaf(wv[2 * r].z, xa.z, xs);
-                xs = fmaf(wv[2 * r].w, xa.w, xs);
-                xs = fmaf(wv[2 * r + 1].x, xb.x, xs);
-                xs = fmaf(wv[2 * r + 1].y, xb.y, xs);
-                g[r] = part_sum(part, half * 4 + r, el) + xs;
+        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            const float4 *hprev = a.h2buf + ((long)((t + 1) & 1) * a.RB + rb) * (H2 * 8);
+            // epilogue operands are fetched before the MFMA phase so their latency hides under it
+            float4 xa, xb;
+            float c_old = 0.f;
+            if (tid < 128) {
+                const float4 *x2 = a.x2buf + ((long)(t & 1) * a.RB + rb) * 64 + clip * 2;
+                xa = x2[0];
+                xb = x2[1];
+                c_old = a.c2[((long)rb * H2 + unit) * 32 + clip];
             }
-            float c = c_old;
-            const float h = lstm_cell(g[0], g[1], g[2], g[3], &c);
-            ctx->c2[((long)rb * H2 + unit) * 32 + clip] = c;
-            float *hout = (float *)(ctx->h2buf + ((long)(t & 1) * ctx->RB + rb) * (H2 * 8));
-            hout[((long)tile * 32 + clip) * 4 + quarter] = h;
+            gemm16_rb(a0, A, hprev, nh, hprev, ks, part, s);
+            __syncthreads();
+            TRACE_STAMP(4);
+            if (tid < 128) {
+                float g[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // x part: W_ih2[gate r, unit][0..5] . frames_boxes[clip][0..5]
+                    float xs = wv[2 * r].x * xa.x;
+                    xs = fmaf(wv[2 * r].y, xa.y, xs);
+                    xs = fmaf(wv[2 * r].z, xa.z, xs);
+                    xs = fmaf(wv[2 * r].w, xa.w, xs);
+                    xs = fmaf(wv[2 * r + 1].x, xb.x, xs);
+                    xs = fmaf(wv[2 * r + 1].y, xb.y, xs);
+                    g[r] = part_sum(part, half * 4 + r, el) + xs;
+                }
+                float c = c_old;
+                const float h = lstm_cell(g[0], g[1], g[2], g[3], &c);
+                a.c2[((long)rb * H2 + unit) * 32 + clip] = c;
+                float *hout = (float *)(a.h2buf + ((long)(t & 1) * a.RB + rb) * (H2 * 8));
+                hout[((long)tile * 32 + clip) * 4 + quarter] = h;
+            }
+            if (rb + (int)gridDim.y < a.RB) __syncthreads();  // partials are rewritten next round
         }
     } else if (bx < n2 + n1) {
         // ---------------- LSTM1 (object_to_track_LSTM, learned_models.py:29,39), step t = s -----
@@ -249,90 +377,119 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const OpnetCtx *__re
         if (t >= T) return;
         const int tile = bx - n2;
         const int nhh = H1 >> 4;
-        const float4 *xsrc = ctx->xp + ((long)t * ctx->RB + rb) * (OPNET_KXQ * 32);
-        const float4 *hprev = ctx->h1buf + ((long)((t + 1) & 1) * ctx->RB + rb) * (H1 * 8);
+        const KSlice ks = wave_slice(OPNET_KXQ / 4 + nhh);
+        const float4 *A = a.w1p + (long)tile * (OPNET_KXQ / 4 + nhh) * 64;
+        load_a_chunk(a0, A, ks.q0, ks.q1);
         const int unit = tile * 4 + quarter;
-        float c_old = 0.f;
-        if (tid < 128) c_old = ctx->c1[((long)rb * H1 + unit) * 32 + clip];
-        gemm16_core(ctx->w1p + (long)tile * (OPNET_KXQ / 4 + nhh) * 64, xsrc, OPNET_KXQ / 4, hprev,
-                    nhh, part);
-        __syncthreads();
-        if (tid < 128) {
-            float c = c_old;
-            const float h = lstm_cell(part_sum(part, half * 4 + 0, el), part_sum(part, half * 4 + 1, el),
-                                      part_sum(part, half * 4 + 2, el), part_sum(part, half * 4 + 3, el), &c);
-            ctx->c1[((long)rb * H1 + unit) * 32 + clip] = c;
-            float *hout = (float *)(ctx->h1buf + ((long)(t & 1) * ctx->RB + rb) * (H1 * 8));
-            hout[((long)tile * 32 + clip) * 4 + quarter] = h;
+        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            const float4 *xsrc = a.xp + ((long)t * a.RB + rb) * (OPNET_KXQ * 32);
+            const float4 *hprev = a.h1buf + ((long)((t + 1) & 1) * a.RB + rb) * (H1 * 8);
+            float c_old = 0.f;
+            if (tid < 128) c_old = a.c1[((long)rb * H1 + unit) * 32 + clip];
+            gemm16_rb(a0, A, xsrc, OPNET_KXQ / 4, hprev, ks, part, s);
+            __syncthreads();
+            TRACE_STAMP(4);
+            if (tid < 128) {
+                float c = c_old;
+                const float h = lstm_cell(part_sum(part, half * 4 + 0, el), part_sum(part, half * 4 + 1, el),
+                                          part_sum(part, half * 4 + 2, el), part_sum(part, half * 4 + 3, el), &c);
+                a.c1[((long)rb * H1 + unit) * 32 + clip] = c;
+                float *hout = (float *)(a.h1buf + ((long)(t & 1) * a.RB + rb) * (H1 * 8));
+                hout[((long)tile * 32 + clip) * 4 + quarter] = h;
+            }
+            if (rb + (int)gridDim.y < a.RB) __syncthreads();
         }
     } else if (bx == n2 + n1) {
         // ---------------- selection head, step t = s-1 (learned_models.py:40-43,50) -------------
         const int t = s - 1;
         if (t < 0 || t >= T) return;
         const int nh = H1 >> 4;
-        const float4 *hcur = ctx->h1buf + ((long)(t & 1) * ctx->RB + rb) * (H1 * 8);
-        gemm16_core(ctx->wselp, hcur, nh, hcur, 0, part);
-        __syncthreads();
-        if (tid < 128) {
-            const int b = rb * 32 + clip;
+        const KSlice ks = wave_slice(nh);
+        load_a_chunk(a0, a.wselp, ks.q0, ks.q1);
+        const int mc = tid >> 3, mf = tid & 7;
+        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            const float4 *hcur = a.h1buf + ((long)(t & 1) * a.RB + rb) * (H1 * 8);
+            // this frame's boxes, for the mix below: feature f of slot o of clip c sits at k = 6*o + f
+            // of the packed LSTM1 input.  Issued before the MFMA phase.
+            float bxv[OPNET_SLOTS_];
+            if (tid < 256) {
+                const float *xs = (const float *)(a.xp + ((long)t * a.RB + rb) * (OPNET_KXQ * 32));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int slot = quarter * 4 + r;
-                const float v = part_sum(part, half * 4 + r, el);
-                lg[clip * 16 + slot] = v;
-                // logits [B][15][T] (the permute(0,2,1).contiguous() of :50)
-                if (slot < OPNET_SLOTS_ && b < B) ctx->logits[((long)b * OPNET_SLOTS_ + slot) * T + t] = v;
+                for (int o = 0; o < OPNET_SLOTS_; ++o) {
+                    const int k = o * OPNET_FEATS_ + (mf < OPNET_FEATS_ ? mf : 0);
+                    bxv[o] = xs[((k >> 2) * 32 + mc) * 4 + (k & 3)];
+                }
             }
-        }
-        __syncthreads();
-        if (tid < 32) {
-            // F.softmax(dim=-1) over the 15 slots of clip `tid`
-            float *row = lg + tid * 16;
-            float m = row[0];
+            gemm16_rb(a0, a.wselp, hcur, nh, hcur, ks, part, s);
+            __syncthreads();
+            TRACE_STAMP(4);
+            if (tid < 128) {
+                // thread (clip, quarter) holds logits of slots 4*quarter .. +3; the 15-way softmax
+                // (F.softmax(dim=-1), :41) spans the four lanes el, el^16, el^32, el^48
+                const long b = rb * 32 + clip;
+                float v[4];
+                float m = -INFINITY;
 #pragma unroll
-            for (int j = 1; j < OPNET_SLOTS_; ++j) m = fmaxf(m, row[j]);
-            float e[OPNET_SLOTS_];
-            float sum = 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const int slot = quarter * 4 + r;
+                    v[r] = part_sum(part, half * 4 + r, el);
+                    // logits [B][15][T] (the permute(0,2,1).contiguous() of :50)
+                    if (slot < OPNET_SLOTS_) {
+                        a.lgstage[(b * OPNET_SLOTS_ + slot) * T + t] = v[r];
+                        m = fmaxf(m, v[r]);
+                    }
+                }
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                float e[4], sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < OPNET_SLOTS_; ++j) { e[j] = expf(row[j] - m); sum += e[j]; }
-#pragma unroll
-            for (int j = 0; j < OPNET_SLOTS_; ++j) row[j] = e[j] / sum;
-        }
-        __syncthreads();
-        {
-            // frames_boxes[clip][f] = sum_o boxes[clip][t][o][f] * p[o]   (einsum "bfot,bfo->bft")
-            const int c2 = tid >> 3, f = tid & 7;
-            const int b = rb * 32 + c2;
-            float acc = 0.f;
-            if (f < OPNET_FEATS_ && b < B) {
-                const float *bx_ = ctx->boxes + ((long)b * T + t) * OPNET_KX + f;
-                const float *p = lg + c2 * 16;
-#pragma unroll
-                for (int o = 0; o < OPNET_SLOTS_; ++o) acc = fmaf(bx_[o * OPNET_FEATS_], p[o], acc);
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = (quarter * 4 + r < OPNET_SLOTS_) ? __expf(v[r] - m) : 0.f;
+                    sum += e[r];
+                }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = 1.0f / sum;
+                float4 pv = make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv);
+                ((float4 *)lg)[clip * 4 + quarter] = pv;
             }
-            float *x2 = (float *)(ctx->x2buf + ((long)(t & 1) * ctx->RB + rb) * 64);
-            x2[c2 * 8 + f] = acc;
+            __syncthreads();
+            if (tid < 256) {
+                // frames_boxes[clip][f] = sum_o boxes[clip][t][o][f] * p[o]   (einsum "bfot,bfo->bft")
+                float acc = 0.f;
+                const float *p = lg + mc * 16;
+#pragma unroll
+                for (int o = 0; o < OPNET_SLOTS_; ++o) acc = fmaf(bxv[o], p[o], acc);
+                float *x2 = (float *)(a.x2buf + ((long)(t & 1) * a.RB + rb) * 64);
+                x2[mc * 8 + mf] = mf < OPNET_FEATS_ ? acc : 0.f;
+            }
+            if (rb + (int)gridDim.y < a.RB) __syncthreads();
         }
     } else {
         // ---------------- output head, step t = s-3 (prediction_layer, learned_models.py:33,47) --
         const int t = s - 3;
         if (t < 0 || t >= T) return;
         const int nh = H2 >> 4;
-        const float4 *hcur = ctx->h2buf + ((long)(t & 1) * ctx->RB + rb) * (H2 * 8);
-        gemm16_core(ctx->woutp, hcur, nh, hcur, 0, part);
-        __syncthreads();
-        if (tid < 128 && quarter == 0) {
-            const int b = rb * 32 + clip;
-            if (b < B) {
+        const KSlice ks = wave_slice(nh);
+        load_a_chunk(a0, a.woutp, ks.q0, ks.q1);
+        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            const float4 *hcur = a.h2buf + ((long)(t & 1) * a.RB + rb) * (H2 * 8);
+            gemm16_rb(a0, a.woutp, hcur, nh, hcur, ks, part, s);
+            __syncthreads();
+            TRACE_STAMP(4);
+            if (tid < 128 && quarter == 0) {
+                const long b = rb * 32 + clip;
                 float4 v;
                 v.x = part_sum(part, half * 4 + 0, el);
                 v.y = part_sum(part, half * 4 + 1, el);
                 v.z = part_sum(part, half * 4 + 2, el);
                 v.w = part_sum(part, half * 4 + 3, el);
-                ((float4 *)ctx->y)[(long)b * T + t] = v;
+                a.ystage[b * T + t] = v;
             }
+            if (rb + (int)gridDim.y < a.RB) __syncthreads();
         }
     }
+    TRACE_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
