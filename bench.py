@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py - OPNet inference throughput on MI355X (the BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--batch 32]
+
+One "step" = one pass of the hot path (OPNet.forward through libopnet_hip.so) over one batch of
+`--batch` synthetic CATER clips (300 frames x 15 slots x 6 features, fp32) that is already resident in
+HBM, followed by the device-side post-processing to int32 pixel boxes.  With N > 1 every rank runs
+its own batch (clips are independent: weak scaling, no data-path collective inside the forward) and
+the per-clip predictions are all-gathered over RCCL on a side stream, overlapped with the next step.
+
+Rank 0 prints ONE JSON line: BASELINE.json's metric (clips/s, whole job), plus
+  roofline     - the dominant kernel (opnet_step) against the HBM roofline under SURVEY.md 8-d4's
+                 per-time-step weight-streaming model, timed live with HIP events on the launch stream;
+  cpu_baseline - oracle/opnet_oracle.c (a C/OpenMP port of the reference algorithm) timed on this
+                 host's cores on a bounded sample of the same workload (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+CFG = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
+T_FRAMES = 300
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+W_BYTES = 5_684_224            # all six fp32 weight tensors
+STATE_BYTES_PER_CLIP = 12_672  # per clip per time step: x_t + h,c read + h,c write of both LSTMs (8-d4)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (BASELINE configs: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(boxes_np, params, seconds):
+    """Time the C/OpenMP port on this host. Returns the dict for the JSON line + its output."""
+    from oracle import c_oracle
+    threads = os.cpu_count() or 1
+    y, _ = c_oracle.opnet_forward(boxes_np, params, threads)  # warm-up (also page-in / build)
+    reps, t_total = 0, 0.0
+    t_end = time.perf_counter() + seconds
+    while True:
+        t0 = time.perf_counter()
+        y, _ = c_oracle.opnet_forward(boxes_np, params, threads)
+        t_total += time.perf_counter() - t0
+        reps += 1
+        if time.perf_counter() >= t_end:
+            break
+    clips = reps * boxes_np.shape[0]
+    return {
+        "value": round(clips / t_total, 2), "unit": "clips/s", "cores": threads, "kind": "port",
+        "sample": f"{reps} x forward of {boxes_np.shape[0]} clips x {boxes_np.shape[1]} frames "
+                  f"(oracle/opnet_oracle.c, gcc -O3 -march=native -fopenmp, {threads} threads, {t_total:.1f} s)",
+    }, y
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    from objectpermanence_amd import ModelsFactory, metrics
+    from oracle import synth
+
+    B = args.batch
+    params = synth.opnet_synth_params(CFG)
+    model = ModelsFactory.get_model("opnet", CFG)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model.eval().to(dev)
+
+    # rank r owns clips [r*B, (r+1)*B) of the synthetic set; distinct clips per rank (weak scaling)
+    n_unique = min(B, 32)
+    boxes_np, labels_np = synth.make_batch(rank * B, n_unique, T_FRAMES)
+    if n_unique < B:
+        reps = (B + n_unique - 1) // n_unique
+        boxes_np = np.tile(boxes_np, (reps, 1, 1, 1))[:B]
+        labels_np = np.tile(labels_np, (reps, 1, 1))[:B]
+    boxes = torch.from_numpy(boxes_np).to(dev)
+    labels = torch.from_numpy(labels_np).to(dev)
+
+    side = torch.cuda.Stream(device=dev)
+    gathered = torch.empty((world * B, T_FRAMES, 4), dtype=torch.int32, device=dev) if world > 1 else None
+    pending = None
+
+    def step():
+        nonlocal pending
+        with torch.no_grad():
+            y, _logits = model(boxes)
+        pred_px, _, _ = metrics.postprocess_and_iou(y)
+        if world > 1:
+            # prediction all-gather on a side stream, overlapped with the next step's recurrence
+            if pending is not None:
+                pending.wait()
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                pred_px.record_stream(side)
+                pending = dist.all_gather_into_tensor(gathered, pred_px, async_op=True)
+        return y, pred_px
+
+    for _ in range(args.warmup):
+        step()
+    if pending is not None:
+        pending.wait()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        y, pred_px = step()
+    ev1.record()
+    if pending is not None:
+        pending.wait()
+        torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream: the kernels only
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        clips_per_s = world * B * args.steps / elapsed
+        # dominant kernel: opnet_step, T+3 launches per forward.  Algorithmic bytes under the
+        # per-time-step streaming model: every step reads all weights once and moves each clip's state.
+        n_launch = args.steps * (T_FRAMES + 3)
+        alg_bytes_per_launch = (W_BYTES + B * STATE_BYTES_PER_CLIP) * T_FRAMES / (T_FRAMES + 3)
+        launch_us = gpu_ms * 1e3 / n_launch
+        achieved = alg_bytes_per_launch / (launch_us * 1e-6) / 1e9
+        out = {
+            "metric": "CATER clips/sec (300f x 10obj) OPNet inference",
+            "value": round(clips_per_s, 1), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"opnet (configs/opnet_model_config.json: H1=256, H2=512) inference, "
+                                   f"batch={B} clips/GPU/step x 300 frames x 15 slots (10 objects) x 6 features, "
+                                   "precomputed bbox input resident in HBM, int32 pixel-box post-process on device",
+                       "global_batch": world * B, "frames": T_FRAMES, "parallelism": f"dp{world}",
+                       "weights": "synthetic (oracle/synth.py counter RNG), fp32"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "opnet_step", "launch_us": round(launch_us, 3),
+                         "alg_bytes_per_launch": int(alg_bytes_per_launch)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, y_cpu = cpu_baseline(boxes_np, params, args.cpu_seconds)
+            out["cpu_baseline"] = cb
+            out["parity_max_abs_dy_vs_cpu_port"] = float(np.abs(y.cpu().numpy() - y_cpu).max())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,39 @@
+"""Video-level data parallelism for the reasoners: one process per GPU, clips sharded in contiguous
+blocks, predictions all-gathered (RCCL over xGMI on GPUs; any torch.distributed backend works).
+
+The reference has no distributed path on the OPNet side; its contract for a
+sharded run is therefore "N-GPU result == 1-GPU result on the same clips", which holds because clips
+are independent.  Sorting / indexing follows the reference's dataset order
+(baselines/datasets.py:74 sorted video names; inference_main.py:210-217 name -> global index).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_size(n_items: int, world: int) -> int:
+    return (n_items + world - 1) // world
+
+
+def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block owned by `rank`: [r*ceil(N/W), min(N, (r+1)*ceil(N/W)))."""
+    per = shard_size(n_items, world)
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per)
+
+
+def all_gather_predictions(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessGroup] = None,
+                           async_op: bool = False):
+    """local [n_local, ...] (this rank's shard, n_local may be short or zero on the last ranks) ->
+    [n_total, ...] on every rank, in global clip order.  Returns (tensor, work|None); when async_op
+    the tensor is valid after work.wait()."""
+    world = dist.get_world_size(group)
+    per = shard_size(n_total, world)
+    pad = local.new_zeros((per,) + tuple(local.shape[1:]))
+    pad[: local.shape[0]] = local
+    out = local.new_empty((world * per,) + tuple(local.shape[1:]))
+    work = dist.all_gather_into_tensor(out, pad, group=group, async_op=async_op)
+    return out[:n_total], work

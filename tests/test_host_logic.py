@@ -1,0 +1,111 @@
+"""CPU-side checks: the C ABI library loads and exports every symbol include/opnet_hip.h declares, host
+argument validation (no GPU work is launched), and the data-parallel sharding logic over gloo."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from objectpermanence_amd import _lib, build
+    build.build()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported():
+    from objectpermanence_amd import _lib as binding
+    lib = _lib()
+    hdr = open(os.path.join(REPO, "include", "opnet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(opnet_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(binding.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/opnet_hip.h but not exported"
+
+
+def test_size_queries_and_validation_without_gpu():
+    lib = _lib()
+    assert lib.opnet_hip_abi_version() == 1
+    w = lib.opnet_workspace_bytes(32, 300, 256, 512)
+    assert w > 32 * 300 * 96 * 4 and lib.opnet_workspace_bytes(64, 300, 256, 512) > w
+    assert lib.opnet_workspace_bytes(33, 300, 256, 512) == lib.opnet_workspace_bytes(64, 300, 256, 512)
+    p = lib.opnet_packed_weights_bytes(256, 512)
+    assert p >= 1_421_056 * 4      # every reference parameter is present (padding only adds)
+    assert lib.opnet_workspace_bytes(0, 300, 256, 512) == 0
+    assert lib.opnet_packed_weights_bytes(250, 512) == 0
+    assert b"multiples of 16" in lib.opnet_last_error()
+    # null pointers are rejected before anything is enqueued
+    assert lib.opnet_forward_f32(None, None, None, None, None, 0, 1, 1, 16, 16, None) == -1
+    assert lib.opnet_pack_weights_f32(None, None, None, None, None, None, None, 0, 16, 16, None) == -1
+    plan = ctypes.c_void_p()
+    assert lib.opnet_plan_create(ctypes.byref(plan), 4, 10, 16, 32) == 0 and plan.value
+    assert lib.opnet_plan_forward(plan, None, None, None, None, None, 0, None) == -1
+    lib.opnet_plan_destroy(plan)
+    assert lib.opnet_plan_create(ctypes.byref(plan), 4, 10, 10, 32) == -2
+    assert lib.opnet_postprocess_iou(None, None, None, None, None, 1, 1, None) == -1
+
+
+def test_module_mirrors_reference_interface():
+    from objectpermanence_amd import ModelsFactory, supported_models
+    cfg = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
+    m = ModelsFactory.get_model("opnet", cfg)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert shapes == {
+        "object_to_track_LSTM.weight_ih_l0": (1024, 90), "object_to_track_LSTM.weight_hh_l0": (1024, 256),
+        "object_to_track_prediction.weight": (15, 256), "video_LSTM.weight_ih_l0": (2048, 6),
+        "video_LSTM.weight_hh_l0": (2048, 512), "prediction_layer.weight": (4, 512)}
+    assert sum(p.numel() for p in m.parameters()) == 1_421_056
+    with pytest.raises(AttributeError, match="Model name is incorrect"):
+        ModelsFactory.get_model("nope", cfg)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 2, 15, 6))
+    assert "opnet" in supported_models.DOUBLE_OUTPUT_MODELS
+
+
+def _dp_worker(rank, world, port, n_total, tmp):
+    import torch.distributed as dist
+    from objectpermanence_amd import parallel
+    from oracle import opnet_oracle as oo, synth
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 16, "videos_hidden_dim": 32}
+    params = synth.opnet_synth_params(cfg)
+    lo, hi = parallel.shard_range(n_total, world, rank)
+    if hi > lo:
+        boxes, _ = synth.make_batch(lo, hi - lo, 10)
+        y, _ = oo.opnet_forward(boxes, params, np.float32)     # stand-in for the per-rank GPU forward
+        local = torch.from_numpy(oo.postprocess_to_pixels(y))
+    else:
+        local = torch.zeros((0, 10, 4), dtype=torch.int32)
+    full, _ = parallel.all_gather_predictions(local, n_total)
+    np.save(os.path.join(tmp, f"r{rank}.npy"), full.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [5, 4, 1])
+def test_dp_shard_and_gather_equals_single_process(tmp_path, n_total):
+    import torch.multiprocessing as mp
+    from oracle import opnet_oracle as oo, synth
+    port = 29500 + (os.getpid() + n_total) % 1000
+    mp.spawn(_dp_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
+    cfg = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 16, "videos_hidden_dim": 32}
+    boxes, _ = synth.make_batch(0, n_total, 10)
+    y, _ = oo.opnet_forward(boxes, synth.opnet_synth_params(cfg), np.float32)
+    ref = oo.postprocess_to_pixels(y)
+    for r in range(2):
+        got = np.load(os.path.join(str(tmp_path), f"r{r}.npy"))
+        assert np.array_equal(got, ref)
+
+
+def test_shard_ranges_cover_everything():
+    from objectpermanence_amd import parallel
+    for n in (0, 1, 7, 8, 9, 255, 256):
+        for w in (1, 2, 8):
+            spans = [parallel.shard_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
