@@ -50,7 +50,7 @@ def parse():
 def cpu_baseline(boxes_np, params, seconds):
     """Time the C/OpenMP port on this host. Returns the dict for the JSON line + its output."""
     from oracle import c_oracle
-    threads = os.cpu_count() or 1
+    threads = c_oracle.usable_cores()  # affinity mask capped by the cgroup CPU quota
     y, _ = c_oracle.opnet_forward(boxes_np, params, threads)  # warm-up (also page-in / build)
     reps, t_total = 0, 0.0
     t_end = time.perf_counter() + seconds
@@ -180,7 +180,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cb, y_cpu = cpu_baseline(boxes_np, params, args.cpu_seconds)
             out["cpu_baseline"] = cb
-            out["parity_max_abs_dy_vs_cpu_port"] = float(np.abs(y.cpu().numpy() - y_cpu).max())
+            err = float(np.abs(y.cpu().numpy() - y_cpu).max())
+            out["parity_max_abs_dy_vs_cpu_port"] = err
+            if not err < 1e-4:
+                raise SystemExit(f"bench: HIP output of the last timed step differs from the CPU port by {err}")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

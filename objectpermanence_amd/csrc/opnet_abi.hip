@@ -167,6 +167,8 @@ static int make_args(StepArgs *a, OpnetIO *io, const float *boxes, const float *
     io->xp = (float4 *)(w + W.xp);
     io->ystage = a->ystage;
     io->lgstage = a->lgstage;
+    io->state = (float4 *)(w + W.state);
+    io->state_f4 = (long)((W.state_end - W.state) / 16);
     return OPNET_OK;
 }
 
@@ -195,7 +197,6 @@ extern "C" int opnet_forward_f32(const float *boxes, const float *packed, float 
     hipStream_t st = (hipStream_t)stream;
     OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
-    HIP_TRY(hipMemsetAsync((char *)workspace + W.state, 0, W.state_end - W.state, st));
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     const dim3 grid = step_grid(a.RB, H1, H2);
     for (int s = 0; s < T + 3; ++s) opnet_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
@@ -242,7 +243,7 @@ extern "C" void opnet_plan_destroy(opnet_plan *p)
     delete p;
 }
 
-// memset(state) -> pack_input -> step 0 -> ... -> step T+2 -> copy_out, one linear dependency chain
+// pack_input (+ state zeroing) -> step 0 -> ... -> step T+2 -> copy_out, one linear dependency chain
 static int plan_build(opnet_plan *p, const StepArgs &a, void *ws)
 {
     plan_drop_graph(p);
@@ -250,17 +251,6 @@ static int plan_build(opnet_plan *p, const StepArgs &a, void *ws)
     OpnetIO *dio = (OpnetIO *)((char *)ws + W.io);
     HIP_TRY(hipGraphCreate(&p->graph, 0));
     hipGraphNode_t prev = nullptr, node = nullptr;
-
-    hipMemsetParams ms;
-    memset(&ms, 0, sizeof(ms));
-    ms.dst = (char *)ws + W.state;
-    ms.value = 0;
-    ms.elementSize = 4;
-    ms.width = (W.state_end - W.state) / 4;
-    ms.height = 1;
-    ms.pitch = 0;
-    HIP_TRY(hipGraphAddMemsetNode(&node, p->graph, nullptr, 0, &ms));
-    prev = node;
 
     auto add_io_kernel = [&](void *func, dim3 grid) -> hipError_t {
         void *args[] = {(void *)&dio};
@@ -270,7 +260,7 @@ static int plan_build(opnet_plan *p, const StepArgs &a, void *ws)
         kp.gridDim = grid;
         kp.blockDim = dim3(256, 1, 1);
         kp.kernelParams = args;
-        hipError_t e = hipGraphAddKernelNode(&node, p->graph, &prev, 1, &kp);
+        hipError_t e = hipGraphAddKernelNode(&node, p->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
         prev = node;
         return e;
     };

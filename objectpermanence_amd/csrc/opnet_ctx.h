@@ -39,4 +39,6 @@ struct OpnetIO {
     float4 *xp;
     const float4 *ystage;
     const float *lgstage;
+    float4 *state;         // recurrent state (h1buf .. x2buf), zeroed by pack_input at the start of a forward
+    long state_f4;         // its size in float4 units
 };

@@ -117,12 +117,22 @@ __global__ void opnet_pack_wih2(float *__restrict__ out, const float *__restrict
 __global__ void opnet_set_io(OpnetIO *dst, OpnetIO src) { *dst = src; }
 
 // boxes [B][T][90] -> xp [t][rb][kq 0..23][clip 0..31][4]  (K padded 90 -> 96 with zeros, clips
-// beyond B zero).  One workgroup per (t, rb).
+// beyond B zero).  One workgroup per (t, rb).  The same launch zeroes the recurrent state (h0 = c0 =
+// 0, learned_models.py:39,46 pass no initial state): it is the first kernel node of the forward, so
+// the zeroing is ordered like every other kernel of the chain (a hipGraph memset root node is not
+// ordered against the tail of a previous replay of the same graph on ROCm 7.2 - measured).
 __global__ void __launch_bounds__(256) opnet_pack_input(const OpnetIO *__restrict__ io)
 {
     const int t = blockIdx.x;
     const int rb = blockIdx.y;
     const int B = io->B, T = io->T, RB = io->RB;
+    {
+        float4 *__restrict__ st = io->state;
+        const long n = io->state_f4;
+        const long nthreads = (long)gridDim.x * gridDim.y * 256;
+        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < n; i += nthreads)
+            st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const float *__restrict__ boxes = io->boxes;
     float4 *__restrict__ xp = io->xp + ((long)t * RB + rb) * (OPNET_KXQ * 32);
     for (int idx = threadIdx.x; idx < OPNET_KXQ * 32; idx += 256) {

@@ -62,9 +62,35 @@ def max_threads() -> int:
     return int(_load().opnet_oracle_max_threads())
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota
+    (a container can see 256 logical CPUs and be throttled to 16 - oversubscribing a spinning
+    OpenMP barrier under a quota is catastrophically slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, q // int(f2.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def opnet_forward(boxes: np.ndarray, p, n_threads: int = 0):
-    """boxes [B,T,15,6] f32, p: OPNet state_dict arrays -> (y [B,T,4], logits [B,15,T]) fp32."""
+    """boxes [B,T,15,6] f32, p: OPNet state_dict arrays -> (y [B,T,4], logits [B,15,T]) fp32.
+    n_threads <= 0 means usable_cores()."""
     lib = _load()
+    if n_threads <= 0:
+        n_threads = usable_cores()
     boxes = np.ascontiguousarray(boxes, dtype=np.float32)
     B, T = boxes.shape[:2]
     names = ("object_to_track_LSTM.weight_ih_l0", "object_to_track_LSTM.weight_hh_l0",
