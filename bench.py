@@ -36,6 +36,19 @@ W_BYTES = 5_684_224            # all six fp32 weight tensors
 STATE_BYTES_PER_CLIP = 12_672  # per clip per time step: x_t + h,c read + h,c write of both LSTMs (8-d4)
 
 
+def pmc_traffic(batch):
+    """HBM bytes per opnet_step launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE; profiles/r*_pmc_b<batch>.json says how they were collected). PMC cannot be
+    sampled from inside this process, so this is the last committed measurement of the same command,
+    or None when there is none for this batch size."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_pmc_b{batch}.json"))):
+        with open(path) as f:
+            best = json.load(f)
+    return None if best is None else int(best["traffic_bytes_per_launch"])
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,7 +186,7 @@ def main():
                        "global_batch": world * B, "frames": T_FRAMES, "parallelism": f"dp{world}",
                        "weights": "synthetic (oracle/synth.py counter RNG), fp32"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(B),
                          "kernel": "opnet_step", "launch_us": round(launch_us, 3),
                          "alg_bytes_per_launch": int(alg_bytes_per_launch)},
         }
