@@ -16,17 +16,22 @@
 
 struct StepArgs {
     int B, T, RB, H1, H2;
+    int train;             // 0: two-deep parity buffers; 1: full-history buffers (slot t+1 holds step t,
+                           //    slot 0 the zero initial state) so the backward pass can read every step
     const float4 *xp;      // [T][RB][24][32]        packed LSTM1 input (also read by the selection head)
     const float4 *w1p;     // [H1/4][(96+H1)/16][64] LSTM1 A tiles  (x part | h part)
     const float4 *w2p;     // [H2/4][H2/16][64]      LSTM2 A tiles  (h part)
     const float4 *wih2p;   // [H2][4 gates][2]       LSTM2 x part (6 -> 8 floats)
     const float4 *wselp;   // [H1/16][64]            selection head (15 -> 16 rows)
     const float4 *woutp;   // [H2/16][64]            output head    (4 -> 16 rows)
-    float4 *h1buf;         // [2 parity][RB][H1/4][32]
-    float *c1;             // [RB][H1][32]
-    float4 *h2buf;         // [2 parity][RB][H2/4][32]
-    float *c2;             // [RB][H2][32]
-    float4 *x2buf;         // [2 parity][RB][32][2]  frames_boxes (6 -> 8 floats)
+    float4 *h1buf;         // [2 parity | T+1][RB][H1/4][32]
+    float *c1;             // [1 | T+1][RB][H1][32]
+    float4 *h2buf;         // [2 parity | T+1][RB][H2/4][32]
+    float *c2;             // [1 | T+1][RB][H2][32]
+    float4 *x2buf;         // [2 parity | T][RB][2 kq][32]  frames_boxes (6 -> 8 floats), kq-major
+    float4 *g1save;        // train only: [T][RB][H1][32] post-activation gates (i,f,g,o) per (unit, clip)
+    float4 *g2save;        // train only: [T][RB][H2][32]
+    float4 *psave;         // train only: [T][RB][4 kq][32] slot probabilities (15 -> 16), kq-major
     float4 *ystage;        // [RB*32][T]             y_boxes staging
     float *lgstage;        // [RB*32][15][T]         logits staging
 };

@@ -303,6 +303,26 @@ __device__ __forceinline__ float lstm_cell(float gi, float gf, float gg, float g
     return o * fast_tanh(c);
 }
 
+// history slots: inference keeps two parity slots per state buffer, training keeps every step
+__device__ __forceinline__ long slot_prev(const StepArgs &a, int t) { return a.train ? t : ((t + 1) & 1); }
+__device__ __forceinline__ long slot_out(const StepArgs &a, int t) { return a.train ? t + 1 : (t & 1); }
+__device__ __forceinline__ long slot_x2(const StepArgs &a, int t) { return a.train ? t : (t & 1); }
+__device__ __forceinline__ long cslot_prev(const StepArgs &a, int t) { return a.train ? t : 0; }
+__device__ __forceinline__ long cslot_out(const StepArgs &a, int t) { return a.train ? t + 1 : 0; }
+
+// LSTM cell update that also returns the post-activation gates (saved for the backward pass)
+__device__ __forceinline__ float lstm_cell_g(float gi, float gf, float gg, float go, float *c_io, float4 *gates)
+{
+    const float i = fast_sigmoid(gi);
+    const float f = fast_sigmoid(gf);
+    const float g = fast_tanh(gg);
+    const float o = fast_sigmoid(go);
+    const float c = f * (*c_io) + i * g;
+    *c_io = c;
+    *gates = make_float4(i, f, g, o);
+    return o * fast_tanh(c);
+}
+
 // ------------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------------
@@ -347,15 +367,15 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
             for (int j = 0; j < 8; ++j) wv[j] = wi[j];
         }
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
-            const float4 *hprev = a.h2buf + ((long)((t + 1) & 1) * a.RB + rb) * (H2 * 8);
+            const float4 *hprev = a.h2buf + (slot_prev(a, t) * a.RB + rb) * (H2 * 8);
             // epilogue operands are fetched before the MFMA phase so their latency hides under it
             float4 xa, xb;
             float c_old = 0.f;
             if (tid < 128) {
-                const float4 *x2 = a.x2buf + ((long)(t & 1) * a.RB + rb) * 64 + clip * 2;
+                const float4 *x2 = a.x2buf + (slot_x2(a, t) * a.RB + rb) * 64 + clip;
                 xa = x2[0];
-                xb = x2[1];
-                c_old = a.c2[((long)rb * H2 + unit) * 32 + clip];
+                xb = x2[32];
+                c_old = a.c2[((cslot_prev(a, t) * a.RB + rb) * H2 + unit) * 32 + clip];
             }
             gemm16_rb(a0, A, hprev, nh, hprev, ks, part, s);
             __syncthreads();
@@ -374,9 +394,11 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
                     g[r] = part_sum(part, half * 4 + r, el) + xs;
                 }
                 float c = c_old;
-                const float h = lstm_cell(g[0], g[1], g[2], g[3], &c);
-                a.c2[((long)rb * H2 + unit) * 32 + clip] = c;
-                float *hout = (float *)(a.h2buf + ((long)(t & 1) * a.RB + rb) * (H2 * 8));
+                float4 gs;
+                const float h = lstm_cell_g(g[0], g[1], g[2], g[3], &c, &gs);
+                a.c2[((cslot_out(a, t) * a.RB + rb) * H2 + unit) * 32 + clip] = c;
+                if (a.train) a.g2save[(((long)t * a.RB + rb) * H2 + unit) * 32 + clip] = gs;
+                float *hout = (float *)(a.h2buf + (slot_out(a, t) * a.RB + rb) * (H2 * 8));
                 hout[((long)tile * 32 + clip) * 4 + quarter] = h;
             }
             if (rb + (int)gridDim.y < a.RB) __syncthreads();  // partials are rewritten next round
@@ -393,18 +415,20 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
         const int unit = tile * 4 + quarter;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
             const float4 *xsrc = a.xp + ((long)t * a.RB + rb) * (OPNET_KXQ * 32);
-            const float4 *hprev = a.h1buf + ((long)((t + 1) & 1) * a.RB + rb) * (H1 * 8);
+            const float4 *hprev = a.h1buf + (slot_prev(a, t) * a.RB + rb) * (H1 * 8);
             float c_old = 0.f;
-            if (tid < 128) c_old = a.c1[((long)rb * H1 + unit) * 32 + clip];
+            if (tid < 128) c_old = a.c1[((cslot_prev(a, t) * a.RB + rb) * H1 + unit) * 32 + clip];
             gemm16_rb(a0, A, xsrc, OPNET_KXQ / 4, hprev, ks, part, s);
             __syncthreads();
             TRACE_STAMP(4);
             if (tid < 128) {
                 float c = c_old;
-                const float h = lstm_cell(part_sum(part, half * 4 + 0, el), part_sum(part, half * 4 + 1, el),
-                                          part_sum(part, half * 4 + 2, el), part_sum(part, half * 4 + 3, el), &c);
-                a.c1[((long)rb * H1 + unit) * 32 + clip] = c;
-                float *hout = (float *)(a.h1buf + ((long)(t & 1) * a.RB + rb) * (H1 * 8));
+                float4 gs;
+                const float h = lstm_cell_g(part_sum(part, half * 4 + 0, el), part_sum(part, half * 4 + 1, el),
+                                            part_sum(part, half * 4 + 2, el), part_sum(part, half * 4 + 3, el), &c, &gs);
+                a.c1[((cslot_out(a, t) * a.RB + rb) * H1 + unit) * 32 + clip] = c;
+                if (a.train) a.g1save[(((long)t * a.RB + rb) * H1 + unit) * 32 + clip] = gs;
+                float *hout = (float *)(a.h1buf + (slot_out(a, t) * a.RB + rb) * (H1 * 8));
                 hout[((long)tile * 32 + clip) * 4 + quarter] = h;
             }
             if (rb + (int)gridDim.y < a.RB) __syncthreads();
@@ -418,7 +442,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
         load_a_chunk(a0, a.wselp, ks.q0, ks.q1);
         const int mc = tid >> 3, mf = tid & 7;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
-            const float4 *hcur = a.h1buf + ((long)(t & 1) * a.RB + rb) * (H1 * 8);
+            const float4 *hcur = a.h1buf + (slot_out(a, t) * a.RB + rb) * (H1 * 8);
             // this frame's boxes, for the mix below: feature f of slot o of clip c sits at k = 6*o + f
             // of the packed LSTM1 input.  Issued before the MFMA phase.
             float bxv[OPNET_SLOTS_];
@@ -462,6 +486,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
                 const float inv = 1.0f / sum;
                 float4 pv = make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv);
                 ((float4 *)lg)[clip * 4 + quarter] = pv;
+                if (a.train) a.psave[(((long)t * a.RB + rb) * 4 + quarter) * 32 + clip] = pv;
             }
             __syncthreads();
             if (tid < 256) {
@@ -470,8 +495,8 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
                 const float *p = lg + mc * 16;
 #pragma unroll
                 for (int o = 0; o < OPNET_SLOTS_; ++o) acc = fmaf(bxv[o], p[o], acc);
-                float *x2 = (float *)(a.x2buf + ((long)(t & 1) * a.RB + rb) * 64);
-                x2[mc * 8 + mf] = mf < OPNET_FEATS_ ? acc : 0.f;
+                float *x2 = (float *)(a.x2buf + (slot_x2(a, t) * a.RB + rb) * 64);
+                x2[((mf >> 2) * 32 + mc) * 4 + (mf & 3)] = mf < OPNET_FEATS_ ? acc : 0.f;
             }
             if (rb + (int)gridDim.y < a.RB) __syncthreads();
         }
@@ -483,7 +508,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
         const KSlice ks = wave_slice(nh);
         load_a_chunk(a0, a.woutp, ks.q0, ks.q1);
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
-            const float4 *hcur = a.h2buf + ((long)(t & 1) * a.RB + rb) * (H2 * 8);
+            const float4 *hcur = a.h2buf + (slot_out(a, t) * a.RB + rb) * (H2 * 8);
             gemm16_rb(a0, a.woutp, hcur, nh, hcur, ks, part, s);
             __syncthreads();
             TRACE_STAMP(4);

@@ -89,6 +89,56 @@ def gen_opnet(lm, cfg, n_clips, t_frames, tag, keep_intermediates):
     return y.numpy(), labels
 
 
+def sample_indices(name, n, k=4096):
+    """deterministic sample of flat indices of a tensor (same helper used by the tests)"""
+    if n <= k:
+        return np.arange(n)
+    u = synth.counter_uniform(synth.name_seed(name, 99), k)
+    return np.unique((u * n).astype(np.int64))
+
+
+def gen_train(lm, cfg, n_clips, t_frames, tag, full, adam_steps):
+    """One training step (and a few Adam steps) of the reference model under torch autograd:
+    training_main.py:150-152 (Adam lr 1e-3, L1Loss(reduction='none')), :183-217."""
+    params = synth.opnet_synth_params(cfg)
+    model = lm.OPNet(cfg)
+    _load_params(model, params)
+    model.train(True)
+    boxes, labels = synth.make_batch(0, n_clips, t_frames)
+    xb, lb = torch.from_numpy(boxes), torch.from_numpy(labels)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    loss_fn = torch.nn.L1Loss(reduction="none")
+    out = {"cfg": np.array(json.dumps(cfg)), "n_clips": n_clips, "t_frames": t_frames}
+    losses = []
+    for step in range(adam_steps):
+        opt.zero_grad()
+        y, _ = model(xb)
+        loss = torch.mean(loss_fn(y, lb))
+        loss.backward()
+        losses.append(float(loss.item()))
+        if step == 0:
+            for k, v in model.named_parameters():
+                g = v.grad.detach().numpy()
+                out["gnorm/" + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                if full:
+                    out["grad/" + k] = g.copy()
+                else:
+                    idx = sample_indices(k, g.size)
+                    out["gidx/" + k] = idx
+                    out["gval/" + k] = g.reshape(-1)[idx].copy()
+        opt.step()
+    out["losses"] = np.array(losses)
+    for k, v in model.state_dict().items():
+        w = v.detach().numpy()
+        if full:
+            out["w_after/" + k] = w.copy()
+        else:
+            idx = sample_indices(k, w.size)
+            out["w_after_val/" + k] = w.reshape(-1)[idx].copy()
+    np.savez_compressed(os.path.join(OUT, f"opnet_train_{tag}.npz"), **out)
+    print(f"opnet_train_{tag}: losses {losses}")
+
+
 def gen_metric(tu, y, labels):
     """ResultsAnalyzer goldens on integer boxes (tracking_utils.py:137-159, 251-256, 278-288)."""
     frame_shapes = np.array([320, 240, 320, 240])
@@ -127,6 +177,8 @@ def main():
         real = json.load(f)
     y, labels = gen_opnet(lm, real, n_clips=4, t_frames=300, tag="real", keep_intermediates=False)
     gen_metric(tu, y, labels)
+    gen_train(lm, tiny, n_clips=3, t_frames=12, tag="tiny", full=True, adam_steps=3)
+    gen_train(lm, real, n_clips=4, t_frames=300, tag="real", full=False, adam_steps=2)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,73 @@
+"""Build-authored torch (CPU, autograd) restatement of the OPNet training step.
+
+TEST INFRASTRUCTURE ONLY.  Used where the checker needs gradients: forward exactly as
+oracle/opnet_oracle.py (reference baselines/learned_models.py:35-52) but written with differentiable
+torch ops as an explicit time loop; the loss and optimiser restate reference
+baselines/training_main.py:150-152,192-217: nn.L1Loss(reduction="none") -> mean, torch.optim.Adam
+(lr 1e-3, betas (0.9, 0.999), eps 1e-8, no weight decay).  Pinned against gradients / Adam steps
+produced by the reference's own model under torch autograd (tests/golden/opnet_train_*.npz).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+
+
+def lstm_seq(x: torch.Tensor, w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
+    """bias-free single-layer LSTM, gates i,f,g,o, zero initial state; x [B,T,I] -> [B,T,H]"""
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    h = x.new_zeros(B, H)
+    c = x.new_zeros(B, H)
+    gx = x @ w_ih.t()
+    outs = []
+    for t in range(T):
+        g = gx[:, t] + h @ w_hh.t()
+        i, f, gg, o = g.split(H, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        outs.append(h)
+    return torch.stack(outs, dim=1)
+
+
+def opnet_forward(boxes: torch.Tensor, p: Dict[str, torch.Tensor]):
+    B, T = boxes.shape[:2]
+    h1 = lstm_seq(boxes.reshape(B, T, -1), p["object_to_track_LSTM.weight_ih_l0"], p["object_to_track_LSTM.weight_hh_l0"])
+    logits = h1 @ p["object_to_track_prediction.weight"].t()
+    probs = torch.softmax(logits, dim=-1)
+    fb = (boxes * probs.unsqueeze(-1)).sum(dim=2)          # einsum "bfot,bfo->bft"
+    h2 = lstm_seq(fb, p["video_LSTM.weight_ih_l0"], p["video_LSTM.weight_hh_l0"])
+    y = h2 @ p["prediction_layer.weight"].t()
+    return y, logits.permute(0, 2, 1).contiguous()
+
+
+def l1_mean(y: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """training_main.py:152,192,204 for the supervised models: mean(|y - label|)."""
+    return (y - labels).abs().mean()
+
+
+def loss_and_grads(boxes: np.ndarray, labels: np.ndarray, params: Dict[str, np.ndarray], dtype=torch.float32):
+    p = {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in params.items()}
+    y, _ = opnet_forward(torch.tensor(boxes, dtype=dtype), p)
+    loss = l1_mean(y, torch.tensor(labels, dtype=dtype))
+    loss.backward()
+    return float(loss.item()), {k: v.grad.numpy() for k, v in p.items()}, y.detach().numpy()
+
+
+def adam_step(params: Dict[str, np.ndarray], grads: Dict[str, np.ndarray], state: dict, lr=1e-3,
+              b1=0.9, b2=0.999, eps=1e-8) -> None:
+    """torch.optim.Adam.step() (single-tensor formulation), in place, fp32."""
+    state["step"] = state.get("step", 0) + 1
+    t = state["step"]
+    bc1 = 1.0 - b1 ** t
+    bc2 = 1.0 - b2 ** t
+    for k in params:
+        g = grads[k].astype(np.float32)
+        m = state.setdefault("m_" + k, np.zeros_like(g))
+        v = state.setdefault("v_" + k, np.zeros_like(g))
+        m *= np.float32(b1); m += np.float32(1.0 - b1) * g
+        v *= np.float32(b2); v += np.float32(1.0 - b2) * g * g
+        denom = np.sqrt(v) / np.float32(np.sqrt(bc2)) + np.float32(eps)
+        params[k] -= np.float32(lr / bc1) * (m / denom)
