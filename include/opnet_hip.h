@@ -70,6 +70,35 @@ int opnet_plan_forward(opnet_plan *plan, const float *boxes, const float *packed
                        float *logits, void *workspace, size_t workspace_bytes, void *stream);
 void opnet_plan_destroy(opnet_plan *plan);
 
+/* ---- training (replaces torch autograd through OPNet.forward, nn.L1Loss and torch.optim.Adam as used
+ *      at training_main.py:150-152,183-217) ---------------------------------------------------------
+ * opnet_train_forward_f32 is opnet_forward_f32 that additionally keeps every step's h, c, gates,
+ * slot probabilities and frames_boxes in `workspace` (5.7 MB/clip at T=300).
+ * opnet_train_backward_f32 consumes that history and dy = dLoss/dy_boxes [B,T,4] and writes the six
+ * weight gradients in the state_dict layouts (`boxes` never requires grad; the logits output is not
+ * differentiated - no reference loss uses it, training_main.py:186-210).  `packed` must come from
+ * opnet_train_pack_weights_f32 (inference tiles + transposed tiles for the backward recurrence).
+ * One workspace holds ONE forward's history: call backward before the next train forward. */
+size_t opnet_train_packed_weights_bytes(int H1, int H2);
+int opnet_train_pack_weights_f32(const float *w_ih1, const float *w_hh1, const float *w_sel,
+                                 const float *w_ih2, const float *w_hh2, const float *w_out,
+                                 float *packed, size_t packed_bytes, int H1, int H2, void *stream);
+size_t opnet_train_workspace_bytes(int B, int T, int H1, int H2);
+int opnet_train_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
+                            void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
+                            void *stream);
+int opnet_train_backward_f32(const float *dy, const float *packed, void *workspace, size_t workspace_bytes,
+                             float *g_ih1, float *g_hh1, float *g_sel, float *g_ih2, float *g_hh2,
+                             float *g_out, int B, int T, int H1, int H2, void *stream);
+/* loss = mean(|y - labels|) over n elements (nn.L1Loss(reduction="none") + torch.mean); dy (may be NULL)
+ * = sign(y - labels) / n.  scratch: >= 4096 bytes of device memory. Deterministic reduction. */
+int opnet_l1_loss_f32(const float *y, const float *labels, float *loss, float *dy, long n, void *scratch,
+                      size_t scratch_bytes, void *stream);
+/* One torch.optim.Adam step on one tensor (no weight decay / amsgrad); `step` counts from 1;
+ * the gradient is multiplied by grad_scale first (1/world for data-parallel sums). */
+int opnet_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,
+                        float beta1, float beta2, float eps, int step, float grad_scale, void *stream);
+
 /* ---- output post-processing + metric (replaces inference_main.py:219 and
  *      tracking_utils.py:137-159,251-256,278-288) ------------------------------------------------
  * y, labels [N, T, 4] fp32 normalised -> pred_px, gt_px [N, T, 4] int32 (float64 multiply by

@@ -39,6 +39,22 @@ def _declare(lib):
     lib.opnet_plan_forward.argtypes = [c_void_p, fp, fp, fp, fp, c_void_p, c_size_t, c_void_p]
     lib.opnet_plan_destroy.restype = None
     lib.opnet_plan_destroy.argtypes = [c_void_p]
+    lib.opnet_train_packed_weights_bytes.restype = c_size_t
+    lib.opnet_train_packed_weights_bytes.argtypes = [c_int, c_int]
+    lib.opnet_train_pack_weights_f32.restype = c_int
+    lib.opnet_train_pack_weights_f32.argtypes = [fp, fp, fp, fp, fp, fp, fp, c_size_t, c_int, c_int, c_void_p]
+    lib.opnet_train_workspace_bytes.restype = c_size_t
+    lib.opnet_train_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    lib.opnet_train_forward_f32.restype = c_int
+    lib.opnet_train_forward_f32.argtypes = [fp, fp, fp, fp, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]
+    lib.opnet_train_backward_f32.restype = c_int
+    lib.opnet_train_backward_f32.argtypes = [fp, fp, c_void_p, c_size_t, fp, fp, fp, fp, fp, fp,
+                                             c_int, c_int, c_int, c_int, c_void_p]
+    lib.opnet_l1_loss_f32.restype = c_int
+    lib.opnet_l1_loss_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_void_p, c_size_t, c_void_p]
+    lib.opnet_adam_step_f32.restype = c_int
+    lib.opnet_adam_step_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_float, c_float, c_float, c_float,
+                                        c_int, c_float, c_void_p]
     lib.opnet_postprocess_iou.restype = c_int
     lib.opnet_postprocess_iou.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_void_p]
 
@@ -47,6 +63,8 @@ EXPORTS = [
     "opnet_hip_abi_version", "opnet_last_error", "opnet_packed_weights_bytes", "opnet_pack_weights_f32",
     "opnet_workspace_bytes", "opnet_forward_f32", "opnet_plan_create", "opnet_plan_forward",
     "opnet_plan_destroy", "opnet_postprocess_iou",
+    "opnet_train_packed_weights_bytes", "opnet_train_pack_weights_f32", "opnet_train_workspace_bytes",
+    "opnet_train_forward_f32", "opnet_train_backward_f32", "opnet_l1_loss_f32", "opnet_adam_step_f32",
 ]
 
 

@@ -1,9 +1,11 @@
 // opnet_abi.hip - host side of libopnet_hip.so: the C ABI declared in include/opnet_hip.h.
 // Plain pointers and sizes in, HIP launches on the caller's stream out; no torch types.
 #include "opnet_kernels.hip"
+#include "opnet_train_kernels.hip"
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <math.h>
 #include <string.h>
 
 #include <new>
@@ -148,6 +150,8 @@ static int make_args(StepArgs *a, OpnetIO *io, const float *boxes, const float *
     char *w = (char *)ws;
     memset(a, 0, sizeof(*a));
     a->B = B; a->T = T; a->RB = (B + 31) / 32; a->H1 = H1; a->H2 = H2;
+    a->train = 0;
+    a->g1save = nullptr; a->g2save = nullptr; a->psave = nullptr;
     a->xp = (const float4 *)(w + W.xp);
     a->w1p = (const float4 *)(packed + P.w1p);
     a->w2p = (const float4 *)(packed + P.w2p);
@@ -302,6 +306,253 @@ extern "C" int opnet_plan_forward(opnet_plan *p, const float *boxes, const float
     opnet_set_io<<<1, 1, 0, st>>>((OpnetIO *)((char *)workspace + W.io), io);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipGraphLaunch(p->exec, st));
+    return OPNET_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// training: forward with saved history, backward, loss, optimiser
+// ------------------------------------------------------------------------------------------------
+struct TrainPackedLayout {  // offsets in floats; the inference layout comes first
+    size_t fwd_total, w2bt, w1bt, wih2t, wsel, wout, total;
+};
+
+static TrainPackedLayout train_packed_layout(int H1, int H2)
+{
+    TrainPackedLayout L;
+    size_t o = packed_layout(H1, H2).total;
+    L.fwd_total = o;
+    o = align_up(o, 4);
+    L.w2bt = o;  o += (size_t)(H2 / 16) * (H2 / 4) * 256;
+    L.w1bt = o;  o += (size_t)(H1 / 16) * (H1 / 4) * 256;
+    L.wih2t = o; o += (size_t)(H2 / 4) * 256;
+    L.wsel = o;  o += align_up((size_t)OPNET_SLOTS * H1, 4);
+    L.wout = o;  o += align_up((size_t)4 * H2, 4);
+    L.total = o;
+    return L;
+}
+
+struct TrainWorkspaceLayout {  // offsets in bytes
+    size_t io, xp, state, h1all, c1all, h2all, c2all, state_end, x2all, g1, g2, psave, ystage, lgstage,
+        dyp, dlall, dhpart2, dhpart1, dx2part, dcz, dc2, dc1, dcz_end, l1part, total;
+};
+
+static TrainWorkspaceLayout train_workspace_layout(int B, int T, int H1, int H2)
+{
+    const size_t RB = (B + 31) / 32, TT = T;
+    TrainWorkspaceLayout L;
+    size_t o = 0;
+    L.io = o;      o += align_up(sizeof(OpnetIO), 256);
+    L.xp = o;      o += TT * RB * OPNET_KXQ * 32 * 16;
+    L.state = o;   // zeroed at the start of every forward (slot 0 = initial state; the rest is overwritten)
+    L.h1all = o;   o += (TT + 1) * RB * (size_t)H1 * 32 * 4;
+    L.c1all = o;   o += (TT + 1) * RB * (size_t)H1 * 32 * 4;
+    L.h2all = o;   o += (TT + 1) * RB * (size_t)H2 * 32 * 4;
+    L.c2all = o;   o += (TT + 1) * RB * (size_t)H2 * 32 * 4;
+    L.state_end = o;
+    L.x2all = o;   o += TT * RB * 64 * 16;
+    L.g1 = o;      o += TT * RB * (size_t)H1 * 32 * 16;
+    L.g2 = o;      o += TT * RB * (size_t)H2 * 32 * 16;
+    L.psave = o;   o += TT * RB * 128 * 16;
+    L.ystage = o;  o += RB * 32 * TT * 16;
+    L.lgstage = o; o += RB * 32 * TT * OPNET_SLOTS * 4;
+    L.dyp = o;     o += TT * RB * 32 * 16;
+    L.dlall = o;   o += TT * RB * 128 * 16;
+    L.dhpart2 = o; o += 4 * RB * (size_t)H2 * 32 * 4;
+    L.dhpart1 = o; o += 4 * RB * (size_t)H1 * 32 * 4;
+    L.dx2part = o; o += 4 * RB * 16 * 32 * 4;
+    L.dcz = o;
+    L.dc2 = o;     o += RB * (size_t)H2 * 32 * 4;
+    L.dc1 = o;     o += RB * (size_t)H1 * 32 * 4;
+    L.dcz_end = o;
+    L.l1part = o;  o += 1024 * 4;
+    L.total = align_up(o, 256);
+    return L;
+}
+
+extern "C" size_t opnet_train_packed_weights_bytes(int H1, int H2)
+{
+    if (check_dims(1, 1, H1, H2)) return 0;
+    return train_packed_layout(H1, H2).total * sizeof(float);
+}
+
+extern "C" size_t opnet_train_workspace_bytes(int B, int T, int H1, int H2)
+{
+    if (check_dims(B, T, H1, H2)) return 0;
+    return train_workspace_layout(B, T, H1, H2).total;
+}
+
+extern "C" int opnet_train_pack_weights_f32(const float *w_ih1, const float *w_hh1, const float *w_sel,
+                                            const float *w_ih2, const float *w_hh2, const float *w_out,
+                                            float *packed, size_t packed_bytes, int H1, int H2, void *stream)
+{
+    if (int rc = check_dims(1, 1, H1, H2)) return rc;
+    const TrainPackedLayout L = train_packed_layout(H1, H2);
+    if (packed_bytes < L.total * sizeof(float))
+        return fail(OPNET_EWORKSPACE, "packed buffer %zu B < %zu B", packed_bytes, L.total * sizeof(float));
+    if (int rc = opnet_pack_weights_f32(w_ih1, w_hh1, w_sel, w_ih2, w_hh2, w_out, packed,
+                                        L.fwd_total * sizeof(float), H1, H2, stream))
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    auto blocks = [](size_t n) { return (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256); };
+    opnet_pack_tiles_t<<<blocks((size_t)(H2 / 16) * (H2 / 4) * 256), 256, 0, st>>>(packed + L.w2bt, w_hh2, H2, 0, 0, H2 / 16);
+    opnet_pack_tiles_t<<<blocks((size_t)(H1 / 16) * (H1 / 4) * 256), 256, 0, st>>>(packed + L.w1bt, w_hh1, H1, 0, 0, H1 / 16);
+    opnet_pack_tiles_t<<<blocks((size_t)(H2 / 4) * 256), 256, 0, st>>>(packed + L.wih2t, w_ih2, H2, OPNET_FEATS, 1, 1);
+    opnet_copy_f32<<<blocks((size_t)OPNET_SLOTS * H1), 256, 0, st>>>(packed + L.wsel, w_sel, (long)OPNET_SLOTS * H1);
+    opnet_copy_f32<<<blocks((size_t)4 * H2), 256, 0, st>>>(packed + L.wout, w_out, (long)4 * H2);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+static int make_train_args(StepArgs *a, OpnetIO *io, BwdArgs *bw, const float *boxes, const float *packed,
+                           float *y, float *logits, void *ws, size_t ws_bytes, int B, int T, int H1, int H2)
+{
+    if (int rc = check_dims(B, T, H1, H2)) return rc;
+    if (!packed || !ws) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(packed) || !aligned16(ws)) return fail(OPNET_EINVAL, "packed/workspace must be 16-byte aligned");
+    const TrainWorkspaceLayout W = train_workspace_layout(B, T, H1, H2);
+    if (ws_bytes < W.total) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", ws_bytes, W.total);
+    const PackedLayout P = packed_layout(H1, H2);
+    const TrainPackedLayout TP = train_packed_layout(H1, H2);
+    char *w = (char *)ws;
+    const int RB = (B + 31) / 32;
+    memset(a, 0, sizeof(*a));
+    a->B = B; a->T = T; a->RB = RB; a->H1 = H1; a->H2 = H2; a->train = 1;
+    a->xp = (const float4 *)(w + W.xp);
+    a->w1p = (const float4 *)(packed + P.w1p);
+    a->w2p = (const float4 *)(packed + P.w2p);
+    a->wih2p = (const float4 *)(packed + P.wih2p);
+    a->wselp = (const float4 *)(packed + P.wselp);
+    a->woutp = (const float4 *)(packed + P.woutp);
+    a->h1buf = (float4 *)(w + W.h1all);
+    a->c1 = (float *)(w + W.c1all);
+    a->h2buf = (float4 *)(w + W.h2all);
+    a->c2 = (float *)(w + W.c2all);
+    a->x2buf = (float4 *)(w + W.x2all);
+    a->g1save = (float4 *)(w + W.g1);
+    a->g2save = (float4 *)(w + W.g2);
+    a->psave = (float4 *)(w + W.psave);
+    a->ystage = (float4 *)(w + W.ystage);
+    a->lgstage = (float *)(w + W.lgstage);
+    memset(io, 0, sizeof(*io));
+    io->B = B; io->T = T; io->RB = RB;
+    io->boxes = boxes; io->y = y; io->logits = logits;
+    io->xp = (float4 *)(w + W.xp);
+    io->ystage = a->ystage;
+    io->lgstage = a->lgstage;
+    io->state = (float4 *)(w + W.state);
+    io->state_f4 = (long)((W.state_end - W.state) / 16);
+    memset(bw, 0, sizeof(*bw));
+    bw->B = B; bw->T = T; bw->RB = RB; bw->H1 = H1; bw->H2 = H2;
+    bw->xp = a->xp; bw->h1all = a->h1buf; bw->c1all = a->c1; bw->h2all = a->h2buf; bw->c2all = a->c2;
+    bw->x2all = a->x2buf; bw->psave = a->psave; bw->g1 = a->g1save; bw->g2 = a->g2save;
+    bw->dyp = (const float4 *)(w + W.dyp);
+    bw->dlall = (float4 *)(w + W.dlall);
+    bw->dhpart2 = (float *)(w + W.dhpart2);
+    bw->dhpart1 = (float *)(w + W.dhpart1);
+    bw->dx2part = (float *)(w + W.dx2part);
+    bw->dc2 = (float *)(w + W.dc2);
+    bw->dc1 = (float *)(w + W.dc1);
+    bw->w2bt = (const float4 *)(packed + TP.w2bt);
+    bw->w1bt = (const float4 *)(packed + TP.w1bt);
+    bw->wih2t = (const float4 *)(packed + TP.wih2t);
+    bw->wsel = packed + TP.wsel;
+    bw->wout = packed + TP.wout;
+    return OPNET_OK;
+}
+
+extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
+                                       void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
+                                       void *stream)
+{
+    StepArgs a; OpnetIO io; BwdArgs bw;
+    if (!boxes || !y || !logits) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(y) || (((uintptr_t)boxes) & 7u)) return fail(OPNET_EINVAL, "y must be 16-byte and boxes 8-byte aligned");
+    if (int rc = make_train_args(&a, &io, &bw, boxes, packed, y, logits, workspace, workspace_bytes, B, T, H1, H2))
+        return rc;
+    const TrainWorkspaceLayout W = train_workspace_layout(B, T, H1, H2);
+    hipStream_t st = (hipStream_t)stream;
+    OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
+    opnet_set_io<<<1, 1, 0, st>>>(dio, io);
+    opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
+    const dim3 grid = step_grid(a.RB, H1, H2);
+    for (int s = 0; s < T + 3; ++s) opnet_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opnet_train_backward_f32(const float *dy, const float *packed, void *workspace,
+                                        size_t workspace_bytes, float *g_ih1, float *g_hh1, float *g_sel,
+                                        float *g_ih2, float *g_hh2, float *g_out, int B, int T, int H1, int H2,
+                                        void *stream)
+{
+    StepArgs a; OpnetIO io; BwdArgs bw;
+    if (!dy || !g_ih1 || !g_hh1 || !g_sel || !g_ih2 || !g_hh2 || !g_out) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(dy)) return fail(OPNET_EINVAL, "dy must be 16-byte aligned");
+    if (int rc = make_train_args(&a, &io, &bw, nullptr, packed, nullptr, nullptr, workspace, workspace_bytes, B, T, H1, H2))
+        return rc;
+    const TrainWorkspaceLayout W = train_workspace_layout(B, T, H1, H2);
+    hipStream_t st = (hipStream_t)stream;
+    const int RB = a.RB;
+    char *w = (char *)workspace;
+    opnet_pack_dy<<<256, 256, 0, st>>>((const float4 *)dy, (float4 *)(w + W.dyp), (float *)(w + W.dcz),
+                                        (long)((W.dcz_end - W.dcz) / 4), B, T, RB);
+    const dim3 gcell(H2 / 8 + H1 / 8, RB, 1);
+    const dim3 ggemm(4 * (H2 / 16) + 4 * (H1 / 16) + 4, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
+    for (int n = 0; n <= T; ++n) {
+        opnet_bwd_cell<<<gcell, 256, 0, st>>>(bw, n);
+        if (n < T) opnet_bwd_gemm<<<ggemm, OPNET_THREADS, 0, st>>>(bw, n);
+    }
+    // weight gradients over the saved histories
+    auto wgrad = [&](const float4 *P, long ps, int MQ, const float4 *Q, long qs, int NQ, float *out, int ld,
+                     int mvalid, int nvalid, int rowmode, int H) {
+        WgradArgs g;
+        g.P = P; g.p_stride = ps; g.MQ = MQ; g.Q = Q; g.q_stride = qs; g.NQ = NQ;
+        g.out = out; g.ld = ld; g.mvalid = mvalid; g.nvalid = nvalid; g.rowmode = rowmode; g.H = H;
+        g.T = T; g.RB = RB;
+        opnet_wgrad<<<dim3((MQ + 15) / 16, (NQ + 15) / 16, 1), 256, 0, st>>>(g);
+    };
+    const long h1s = (long)(H1 / 4) * 32, h2s = (long)(H2 / 4) * 32;
+    // video_LSTM.weight_hh_l0 [4H2][H2]: da2_t x h2_{t-1} (slot t) ; weight_ih_l0 [4H2][6]: da2_t x frames_boxes_t
+    wgrad(bw.g2, (long)H2 * 32, H2, bw.h2all, h2s, H2 / 4, g_hh2, H2, 4 * H2, H2, 1, H2);
+    wgrad(bw.g2, (long)H2 * 32, H2, bw.x2all, 64, 2, g_ih2, OPNET_FEATS, 4 * H2, OPNET_FEATS, 1, H2);
+    // object_to_track_LSTM.weight_hh_l0 [4H1][H1], weight_ih_l0 [4H1][90]
+    wgrad(bw.g1, (long)H1 * 32, H1, bw.h1all, h1s, H1 / 4, g_hh1, H1, 4 * H1, H1, 1, H1);
+    wgrad(bw.g1, (long)H1 * 32, H1, bw.xp, OPNET_KXQ * 32, OPNET_KXQ, g_ih1, OPNET_KX, 4 * H1, OPNET_KX, 1, H1);
+    // object_to_track_prediction.weight [15][H1]: dl_t x h1_t (slot t+1)
+    wgrad(bw.dlall, 128, 4, bw.h1all + (long)RB * h1s, h1s, H1 / 4, g_sel, H1, OPNET_SLOTS, H1, 0, 0);
+    // prediction_layer.weight [4][H2]: dy_t x h2_t (slot t+1)
+    wgrad(bw.dyp, 32, 1, bw.h2all + (long)RB * h2s, h2s, H2 / 4, g_out, H2, 4, H2, 0, 0);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opnet_l1_loss_f32(const float *y, const float *labels, float *loss, float *dy, long n,
+                                 void *scratch, size_t scratch_bytes, void *stream)
+{
+    if (!y || !labels || !loss || !scratch) return fail(OPNET_EINVAL, "null pointer");
+    if (n <= 0) return fail(OPNET_ESHAPE, "n must be positive");
+    int nb = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    if (scratch_bytes < (size_t)nb * 4) return fail(OPNET_EWORKSPACE, "scratch %zu B < %d B", scratch_bytes, nb * 4);
+    hipStream_t st = (hipStream_t)stream;
+    opnet_l1_partial<<<nb, 256, 0, st>>>(y, labels, dy, (float *)scratch, n);
+    opnet_l1_final<<<1, 64, 0, st>>>((const float *)scratch, nb, loss, n);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opnet_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n,
+                                   float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                                   void *stream)
+{
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(OPNET_EINVAL, "null pointer");
+    if (n <= 0 || step <= 0) return fail(OPNET_ESHAPE, "n and step must be positive");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const unsigned nb = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    opnet_adam<<<nb, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps,
+                                                    (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+    HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }
 

@@ -1,0 +1,402 @@
+// opnet_train_kernels.hip - backward pass (BPTT), weight-gradient GEMMs, L1 loss and Adam for OPNet.
+//
+// Replaces what torch autograd + torch.optim.Adam do for the reference's training step
+// (reference baselines/training_main.py:150-152 Adam / L1Loss, :183-217 step; model
+// baselines/learned_models.py:35-52).  Restated for checking in oracle/torch_port.py.
+//
+// Backward recurrence.  With a_t the pre-activation gates and (i,f,g,o) their activations
+//     dh_t   = [upstream]_t + W_hh^T da_{t+1}                 (all-to-all over 4H gate columns)
+//     dc_t   = dc_carry + dh_t * o * (1 - tanh(c_t)^2) ;  dc_carry' = dc_t * f
+//     da_t   = ( dc*g*i(1-i), dc*c_{t-1}*f(1-f), dc*i*(1-g^2), dh*tanh(c_t)*o(1-o) )
+// The reduction dimension of the recurrent product is 4H (4x the forward's), so a workgroup that
+// owned complete dh rows would have to read all of da (256 KB per workgroup at B=32); instead the
+// product is split-K over 4 workgroups per 16-unit tile (same per-workgroup traffic as a forward
+// tile) and the 4 partials are summed, in fixed order, by the cell kernel of the next launch.
+// Per reverse step there are therefore two launches (launch index n = 0, 1, ...):
+//     opnet_bwd_cell(n):  LSTM2 cell backward at t = T-1-n   |  head + LSTM1 cell backward at t = T-n
+//     opnet_bwd_gemm(n):  W_hh2^T da2_t, W_ih2^T da2_t (t = T-1-n)  |  W_hh1^T da1_t (t = T-n)
+// da_t overwrites the saved gates in place ([T][RB][H][32] float4 = (unit, clip) -> 4 gate values,
+// which is exactly the kq-major activation layout with k = 4*unit + gate), so that afterwards every
+// weight gradient is one GEMM  dW[m][n] = sum_{t,clip} P_t[clip][m] * Q_t[clip][n]  over the saved
+// histories (opnet_wgrad).
+#include "opnet_ctx.h"
+
+struct BwdArgs {
+    int B, T, RB, H1, H2;
+    // saved by the training forward
+    const float4 *xp;       // [T][RB][24][32]
+    const float4 *h1all;    // [T+1][RB][H1/4][32]   slot t+1 = h1_t, slot 0 = 0
+    const float *c1all;     // [T+1][RB][H1][32]
+    const float4 *h2all;    // [T+1][RB][H2/4][32]
+    const float *c2all;     // [T+1][RB][H2][32]
+    const float4 *x2all;    // [T][RB][2][32]
+    const float4 *psave;    // [T][RB][4][32]
+    float4 *g1;             // [T][RB][H1][32]  gates in, da1 out
+    float4 *g2;             // [T][RB][H2][32]  gates in, da2 out
+    // backward state
+    const float4 *dyp;      // [T][RB][32]   upstream gradient of y_boxes, packed
+    float4 *dlall;          // [T][RB][4][32] gradient of the selection logits (15 -> 16)
+    float *dhpart2;         // [4][RB][H2][32] split-K partials of W_hh2^T da2
+    float *dhpart1;         // [4][RB][H1][32]
+    float *dx2part;         // [4][RB][16][32]  split-K partials of W_ih2^T da2 (6 rows valid)
+    float *dc2;             // [RB][H2][32] cell-gradient carry
+    float *dc1;             // [RB][H1][32]
+    // backward weights
+    const float4 *w2bt;     // [H2/16][4*H2/16][64]  W_hh2^T tiles, k = 4*unit' + gate
+    const float4 *w1bt;     // [H1/16][4*H1/16][64]
+    const float4 *wih2t;    // [4*H2/16][64]         W_ih2^T (6 -> 16 rows)
+    const float *wsel;      // [15][H1] raw
+    const float *wout;      // [4][H2] raw
+};
+
+// ------------------------------------------------------------------------------------------------
+// transposed weight tiles for the backward recurrence
+// ------------------------------------------------------------------------------------------------
+// out[tile][q][lane][e], row i = lane&15, k = 16q + 4(lane>>4) + e  with  k = 4*unit' + gate.
+// mode 0: A[row u = tile*16+i][k] = W_hh[gate*H + unit'][u]          (W_hh is [4H][H])
+// mode 1: A[row f = i][k]         = W_ih[gate*H + unit'][f], f < nf   (W_ih is [4H][nf]); one tile
+__global__ void opnet_pack_tiles_t(float *__restrict__ out, const float *__restrict__ w, int H, int nf,
+                                   int mode, int ntiles)
+{
+    const int nhex = (4 * H) / 16;
+    const long total = (long)ntiles * nhex * 256;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int e = idx & 3;
+        const int lane = (idx >> 2) & 63;
+        const long tq = idx >> 8;
+        const int q = tq % nhex;
+        const int tile = tq / nhex;
+        const int i = lane & 15;
+        const int k = 16 * q + 4 * (lane >> 4) + e;
+        const int unit = k >> 2, gate = k & 3;
+        const long wrow = (long)gate * H + unit;
+        float v;
+        if (mode == 0)
+            v = w[wrow * H + tile * 16 + i];
+        else
+            v = i < nf ? w[wrow * nf + i] : 0.f;
+        out[idx] = v;
+    }
+}
+
+__global__ void opnet_copy_f32(float *__restrict__ dst, const float *__restrict__ src, long n)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+// dy [B][T][4] -> dyp [T][RB][32] float4 (zero for clips beyond B); also zeroes the cell-gradient carries
+__global__ void __launch_bounds__(256) opnet_pack_dy(const float4 *__restrict__ dy, float4 *__restrict__ dyp,
+                                                     float *__restrict__ dc_zero, long n_dc, int B, int T, int RB)
+{
+    const long n = (long)T * RB * 32;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += stride) {
+        const int clip = idx & 31;
+        const long trb = idx >> 5;
+        const int rb = trb % RB;
+        const int t = trb / RB;
+        const int b = rb * 32 + clip;
+        dyp[idx] = b < B ? dy[(long)b * T + t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n_dc; idx += stride) dc_zero[idx] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward step, launch A: split-K recurrent products
+// ------------------------------------------------------------------------------------------------
+// grid.x = 4*(H2/16) LSTM2 tiles x K-quarters + 4*(H1/16) LSTM1 + 4 (W_ih2^T) ; grid.y <= RB
+__global__ void __launch_bounds__(OPNET_THREADS) opnet_bwd_gemm(const BwdArgs a, const int n)
+{
+    __shared__ __attribute__((aligned(16))) float part[OPNET_NW * 8 * 64];
+    const int s = n;  // (trace hook name used by the shared core)
+    const int T = a.T, H1 = a.H1, H2 = a.H2;
+    const int n2 = 4 * (H2 >> 4), n1 = 4 * (H1 >> 4);
+    const int bx = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int el = tid & 63, half = tid >> 6;
+    const int clip = half * 16 + (el & 15), quarter = el >> 4;
+    float4 a0[OPNET_CH];
+
+    int t, H, tile, ks, nrows_out;
+    const float4 *A;
+    const float4 *da;
+    float *dst;
+    if (bx < n2) {
+        t = T - 1 - n; H = H2; tile = bx >> 2; ks = bx & 3;
+        A = a.w2bt + ((long)tile * (H2 >> 2) + ks * (H2 >> 4)) * 64;   // tile has 4H/16 = H/4 hexadecets
+        da = a.g2; dst = a.dhpart2; nrows_out = H2;
+    } else if (bx < n2 + n1) {
+        t = T - n; H = H1; tile = (bx - n2) >> 2; ks = (bx - n2) & 3;
+        A = a.w1bt + ((long)tile * (H1 >> 2) + ks * (H1 >> 4)) * 64;
+        da = a.g1; dst = a.dhpart1; nrows_out = H1;
+    } else {
+        t = T - 1 - n; H = H2; tile = 0; ks = bx - n2 - n1;
+        A = a.wih2t + (long)ks * (H2 >> 4) * 64;
+        da = a.g2; dst = a.dx2part; nrows_out = 16;
+    }
+    if (t < 0 || t >= T) return;
+    const int nh = H >> 4;  // hexadecets in this K quarter ( (4H/16) / 4 )
+    const KSlice ksl = wave_slice(nh);
+    load_a_chunk(a0, A, ksl.q0, ksl.q1);
+    for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+        // da_t as a kq-major activation segment: kq = unit, this quarter starts at unit ks*H/4
+        const float4 *seg = da + (((long)t * a.RB + rb) * H + (long)ks * (H >> 2)) * 32;
+        gemm16_rb(a0, A, seg, nh, seg, ksl, part, s);
+        __syncthreads();
+        if (tid < 128) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = tile * 16 + quarter * 4 + r;
+                dst[(((long)ks * a.RB + rb) * nrows_out + row) * 32 + clip] = part_sum(part, half * 4 + r, el);
+            }
+        }
+        if (rb + (int)gridDim.y < a.RB) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward step, launch B: cell backward (+ head backward for LSTM1)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 cell_backward(float dh, float dc_carry, float4 g, float c_t, float c_prev,
+                                                float *dc_out)
+{
+    const float i = g.x, f = g.y, gg = g.z, o = g.w;
+    const float tc = fast_tanh(c_t);
+    const float dc = dc_carry + dh * o * (1.0f - tc * tc);
+    *dc_out = dc * f;
+    float4 da;
+    da.x = dc * gg * i * (1.0f - i);
+    da.y = dc * c_prev * f * (1.0f - f);
+    da.z = dc * i * (1.0f - gg * gg);
+    da.w = dh * tc * o * (1.0f - o);
+    return da;
+}
+
+// grid.x = H2/8 (LSTM2, 8 units x 32 clips per workgroup) + H1/8 (LSTM1) ; grid.y = RB
+__global__ void __launch_bounds__(256) opnet_bwd_cell(const BwdArgs a, const int n)
+{
+    __shared__ float dl_s[32][17];
+    const int T = a.T, H1 = a.H1, H2 = a.H2;
+    const int nc2 = H2 >> 3;
+    const int bx = blockIdx.x, rb = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int clip = tid & 31;
+    if (bx < nc2) {
+        // ---------------- LSTM2 at t = T-1-n ----------------
+        const int t = T - 1 - n;
+        if (t < 0) return;
+        const int u = bx * 8 + (tid >> 5);
+        const long e = ((long)rb * H2 + u) * 32 + clip;
+        // upstream: prediction_layer (learned_models.py:47): dh += W_out^T dy_t
+        const float4 dy = a.dyp[((long)t * a.RB + rb) * 32 + clip];
+        float dh = a.wout[u] * dy.x;
+        dh = fmaf(a.wout[H2 + u], dy.y, dh);
+        dh = fmaf(a.wout[2 * H2 + u], dy.z, dh);
+        dh = fmaf(a.wout[3 * H2 + u], dy.w, dh);
+        float dcc = 0.f;
+        if (t < T - 1) {
+            const long ps = (long)a.RB * H2 * 32;
+            dh += ((a.dhpart2[e] + a.dhpart2[ps + e]) + a.dhpart2[2 * ps + e]) + a.dhpart2[3 * ps + e];
+            dcc = a.dc2[e];
+        }
+        const long ge = (((long)t * a.RB + rb) * H2 + u) * 32 + clip;
+        const float c_t = a.c2all[(((long)(t + 1)) * a.RB + rb) * H2 * 32 + (long)u * 32 + clip];
+        const float c_p = a.c2all[((long)t * a.RB + rb) * H2 * 32 + (long)u * 32 + clip];
+        float dco;
+        a.g2[ge] = cell_backward(dh, dcc, a.g2[ge], c_t, c_p, &dco);
+        a.dc2[e] = dco;
+    } else {
+        // ---------------- head backward + LSTM1 at t = T-n ----------------
+        const int t = T - n;
+        if (t < 0 || t >= T) return;
+        if (tid < 32) {
+            // d frames_boxes[f] = sum of the split-K partials of W_ih2^T da2_t   (LSTM2 input part)
+            float dx[OPNET_FEATS_];
+            const long ps = (long)a.RB * 16 * 32;
+#pragma unroll
+            for (int f = 0; f < OPNET_FEATS_; ++f) {
+                const long e = ((long)rb * 16 + f) * 32 + clip;
+                dx[f] = ((a.dx2part[e] + a.dx2part[ps + e]) + a.dx2part[2 * ps + e]) + a.dx2part[3 * ps + e];
+            }
+            // einsum backward: dp[o] = sum_f boxes[o][f] dx[f]; softmax backward: dl = p * (dp - <p, dp>)
+            const float *xs = (const float *)(a.xp + ((long)t * a.RB + rb) * (OPNET_KXQ * 32));
+            const float4 *pp = a.psave + ((long)t * a.RB + rb) * 128 + clip;
+            float p[16], dp[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = pp[q * 32];
+                p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+            }
+            float dot = 0.f;
+#pragma unroll
+            for (int o = 0; o < OPNET_SLOTS_; ++o) {
+                float acc = 0.f;
+#pragma unroll
+                for (int f = 0; f < OPNET_FEATS_; ++f) {
+                    const int k = o * OPNET_FEATS_ + f;
+                    acc = fmaf(xs[((k >> 2) * 32 + clip) * 4 + (k & 3)], dx[f], acc);
+                }
+                dp[o] = acc;
+                dot = fmaf(p[o], acc, dot);
+            }
+            float dl[16];
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                dl[o] = o < OPNET_SLOTS_ ? p[o] * (dp[o] - dot) : 0.f;
+                dl_s[clip][o] = dl[o];
+            }
+            if (bx == nc2) {
+                float4 *dst = a.dlall + ((long)t * a.RB + rb) * 128 + clip;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q * 32] = make_float4(dl[4 * q], dl[4 * q + 1], dl[4 * q + 2], dl[4 * q + 3]);
+            }
+        }
+        __syncthreads();
+        const int u = (bx - nc2) * 8 + (tid >> 5);
+        const long e = ((long)rb * H1 + u) * 32 + clip;
+        // upstream: object_to_track_prediction (learned_models.py:40): dh += W_sel^T dl_t
+        float dh = 0.f;
+#pragma unroll
+        for (int o = 0; o < OPNET_SLOTS_; ++o) dh = fmaf(a.wsel[o * H1 + u], dl_s[clip][o], dh);
+        float dcc = 0.f;
+        if (t < T - 1) {
+            const long ps = (long)a.RB * H1 * 32;
+            dh += ((a.dhpart1[e] + a.dhpart1[ps + e]) + a.dhpart1[2 * ps + e]) + a.dhpart1[3 * ps + e];
+            dcc = a.dc1[e];
+        }
+        const long ge = (((long)t * a.RB + rb) * H1 + u) * 32 + clip;
+        const float c_t = a.c1all[(((long)(t + 1)) * a.RB + rb) * H1 * 32 + (long)u * 32 + clip];
+        const float c_p = a.c1all[((long)t * a.RB + rb) * H1 * 32 + (long)u * 32 + clip];
+        float dco;
+        a.g1[ge] = cell_backward(dh, dcc, a.g1[ge], c_t, c_p, &dco);
+        a.dc1[e] = dco;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradients: dW[m][n] = sum_{t, rb, clip} P[t][rb][m/4][clip][m%4] * Q[t][rb][n/4][clip][n%4]
+// ------------------------------------------------------------------------------------------------
+// One workgroup = one 64x64 output tile; its 4 waves split the time range and are reduced through LDS
+// in fixed order.  v_mfma_f32_16x16x4_f32 contracts over 4 clips: lane (i = l&15, kc = l>>4) loads ONE
+// float4 of P (m-quad mq0+i, clip 4cg+kc) and one of Q, and their 4x4 element pairs feed 16
+// accumulators (accumulator (e, e') covers rows 4(mq0+i')+e, columns 4(nq0+j)+e').
+// rowmode 0: output row = m;  1: m = 4*unit + gate -> torch LSTM row gate*H + unit.
+struct WgradArgs {
+    const float4 *P; long p_stride; int MQ;   // stride per (t, rb) in float4, number of valid m-quads
+    const float4 *Q; long q_stride; int NQ;
+    float *out; int ld; int mvalid; int nvalid; int rowmode; int H;
+    int T, RB;
+};
+
+__global__ void __launch_bounds__(256) opnet_wgrad(const WgradArgs g)
+{
+    __shared__ float red[4][64][64];  // [wave][acc*4 + r][lane]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mq0 = blockIdx.x * 16, nq0 = blockIdx.y * 16;
+    const int i = lane & 15, kc = lane >> 4;
+    const bool pa = (mq0 + i) < g.MQ, pb = (nq0 + i) < g.NQ;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int t0 = (w * g.T) / 4, t1 = ((w + 1) * g.T) / 4;
+    for (int t = t0; t < t1; ++t) {
+        for (int rb = 0; rb < g.RB; ++rb) {
+            const float4 *Pp = g.P + ((long)t * g.RB + rb) * g.p_stride + (long)(mq0 + i) * 32 + kc;
+            const float4 *Qp = g.Q + ((long)t * g.RB + rb) * g.q_stride + (long)(nq0 + i) * 32 + kc;
+            float4 av[8], bv[8];
+#pragma unroll
+            for (int cg = 0; cg < 8; ++cg) {
+                av[cg] = pa ? Pp[cg * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[cg] = pb ? Qp[cg * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int cg = 0; cg < 8; ++cg) {
+                const float ae[4] = {av[cg].x, av[cg].y, av[cg].z, av[cg].w};
+                const float be[4] = {bv[cg].x, bv[cg].y, bv[cg].z, bv[cg].w};
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[x], be[y], acc[x][y], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w][(x * 4 + y) * 4 + r][lane] = acc[x][y][r];
+    __syncthreads();
+    // 64 x 64 outputs, 16 per thread: element id = (a = x*4+y, r, lane)
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int l = idx & 63, ar = idx >> 6;
+        const int r = ar & 3, y = (ar >> 2) & 3, x = ar >> 4;
+        const float v = ((red[0][ar][l] + red[1][ar][l]) + red[2][ar][l]) + red[3][ar][l];
+        // D layout of 16x16x4: lane l holds column j = l&15, rows 4*(l>>4) + r
+        const int m = 4 * (mq0 + 4 * (l >> 4) + r) + x;
+        const int nn = 4 * (nq0 + (l & 15)) + y;
+        if (m < g.mvalid && nn < g.nvalid) {
+            const int row = g.rowmode == 1 ? (m & 3) * g.H + (m >> 2) : m;
+            g.out[(long)row * g.ld + nn] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss and optimiser
+// ------------------------------------------------------------------------------------------------
+// mean(|y - label|) (nn.L1Loss(reduction="none") then torch.mean, training_main.py:152,192,204) and
+// its gradient sign(y - label) / n.  Two-stage deterministic reduction: per-block partials, then
+// block 0... a second tiny launch sums them in fixed order.
+__global__ void __launch_bounds__(256) opnet_l1_partial(const float *__restrict__ y, const float *__restrict__ lab,
+                                                        float *__restrict__ dy, float *__restrict__ partial, long n)
+{
+    __shared__ float red[256];
+    const float inv = 1.0f / (float)n;
+    float s = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = y[i] - lab[i];
+        s += fabsf(d);
+        if (dy) dy[i] = d > 0.f ? inv : (d < 0.f ? -inv : 0.f);   // torch: sign(0) = 0
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void opnet_l1_final(const float *__restrict__ partial, int nblocks, float *__restrict__ loss, long n)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nblocks; ++i) s += (double)partial[i];
+        *loss = (float)(s / (double)n);
+    }
+}
+
+// torch.optim.Adam.step (training_main.py:150,217): defaults betas (0.9, 0.999), eps 1e-8, no weight
+// decay, no amsgrad:  m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+//                     p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+__global__ void __launch_bounds__(256) opnet_adam(float *__restrict__ p, const float *__restrict__ gr,
+                                                  float *__restrict__ m, float *__restrict__ v, long n,
+                                                  float b1, float b2, float eps, float step_size,
+                                                  float inv_sqrt_bc2, float grad_scale)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float g = gr[i] * grad_scale;
+        const float mi = b1 * m[i] + (1.0f - b1) * g;
+        const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    }
+}

@@ -63,6 +63,67 @@ def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class _OPNetTrainFunction(torch.autograd.Function):
+    """Autograd bridge: forward = opnet_train_forward_f32 (keeps the history in the module's training
+    workspace), backward = opnet_train_backward_f32 (BPTT + weight-gradient GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, module, boxes, *weights):
+        lib = _lib.load()
+        B, T = int(boxes.shape[0]), int(boxes.shape[1])
+        dev = boxes.device
+        h1, h2 = module._h1, module._h2
+        with torch.cuda.device(dev):
+            stream = _stream_ptr(dev)
+            nbytes = lib.opnet_train_packed_weights_bytes(h1, h2)
+            if module._tpacked is None or module._tpacked.device != dev:
+                module._tpacked = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            rc = lib.opnet_train_pack_weights_f32(*(w.data_ptr() for w in weights), module._tpacked.data_ptr(),
+                                                  nbytes, h1, h2, stream)
+            _lib.check(rc, "opnet_train_pack_weights_f32")
+            key = (B, T, str(dev))
+            if module._tws_key != key:
+                wsb = lib.opnet_train_workspace_bytes(B, T, h1, h2)
+                if wsb == 0:
+                    _lib.check(-2, "opnet_train_workspace_bytes")
+                module._tws = None          # release the old history first
+                module._tws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                module._tws_key = key
+            y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+            logits = torch.empty((B, 15, T), dtype=torch.float32, device=dev)
+            rc = lib.opnet_train_forward_f32(boxes.data_ptr(), module._tpacked.data_ptr(), y.data_ptr(),
+                                             logits.data_ptr(), module._tws.data_ptr(), module._tws.numel(),
+                                             B, T, h1, h2, stream)
+            _lib.check(rc, "opnet_train_forward_f32")
+        module._train_gen += 1
+        ctx.module, ctx.gen, ctx.shape = module, module._train_gen, (B, T)
+        ctx.wshapes = [tuple(w.shape) for w in weights]
+        ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)
+        return y, logits
+
+    @staticmethod
+    def backward(ctx, grad_y, grad_logits):
+        module = ctx.module
+        if ctx.gen != module._train_gen:
+            raise RuntimeError("OPNet: backward() after another training forward - the saved history of this "
+                               "forward has been overwritten (one history per module)")
+        n_in = 2 + len(ctx.wshapes)
+        if grad_y is None:
+            return (None,) * n_in
+        lib = _lib.load()
+        B, T = ctx.shape
+        dev = grad_y.device
+        grad_y = grad_y.contiguous().float()
+        grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.wshapes]
+        with torch.cuda.device(dev):
+            rc = lib.opnet_train_backward_f32(grad_y.data_ptr(), module._tpacked.data_ptr(), module._tws.data_ptr(),
+                                              module._tws.numel(), *(g.data_ptr() for g in grads), B, T,
+                                              module._h1, module._h2, _stream_ptr(dev))
+        _lib.check(rc, "opnet_train_backward_f32")
+        return (None, None) + tuple(grads)
+
+
 class OPNet(AbstractCaterModel):
     """reference learned_models.py:18-52.  forward(boxes [B,T,15,6]) -> (y_boxes [B,T,4],
     object_to_track_prediction [B,15,T])."""
@@ -84,6 +145,10 @@ class OPNet(AbstractCaterModel):
         self._packed = None
         self._packed_key = None
         self._plans: Dict[Tuple[int, int, int], Tuple[int, torch.Tensor]] = {}
+        self._tpacked = None     # training: inference tiles + transposed tiles
+        self._tws = None         # training workspace (one forward's history)
+        self._tws_key = None
+        self._train_gen = 0
         self.use_graph = os.environ.get("OPNET_HIP_EAGER", "0") != "1"
 
     # -- weights ------------------------------------------------------------------------------
@@ -119,11 +184,14 @@ class OPNet(AbstractCaterModel):
                                "to a ROCm device; there is no CPU fallback")
         if boxes.dim() != 4 or boxes.shape[2] != 15 or boxes.shape[3] != 6:
             raise ValueError(f"boxes must be [B, T, 15, 6], got {tuple(boxes.shape)}")
-        if torch.is_grad_enabled() and any(w.requires_grad for w in self._weights()):
-            raise RuntimeError("OPNet.forward: autograd through the HIP path is not available yet; "
-                               "wrap inference in torch.no_grad()")
         lib = _lib.load()
         boxes = boxes.contiguous().float()
+        if torch.is_grad_enabled() and any(w.requires_grad for w in self._weights()):
+            ws = self._weights()
+            for w in ws:
+                if w.device != boxes.device or w.dtype != torch.float32 or not w.is_contiguous():
+                    raise RuntimeError("OPNet parameters must be contiguous fp32 on the input's device")
+            return _OPNetTrainFunction.apply(self, boxes, *ws)
         B, T = int(boxes.shape[0]), int(boxes.shape[1])
         dev = boxes.device
         with torch.cuda.device(dev):

@@ -1,0 +1,78 @@
+"""Loss and optimiser of the reference's training step on device.
+
+* ``l1_mean(y, labels)``  == ``torch.mean(nn.L1Loss(reduction="none")(y, labels))``
+  (reference baselines/training_main.py:152,192,204) - one fused forward+backward kernel pair.
+* ``FusedAdam``           == ``torch.optim.Adam(params, lr)`` with the reference's defaults
+  (training_main.py:150): betas (0.9, 0.999), eps 1e-8, no weight decay.  It is a
+  ``torch.optim.Optimizer`` so ``ReduceLROnPlateau`` (training_main.py:151,247) drives it unchanged.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+class _L1Mean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, labels):
+        if not y.is_cuda:
+            raise RuntimeError("l1_mean runs on the GPU only (no CPU fallback)")
+        lib = _lib.load()
+        y = y.contiguous().float()
+        labels = labels.to(y.device).contiguous().float()
+        n = y.numel()
+        loss = torch.empty((), dtype=torch.float32, device=y.device)
+        dy = torch.empty_like(y)
+        scratch = torch.empty(4096, dtype=torch.uint8, device=y.device)
+        with torch.cuda.device(y.device):
+            rc = lib.opnet_l1_loss_f32(y.data_ptr(), labels.data_ptr(), loss.data_ptr(), dy.data_ptr(), n,
+                                       scratch.data_ptr(), scratch.numel(),
+                                       torch.cuda.current_stream(y.device).cuda_stream)
+        _lib.check(rc, "opnet_l1_loss_f32")
+        ctx.save_for_backward(dy)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (dy,) = ctx.saved_tensors
+        return dy * grad_out, None
+
+
+def l1_mean(y: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    return _L1Mean.apply(y, labels)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, grad_scale=grad_scale))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("FusedAdam runs on the GPU only (no CPU fallback)")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                g = p.grad.contiguous()
+                with torch.cuda.device(p.device):
+                    rc = lib.opnet_adam_step_f32(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                                 st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]),
+                                                 float(b1), float(b2), float(group["eps"]), int(st["step"]),
+                                                 float(group["grad_scale"]),
+                                                 torch.cuda.current_stream(p.device).cuda_stream)
+                _lib.check(rc, "opnet_adam_step_f32")
+        return loss

@@ -37,3 +37,26 @@ def all_gather_predictions(local: torch.Tensor, n_total: int, group: Optional[di
     out = local.new_empty((world * per,) + tuple(local.shape[1:]))
     work = dist.all_gather_into_tensor(out, pad, group=group, async_op=async_op)
     return out[:n_total], work
+
+
+def all_reduce_gradients(params, n_local: int, n_global: int, group: Optional[dist.ProcessGroup] = None,
+                         async_op: bool = False):
+    """Data-parallel gradient exchange for the training step: ONE all-reduce (sum) over the flat fp32
+    gradient buffer (1 421 056 floats = 5.68 MB for OPNet).  Each rank's loss is a mean over its own
+    n_local clips, so its gradient is weighted by n_local / n_global before the sum - with equal shards
+    that is the usual 1/world, with an uneven last shard it still reproduces the single-process mean
+    exactly.  Returns (flat, work|None); call `unflatten_gradients` after work.wait()."""
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads]) * (float(n_local) / float(n_global))
+    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return flat, work
+
+
+def unflatten_gradients(params, flat: torch.Tensor) -> None:
+    o = 0
+    for p in params:
+        if p.grad is None:
+            continue
+        n = p.grad.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        o += n
