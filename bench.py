@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (BASELINE configs: 32)")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer = the BASELINE metric (default); train = fwd + L1 + bwd + Adam step (configs 2/5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
@@ -80,6 +82,46 @@ def cpu_baseline(boxes_np, params, seconds):
         "sample": f"{reps} x forward of {boxes_np.shape[0]} clips x {boxes_np.shape[1]} frames "
                   f"(oracle/opnet_oracle.c, gcc -O3 -march=native -fopenmp, {threads} threads, {t_total:.1f} s)",
     }, y
+
+
+def bench_train(args, model, boxes, labels, world, rank, dev, dist):
+    """Training throughput (not the BASELINE headline): one step = forward + L1 + backward + Adam on
+    `--batch` clips per GPU, gradients all-reduced over RCCL when N > 1."""
+    from objectpermanence_amd import FusedAdam
+    from objectpermanence_amd.training import train_step
+    model.train(True)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    comm = torch.cuda.Stream(device=dev)
+    B = int(boxes.shape[0])
+    for _ in range(args.warmup):
+        train_step("opnet", model, opt, boxes, labels, n_global=world * B, comm_stream=comm)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step("opnet", model, opt, boxes, labels, n_global=world * B, comm_stream=comm)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "CATER clips/sec OPNet training step (fwd + L1 + bwd + Adam)",
+            "value": round(world * B * args.steps / elapsed, 1), "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"opnet training, batch={B} clips/GPU x 300 frames x 15 slots, L1 loss, Adam lr 1e-3",
+                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "final_loss": float(loss.item())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -121,6 +163,9 @@ def main():
     side = torch.cuda.Stream(device=dev)
     gathered = torch.empty((world * B, T_FRAMES, 4), dtype=torch.int32, device=dev) if world > 1 else None
     pending = None
+
+    if args.mode == "train":
+        return bench_train(args, model, boxes, labels, world, rank, dev, dist)
 
     def step():
         nonlocal pending

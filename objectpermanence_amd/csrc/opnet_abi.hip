@@ -504,13 +504,17 @@ extern "C" int opnet_train_backward_f32(const float *dy, const float *packed, vo
         if (n < T) opnet_bwd_gemm<<<ggemm, OPNET_THREADS, 0, st>>>(bw, n);
     }
     // weight gradients over the saved histories
+    WgradBatch wb;
+    int njobs = 0, ntiles = 0;
     auto wgrad = [&](const float4 *P, long ps, int MQ, const float4 *Q, long qs, int NQ, float *out, int ld,
                      int mvalid, int nvalid, int rowmode, int H) {
-        WgradArgs g;
+        WgradArgs &g = wb.job[njobs++];
         g.P = P; g.p_stride = ps; g.MQ = MQ; g.Q = Q; g.q_stride = qs; g.NQ = NQ;
         g.out = out; g.ld = ld; g.mvalid = mvalid; g.nvalid = nvalid; g.rowmode = rowmode; g.H = H;
         g.T = T; g.RB = RB;
-        opnet_wgrad<<<dim3((MQ + 15) / 16, (NQ + 15) / 16, 1), 256, 0, st>>>(g);
+        g.tiles_m = (MQ + 15) / 16;
+        g.tile_begin = ntiles;
+        ntiles += g.tiles_m * ((NQ + 15) / 16);
     };
     const long h1s = (long)(H1 / 4) * 32, h2s = (long)(H2 / 4) * 32;
     // video_LSTM.weight_hh_l0 [4H2][H2]: da2_t x h2_{t-1} (slot t) ; weight_ih_l0 [4H2][6]: da2_t x frames_boxes_t
@@ -523,6 +527,7 @@ extern "C" int opnet_train_backward_f32(const float *dy, const float *packed, vo
     wgrad(bw.dlall, 128, 4, bw.h1all + (long)RB * h1s, h1s, H1 / 4, g_sel, H1, OPNET_SLOTS, H1, 0, 0);
     // prediction_layer.weight [4][H2]: dy_t x h2_t (slot t+1)
     wgrad(bw.dyp, 32, 1, bw.h2all + (long)RB * h2s, h2s, H2 / 4, g_out, H2, 4, H2, 0, 0);
+    opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

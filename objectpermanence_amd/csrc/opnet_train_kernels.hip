@@ -288,14 +288,29 @@ struct WgradArgs {
     const float4 *Q; long q_stride; int NQ;
     float *out; int ld; int mvalid; int nvalid; int rowmode; int H;
     int T, RB;
+    int tiles_m, tile_begin;   // tile grid of this job inside the merged launch
 };
 
-__global__ void __launch_bounds__(256) opnet_wgrad(const WgradArgs g)
+// All six weight gradients run as ONE launch (396 workgroups at H1=256/H2=512) so the small GEMMs
+// fill the CUs the big one leaves idle; blockIdx.x -> (job, tile) through tile_begin.
+#define OPNET_WGRAD_JOBS 6
+struct WgradBatch {
+    WgradArgs job[OPNET_WGRAD_JOBS];
+};
+
+__global__ void __launch_bounds__(256) opnet_wgrad(const WgradBatch batch)
 {
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < OPNET_WGRAD_JOBS; ++k)
+        if ((int)blockIdx.x >= batch.job[k].tile_begin) j = k;
+    const WgradArgs &g = batch.job[j];
+    const int tile = blockIdx.x - g.tile_begin;
+    const int tile_x = tile % g.tiles_m, tile_y = tile / g.tiles_m;
     __shared__ float red[4][64][64];  // [wave][acc*4 + r][lane]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mq0 = blockIdx.x * 16, nq0 = blockIdx.y * 16;
+    const int mq0 = tile_x * 16, nq0 = tile_y * 16;
     const int i = lane & 15, kc = lane >> 4;
     const bool pa = (mq0 + i) < g.MQ, pb = (nq0 + i) < g.NQ;
     f32x4 acc[4][4];

@@ -1,0 +1,55 @@
+"""One training step of a reasoner, single- or multi-GPU, with the reference's semantics
+(reference baselines/training_main.py:183-217): zero_grad -> forward -> loss -> backward -> Adam.
+
+Loss selection mirrors training_main.py:192-210: supervised models use mean(|y - label|);
+``*_no_labels`` models use mean(|y - label| * mask) + 0.5 * mean(||y[:,1:] - y[:,:-1]||_2).  The latter is
+a few elementwise torch ops on [B,T,4] whose gradient enters the HIP backward through dL/dy.
+
+Data parallel (not in the reference - SURVEY.md section 2.3): every rank runs the step on its own clips,
+then ONE all-reduce over the flat 5.68 MB gradient buffer (parallel.all_reduce_gradients) on a side
+stream, weighted n_local/n_global so the result equals the single-process mean-loss gradient.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import parallel
+from .optim import l1_mean
+from .supported_models import DOUBLE_OUTPUT_MODELS, NO_LABELS_MODELS
+
+
+def compute_loss(model_name: str, output: torch.Tensor, labels: torch.Tensor, mask: Optional[torch.Tensor] = None):
+    """Returns (loss, pred_loss, consistency_loss) as training_main.py:192-210 does."""
+    nxt, cur = output[:, 1:, :], output[:, :-1, :]
+    consistency = torch.mean(torch.norm(nxt - cur, p=2, dim=-1)) if output.shape[1] > 1 else output.new_zeros(())
+    if model_name in NO_LABELS_MODELS:
+        pred = torch.mean(torch.abs(output - labels) * mask)
+        return pred + 0.5 * consistency, pred, consistency
+    pred = l1_mean(output, labels)
+    return pred, pred, consistency.detach()
+
+
+def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.Optimizer, boxes: torch.Tensor,
+               labels: torch.Tensor, mask: Optional[torch.Tensor] = None, group: Optional[dist.ProcessGroup] = None,
+               n_global: Optional[int] = None, comm_stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+    optimizer.zero_grad(set_to_none=True)
+    out = model(boxes)
+    output = out[0] if model_name in DOUBLE_OUTPUT_MODELS else out
+    loss, _, _ = compute_loss(model_name, output, labels, mask)
+    loss.backward()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        params = [p for p in model.parameters() if p.grad is not None]
+        n_local = int(boxes.shape[0])
+        n_glob = n_global if n_global is not None else n_local * dist.get_world_size(group)
+        cur = torch.cuda.current_stream(boxes.device)
+        st = comm_stream or cur
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            flat, _ = parallel.all_reduce_gradients(params, n_local, n_glob, group)
+            parallel.unflatten_gradients(params, flat)
+        cur.wait_stream(st)
+    optimizer.step()
+    return loss.detach()
