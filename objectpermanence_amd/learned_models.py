@@ -144,7 +144,7 @@ class OPNet(AbstractCaterModel):
         self._h1, self._h2 = h1, h2
         self._packed = None
         self._packed_key = None
-        self._plans: Dict[Tuple[int, int, int], Tuple[int, torch.Tensor]] = {}
+        self._plans: Dict[Tuple[int, int, int, int], Tuple[int, torch.Tensor]] = {}
         self._tpacked = None     # training: inference tiles + transposed tiles
         self._tws = None         # training workspace (one forward's history)
         self._tws_key = None
@@ -196,7 +196,10 @@ class OPNet(AbstractCaterModel):
         dev = boxes.device
         with torch.cuda.device(dev):
             packed = self._packed_weights(dev)
-            key = (B, T, dev.index if dev.index is not None else torch.cuda.current_device())
+            stream = _stream_ptr(dev)
+            # one workspace + graph per (shape, device, stream): forwards enqueued on different HIP
+            # streams run concurrently (the step kernel leaves most of a CU idle at small batches)
+            key = (B, T, dev.index if dev.index is not None else torch.cuda.current_device(), stream)
             if key not in self._plans:
                 nbytes = lib.opnet_workspace_bytes(B, T, self._h1, self._h2)
                 if nbytes == 0:
@@ -209,7 +212,6 @@ class OPNet(AbstractCaterModel):
             plan, ws = self._plans[key]
             y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
             logits = torch.empty((B, 15, T), dtype=torch.float32, device=dev)
-            stream = _stream_ptr(dev)
             if self.use_graph:
                 rc = lib.opnet_plan_forward(plan, boxes.data_ptr(), packed.data_ptr(), y.data_ptr(),
                                             logits.data_ptr(), ws.data_ptr(), ws.numel(), stream)
