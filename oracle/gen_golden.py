@@ -89,6 +89,60 @@ def gen_opnet(lm, cfg, n_clips, t_frames, tag, keep_intermediates):
     return y.numpy(), labels
 
 
+def gen_siblings(lm):
+    """forward goldens of BaselineLstm, NonLinearLstm, OPNetLstmMlp, TransformerLstm (learned_models.py:55-197)"""
+    torch.manual_seed(0)
+    out = {}
+    cases = {
+        "baseline_lstm": (lm.BaselineLstm, synth.baseline_lstm_synth_params,
+                          [("tiny", {"videos_hidden_dim": 32}, 2, 10), ("real", {"videos_hidden_dim": 512}, 3, 300)]),
+        "non_linear_lstm": (lm.NonLinearLstm, synth.non_linear_lstm_synth_params,
+                            [("tiny", {"boxes_features_dim": 16, "videos_hidden_dim": 32}, 2, 10),
+                             ("real", {"boxes_features_dim": 256, "videos_hidden_dim": 512}, 2, 60)]),
+        "opnet_lstm_mlp": (lm.OPNetLstmMlp, synth.opnet_lstm_mlp_synth_params,
+                           [("tiny", {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 16, "videos_hidden_dim": 32}, 2, 10),
+                            ("real", {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}, 3, 300)]),
+    }
+    for name, (cls, pfn, variants) in cases.items():
+        for tag, cfg, n, t in variants:
+            model = cls(cfg)
+            _load_params(model, pfn(cfg))
+            model.eval()
+            boxes, _ = synth.make_batch(0, n, t)
+            x = boxes if name == "opnet_lstm_mlp" else synth.boxes5(boxes)
+            with torch.no_grad():
+                y = model(torch.from_numpy(x))
+            if isinstance(y, tuple):
+                out[f"{name}/{tag}/logits"] = y[1].numpy()
+                y = y[0]
+            out[f"{name}/{tag}/y"] = y.numpy()
+            out[f"{name}/{tag}/cfg"] = np.array(json.dumps(cfg))
+            out[f"{name}/{tag}/shape"] = np.array([n, t])
+            print(f"{name}/{tag}: y range [{float(y.min()):.3f}, {float(y.max()):.3f}]")
+    # transformer_lstm: tiny, the JSON config (2 heads) at B=1 and B=2 (batch coupling), BASELINE's 4 heads
+    tcases = [("tiny", {"boxes_features_dim": 16, "num_attention_heads": 2, "num_attention_layers": 2,
+                        "num_lstm_layers": 2, "lstm_hidden_dim": 32}, 2, 6),
+              ("real_b1", None, 1, 300), ("real_b2", None, 2, 300), ("heads4_b1", "h4", 1, 300)]
+    with open(os.path.join(REF, "configs", "transformer_lstm_model_config.json")) as f:
+        real = json.load(f)
+    for tag, cfg, n, t in tcases:
+        if cfg is None:
+            cfg = dict(real)
+        elif cfg == "h4":
+            cfg = dict(real); cfg["num_attention_heads"] = 4
+        model = lm.TransformerLstm(cfg)
+        _load_params(model, synth.transformer_lstm_synth_params(cfg))
+        model.eval()
+        boxes, _ = synth.make_batch(0, n, t)
+        with torch.no_grad():
+            y = model(torch.from_numpy(synth.boxes5(boxes)))
+        out[f"transformer_lstm/{tag}/y"] = y.numpy()
+        out[f"transformer_lstm/{tag}/cfg"] = np.array(json.dumps(cfg))
+        out[f"transformer_lstm/{tag}/shape"] = np.array([n, t])
+        print(f"transformer_lstm/{tag}: y range [{float(y.min()):.3f}, {float(y.max()):.3f}]")
+    np.savez_compressed(os.path.join(OUT, "siblings.npz"), **out)
+
+
 def sample_indices(name, n, k=4096):
     """deterministic sample of flat indices of a tensor (same helper used by the tests)"""
     if n <= k:
@@ -177,6 +231,7 @@ def main():
         real = json.load(f)
     y, labels = gen_opnet(lm, real, n_clips=4, t_frames=300, tag="real", keep_intermediates=False)
     gen_metric(tu, y, labels)
+    gen_siblings(lm)
     gen_train(lm, tiny, n_clips=3, t_frames=12, tag="tiny", full=True, adam_steps=3)
     gen_train(lm, real, n_clips=4, t_frames=300, tag="real", full=False, adam_steps=2)
 

@@ -139,3 +139,92 @@ def mean_iou_and_map(pred_px: np.ndarray, gt_px: np.ndarray, thr: float = 0.5) -
     video_mean = ious.mean(axis=1)
     video_map = (ious > thr).mean(axis=1)
     return float(video_mean.mean()), float(video_map.mean())
+
+
+# --------------------------------------------------------------------------------------
+# sibling reasoners (reference baselines/learned_models.py:55-197)
+# --------------------------------------------------------------------------------------
+
+def lstm_stack(x: np.ndarray, p: Dict[str, np.ndarray], prefix: str, num_layers: int) -> np.ndarray:
+    """nn.LSTM(num_layers=n, bias=False, batch_first=True): layer l consumes layer l-1's outputs
+    (learned_models.py:135-136, 170-171; no inter-layer dropout is configured)."""
+    h = x
+    for layer in range(num_layers):
+        h = lstm_seq(h, p[f"{prefix}.weight_ih_l{layer}"], p[f"{prefix}.weight_hh_l{layer}"])
+    return h
+
+
+def baseline_lstm_forward(x: np.ndarray, p: Dict[str, np.ndarray], dtype=np.float64) -> np.ndarray:
+    """BaselineLstm.forward (learned_models.py:104-118): [B,T,15,5] -> view [B,T,75] -> LSTM -> Linear."""
+    B, T = x.shape[:2]
+    P = {k: v.astype(dtype) for k, v in p.items()}
+    h = lstm_seq(x.astype(dtype).reshape(B, T, -1), P["video_LSTM.weight_ih_l0"], P["video_LSTM.weight_hh_l0"])
+    return h @ P["predictions_layer.weight"].T
+
+
+def non_linear_lstm_forward(x: np.ndarray, p: Dict[str, np.ndarray], dtype=np.float64) -> np.ndarray:
+    """NonLinearLstm.forward (learned_models.py:134-151): relu(Linear 5->F) per slot -> [B,T,15F] ->
+    2-layer LSTM -> Linear."""
+    B, T = x.shape[:2]
+    P = {k: v.astype(dtype) for k, v in p.items()}
+    feats = np.maximum(x.astype(dtype) @ P["boxes_linear.weight"].T, 0.0)      # :138
+    h = lstm_stack(feats.reshape(B, T, -1), P, "video_LSTM", 2)                # :142-145
+    return h @ P["predictions_layer.weight"].T                                 # :148
+
+
+def opnet_lstm_mlp_forward(boxes: np.ndarray, p: Dict[str, np.ndarray], dtype=np.float64):
+    """OPNetLstmMlp.forward (learned_models.py:72-89): OPNet with the video LSTM replaced by
+    relu(Linear 6->H2) (:83)."""
+    B, T, S, F = boxes.shape
+    x = boxes.astype(dtype)
+    P = {k: v.astype(dtype) for k, v in p.items()}
+    h1 = lstm_seq(x.reshape(B, T, S * F), P["object_to_track_LSTM.weight_ih_l0"], P["object_to_track_LSTM.weight_hh_l0"])
+    logits = h1 @ P["object_to_track_prediction.weight"].T
+    probs = softmax_lastdim(logits)
+    fb = np.einsum("bfot,bfo->bft", x, probs)
+    hidden = np.maximum(fb @ P["hidden_layer.weight"].T, 0.0)
+    y = hidden @ P["prediction_layer.weight"].T
+    return y, np.ascontiguousarray(np.transpose(logits, (0, 2, 1)))
+
+
+def layer_norm(x: np.ndarray, g: np.ndarray, b: np.ndarray, eps: float = 1e-5) -> np.ndarray:
+    """nn.LayerNorm over the last dim: biased variance, eps inside the sqrt."""
+    mu = x.mean(axis=-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=-1, keepdims=True)
+    return (x - mu) / np.sqrt(var + eps) * g + b
+
+
+def encoder_layer(z: np.ndarray, P: Dict[str, np.ndarray], pre: str, nhead: int) -> np.ndarray:
+    """One post-LN nn.TransformerEncoderLayer in eval mode (dropout off), ReLU FFN, on ONE sequence
+    z [S, E] (torch.nn.MultiheadAttention: q scaled by 1/sqrt(head_dim), softmax over keys, no mask)."""
+    S, E = z.shape
+    hd = E // nhead
+    qkv = z @ P[pre + "self_attn.in_proj_weight"].T + P[pre + "self_attn.in_proj_bias"]
+    q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+    heads = []
+    for h in range(nhead):
+        sl = slice(h * hd, (h + 1) * hd)
+        sc = (q[:, sl] / np.sqrt(hd)) @ k[:, sl].T
+        heads.append(softmax_lastdim(sc) @ v[:, sl])
+    a = np.concatenate(heads, axis=1) @ P[pre + "self_attn.out_proj.weight"].T + P[pre + "self_attn.out_proj.bias"]
+    z = layer_norm(z + a, P[pre + "norm1.weight"], P[pre + "norm1.bias"])
+    f = np.maximum(z @ P[pre + "linear1.weight"].T + P[pre + "linear1.bias"], 0.0)
+    f = f @ P[pre + "linear2.weight"].T + P[pre + "linear2.bias"]
+    return layer_norm(z + f, P[pre + "norm2.weight"], P[pre + "norm2.bias"])
+
+
+def transformer_lstm_forward(x: np.ndarray, p: Dict[str, np.ndarray], cfg: Dict[str, int], dtype=np.float64) -> np.ndarray:
+    """TransformerLstm.forward (learned_models.py:174-197), eval mode, restated on its LIVE path.
+
+    The reference feeds [B*T, 15, E] to a sequence-first encoder, so attention runs over the
+    S = B*T frame axis independently per object slot (the "batch" axis of the encoder), across all
+    clips of the minibatch and non-causally; only slot 0 is kept (:185).  Slots 1..14 never influence
+    the output, so this restatement evaluates slot 0 only (tests pin it against the
+    reference's full 15-slot evaluation, including the batch-composition dependence)."""
+    B, T = x.shape[:2]
+    P = {k: v.astype(dtype) for k, v in p.items()}
+    z = np.maximum(x[:, :, 0, :].astype(dtype) @ P["boxes_linear.weight"].T, 0.0).reshape(B * T, -1)  # :178, slot 0
+    for layer in range(cfg["num_attention_layers"]):
+        z = encoder_layer(z, P, f"attention_encoder.layers.{layer}.", cfg["num_attention_heads"])          # :184
+    h = lstm_stack(z.reshape(B, T, -1), P, "video_LSTM", cfg["num_lstm_layers"])                           # :189-192
+    return h @ P["predictions_layer.weight"].T                                                              # :195

@@ -105,6 +105,68 @@ def opnet_synth_params(cfg: Dict[str, int], salt: int = 0) -> Dict[str, np.ndarr
             for name, shape in opnet_shapes(cfg).items()}
 
 
+def _lstm_params(prefix, in_dim, hidden, layers, gain=2.0, salt=0):
+    out = {}
+    for l in range(layers):
+        k_in = in_dim if l == 0 else hidden
+        out[f"{prefix}.weight_ih_l{l}"] = synth_tensor(f"{prefix}.weight_ih_l{l}", (4 * hidden, k_in), gain / np.sqrt(max(k_in, 16)), salt)
+        out[f"{prefix}.weight_hh_l{l}"] = synth_tensor(f"{prefix}.weight_hh_l{l}", (4 * hidden, hidden), gain / np.sqrt(hidden), salt)
+    return out
+
+
+def baseline_lstm_synth_params(cfg, salt=0):
+    """BaselineLstm state_dict."""
+    h = cfg["videos_hidden_dim"]
+    p = _lstm_params("video_LSTM", 75, h, 1, salt=salt)
+    p["predictions_layer.weight"] = synth_tensor("predictions_layer.weight", (4, h), 8.0 / np.sqrt(h), salt)
+    return p
+
+
+def non_linear_lstm_synth_params(cfg, salt=0):
+    f, h = cfg["boxes_features_dim"], cfg["videos_hidden_dim"]
+    p = {"boxes_linear.weight": synth_tensor("boxes_linear.weight", (f, 5), 0.9, salt)}
+    p.update(_lstm_params("video_LSTM", 15 * f, h, 2, salt=salt))
+    p["predictions_layer.weight"] = synth_tensor("predictions_layer.weight", (4, h), 8.0 / np.sqrt(h), salt)
+    return p
+
+
+def opnet_lstm_mlp_synth_params(cfg, salt=0):
+    h1, h2 = cfg["object_to_track_hidden_dim"], cfg["videos_hidden_dim"]
+    full = opnet_synth_params(cfg, salt)
+    p = {k: v for k, v in full.items() if k.startswith("object_to_track")}
+    p["hidden_layer.weight"] = synth_tensor("hidden_layer.weight", (h2, 6), 1.0, salt)
+    p["prediction_layer.weight"] = synth_tensor("prediction_layer.weight", (4, h2), 4.0 / np.sqrt(h2), salt)
+    return p
+
+
+def transformer_lstm_synth_params(cfg, ffn=2048, salt=0):
+    """TransformerLstm state_dict; dim_feedforward = 2048 is the torch default the
+    reference relies on (learned_models.py:166)."""
+    e, h = cfg["boxes_features_dim"], cfg["lstm_hidden_dim"]
+    p = {"boxes_linear.weight": synth_tensor("boxes_linear.weight", (e, 5), 0.9, salt)}
+    for l in range(cfg["num_attention_layers"]):
+        pre = f"attention_encoder.layers.{l}."
+        p[pre + "self_attn.in_proj_weight"] = synth_tensor(pre + "in_w", (3 * e, e), 2.0 / np.sqrt(e), salt)
+        p[pre + "self_attn.in_proj_bias"] = synth_tensor(pre + "in_b", (3 * e,), 0.1, salt)
+        p[pre + "self_attn.out_proj.weight"] = synth_tensor(pre + "out_w", (e, e), 1.5 / np.sqrt(e), salt)
+        p[pre + "self_attn.out_proj.bias"] = synth_tensor(pre + "out_b", (e,), 0.05, salt)
+        p[pre + "linear1.weight"] = synth_tensor(pre + "l1_w", (ffn, e), 1.5 / np.sqrt(e), salt)
+        p[pre + "linear1.bias"] = synth_tensor(pre + "l1_b", (ffn,), 0.05, salt)
+        p[pre + "linear2.weight"] = synth_tensor(pre + "l2_w", (e, ffn), 1.5 / np.sqrt(ffn), salt)
+        p[pre + "linear2.bias"] = synth_tensor(pre + "l2_b", (e,), 0.05, salt)
+        for n in ("norm1", "norm2"):
+            p[pre + n + ".weight"] = (1.0 + synth_tensor(pre + n + "_w", (e,), 0.1, salt)).astype(np.float32)
+            p[pre + n + ".bias"] = synth_tensor(pre + n + "_b", (e,), 0.05, salt)
+    p.update(_lstm_params("video_LSTM", e, h, cfg["num_lstm_layers"], salt=salt))
+    p["predictions_layer.weight"] = synth_tensor("predictions_layer.weight", (4, h), 8.0 / np.sqrt(h), salt)
+    return p
+
+
+def boxes5(boxes6: np.ndarray) -> np.ndarray:
+    """the 5-track input of the non-OPNet models (datasets.py:128-196): the 6-track tensor without is_cone"""
+    return np.ascontiguousarray(boxes6[..., :5])
+
+
 # --------------------------------------------------------------------------------------
 # synthetic clips
 # --------------------------------------------------------------------------------------
