@@ -99,6 +99,40 @@ int opnet_l1_loss_f32(const float *y, const float *labels, float *loss, float *d
 int opnet_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,
                         float beta1, float beta2, float eps, int step, float grad_scale, void *stream);
 
+/* ---- sibling reasoners (reference learned_models.py:55-197) ----------------------------------------
+ * OPNetLstmMlp (:55-89): OPNet whose video LSTM is relu(Linear 6->H2) (hidden_layer.weight [H2,6]);
+ * same packed/workspace sizes as OPNet (opnet_packed_weights_bytes / opnet_workspace_bytes). */
+int opnet_mlp_pack_weights_f32(const float *w_ih1, const float *w_hh1, const float *w_sel,
+                               const float *w_hidden, const float *w_out, float *packed,
+                               size_t packed_bytes, int H1, int H2, void *stream);
+int opnet_mlp_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
+                          void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2, void *stream);
+/* L (1..3) stacked bias-free LSTM layers (input width KX, hidden H each) + Linear H->4:
+ *   x [B,T,KX] -> y [B,T,4].  BaselineLstm (:92-118): L=1, KX=75.  NonLinearLstm (:121-151): L=2,
+ *   KX=15*F after opseq_slot_embed_relu_f32.  TransformerLstm's LSTM half (:170-172,192-195): L=2, KX=E.
+ * w_ih / w_hh are HOST arrays of L device pointers (video_LSTM.weight_ih_l{k} [4H,K_k], weight_hh_l{k}
+ * [4H,H]); w_head = predictions_layer.weight [4,H]. */
+size_t opseq_lstm_stack_packed_bytes(int L, int KX, int H);
+size_t opseq_lstm_stack_workspace_bytes(int B, int T, int L, int KX, int H);
+int opseq_lstm_stack_pack_weights_f32(const float *const *w_ih, const float *const *w_hh, const float *w_head,
+                                      float *packed, size_t packed_bytes, int L, int KX, int H, void *stream);
+int opseq_lstm_stack_forward_f32(const float *x, const float *packed, float *y, void *workspace,
+                                 size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream);
+/* relu(boxes_linear(x)) (:138,:178): x [ntok,15,5], W [F,5] -> out [ntok, nslots_out, F];
+ * nslots_out = 15 (all slots) or 1 (slot 0 only - the live path of TransformerLstm). */
+int opseq_slot_embed_relu_f32(const float *x, const float *W, float *out, long ntok, int nslots_out, int F,
+                              void *stream);
+/* One post-LN nn.TransformerEncoderLayer (eval mode, ReLU FFN, eps 1e-5; :166-168,184) applied IN PLACE
+ * to ONE sequence z [S,E] (S = B*T: the reference's sequence-first call attends across all frames
+ * of the minibatch). Parameters in state_dict layouts: in_proj [3E,E]+[3E], out_proj [E,E]+[E],
+ * linear1 [ffn,E]+[ffn], linear2 [E,ffn]+[E], norm1/norm2 weight+bias [E]. E and E/nhead multiples of 16. */
+size_t opseq_encoder_workspace_bytes(long S, int E, int nhead, int ffn);
+int opseq_encoder_layer_f32(float *z, const float *in_w, const float *in_b, const float *out_w,
+                            const float *out_b, const float *l1_w, const float *l1_b, const float *l2_w,
+                            const float *l2_b, const float *n1_w, const float *n1_b, const float *n2_w,
+                            const float *n2_b, void *workspace, size_t workspace_bytes, long S, int E,
+                            int nhead, int ffn, void *stream);
+
 /* ---- output post-processing + metric (replaces inference_main.py:219 and
  *      tracking_utils.py:137-159,251-256,278-288) ------------------------------------------------
  * y, labels [N, T, 4] fp32 normalised -> pred_px, gt_px [N, T, 4] int32 (float64 multiply by

@@ -55,6 +55,25 @@ def _declare(lib):
     lib.opnet_adam_step_f32.restype = c_int
     lib.opnet_adam_step_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_float, c_float, c_float, c_float,
                                         c_int, c_float, c_void_p]
+    lib.opnet_mlp_pack_weights_f32.restype = c_int
+    lib.opnet_mlp_pack_weights_f32.argtypes = [fp, fp, fp, fp, fp, fp, c_size_t, c_int, c_int, c_void_p]
+    lib.opnet_mlp_forward_f32.restype = c_int
+    lib.opnet_mlp_forward_f32.argtypes = [fp, fp, fp, fp, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]
+    lib.opseq_lstm_stack_packed_bytes.restype = c_size_t
+    lib.opseq_lstm_stack_packed_bytes.argtypes = [c_int, c_int, c_int]
+    lib.opseq_lstm_stack_workspace_bytes.restype = c_size_t
+    lib.opseq_lstm_stack_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    lib.opseq_lstm_stack_pack_weights_f32.restype = c_int
+    lib.opseq_lstm_stack_pack_weights_f32.argtypes = [POINTER(c_void_p), POINTER(c_void_p), fp, fp, c_size_t,
+                                                      c_int, c_int, c_int, c_void_p]
+    lib.opseq_lstm_stack_forward_f32.restype = c_int
+    lib.opseq_lstm_stack_forward_f32.argtypes = [fp, fp, fp, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.opseq_slot_embed_relu_f32.restype = c_int
+    lib.opseq_slot_embed_relu_f32.argtypes = [fp, fp, fp, ctypes.c_long, c_int, c_int, c_void_p]
+    lib.opseq_encoder_workspace_bytes.restype = c_size_t
+    lib.opseq_encoder_workspace_bytes.argtypes = [ctypes.c_long, c_int, c_int, c_int]
+    lib.opseq_encoder_layer_f32.restype = c_int
+    lib.opseq_encoder_layer_f32.argtypes = [fp] * 13 + [c_void_p, c_size_t, ctypes.c_long, c_int, c_int, c_int, c_void_p]
     lib.opnet_postprocess_iou.restype = c_int
     lib.opnet_postprocess_iou.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_void_p]
 
@@ -65,6 +84,10 @@ EXPORTS = [
     "opnet_plan_destroy", "opnet_postprocess_iou",
     "opnet_train_packed_weights_bytes", "opnet_train_pack_weights_f32", "opnet_train_workspace_bytes",
     "opnet_train_forward_f32", "opnet_train_backward_f32", "opnet_l1_loss_f32", "opnet_adam_step_f32",
+    "opnet_mlp_pack_weights_f32", "opnet_mlp_forward_f32",
+    "opseq_lstm_stack_packed_bytes", "opseq_lstm_stack_workspace_bytes", "opseq_lstm_stack_pack_weights_f32",
+    "opseq_lstm_stack_forward_f32", "opseq_slot_embed_relu_f32", "opseq_encoder_workspace_bytes",
+    "opseq_encoder_layer_f32",
 ]
 
 

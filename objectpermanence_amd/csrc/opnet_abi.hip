@@ -2,6 +2,7 @@
 // Plain pointers and sizes in, HIP launches on the caller's stream out; no torch types.
 #include "opnet_kernels.hip"
 #include "opnet_train_kernels.hip"
+#include "seq_kernels.hip"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -197,6 +198,57 @@ extern "C" int opnet_forward_f32(const float *boxes, const float *packed, float 
     OpnetIO io;
     if (int rc = make_args(&a, &io, boxes, packed, y, logits, workspace, workspace_bytes, B, T, H1, H2))
         return rc;
+    const WorkspaceLayout W = workspace_layout(B, T, H1, H2);
+    hipStream_t st = (hipStream_t)stream;
+    OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
+    opnet_set_io<<<1, 1, 0, st>>>(dio, io);
+    opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
+    const dim3 grid = step_grid(a.RB, H1, H2);
+    for (int s = 0; s < T + 3; ++s) opnet_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+// OPNetLstmMlp (learned_models.py:55-89): same packed layout; w_hidden [H2][6] takes the place of the
+// video LSTM's input weights (gate-0 slot), the recurrent tiles stay unused.
+__global__ void opnet_pack_hidden(float *__restrict__ out, const float *__restrict__ w_hidden, int H2)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H2 * 4 * 8) return;
+    const int f = idx & 7, gate = (idx >> 3) & 3, unit = idx >> 5;
+    out[idx] = (gate == 0 && f < OPNET_FEATS_) ? w_hidden[(long)unit * OPNET_FEATS_ + f] : 0.f;
+}
+
+extern "C" int opnet_mlp_pack_weights_f32(const float *w_ih1, const float *w_hh1, const float *w_sel,
+                                          const float *w_hidden, const float *w_out, float *packed,
+                                          size_t packed_bytes, int H1, int H2, void *stream)
+{
+    if (int rc = check_dims(1, 1, H1, H2)) return rc;
+    if (!w_ih1 || !w_hh1 || !w_sel || !w_hidden || !w_out || !packed) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(packed)) return fail(OPNET_EINVAL, "packed must be 16-byte aligned");
+    const PackedLayout L = packed_layout(H1, H2);
+    if (packed_bytes < L.total * sizeof(float)) return fail(OPNET_EWORKSPACE, "packed buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    auto blocks = [](size_t n) { return (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256); };
+    opnet_pack_tiles<<<blocks((size_t)(H1 / 4) * ((96 + H1) / 16) * 256), 256, 0, st>>>(
+        packed + L.w1p, w_ih1, w_hh1, OPNET_KX, OPNET_KXQ * 4, H1, H1, 0, 0, H1 / 4);
+    opnet_pack_hidden<<<(H2 * 32 + 255) / 256, 256, 0, st>>>(packed + L.wih2p, w_hidden, H2);
+    opnet_pack_tiles<<<blocks((size_t)(H1 / 16) * 256), 256, 0, st>>>(packed + L.wselp, nullptr, w_sel, 0, 0, H1, 0, OPNET_SLOTS, 1, 1);
+    opnet_pack_tiles<<<blocks((size_t)(H2 / 16) * 256), 256, 0, st>>>(packed + L.woutp, nullptr, w_out, 0, 0, H2, 0, 4, 1, 1);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opnet_mlp_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
+                                     void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
+                                     void *stream)
+{
+    StepArgs a;
+    OpnetIO io;
+    if (int rc = make_args(&a, &io, boxes, packed, y, logits, workspace, workspace_bytes, B, T, H1, H2))
+        return rc;
+    a.mlp = 1;
     const WorkspaceLayout W = workspace_layout(B, T, H1, H2);
     hipStream_t st = (hipStream_t)stream;
     OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
@@ -557,6 +609,189 @@ extern "C" int opnet_adam_step_f32(float *param, const float *grad, float *exp_a
     const unsigned nb = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     opnet_adam<<<nb, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps,
                                                     (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sibling reasoners: stacked LSTM + head, slot embedding, transformer encoder layer
+// ------------------------------------------------------------------------------------------------
+static int check_stack(int B, int T, int L, int KX, int H)
+{
+    if (B <= 0 || T <= 0) return fail(OPNET_ESHAPE, "B=%d T=%d must be positive", B, T);
+    if (L < 1 || L > SEQ_MAX_LAYERS) return fail(OPNET_ESHAPE, "1..%d LSTM layers supported (L=%d)", SEQ_MAX_LAYERS, L);
+    if (KX <= 0 || H <= 0 || (H & 15)) return fail(OPNET_ESHAPE, "H must be a positive multiple of 16 (KX=%d H=%d)", KX, H);
+    return OPNET_OK;
+}
+
+struct StackPackedLayout { size_t layer[SEQ_MAX_LAYERS], head, total; int nhx[SEQ_MAX_LAYERS]; };
+
+static StackPackedLayout stack_packed_layout(int L, int KX, int H)
+{
+    StackPackedLayout P;
+    size_t o = 0;
+    for (int l = 0; l < L; ++l) {
+        P.nhx[l] = l == 0 ? (KX + 15) / 16 : H / 16;
+        P.layer[l] = o;
+        o += (size_t)(H / 4) * (P.nhx[l] + H / 16) * 256;
+    }
+    P.head = o; o += (size_t)(H / 16) * 256;
+    P.total = o;
+    return P;
+}
+
+struct StackWorkspaceLayout { size_t xp, state, hbuf[SEQ_MAX_LAYERS], c[SEQ_MAX_LAYERS], state_end, ystage, total; };
+
+static StackWorkspaceLayout stack_workspace_layout(int B, int T, int L, int KX, int H)
+{
+    const size_t RB = (B + 31) / 32, KXP = (size_t)((KX + 15) / 16) * 16;
+    StackWorkspaceLayout W;
+    size_t o = 0;
+    W.xp = o; o += (size_t)T * RB * (KXP / 4) * 32 * 16;
+    W.state = o;
+    for (int l = 0; l < L; ++l) {
+        W.hbuf[l] = o; o += 2 * RB * (size_t)H * 32 * 4;
+        W.c[l] = o;    o += RB * (size_t)H * 32 * 4;
+    }
+    W.state_end = o;
+    W.ystage = o; o += RB * 32 * (size_t)T * 16;
+    W.total = align_up(o, 256);
+    return W;
+}
+
+extern "C" size_t opseq_lstm_stack_packed_bytes(int L, int KX, int H)
+{
+    if (check_stack(1, 1, L, KX, H)) return 0;
+    return stack_packed_layout(L, KX, H).total * sizeof(float);
+}
+
+extern "C" size_t opseq_lstm_stack_workspace_bytes(int B, int T, int L, int KX, int H)
+{
+    if (check_stack(B, T, L, KX, H)) return 0;
+    return stack_workspace_layout(B, T, L, KX, H).total;
+}
+
+extern "C" int opseq_lstm_stack_pack_weights_f32(const float *const *w_ih, const float *const *w_hh,
+                                                 const float *w_head, float *packed, size_t packed_bytes,
+                                                 int L, int KX, int H, void *stream)
+{
+    if (int rc = check_stack(1, 1, L, KX, H)) return rc;
+    if (!w_ih || !w_hh || !w_head || !packed) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(packed)) return fail(OPNET_EINVAL, "packed must be 16-byte aligned");
+    const StackPackedLayout P = stack_packed_layout(L, KX, H);
+    if (packed_bytes < P.total * sizeof(float)) return fail(OPNET_EWORKSPACE, "packed buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    auto blocks = [](size_t n) { return (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256); };
+    for (int l = 0; l < L; ++l) {
+        if (!w_ih[l] || !w_hh[l]) return fail(OPNET_EINVAL, "null weight pointer (layer %d)", l);
+        const int kx = l == 0 ? KX : H;
+        opnet_pack_tiles<<<blocks((size_t)(H / 4) * (P.nhx[l] + H / 16) * 256), 256, 0, st>>>(
+            packed + P.layer[l], w_ih[l], w_hh[l], kx, P.nhx[l] * 16, H, H, 0, 0, H / 4);
+    }
+    opnet_pack_tiles<<<blocks((size_t)(H / 16) * 256), 256, 0, st>>>(packed + P.head, nullptr, w_head, 0, 0, H, 0, 4, 1, 1);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opseq_lstm_stack_forward_f32(const float *x, const float *packed, float *y, void *workspace,
+                                            size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream)
+{
+    if (int rc = check_stack(B, T, L, KX, H)) return rc;
+    if (!x || !packed || !y || !workspace) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(packed) || !aligned16(y) || !aligned16(workspace))
+        return fail(OPNET_EINVAL, "packed/y/workspace must be 16-byte aligned");
+    const StackWorkspaceLayout W = stack_workspace_layout(B, T, L, KX, H);
+    if (workspace_bytes < W.total) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", workspace_bytes, W.total);
+    const StackPackedLayout P = stack_packed_layout(L, KX, H);
+    char *w = (char *)workspace;
+    const int RB = (B + 31) / 32;
+    StackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.RB = RB; a.L = L;
+    a.xp = (const float4 *)(w + W.xp);
+    int ntiles = 1;
+    for (int l = 0; l < L; ++l) {
+        a.layer[l].A = (const float4 *)(packed + P.layer[l]);
+        a.layer[l].H = H;
+        a.layer[l].nhx = P.nhx[l];
+        a.layer[l].hbuf = (float4 *)(w + W.hbuf[l]);
+        a.layer[l].c = (float *)(w + W.c[l]);
+        ntiles += H / 4;
+    }
+    a.headA = (const float4 *)(packed + P.head);
+    a.ystage = (float4 *)(w + W.ystage);
+    hipStream_t st = (hipStream_t)stream;
+    rows_to_packed<<<2048, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, RB, KX, P.nhx[0] * 16,
+                                          (float4 *)(w + W.state), (long)((W.state_end - W.state) / 16));
+    const dim3 grid(ntiles, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
+    for (int s = 0; s < T + L; ++s) lstm_stack_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    const long ny = (long)B * T;
+    copy_y_out<<<(unsigned)((ny + 255) / 256 > 1024 ? 1024 : (ny + 255) / 256), 256, 0, st>>>(a.ystage, (float4 *)y, ny);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opseq_slot_embed_relu_f32(const float *x, const float *W, float *out, long ntok, int nslots_out,
+                                         int F, void *stream)
+{
+    if (!x || !W || !out) return fail(OPNET_EINVAL, "null pointer");
+    if (ntok <= 0 || F <= 0 || (nslots_out != 1 && nslots_out != 15))
+        return fail(OPNET_ESHAPE, "ntok=%ld F=%d nslots_out=%d", ntok, F, nslots_out);
+    const long n = ntok * nslots_out * F;
+    slot_embed_relu<<<(unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        x, W, out, ntok, nslots_out, F);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+static int check_encoder(long S, int E, int nhead, int ffn)
+{
+    if (S <= 0 || S > 0x7fffffffL) return fail(OPNET_ESHAPE, "S=%ld out of range", S);
+    if (E <= 0 || (E & 15) || E > 64 * LN_MAX_PER_LANE) return fail(OPNET_ESHAPE, "E=%d must be a multiple of 16, <= %d", E, 64 * LN_MAX_PER_LANE);
+    if (nhead <= 0 || E % nhead) return fail(OPNET_ESHAPE, "E=%d not divisible by nhead=%d", E, nhead);
+    const int hd = E / nhead;
+    if ((hd & 15) || hd > 16 * ATT_MAX_HEX) return fail(OPNET_ESHAPE, "head dim %d must be a multiple of 16, <= %d", hd, 16 * ATT_MAX_HEX);
+    if (ffn <= 0 || (ffn & 15)) return fail(OPNET_ESHAPE, "ffn=%d must be a multiple of 16", ffn);
+    return OPNET_OK;
+}
+
+extern "C" size_t opseq_encoder_workspace_bytes(long S, int E, int nhead, int ffn)
+{
+    if (check_encoder(S, E, nhead, ffn)) return 0;
+    return align_up((size_t)S * (3 * E + 3 * E + ffn) * sizeof(float), 256);
+}
+
+/* one post-LN nn.TransformerEncoderLayer (eval), in place on z [S][E] */
+extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float *in_b, const float *out_w,
+                                       const float *out_b, const float *l1_w, const float *l1_b, const float *l2_w,
+                                       const float *l2_b, const float *n1_w, const float *n1_b, const float *n2_w,
+                                       const float *n2_b, void *workspace, size_t workspace_bytes, long S, int E,
+                                       int nhead, int ffn, void *stream)
+{
+    if (int rc = check_encoder(S, E, nhead, ffn)) return rc;
+    if (!z || !in_w || !in_b || !out_w || !out_b || !l1_w || !l1_b || !l2_w || !l2_b || !n1_w || !n1_b || !n2_w ||
+        !n2_b || !workspace)
+        return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(z) || !aligned16(workspace) || !aligned16(in_w) || !aligned16(out_w) || !aligned16(l1_w) || !aligned16(l2_w))
+        return fail(OPNET_EINVAL, "z / workspace / weight matrices must be 16-byte aligned");
+    if (workspace_bytes < opseq_encoder_workspace_bytes(S, E, nhead, ffn)) return fail(OPNET_EWORKSPACE, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float *qkv = (float *)workspace;
+    float *att = qkv + (size_t)S * 3 * E;
+    float *proj = att + (size_t)S * E;
+    float *z1 = proj + (size_t)S * E;
+    float *hid = z1 + (size_t)S * E;
+    const int M = (int)S, hd = E / nhead;
+    auto gemm = [&](const float *A, const float *Wt, const float *b, float *C, int N, int K, int act) {
+        gemm_bias_act<<<dim3((M + 63) / 64, (N + 63) / 64, 1), 256, 0, st>>>(A, Wt, b, C, M, N, K, act);
+    };
+    gemm(z, in_w, in_b, qkv, 3 * E, E, 0);
+    attention_f32<<<dim3((M + 63) / 64, nhead, 1), 256, 0, st>>>(qkv, att, M, E, hd, 1.0f / sqrtf((float)hd));
+    gemm(att, out_w, out_b, proj, E, E, 0);
+    add_layernorm<<<(M + 3) / 4, 256, 0, st>>>(z, proj, n1_w, n1_b, z1, M, E, 1e-5f);
+    gemm(z1, l1_w, l1_b, hid, ffn, E, 1);
+    gemm(hid, l2_w, l2_b, proj, E, ffn, 0);
+    add_layernorm<<<(M + 3) / 4, 256, 0, st>>>(z1, proj, n2_w, n2_b, z, M, E, 1e-5f);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

@@ -16,6 +16,8 @@
 
 struct StepArgs {
     int B, T, RB, H1, H2;
+    int mlp;               // 1: OPNetLstmMlp (learned_models.py:55-89) - the video LSTM is replaced by
+                           //    relu(Linear 6->H2): the LSTM2 tiles skip the recurrent product
     int train;             // 0: two-deep parity buffers; 1: full-history buffers (slot t+1 holds step t,
                            //    slot 0 the zero initial state) so the backward pass can read every step
     const float4 *xp;      // [T][RB][24][32]        packed LSTM1 input (also read by the selection head)

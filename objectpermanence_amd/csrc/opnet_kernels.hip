@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
         const int nh = H2 >> 4;
         const KSlice ks = wave_slice(nh);
         const float4 *A = a.w2p + (long)tile * nh * 64;
-        load_a_chunk(a0, A, ks.q0, ks.q1);
+        if (!a.mlp) load_a_chunk(a0, A, ks.q0, ks.q1);
         const int unit = tile * 4 + quarter;
         float4 wv[8];
         if (tid < 128) {
@@ -376,6 +376,21 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
                 xa = x2[0];
                 xb = x2[32];
                 c_old = a.c2[((cslot_prev(a, t) * a.RB + rb) * H2 + unit) * 32 + clip];
+            }
+            if (a.mlp) {
+                // hidden = relu(hidden_layer(frames_boxes)) (learned_models.py:83): no recurrence, the
+                // weight rows sit in the "gate 0" slot of the packed x-part
+                if (tid < 128) {
+                    float xs = wv[0].x * xa.x;
+                    xs = fmaf(wv[0].y, xa.y, xs);
+                    xs = fmaf(wv[0].z, xa.z, xs);
+                    xs = fmaf(wv[0].w, xa.w, xs);
+                    xs = fmaf(wv[1].x, xb.x, xs);
+                    xs = fmaf(wv[1].y, xb.y, xs);
+                    float *hout = (float *)(a.h2buf + (slot_out(a, t) * a.RB + rb) * (H2 * 8));
+                    hout[((long)tile * 32 + clip) * 4 + quarter] = fmaxf(xs, 0.f);
+                }
+                continue;
             }
             gemm16_rb(a0, A, hprev, nh, hprev, ks, part, s);
             __syncthreads();

@@ -1,0 +1,394 @@
+// seq_kernels.hip - generic sequence-model kernels for the sibling reasoners of
+// reference baselines/learned_models.py:92-197 (BaselineLstm, NonLinearLstm, TransformerLstm):
+//   * lstm_stack_step  - L stacked bias-free LSTM layers + a 4-row linear head, one launch per time
+//                        step, layers software-pipelined (layer l runs step s-l), same MFMA tile
+//                        primitive and layouts as opnet_step (opnet_kernels.hip);
+//   * slot_embed_relu  - relu(Linear 5->F) on the per-slot box features (learned_models.py:138,178);
+//   * gemm_bias_act    - C = act(A W^T + b), fp32 MFMA, row-major operands (encoder projections/FFN);
+//   * attention_f32    - softmax(Q K^T / sqrt(hd)) V over ONE sequence of S tokens, flash-style
+//                        (online softmax), fp32 MFMA for both products;
+//   * add_layernorm    - LayerNorm(x + y) (post-LN encoder layer);
+//   * rows_to_packed   - [B][T][K] row-major -> the kq-major row-block layout the step kernels stream.
+// Restated for checking in oracle/opnet_oracle.py (lstm_stack, encoder_layer, ...).
+#include "opnet_ctx.h"
+
+#define SEQ_MAX_LAYERS 3
+
+struct StackLayer {
+    const float4 *A;       // [H/4 tiles][nhx + H/16][64]  A tiles: K = [x part (nhx hexadecets) | h part]
+    int H;                 // hidden size
+    int nhx;               // hexadecets of the x part (input width padded to 16)
+    float4 *hbuf;          // [2 parity][RB][H/4][32]
+    float *c;              // [RB][H][32]
+};
+
+struct StackArgs {
+    int B, T, RB, L;
+    const float4 *xp;      // layer 0 input, packed [T][RB][4*nhx0][32]
+    StackLayer layer[SEQ_MAX_LAYERS];
+    const float4 *headA;   // [H_last/16][64]  4 -> 16 rows
+    float4 *ystage;        // [RB*32][T]
+};
+
+// grid.x = sum_l H_l/4 + 1 ; grid.y <= RB.  Launch s: layer l runs step t = s - l, the head t = s - L.
+__global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs a, const int s)
+{
+    __shared__ __attribute__((aligned(16))) float part[OPNET_NW * 8 * 64];
+    const int tid = threadIdx.x;
+    const int el = tid & 63, half = tid >> 6;
+    const int clip = half * 16 + (el & 15), quarter = el >> 4;
+    float4 a0[OPNET_CH];
+
+    int bx = blockIdx.x;
+    int l = 0;
+    // deepest layer first in block order: it has the longest K when the input is another layer's h
+    for (l = a.L - 1; l >= 0; --l) {
+        const int nt = a.layer[l].H >> 2;
+        if (bx < nt) break;
+        bx -= nt;
+    }
+    if (l >= 0) {
+        const StackLayer &ly = a.layer[l];
+        const int t = s - l;
+        if (t < 0 || t >= a.T) return;
+        const int H = ly.H, nhh = H >> 4, nhx = ly.nhx;
+        const int tile = bx;
+        const KSlice ks = wave_slice(nhx + nhh);
+        const float4 *A = ly.A + (long)tile * (nhx + nhh) * 64;
+        load_a_chunk(a0, A, ks.q0, ks.q1);
+        const int unit = tile * 4 + quarter;
+        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            const float4 *xseg = (l == 0)
+                ? a.xp + ((long)t * a.RB + rb) * ((long)nhx * 128)
+                : a.layer[l - 1].hbuf + ((long)(t & 1) * a.RB + rb) * ((long)a.layer[l - 1].H * 8);
+            const float4 *hprev = ly.hbuf + ((long)((t + 1) & 1) * a.RB + rb) * ((long)H * 8);
+            float c_old = 0.f;
+            if (tid < 128) c_old = ly.c[((long)rb * H + unit) * 32 + clip];
+            gemm16_rb(a0, A, xseg, nhx, hprev, ks, part, s);
+            __syncthreads();
+            if (tid < 128) {
+                float c = c_old;
+                const float h = lstm_cell(part_sum(part, half * 4 + 0, el), part_sum(part, half * 4 + 1, el),
+                                          part_sum(part, half * 4 + 2, el), part_sum(part, half * 4 + 3, el), &c);
+                ly.c[((long)rb * H + unit) * 32 + clip] = c;
+                float *hout = (float *)(ly.hbuf + ((long)(t & 1) * a.RB + rb) * ((long)H * 8));
+                hout[((long)tile * 32 + clip) * 4 + quarter] = h;
+            }
+            if (rb + (int)gridDim.y < a.RB) __syncthreads();
+        }
+    } else {
+        // head: predictions_layer (learned_models.py:101,113 / 137,148 / 172,195)
+        const int t = s - a.L;
+        if (t < 0 || t >= a.T) return;
+        const StackLayer &ly = a.layer[a.L - 1];
+        const int nh = ly.H >> 4;
+        const KSlice ks = wave_slice(nh);
+        load_a_chunk(a0, a.headA, ks.q0, ks.q1);
+        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            const float4 *hcur = ly.hbuf + ((long)(t & 1) * a.RB + rb) * ((long)ly.H * 8);
+            gemm16_rb(a0, a.headA, hcur, nh, hcur, ks, part, s);
+            __syncthreads();
+            if (tid < 128 && quarter == 0) {
+                const long b = rb * 32 + clip;
+                float4 v;
+                v.x = part_sum(part, half * 4 + 0, el);
+                v.y = part_sum(part, half * 4 + 1, el);
+                v.z = part_sum(part, half * 4 + 2, el);
+                v.w = part_sum(part, half * 4 + 3, el);
+                a.ystage[b * a.T + t] = v;
+            }
+            if (rb + (int)gridDim.y < a.RB) __syncthreads();
+        }
+    }
+}
+
+// x [B][T][K] row-major -> xp [t][rb][KP/4][clip][4], K padded with zeros to KP (multiple of 16),
+// clips beyond B zero.  Also zeroes `state` (the recurrent buffers) - first kernel of a forward.
+__global__ void __launch_bounds__(256) rows_to_packed(const float *__restrict__ x, float4 *__restrict__ xp,
+                                                      int B, int T, int RB, int K, int KP,
+                                                      float4 *__restrict__ state, long state_f4)
+{
+    const long stride = (long)gridDim.x * 256;
+    const long gid = blockIdx.x * 256L + threadIdx.x;
+    for (long i = gid; i < state_f4; i += stride) state[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int KQ = KP >> 2;
+    const long n = (long)T * RB * KQ * 32;
+    for (long idx = gid; idx < n; idx += stride) {
+        // consecutive threads walk k within one (t, clip) row: coalesced reads
+        const int kq = idx % KQ;
+        long r = idx / KQ;
+        const int clip = r & 31; r >>= 5;
+        const int rb = r % RB;
+        const int t = r / RB;
+        const int b = rb * 32 + clip;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (b < B) {
+            const float *src = x + ((long)b * T + t) * K + kq * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (kq * 4 + e < K) v[e] = src[e];
+        }
+        xp[(((long)t * RB + rb) * KQ + kq) * 32 + clip] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ystage [RB*32][T] float4 -> y [B][T][4]
+__global__ void __launch_bounds__(256) copy_y_out(const float4 *__restrict__ ys, float4 *__restrict__ y, long n)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = ys[i];
+}
+
+// out[(b*T+t)*nslots_out + slot][f] = relu(sum_k W[f][k] * x[b][t][slot][k]), k < 5
+// nslots_out = 15 (NonLinearLstm, learned_models.py:138) or 1 = slot 0 only (TransformerLstm's live path).
+__global__ void __launch_bounds__(256) slot_embed_relu(const float *__restrict__ x, const float *__restrict__ W,
+                                                       float *__restrict__ out, long ntok, int nslots_out, int F)
+{
+    const long n = ntok * nslots_out * F;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const int f = idx % F;
+        const long ts = idx / F;
+        const int slot = ts % nslots_out;
+        const long tok = ts / nslots_out;
+        const float *xi = x + (tok * 15 + slot) * 5;
+        const float *w = W + (long)f * 5;
+        float acc = w[0] * xi[0];
+        acc = fmaf(w[1], xi[1], acc);
+        acc = fmaf(w[2], xi[2], acc);
+        acc = fmaf(w[3], xi[3], acc);
+        acc = fmaf(w[4], xi[4], acc);
+        out[idx] = fmaxf(acc, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C[M][N] = act(A[M][K] * W[N][K]^T + bias[N])   (row-major fp32; K % 16 == 0)
+// ------------------------------------------------------------------------------------------------
+// Workgroup tile 64 x 64, wave (wm, wn) owns 32 x 32 = 2 x 2 fragments of v_mfma_f32_16x16x4_f32.
+// Both operands are K-contiguous, so a lane's float4 at k = 16q + 4(l>>4) .. +3 of row (l&15) feeds
+// four consecutive MFMAs (the same "hexadecet" trick as the step kernels); no LDS staging - the
+// operands are L2-resident at these sizes (cdna guide, common mistake 7).
+__global__ void __launch_bounds__(256) gemm_bias_act(const float *__restrict__ A, const float *__restrict__ W,
+                                                     const float *__restrict__ bias, float *__restrict__ C,
+                                                     int M, int N, int K, int act)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 64 + (w >> 1) * 32, n0 = blockIdx.y * 64 + (w & 1) * 32;
+    const int i = lane & 15, kk = lane >> 4;
+    const float4 *a_row[2], *w_row[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int m = min(m0 + f * 16 + i, M - 1), nn = min(n0 + f * 16 + i, N - 1);
+        a_row[f] = (const float4 *)(A + (long)m * K) + kk;
+        w_row[f] = (const float4 *)(W + (long)nn * K) + kk;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nhex = K >> 4;
+#pragma unroll 4
+    for (int q = 0; q < nhex; ++q) {
+        const float4 av0 = a_row[0][q * 4], av1 = a_row[1][q * 4];
+        const float4 wv0 = w_row[0][q * 4], wv1 = w_row[1][q * 4];
+        const float ae[2][4] = {{av0.x, av0.y, av0.z, av0.w}, {av1.x, av1.y, av1.z, av1.w}};
+        const float we[2][4] = {{wv0.x, wv0.y, wv0.z, wv0.w}, {wv1.x, wv1.y, wv1.z, wv1.w}};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[x][e], we[y][e], acc[x][y], 0, 0, 0);
+    }
+    // D layout: lane holds column j = l&15, rows 4*(l>>4) + r
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int nn = n0 + y * 16 + i;
+            if (nn >= N) continue;
+            const float b = bias ? bias[nn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + x * 16 + kk * 4 + r;
+                if (m < M) {
+                    float v = acc[x][y][r] + b;
+                    if (act == 1) v = fmaxf(v, 0.f);
+                    C[(long)m * N + nn] = v;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[S][E] = LayerNorm(x + y) * g + b   (nn.LayerNorm: biased variance, eps inside the sqrt)
+// ------------------------------------------------------------------------------------------------
+// one wave per row; E <= 64 * LN_MAX_PER_LANE
+#define LN_MAX_PER_LANE 8
+__global__ void __launch_bounds__(256) add_layernorm(const float *__restrict__ x, const float *__restrict__ y,
+                                                     const float *__restrict__ g, const float *__restrict__ b,
+                                                     float *__restrict__ out, int S, int E, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= S) return;
+    float v[LN_MAX_PER_LANE];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
+        const int e = j * 64 + lane;
+        v[j] = e < E ? x[(long)row * E + e] + y[(long)row * E + e] : 0.f;
+        sum += v[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mu = sum / (float)E;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
+        const int e = j * 64 + lane;
+        const float d = e < E ? v[j] - mu : 0.f;
+        var += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var / (float)E + eps);
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
+        const int e = j * 64 + lane;
+        if (e < E) out[(long)row * E + e] = (v[j] - mu) * rstd * g[e] + b[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention over one sequence: O[s][h*hd + d] = sum_k softmax_k(q_s . k_k / sqrt(hd)) v_k[d]
+// ------------------------------------------------------------------------------------------------
+// qkv [S][3E] (q | k | v), head h uses columns h*hd .. of each third.  hd % 16 == 0, hd <= 128.
+// One wave = 16 queries of one head; a workgroup = 4 waves = 64 queries.  Per block of 16 keys:
+//   S^T[key][query] = K_blk Q^T          (A = K rows, B = Q rows; hd/4 MFMAs of 16x16x4)
+//   online softmax over keys: a lane holds 4 keys (rows 4*(l>>4)+r) of ONE query (column l&15), so the
+//     row statistics are a 4-register reduction plus two cross-group shuffles (xor 16, 32)
+//   O^T[d][query] += V_blk^T P^T         (B = the score registers themselves: MFMA r contracts keys
+//     {r, 4+r, 8+r, 12+r}; A = V read as float4 along d, element e of the float4 -> accumulator e
+//     holding d = 64c + 4i + e)
+// so neither product needs a transpose or an LDS round trip.
+#define ATT_MAX_HEX 8  // hd / 16
+__global__ void __launch_bounds__(256) attention_f32(const float *__restrict__ qkv, float *__restrict__ out,
+                                                     int S, int E, int hd, float scale)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int head = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + w) * 16;
+    if (q0 >= S) return;
+    const int i = lane & 15, kk = lane >> 4;
+    const int nhex = hd >> 4;
+    const int nc = (hd + 63) >> 6;  // 64-wide d chunks
+    const long ld = 3L * E;
+    const float *Qb = qkv + (long)head * hd;
+    const float *Kb = qkv + E + (long)head * hd;
+    const float *Vb = qkv + 2L * E + (long)head * hd;
+
+    // Q fragments (B operand of S^T): lane (query j = i, kk) holds Q[q0+j][16c + 4kk .. +3] * scale
+    float4 qf[ATT_MAX_HEX];
+    {
+        const int qi = min(q0 + i, S - 1);
+        const float4 *qp = (const float4 *)(Qb + (long)qi * ld) + kk;
+#pragma unroll
+        for (int c = 0; c < ATT_MAX_HEX; ++c)
+            if (c < nhex) {
+                float4 v = qp[c * 4];
+                qf[c] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+            }
+    }
+    f32x4 o[2][4];  // [d chunk c][element e] -> rows i' = 4*(l>>4)+r  <->  d = 64c + 4i' + e
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[c][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < S; k0 += 16) {
+        // ---- scores^T for 16 keys ----
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int ki = min(k0 + i, S - 1);
+            const float4 *kp = (const float4 *)(Kb + (long)ki * ld) + kk;
+            float4 kf[ATT_MAX_HEX];
+#pragma unroll
+            for (int c = 0; c < ATT_MAX_HEX; ++c)
+                if (c < nhex) kf[c] = kp[c * 4];
+#pragma unroll
+            for (int c = 0; c < ATT_MAX_HEX; ++c)
+                if (c < nhex) {
+                    sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].x, qf[c].x, sc, 0, 0, 0);
+                    sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].y, qf[c].y, sc, 0, 0, 0);
+                    sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].z, qf[c].z, sc, 0, 0, 0);
+                    sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c].w, qf[c].w, sc, 0, 0, 0);
+                }
+        }
+        // V fragments for this key block, issued before the softmax arithmetic
+        float4 vf[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = min(k0 + 4 * kk + r, S - 1);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (c < nc) {
+                    const int d = 64 * c + 4 * i;
+                    vf[r][c] = d < hd ? *(const float4 *)(Vb + (long)key * ld + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        }
+        // ---- online softmax: this lane holds keys k0 + 4*kk + r of query q0 + i ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (k0 + 4 * kk + r >= S) sc[r] = -INFINITY;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);   // first block: exp(-inf) = 0
+        float p[4], ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p[r] = __expf(sc[r] - m_new);
+            ps += p[r];
+        }
+        ps += __shfl_xor(ps, 16);
+        ps += __shfl_xor(ps, 32);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+        // ---- O^T = O^T * alpha + V^T P^T ----
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (c < nc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[c][e][0] *= alpha; o[c][e][1] *= alpha; o[c][e][2] *= alpha; o[c][e][3] *= alpha;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r][c].x, p[r], o[c][0], 0, 0, 0);
+                    o[c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r][c].y, p[r], o[c][1], 0, 0, 0);
+                    o[c][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r][c].z, p[r], o[c][2], 0, 0, 0);
+                    o[c][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r][c].w, p[r], o[c][3], 0, 0, 0);
+                }
+            }
+    }
+    // ---- normalise and store: lane holds query q0 + i, d = 64c + 4*(4*kk + r) + e ----
+    if (q0 + i < S) {
+        const float inv = 1.0f / l_run;
+        float *op = out + (long)(q0 + i) * E + (long)head * hd;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (c < nc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 64 * c + 4 * (4 * kk + r);
+                    if (d < hd)
+                        *(float4 *)(op + d) = make_float4(o[c][0][r] * inv, o[c][1][r] * inv, o[c][2][r] * inv, o[c][3][r] * inv);
+                }
+    }
+}

@@ -230,3 +230,240 @@ class OPNet(AbstractCaterModel):
                 lib.opnet_plan_destroy(plan)
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------------------------------------
+# sibling reasoners (reference learned_models.py:55-197) - inference through the HIP library
+# ------------------------------------------------------------------------------------------------
+def _require_inference(module: nn.Module, x: torch.Tensor, feat: int):
+    if not x.is_cuda:
+        raise RuntimeError(f"objectpermanence_amd.{type(module).__name__} runs on MI355X only: move the input "
+                           "(and the model) to a ROCm device; there is no CPU fallback")
+    if x.dim() != 4 or x.shape[2] != 15 or x.shape[3] != feat:
+        raise ValueError(f"input must be [B, T, 15, {feat}], got {tuple(x.shape)}")
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise RuntimeError(f"{type(module).__name__}: training through the HIP path is implemented for OPNet only; "
+                           "wrap inference in torch.no_grad()")
+
+
+def _weights_key(ws, dev):
+    return tuple((w.data_ptr(), w._version) for w in ws) + (str(dev),)
+
+
+class _LstmStackRunner:
+    """Packs L stacked LSTM layers + head once per weight version and runs opseq_lstm_stack_forward_f32."""
+
+    def __init__(self, layers: int, kx: int, hidden: int):
+        self.L, self.KX, self.H = layers, kx, hidden
+        self.packed = None
+        self.key = None
+        self.ws = {}
+
+    def run(self, x: torch.Tensor, lstm: "LSTMWeights", head: "LinearWeight") -> torch.Tensor:
+        lib = _lib.load()
+        dev = x.device
+        B, T = int(x.shape[0]), int(x.shape[1])
+        ws_list = [getattr(lstm, f"weight_ih_l{l}") for l in range(self.L)] + \
+                  [getattr(lstm, f"weight_hh_l{l}") for l in range(self.L)] + [head.weight]
+        stream = _stream_ptr(dev)
+        key = _weights_key(ws_list, dev)
+        if self.key != key:
+            for w in ws_list:
+                if w.device != dev or w.dtype != torch.float32 or not w.is_contiguous():
+                    raise RuntimeError("parameters must be contiguous fp32 on the input's device")
+            nbytes = lib.opseq_lstm_stack_packed_bytes(self.L, self.KX, self.H)
+            if nbytes == 0:
+                _lib.check(-2, "opseq_lstm_stack_packed_bytes")
+            if self.packed is None or self.packed.device != dev:
+                self.packed = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            arr = _lib.c_void_p * self.L
+            ih = arr(*[w.data_ptr() for w in ws_list[:self.L]])
+            hh = arr(*[w.data_ptr() for w in ws_list[self.L:2 * self.L]])
+            rc = lib.opseq_lstm_stack_pack_weights_f32(ih, hh, head.weight.data_ptr(), self.packed.data_ptr(), nbytes,
+                                                       self.L, self.KX, self.H, stream)
+            _lib.check(rc, "opseq_lstm_stack_pack_weights_f32")
+            self.key = key
+        wkey = (B, T, str(dev), stream)
+        if wkey not in self.ws:
+            nb = lib.opseq_lstm_stack_workspace_bytes(B, T, self.L, self.KX, self.H)
+            if nb == 0:
+                _lib.check(-2, "opseq_lstm_stack_workspace_bytes")
+            self.ws = {wkey: torch.empty(nb, dtype=torch.uint8, device=dev)}   # keep one shape at a time
+        ws = self.ws[wkey]
+        y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+        rc = lib.opseq_lstm_stack_forward_f32(x.data_ptr(), self.packed.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                              ws.numel(), B, T, self.L, self.KX, self.H, stream)
+        _lib.check(rc, "opseq_lstm_stack_forward_f32")
+        return y
+
+
+class BaselineLstm(AbstractCaterModel):
+    """reference learned_models.py:92-118. forward(x [B,T,15,5]) -> y_boxes [B,T,4]."""
+
+    def __init__(self, config: Dict[str, int]):
+        super().__init__(config)
+        h = config["videos_hidden_dim"]
+        self.video_LSTM = LSTMWeights(self.max_objects_in_frame * self.bb_in_dim, h)
+        self.predictions_layer = LinearWeight(h, self.bb_out_dim)
+        self._runner = _LstmStackRunner(1, self.max_objects_in_frame * self.bb_in_dim, h)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _require_inference(self, x, 5)
+        x = x.contiguous().float()
+        with torch.cuda.device(x.device):
+            return self._runner.run(x.view(x.shape[0], x.shape[1], -1), self.video_LSTM, self.predictions_layer)
+
+
+class NonLinearLstm(AbstractCaterModel):
+    """reference learned_models.py:121-151: relu(Linear 5->F) per slot -> 2-layer LSTM -> Linear."""
+
+    def __init__(self, config: Dict[str, int]):
+        super().__init__(config)
+        f, h = config["boxes_features_dim"], config["videos_hidden_dim"]
+        self.boxes_linear = LinearWeight(self.bb_in_dim, f)
+        self.video_LSTM = LSTMWeights(self.max_objects_in_frame * f, h, num_layers=2)
+        self.predictions_layer = LinearWeight(h, self.bb_out_dim)
+        self._f = f
+        self._runner = _LstmStackRunner(2, self.max_objects_in_frame * f, h)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _require_inference(self, x, 5)
+        lib = _lib.load()
+        x = x.contiguous().float()
+        B, T = int(x.shape[0]), int(x.shape[1])
+        with torch.cuda.device(x.device):
+            feats = torch.empty((B, T, 15 * self._f), dtype=torch.float32, device=x.device)
+            rc = lib.opseq_slot_embed_relu_f32(x.data_ptr(), self.boxes_linear.weight.data_ptr(), feats.data_ptr(),
+                                               B * T, 15, self._f, _stream_ptr(x.device))
+            _lib.check(rc, "opseq_slot_embed_relu_f32")
+            return self._runner.run(feats, self.video_LSTM, self.predictions_layer)
+
+
+class _EncoderLayerWeights(nn.Module):
+    """Parameter holder with nn.TransformerEncoderLayer's parameter names (torch defaults for init)."""
+
+    class _Attn(nn.Module):
+        def __init__(self, e):
+            super().__init__()
+            self.in_proj_weight = nn.Parameter(torch.empty(3 * e, e))
+            self.in_proj_bias = nn.Parameter(torch.zeros(3 * e))
+            self.out_proj = nn.Linear(e, e)      # holder only: never called
+            nn.init.xavier_uniform_(self.in_proj_weight)
+            nn.init.zeros_(self.out_proj.bias)
+
+    def __init__(self, e: int, ffn: int):
+        super().__init__()
+        self.self_attn = self._Attn(e)
+        self.linear1 = nn.Linear(e, ffn)         # holders only: never called
+        self.linear2 = nn.Linear(ffn, e)
+        self.norm1 = nn.LayerNorm(e)
+        self.norm2 = nn.LayerNorm(e)
+
+    def tensors(self):
+        return [self.self_attn.in_proj_weight, self.self_attn.in_proj_bias, self.self_attn.out_proj.weight,
+                self.self_attn.out_proj.bias, self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                self.linear2.bias, self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias]
+
+
+class _EncoderWeights(nn.Module):
+    def __init__(self, e: int, ffn: int, layers: int):
+        super().__init__()
+        self.layers = nn.ModuleList([_EncoderLayerWeights(e, ffn) for _ in range(layers)])
+
+
+class TransformerLstm(AbstractCaterModel):
+    """reference learned_models.py:154-197 (eval mode).  The reference hands [B*T, 15, E] to a
+    sequence-first encoder: attention spans the S = B*T frame axis (all clips of the minibatch,
+    non-causal) independently per slot, and only slot 0 is kept - so only slot 0 is evaluated here
+    (bit-for-bit the same function).  dim_feedforward is torch's default 2048."""
+
+    FFN = 2048
+
+    def __init__(self, config: Dict[str, int]):
+        super().__init__(config)
+        e = config["boxes_features_dim"]
+        self._e, self._nhead = e, config["num_attention_heads"]
+        self._nl = config["num_attention_layers"]
+        h, ll = config["lstm_hidden_dim"], config["num_lstm_layers"]
+        self.boxes_linear = LinearWeight(self.bb_in_dim, e)
+        self.attention_encoder = _EncoderWeights(e, self.FFN, self._nl)
+        self.video_LSTM = LSTMWeights(e, h, num_layers=ll)
+        self.predictions_layer = LinearWeight(h, self.bb_out_dim)
+        self._runner = _LstmStackRunner(ll, e, h)
+        self._ews = None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _require_inference(self, x, 5)
+        if self.training:
+            raise RuntimeError("TransformerLstm: only eval mode is implemented (train mode adds dropout 0.1)")
+        lib = _lib.load()
+        x = x.contiguous().float()
+        B, T = int(x.shape[0]), int(x.shape[1])
+        S, e, dev = B * T, self._e, x.device
+        with torch.cuda.device(dev):
+            stream = _stream_ptr(dev)
+            z = torch.empty((S, e), dtype=torch.float32, device=dev)
+            rc = lib.opseq_slot_embed_relu_f32(x.data_ptr(), self.boxes_linear.weight.data_ptr(), z.data_ptr(), S, 1, e, stream)
+            _lib.check(rc, "opseq_slot_embed_relu_f32")
+            nb = lib.opseq_encoder_workspace_bytes(S, e, self._nhead, self.FFN)
+            if nb == 0:
+                _lib.check(-2, "opseq_encoder_workspace_bytes")
+            if self._ews is None or self._ews.numel() < nb or self._ews.device != dev:
+                self._ews = torch.empty(nb, dtype=torch.uint8, device=dev)
+            for layer in self.attention_encoder.layers:
+                ts = layer.tensors()
+                for t_ in ts:
+                    if t_.device != dev or not t_.is_contiguous() or t_.dtype != torch.float32:
+                        raise RuntimeError("parameters must be contiguous fp32 on the input's device")
+                rc = lib.opseq_encoder_layer_f32(z.data_ptr(), *(t_.data_ptr() for t_ in ts), self._ews.data_ptr(),
+                                                 self._ews.numel(), S, e, self._nhead, self.FFN, stream)
+                _lib.check(rc, "opseq_encoder_layer_f32")
+            return self._runner.run(z.view(B, T, e), self.video_LSTM, self.predictions_layer)
+
+
+class OPNetLstmMlp(AbstractCaterModel):
+    """reference learned_models.py:55-89: OPNet with relu(Linear 6->H2) in place of the video LSTM."""
+
+    def __init__(self, config: Dict[str, int]):
+        super().__init__(config)
+        self.bb_in_dim = 6
+        if config["object_to_track_pred_dim"] != 15:
+            raise ValueError("object_to_track_pred_dim must be 15 (number of object slots)")
+        h1, h2 = config["object_to_track_hidden_dim"], config["videos_hidden_dim"]
+        self.object_to_track_LSTM = LSTMWeights(self.bb_in_dim * 15, h1)
+        self.object_to_track_prediction = LinearWeight(h1, 15)
+        self.hidden_layer = LinearWeight(self.bb_in_dim, h2)
+        self.prediction_layer = LinearWeight(h2, self.bb_out_dim)
+        self._h1, self._h2 = h1, h2
+        self._packed, self._key, self._ws = None, None, {}
+
+    def forward(self, boxes: torch.Tensor):
+        _require_inference(self, boxes, 6)
+        lib = _lib.load()
+        boxes = boxes.contiguous().float()
+        B, T, dev = int(boxes.shape[0]), int(boxes.shape[1]), boxes.device
+        ws_list = [self.object_to_track_LSTM.weight_ih_l0, self.object_to_track_LSTM.weight_hh_l0,
+                   self.object_to_track_prediction.weight, self.hidden_layer.weight, self.prediction_layer.weight]
+        with torch.cuda.device(dev):
+            stream = _stream_ptr(dev)
+            key = _weights_key(ws_list, dev)
+            if self._key != key:
+                nbytes = lib.opnet_packed_weights_bytes(self._h1, self._h2)
+                if nbytes == 0:
+                    _lib.check(-2, "opnet_packed_weights_bytes")
+                if self._packed is None or self._packed.device != dev:
+                    self._packed = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
+                rc = lib.opnet_mlp_pack_weights_f32(*(w.data_ptr() for w in ws_list), self._packed.data_ptr(), nbytes,
+                                                    self._h1, self._h2, stream)
+                _lib.check(rc, "opnet_mlp_pack_weights_f32")
+                self._key = key
+            wkey = (B, T, str(dev), stream)
+            if wkey not in self._ws:
+                self._ws = {wkey: torch.empty(lib.opnet_workspace_bytes(B, T, self._h1, self._h2), dtype=torch.uint8, device=dev)}
+            ws = self._ws[wkey]
+            y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+            logits = torch.empty((B, 15, T), dtype=torch.float32, device=dev)
+            rc = lib.opnet_mlp_forward_f32(boxes.data_ptr(), self._packed.data_ptr(), y.data_ptr(), logits.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), B, T, self._h1, self._h2, stream)
+            _lib.check(rc, "opnet_mlp_forward_f32")
+        return y, logits

@@ -9,6 +9,14 @@ import torch
 from . import learned_models as lm
 
 _REGISTRY = {
+    "baseline_lstm": "BaselineLstm",
+    "baseline_lstm_no_labels": "BaselineLstm",
+    "non_linear_lstm": "NonLinearLstm",
+    "non_linear_lstm_no_labels": "NonLinearLstm",
+    "transformer_lstm": "TransformerLstm",
+    "transformer_lstm_no_labels": "TransformerLstm",
+    "opnet_lstm_mlp": "OPNetLstmMlp",
+    "opnet_lstm_mlp_no_labels": "OPNetLstmMlp",
     "opnet": "OPNet",
     # the reference registers the no-labels variant under the misspelt key "opent_no_labels"
     # (models_factory.py:64) while argparse offers "opnet_no_labels" (supported_models.py:12), so the

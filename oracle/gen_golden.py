@@ -120,7 +120,7 @@ def gen_siblings(lm):
             out[f"{name}/{tag}/shape"] = np.array([n, t])
             print(f"{name}/{tag}: y range [{float(y.min()):.3f}, {float(y.max()):.3f}]")
     # transformer_lstm: tiny, the JSON config (2 heads) at B=1 and B=2 (batch coupling), BASELINE's 4 heads
-    tcases = [("tiny", {"boxes_features_dim": 16, "num_attention_heads": 2, "num_attention_layers": 2,
+    tcases = [("tiny", {"boxes_features_dim": 32, "num_attention_heads": 2, "num_attention_layers": 2,
                         "num_lstm_layers": 2, "lstm_hidden_dim": 32}, 2, 6),
               ("real_b1", None, 1, 300), ("real_b2", None, 2, 300), ("heads4_b1", "h4", 1, 300)]
     with open(os.path.join(REF, "configs", "transformer_lstm_model_config.json")) as f:
