@@ -133,6 +133,24 @@ int opseq_encoder_layer_f32(float *z, const float *in_w, const float *in_b, cons
                             const float *n2_b, void *workspace, size_t workspace_bytes, long S, int E,
                             int nhead, int ffn, void *stream);
 
+/* ---- detector backbone primitives (torchvision fasterrcnn_resnet50_fpn built at
+ *      object_detection/models.py:6-20, called at baselines/detector.py:71-86).  fp32, NHWC.  The
+ *      network's arithmetic is torchvision 0.5.0's (not vendored): parity with the reference detector is
+ *      UNPINNED; these are checked against oracle/detector_oracle.py (build-authored torch restatement).
+ * conv: y[n,oy,ox,co] = act(sum x[n,oy*s-p+dy,ox*s-p+dx,ci] w[co][(dy*KW+dx)*Cin+ci] + bias[co] (+ residual)),
+ *       w rows padded with zeros to KP (multiple of 16); Cin multiple of 4; frozen BatchNorm pre-folded. */
+int opdet_conv2d_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,
+                     int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int KP,
+                     int relu, void *stream);
+int opdet_maxpool3x3s2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
+int opdet_subsample2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
+int opdet_upsample_add_f32(const float *lateral, const float *top, float *y, int N, int H, int W, int C,
+                           int TH, int TW, void *stream);
+/* frame_bgr: DEVICE uint8 [H,W,3]; mean/std: HOST float[3] (RGB). BGR->RGB, /256 (detector.py:75-76), normalise,
+ * bilinear resize (align_corners=False) to [RH,RW], zero-pad to [PH,PW], 4 channels (4th = 0). */
+int opdet_preprocess_frame_f32(const unsigned char *frame_bgr, float *y, int H, int W, int RH, int RW, int PH,
+                               int PW, const float *mean3_host, const float *std3_host, void *stream);
+
 /* ---- output post-processing + metric (replaces inference_main.py:219 and
  *      tracking_utils.py:137-159,251-256,278-288) ------------------------------------------------
  * y, labels [N, T, 4] fp32 normalised -> pred_px, gt_px [N, T, 4] int32 (float64 multiply by

@@ -74,6 +74,17 @@ def _declare(lib):
     lib.opseq_encoder_workspace_bytes.argtypes = [ctypes.c_long, c_int, c_int, c_int]
     lib.opseq_encoder_layer_f32.restype = c_int
     lib.opseq_encoder_layer_f32.argtypes = [fp] * 13 + [c_void_p, c_size_t, ctypes.c_long, c_int, c_int, c_int, c_void_p]
+    lib.opdet_conv2d_f32.restype = c_int
+    lib.opdet_conv2d_f32.argtypes = [fp, fp, fp, fp, fp] + [c_int] * 11 + [c_void_p]
+    lib.opdet_maxpool3x3s2_f32.restype = c_int
+    lib.opdet_maxpool3x3s2_f32.argtypes = [fp, fp, c_int, c_int, c_int, c_int, c_void_p]
+    lib.opdet_subsample2_f32.restype = c_int
+    lib.opdet_subsample2_f32.argtypes = [fp, fp, c_int, c_int, c_int, c_int, c_void_p]
+    lib.opdet_upsample_add_f32.restype = c_int
+    lib.opdet_upsample_add_f32.argtypes = [fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.opdet_preprocess_frame_f32.restype = c_int
+    lib.opdet_preprocess_frame_f32.argtypes = [fp, fp, c_int, c_int, c_int, c_int, c_int, c_int,
+                                               POINTER(c_float), POINTER(c_float), c_void_p]
     lib.opnet_postprocess_iou.restype = c_int
     lib.opnet_postprocess_iou.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_void_p]
 
@@ -88,11 +99,14 @@ EXPORTS = [
     "opseq_lstm_stack_packed_bytes", "opseq_lstm_stack_workspace_bytes", "opseq_lstm_stack_pack_weights_f32",
     "opseq_lstm_stack_forward_f32", "opseq_slot_embed_relu_f32", "opseq_encoder_workspace_bytes",
     "opseq_encoder_layer_f32",
+    "opdet_conv2d_f32", "opdet_maxpool3x3s2_f32", "opdet_subsample2_f32", "opdet_upsample_add_f32",
+    "opdet_preprocess_frame_f32",
 ]
 
 
 def lib_path() -> str:
-    return _build.LIB
+    # OPNET_HIP_LIB: load another build of the same ABI (kernel-variant experiments, tools/)
+    return os.environ.get("OPNET_HIP_LIB") or _build.LIB
 
 
 def load():

@@ -1,0 +1,191 @@
+// conv_kernels.hip - convolution path of the detector backbone (torchvision
+// fasterrcnn_resnet50_fpn as built at reference object_detection/models.py:6-20 and called per frame at
+// baselines/detector.py:71-86).  fp32, NHWC activations, implicit GEMM on v_mfma_f32_16x16x4_f32.
+//
+// The arithmetic of the network itself lives in torchvision 0.5.0, which is neither under
+// /root/reference nor installed: these kernels are checked against a build-authored torch restatement
+// (oracle/detector_oracle.py) - parity with the reference's detector is UNPINNED.
+//
+//   conv2d_nhwc      Y[p][co] = act( sum_{tap,ci} X[pix(p,tap)][ci] * W[co][tap][ci] + bias[co] (+ R[p][co]) )
+//                    GEMM view: M = N*OH*OW pixels, N = Cout, K = KH*KW*Cin with k = tap*Cin + ci, so
+//                    both operands are K-contiguous and one float4 per lane at k = 16q + 4(l>>4) feeds four
+//                    consecutive MFMAs (the step kernels' "hexadecet" trick).  Cin % 4 == 0: for the stem
+//                    (Cin = 3 -> 4) a float4 is one tap's channels, for Cin >= 16 a hexadecet lies in one
+//                    tap.  Zero padding = masked loads.  BatchNorm (frozen) is folded into W / bias on load.
+//   maxpool3x3s2     ResNet stem pool (kernel 3, stride 2, pad 1)
+//   subsample2       FPN LastLevelMaxPool (kernel 1, stride 2)
+//   upsample_add     FPN top-down: Y = lateral + nearest_upsample(top) to lateral's size
+//   preprocess_frame detector.py:74-80 (BGR->RGB, /256) + GeneralizedRCNNTransform (normalize, bilinear
+//                    resize align_corners=False, zero pad) -> NHWC with C = 4 (4th channel 0)
+#include <hip/hip_runtime.h>
+
+struct ConvArgs {
+    const float *X;     // [N][H][W][Cin]
+    const float *Wt;    // [Cout][KP]  KP = K padded to a multiple of 16, k = (dy*KW + dx)*Cin + ci
+    const float *bias;  // [Cout]
+    const float *R;     // residual [N][OH][OW][Cout] or null
+    float *Y;           // [N][OH][OW][Cout]
+    int N, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, KP, relu;
+};
+
+__global__ void __launch_bounds__(256) conv2d_nhwc(const ConvArgs a)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    const long M = (long)a.N * a.OH * a.OW;
+    const long m0 = (long)blockIdx.x * 64 + (w >> 1) * 32;
+    const int n0 = blockIdx.y * 64 + (w & 1) * 32;
+    const int K = a.KH * a.KW * a.Cin;
+    // this lane's two A rows (output pixels) and two B rows (output channels)
+    int iy0[2], ix0[2];
+    const float *xn[2];
+    bool pv[2];
+    const float4 *w_row[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        long p = m0 + f * 16 + i;
+        pv[f] = p < M;
+        if (!pv[f]) p = M - 1;
+        const int ox = p % a.OW;
+        const long t = p / a.OW;
+        const int oy = t % a.OH;
+        const int n = t / a.OH;
+        iy0[f] = oy * a.stride - a.pad;
+        ix0[f] = ox * a.stride - a.pad;
+        xn[f] = a.X + (long)n * a.H * a.W * a.Cin;
+        const int co = min(n0 + f * 16 + i, a.Cout - 1);
+        w_row[f] = (const float4 *)(a.Wt + (long)co * a.KP) + kk;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nhex = a.KP >> 4;
+    for (int q = 0; q < nhex; ++q) {
+        const int k4 = 16 * q + 4 * kk;           // this lane's 4 consecutive k
+        const int tap = k4 / a.Cin, c = k4 - tap * a.Cin;
+        const int dy = tap / a.KW, dx = tap - dy * a.KW;
+        float4 av[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int y = iy0[f] + dy, x = ix0[f] + dx;
+            const bool ok = k4 < K && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            av[f] = ok ? *(const float4 *)(xn[f] + ((long)y * a.W + x) * a.Cin + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float4 wv0 = w_row[0][q * 4], wv1 = w_row[1][q * 4];
+        const float ae[2][4] = {{av[0].x, av[0].y, av[0].z, av[0].w}, {av[1].x, av[1].y, av[1].z, av[1].w}};
+        const float we[2][4] = {{wv0.x, wv0.y, wv0.z, wv0.w}, {wv1.x, wv1.y, wv1.z, wv1.w}};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[x][e], we[y][e], acc[x][y], 0, 0, 0);
+    }
+    // D layout: lane holds column j = l&15 (output channel), rows 4*(l>>4) + r (pixels)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int co = n0 + y * 16 + i;
+            if (co >= a.Cout) continue;
+            const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long p = m0 + x * 16 + kk * 4 + r;
+                if (p < M) {
+                    float v = acc[x][y][r] + b;
+                    if (a.R) v += a.R[p * a.Cout + co];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.Y[p * a.Cout + co] = v;
+                }
+            }
+        }
+}
+
+__global__ void __launch_bounds__(256) maxpool3x3s2(const float *__restrict__ X, float *__restrict__ Y, int N,
+                                                    int H, int W, int C, int OH, int OW)
+{
+    const long n_out = (long)N * OH * OW * C;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n_out; idx += (long)gridDim.x * 256) {
+        const int c = idx % C;
+        long t = idx / C;
+        const int ox = t % OW; t /= OW;
+        const int oy = t % OH;
+        const int n = t / OH;
+        float m = -INFINITY;
+        for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) {
+                const int y = oy * 2 - 1 + dy, x = ox * 2 - 1 + dx;
+                if (y >= 0 && y < H && x >= 0 && x < W) m = fmaxf(m, X[(((long)n * H + y) * W + x) * C + c]);
+            }
+        Y[idx] = m;
+    }
+}
+
+__global__ void __launch_bounds__(256) subsample2(const float *__restrict__ X, float *__restrict__ Y, int N, int H,
+                                                  int W, int C, int OH, int OW)
+{
+    const long n_out = (long)N * OH * OW * C;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n_out; idx += (long)gridDim.x * 256) {
+        const int c = idx % C;
+        long t = idx / C;
+        const int ox = t % OW; t /= OW;
+        const int oy = t % OH;
+        const int n = t / OH;
+        Y[idx] = X[(((long)n * H + oy * 2) * W + ox * 2) * C + c];
+    }
+}
+
+// Y[n][y][x][c] = L[n][y][x][c] + T[n][floor(y*TH/H)][floor(x*TW/W)][c]   (F.interpolate nearest to L's size)
+__global__ void __launch_bounds__(256) upsample_add(const float *__restrict__ L, const float *__restrict__ T,
+                                                    float *__restrict__ Y, int N, int H, int W, int C, int TH, int TW)
+{
+    const long n_out = (long)N * H * W * C;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n_out; idx += (long)gridDim.x * 256) {
+        const int c = idx % C;
+        long t = idx / C;
+        const int x = t % W; t /= W;
+        const int y = t % H;
+        const int n = t / H;
+        const int ty = min((int)(((long)y * TH) / H), TH - 1), tx = min((int)(((long)x * TW) / W), TW - 1);
+        Y[idx] = L[idx] + T[(((long)n * TH + ty) * TW + tx) * C + c];
+    }
+}
+
+// frame uint8 [H][W][3] BGR  ->  Y [PH][PW][4] fp32: ch c<3 = (rgb_c/256 - mean_c)/std_c resized bilinearly
+// (align_corners = False, source index (dst + 0.5)/scale - 0.5 clamped at 0) to [RH][RW], zero outside.
+__global__ void __launch_bounds__(256) preprocess_frame(const unsigned char *__restrict__ frame, float *__restrict__ Y,
+                                                        int H, int W, int RH, int RW, int PH, int PW, float inv_sy,
+                                                        float inv_sx, float m0, float m1, float m2, float s0, float s1,
+                                                        float s2)
+{
+    const long n_out = (long)PH * PW;
+    const float mean[3] = {m0, m1, m2}, istd[3] = {1.0f / s0, 1.0f / s1, 1.0f / s2};
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n_out; idx += (long)gridDim.x * 256) {
+        const int x = idx % PW, y = idx / PW;
+        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y < RH && x < RW) {
+            const float fy = fmaxf(((float)y + 0.5f) * inv_sy - 0.5f, 0.f);
+            const float fx = fmaxf(((float)x + 0.5f) * inv_sx - 0.5f, 0.f);
+            const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+            const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            float v[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int cb = 2 - c;  // BGR -> RGB (cv2.COLOR_BGR2RGB, detector.py:75)
+                auto px = [&](int yy, int xx) {
+                    return ((float)frame[((long)yy * W + xx) * 3 + cb] / 256.0f - mean[c]) * istd[c];
+                };
+                const float top = px(y0, x0) * (1.f - lx) + px(y0, x1) * lx;
+                const float bot = px(y1, x0) * (1.f - lx) + px(y1, x1) * lx;
+                v[c] = top * (1.f - ly) + bot * ly;
+            }
+            out = make_float4(v[0], v[1], v[2], 0.f);
+        }
+        ((float4 *)Y)[idx] = out;
+    }
+}

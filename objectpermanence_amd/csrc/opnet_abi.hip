@@ -3,6 +3,7 @@
 #include "opnet_kernels.hip"
 #include "opnet_train_kernels.hip"
 #include "seq_kernels.hip"
+#include "conv_kernels.hip"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -792,6 +793,74 @@ extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float 
     gemm(z1, l1_w, l1_b, hid, ffn, E, 1);
     gemm(hid, l2_w, l2_b, proj, E, ffn, 0);
     add_layernorm<<<(M + 3) / 4, 256, 0, st>>>(z1, proj, n2_w, n2_b, z, M, E, 1e-5f);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// detector backbone primitives (NHWC fp32)
+// ------------------------------------------------------------------------------------------------
+static unsigned ew_blocks(long n) { return (unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256); }
+
+extern "C" int opdet_conv2d_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,
+                                int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int KP,
+                                int relu, void *stream)
+{
+    if (!x || !w || !y) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return fail(OPNET_EINVAL, "x / w / y must be 16-byte aligned");
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+        return fail(OPNET_ESHAPE, "bad conv shape (Cin must be a multiple of 4)");
+    if ((KP & 15) || KP < KH * KW * Cin) return fail(OPNET_ESHAPE, "KP=%d must be a multiple of 16 >= KH*KW*Cin=%d", KP, KH * KW * Cin);
+    ConvArgs a;
+    a.X = x; a.Wt = w; a.bias = bias; a.R = residual; a.Y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.OH = (H + 2 * pad - KH) / stride + 1;
+    a.OW = (W + 2 * pad - KW) / stride + 1;
+    a.KP = KP; a.relu = relu;
+    if (a.OH <= 0 || a.OW <= 0) return fail(OPNET_ESHAPE, "empty conv output");
+    const long M = (long)N * a.OH * a.OW;
+    conv2d_nhwc<<<dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, 1), 256, 0, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opdet_maxpool3x3s2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream)
+{
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(OPNET_EINVAL, "bad argument");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    maxpool3x3s2<<<ew_blocks((long)N * OH * OW * C), 256, 0, (hipStream_t)stream>>>(x, y, N, H, W, C, OH, OW);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opdet_subsample2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream)
+{
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(OPNET_EINVAL, "bad argument");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    subsample2<<<ew_blocks((long)N * OH * OW * C), 256, 0, (hipStream_t)stream>>>(x, y, N, H, W, C, OH, OW);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opdet_upsample_add_f32(const float *lateral, const float *top, float *y, int N, int H, int W, int C,
+                                      int TH, int TW, void *stream)
+{
+    if (!lateral || !top || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || TH <= 0 || TW <= 0)
+        return fail(OPNET_EINVAL, "bad argument");
+    upsample_add<<<ew_blocks((long)N * H * W * C), 256, 0, (hipStream_t)stream>>>(lateral, top, y, N, H, W, C, TH, TW);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opdet_preprocess_frame_f32(const unsigned char *frame_bgr, float *y, int H, int W, int RH, int RW,
+                                          int PH, int PW, const float *mean3_host, const float *std3_host, void *stream)
+{
+    if (!frame_bgr || !y || !mean3_host || !std3_host) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(y)) return fail(OPNET_EINVAL, "y must be 16-byte aligned");
+    if (H <= 0 || W <= 0 || RH <= 0 || RW <= 0 || PH < RH || PW < RW) return fail(OPNET_ESHAPE, "bad sizes");
+    preprocess_frame<<<ew_blocks((long)PH * PW), 256, 0, (hipStream_t)stream>>>(
+        frame_bgr, y, H, W, RH, RW, PH, PW, (float)H / (float)RH, (float)W / (float)RW, mean3_host[0], mean3_host[1],
+        mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

@@ -177,7 +177,9 @@ __global__ void __launch_bounds__(256) opnet_copy_out(const OpnetIO *__restrict_
 // A workgroup that serves several row blocks keeps its A fragments (the weights) in registers
 // across them when its K slice fits one chunk (true for H1=256/H2=512: 4..8 hexadecets a wave).
 // part layout in LDS: [wave][acc reg 0..7][lane]; acc regs 0..3 = clips 0..15, 4..7 = clips 16..31.
+#ifndef OPNET_CH
 #define OPNET_CH 8
+#endif
 
 struct KSlice {
     int q0, q1;  // this wave's hexadecet range (wave-uniform)

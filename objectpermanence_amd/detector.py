@@ -1,0 +1,175 @@
+"""Detector front-end on MI355X - mirror of reference baselines/detector.py (CaterObjectDetector) and
+object_detection/models.py:6-20 for the part that is built: frame preprocessing + the ResNet-50-FPN
+backbone of torchvision's fasterrcnn_resnet50_fpn, as hand-written HIP conv kernels (conv_kernels.hip).
+
+PARITY UNPINNED: torchvision 0.5.0 and the fine-tuned weights are absent, so the
+kernels are checked against a build-authored torch restatement (oracle/detector_oracle.py), not against
+the reference's detector.  The RPN, RoIAlign and box heads are NOT built: ``CaterObjectDetector.__call__``
+raises; ``backbone_features`` returns the five FPN maps; the score filter of detector.py:14-28 is provided.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+_LAYERS = (3, 4, 6, 3)
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _Conv:
+    """one conv (+ folded FrozenBatchNorm) packed for opdet_conv2d_f32: weight [Cout][KP], k = (dy*KW+dx)*Cin + ci"""
+
+    def __init__(self, sd, wname: str, bn: str = None, bias: str = None, stride=1, pad=0, bn_eps=0.0, device="cuda:0"):
+        w = torch.as_tensor(sd[wname], dtype=torch.float32)
+        cout, cin, kh, kw = w.shape
+        b = torch.zeros(cout) if bias is None else torch.as_tensor(sd[bias], dtype=torch.float32).clone()
+        if bn is not None:
+            g, beta = torch.as_tensor(sd[bn + ".weight"]).float(), torch.as_tensor(sd[bn + ".bias"]).float()
+            rm, rv = torch.as_tensor(sd[bn + ".running_mean"]).float(), torch.as_tensor(sd[bn + ".running_var"]).float()
+            scale = g / torch.sqrt(rv + bn_eps)
+            w = w * scale[:, None, None, None]
+            b = beta - rm * scale
+        cin_p = (cin + 3) // 4 * 4                     # stem: 3 -> 4 channels
+        wp = torch.zeros((cout, kh, kw, cin_p))
+        wp[..., :cin] = w.permute(0, 2, 3, 1)
+        k = kh * kw * cin_p
+        self.kp = (k + 15) // 16 * 16
+        packed = torch.zeros((cout, self.kp))
+        packed[:, :k] = wp.reshape(cout, k)
+        self.w = packed.contiguous().to(device)
+        self.b = b.contiguous().to(device)
+        self.cin, self.cout, self.kh, self.kw, self.stride, self.pad = cin_p, cout, kh, kw, stride, pad
+
+    def __call__(self, x: torch.Tensor, relu: bool, residual: torch.Tensor = None) -> torch.Tensor:
+        lib = _lib.load()
+        n, h, w, c = x.shape
+        assert c == self.cin, (c, self.cin)
+        oh = (h + 2 * self.pad - self.kh) // self.stride + 1
+        ow = (w + 2 * self.pad - self.kw) // self.stride + 1
+        y = torch.empty((n, oh, ow, self.cout), dtype=torch.float32, device=x.device)
+        rc = lib.opdet_conv2d_f32(x.data_ptr(), self.w.data_ptr(), self.b.data_ptr(),
+                                  None if residual is None else residual.data_ptr(), y.data_ptr(), n, h, w, c,
+                                  self.cout, self.kh, self.kw, self.stride, self.pad, self.kp, int(relu), _stream(x.device))
+        _lib.check(rc, "opdet_conv2d_f32")
+        return y
+
+
+class ResNet50FPNBackbone:
+    """model.backbone of fasterrcnn_resnet50_fpn (BackboneWithFPN): NHWC fp32 in, five 256-channel maps out."""
+
+    def __init__(self, state_dict: Dict[str, np.ndarray], device="cuda:0", bn_eps: float = 0.0):
+        sd, dev = state_dict, device
+        b = "backbone.body."
+        mk = lambda *a, **k: _Conv(sd, *a, bn_eps=bn_eps, device=dev, **k)
+        self.stem = mk(b + "conv1.weight", bn=b + "bn1", stride=2, pad=3)
+        self.blocks: List[List[Tuple]] = []
+        for li, nblocks in enumerate(_LAYERS, start=1):
+            layer = []
+            for blk in range(nblocks):
+                p = f"{b}layer{li}.{blk}"
+                stride = 2 if (blk == 0 and li > 1) else 1
+                c1 = mk(p + ".conv1.weight", bn=p + ".bn1")
+                c2 = mk(p + ".conv2.weight", bn=p + ".bn2", stride=stride, pad=1)     # stride on the 3x3 ("v1.5")
+                c3 = mk(p + ".conv3.weight", bn=p + ".bn3")
+                ds = mk(p + ".downsample.0.weight", bn=p + ".downsample.1", stride=stride) if blk == 0 else None
+                layer.append((c1, c2, c3, ds))
+            self.blocks.append(layer)
+        f = "backbone.fpn."
+        self.inner = [mk(f + f"inner_blocks.{i}.weight", bias=f + f"inner_blocks.{i}.bias") for i in range(4)]
+        self.outer = [mk(f + f"layer_blocks.{i}.weight", bias=f + f"layer_blocks.{i}.bias", pad=1) for i in range(4)]
+        self.device = torch.device(device)
+
+    def forward_nhwc(self, x: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
+        lib = _lib.load()
+        st = _stream(x.device)
+        x = self.stem(x, relu=True)
+        n, h, w, c = x.shape
+        y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
+        _lib.check(lib.opdet_maxpool3x3s2_f32(x.data_ptr(), y.data_ptr(), n, h, w, c, st), "opdet_maxpool3x3s2_f32")
+        x = y
+        feats = []
+        for layer in self.blocks:
+            for c1, c2, c3, ds in layer:
+                idt = x if ds is None else ds(x, relu=False)
+                out = c2(c1(x, relu=True), relu=True)
+                x = c3(out, relu=True, residual=idt)          # relu(bn3(conv3) + identity) fused in the epilogue
+            feats.append(x)
+        last = self.inner[3](feats[3], relu=False)
+        results = [self.outer[3](last, relu=False)]
+        for i in (2, 1, 0):
+            lat = self.inner[i](feats[i], relu=False)
+            n, h, w, c = lat.shape
+            merged = torch.empty_like(lat)
+            _lib.check(lib.opdet_upsample_add_f32(lat.data_ptr(), last.data_ptr(), merged.data_ptr(), n, h, w, c,
+                                                  last.shape[1], last.shape[2], st), "opdet_upsample_add_f32")
+            last = merged
+            results.insert(0, self.outer[i](last, relu=False))
+        top = results[-1]
+        n, h, w, c = top.shape
+        pool = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=top.device)
+        _lib.check(lib.opdet_subsample2_f32(top.data_ptr(), pool.data_ptr(), n, h, w, c, st), "opdet_subsample2_f32")
+        results.append(pool)
+        return OrderedDict(zip(["0", "1", "2", "3", "pool"], results))
+
+
+def preprocess_frame(frame_bgr: np.ndarray, device="cuda:0", min_size: int = 800, max_size: int = 1333) -> torch.Tensor:
+    """uint8 [H,W,3] BGR frame (cv2 order, detector.py:71) -> NHWC fp32 [1,PH,PW,4] on the device."""
+    if frame_bgr.dtype != np.uint8 or frame_bgr.ndim != 3 or frame_bgr.shape[2] != 3:
+        raise ValueError("frame must be uint8 [H, W, 3] (BGR)")
+    lib = _lib.load()
+    h, w = frame_bgr.shape[:2]
+    scale = min(float(min_size) / min(h, w), float(max_size) / max(h, w))
+    rh, rw = int(np.floor(h * scale)), int(np.floor(w * scale))
+    ph, pw = (rh + 31) // 32 * 32, (rw + 31) // 32 * 32
+    dev = torch.device(device)
+    fr = torch.from_numpy(np.ascontiguousarray(frame_bgr)).to(dev)
+    y = torch.empty((1, ph, pw, 4), dtype=torch.float32, device=dev)
+    mean = (ctypes.c_float * 3)(*IMAGENET_MEAN)
+    std = (ctypes.c_float * 3)(*IMAGENET_STD)
+    with torch.cuda.device(dev):
+        rc = lib.opdet_preprocess_frame_f32(fr.data_ptr(), y.data_ptr(), h, w, rh, rw, ph, pw, mean, std, _stream(dev))
+    _lib.check(rc, "opdet_preprocess_frame_f32")
+    return y
+
+
+class CaterObjectDetector(object):
+    """reference baselines/detector.py:11-86."""
+
+    @staticmethod
+    def remove_low_probability_object(model_output: dict, accuracy_threshold: float = 0.8) -> dict:
+        """detector.py:14-28: keep the first k rows, k = count(scores >= threshold) - relies on the
+        detector returning scores in descending order."""
+        scores = model_output["scores"]
+        k = int(torch.sum((scores >= accuracy_threshold)).item())
+        return {"boxes": model_output["boxes"][:k, :], "labels": model_output["labels"][:k], "scores": scores[:k]}
+
+    def __init__(self, saved_detector_path, class_names_to_indices: dict = None):
+        self.saved_detector_path = saved_detector_path
+        self.num_classes = 193
+        self.indices_to_names = {i: n for n, i in (class_names_to_indices or {}).items()}
+        self.backbone: ResNet50FPNBackbone = None
+
+    def load_model(self, compute_device: torch.device) -> None:
+        saved = torch.load(self.saved_detector_path, map_location="cpu")          # detector.py:61-63
+        self.backbone = ResNet50FPNBackbone(saved["model_state_dict"], device=compute_device)
+
+    def backbone_features(self, frame: np.ndarray, compute_device: torch.device) -> "OrderedDict[str, torch.Tensor]":
+        x = preprocess_frame(frame, compute_device)
+        with torch.cuda.device(x.device):
+            return self.backbone.forward_nhwc(x)
+
+    def __call__(self, frame: np.ndarray, compute_device: torch.device):
+        raise NotImplementedError(
+            "the RPN / RoIAlign / box heads of fasterrcnn_resnet50_fpn are not built (their arithmetic is "
+            "torchvision 0.5.0's, absent here, so parity could not be pinned); use backbone_features()")

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported():
     lib = _lib()
     hdr = open(os.path.join(REPO, "include", "opnet_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(op(?:net|seq)_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(op(?:net|seq|det)_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(binding.EXPORTS)
     for name in declared:
