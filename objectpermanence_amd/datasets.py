@@ -1,0 +1,237 @@
+"""Input encoding of the reasoners: `<video>.pkl` + `<video>_bb.json` -> model tensors.
+
+Mirror of reference baselines/datasets.py (dataset classes, same names and __getitem__ tuples) and
+datasets_factory.py.  The reference encodes a clip with nested Python loops and cmp_to_key sorts
+(16.7 ms/clip); here the slot assignment is vectorised with numpy:
+
+  slot order   = the video's distinct class ids, snitch (140) first then ascending (datasets.py:47-54,
+                 :271-274), truncated to 15 slots (:291-292);
+  slot content = the FIRST occurrence (in the frame's original order) of that class id in the frame
+                 (a stable sort + "skip repeated id" walk, :294-309, selects exactly that; for a repeated
+                 snitch id the reference's inconsistent comparator selects the LAST one instead), as
+                 [x1,y1,x2,y2,1(,is_cone)]; a missing object is all zeros, except that a missing cone keeps
+                 its cone bit (:311-318); then divide by [320,240,320,240,1(,1)] in float64 and cast to fp32.
+
+Results are bit-identical to the reference's (tests/test_datasets.py vs tests/golden/datasets.npz).
+The heuristic "object to track" index vector (:199-257, :338-416) is sequential by nature and is restated
+as a small state machine; no loss uses it but it is part of the dataset tuple.
+"""
+from __future__ import annotations
+
+import json
+import pickle
+from pathlib import Path
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from .object_indices import CONE_IDS, SNITCH_INDEX
+from .supported_models import TRAINING_SUPPORTED_MODELS_5_TRACKS, TRAINING_SUPPORTED_MODELS_6_TRACKS
+
+SNITCH_NAME = "small_gold_spl_metal_Spl_0"
+VIDEO_NUM_FRAMES = 300
+MAX_OBJECTS = 15
+FRAME_SHAPES = np.array([320, 240, 320, 240], dtype=np.float64)
+
+
+def slot_order(labels: List[np.ndarray]) -> List[int]:
+    ids = set()
+    for frame in labels:
+        ids.update(int(v) for v in np.asarray(frame).reshape(-1))
+    rest = sorted(i for i in ids if i != SNITCH_INDEX)
+    return ([SNITCH_INDEX] if SNITCH_INDEX in ids else []) + rest
+
+
+def encode_boxes(bb: List[np.ndarray], labels: List[np.ndarray], n_tracks: int = 6) -> np.ndarray:
+    """-> float64 [T, 15, n_tracks] normalised boxes (cast to float32 by the caller, like the reference)."""
+    T = len(labels)
+    order = slot_order(labels)[:MAX_OBJECTS]
+    out = np.zeros((T, MAX_OBJECTS, n_tracks), dtype=np.float64)
+    if n_tracks == 6:
+        for s, oid in enumerate(order):
+            out[:, s, 5] = 1.0 if oid in CONE_IDS else 0.0        # a cone slot carries its cone bit even when empty
+    counts = np.array([len(l) for l in labels], dtype=np.int64)
+    if counts.sum() > 0:
+        all_ids = np.concatenate([np.asarray(l, dtype=np.int64).reshape(-1) for l in labels])
+        all_bb = np.concatenate([np.asarray(b, dtype=np.float64).reshape(-1, 4) for b, n in zip(bb, counts) if n > 0])
+        frame = np.repeat(np.arange(T, dtype=np.int64), counts)
+        lut = np.full(max(int(all_ids.max()) + 1, SNITCH_INDEX + 1), -1, dtype=np.int64)
+        for s, oid in enumerate(order):
+            lut[oid] = s
+        slot = lut[all_ids]
+        keep = slot >= 0
+        key = frame[keep] * MAX_OBJECTS + slot[keep]
+        _, first = np.unique(key, return_index=True)              # first occurrence of every (frame, slot)
+        rows = np.flatnonzero(keep)[first]
+        # ... except for a repeated SNITCH id: the reference's comparator returns -1 for (snitch, snitch) in
+        # either order (datasets.py:47-54), so Python's insertion sort puts every later snitch in FRONT of the
+        # earlier ones and the walk then takes the LAST occurrence of the frame (pinned by the "dups" golden)
+        snitch_rows = np.flatnonzero(all_ids == SNITCH_INDEX)
+        if len(snitch_rows) > 0 and lut[SNITCH_INDEX] >= 0:
+            rev = snitch_rows[::-1]
+            _, last = np.unique(frame[rev], return_index=True)
+            rows = np.concatenate([rows[slot[rows] != lut[SNITCH_INDEX]], rev[last]])
+        out[frame[rows], slot[rows], :4] = all_bb[rows]
+        out[frame[rows], slot[rows], 4] = 1.0
+    out[..., :4] /= FRAME_SHAPES
+    return out
+
+
+def _center(box: np.ndarray) -> np.ndarray:
+    return np.array([(box[0] + box[2]) / 2, (box[1] + box[3]) / 2])
+
+
+def _closest(frame_boxes: np.ndarray, last_location: np.ndarray) -> int:
+    centers = np.stack([(frame_boxes[:, 0] + frame_boxes[:, 2]) / 2, (frame_boxes[:, 1] + frame_boxes[:, 3]) / 2], axis=1)
+    return int(np.argmin(np.linalg.norm(centers - _center(last_location), axis=1)))
+
+
+def index_to_track(boxes: np.ndarray) -> List[int]:
+    """Heuristic object-to-track vector: datasets.py:199-257 (5 tracks) / :338-416 (6 tracks: only a cone can
+    take over the track when the tracked object disappears)."""
+    six = boxes.shape[2] == 6
+    out: List[int] = []
+    stack: List[int] = []
+    last = np.zeros(boxes.shape[2])
+    cur = 0
+    for fb in boxes:
+        if fb[0, 4]:
+            out.append(0); last = fb[0]; cur = 0; stack = []
+        elif cur == 0:
+            c = _closest(fb, last)
+            if six and not fb[c, 5]:
+                out.append(0)                                      # occlusion by a non-cone: keep the snitch
+            else:
+                out.append(c); last = fb[c]; cur = c; stack.append(0)
+        elif not fb[cur, 4]:
+            c = _closest(fb, last)
+            if six and not fb[c, 5]:
+                out.append(cur)
+            else:
+                out.append(c); last = fb[c]; stack.append(cur); cur = c
+        else:
+            prev = stack[-1]
+            if fb[prev, 4]:
+                stack.pop(-1); out.append(prev); last = fb[prev]; cur = prev
+            else:
+                out.append(cur); last = fb[cur]
+    return out
+
+
+def load_snitch_labels(path: str) -> np.ndarray:
+    """datasets.py:33-45: [x,y,w,h] -> [x,y,x+w,y+h] / [320,240,320,240] (float64)."""
+    with open(path, "rb") as f:
+        video_labels = json.load(f)
+    arr = np.array(video_labels[SNITCH_NAME], dtype=np.int64).reshape(-1, 4)
+    xyxy = np.stack([arr[:, 0], arr[:, 1], arr[:, 0] + arr[:, 2], arr[:, 1] + arr[:, 3]], axis=1)
+    return xyxy / FRAME_SHAPES
+
+
+def read_mask_file(path: str, names) -> Dict[str, np.ndarray]:
+    """containment / occlusion TSV: `name\\tf1,f2,...\\n`, parsed with line[:-1] like the
+    reference (datasets.py:525-534) - a trailing newline is mandatory."""
+    names = set(names)
+    out: Dict[str, np.ndarray] = {}
+    with open(path, "r") as f:
+        for line in f:
+            line = line[:-1]
+            name, frames = line.split(sep="\t")
+            if name in names:
+                out[name] = np.array([], dtype=np.int64) if len(frames) == 0 else np.array(frames.split(","), dtype=np.int64)
+    return out
+
+
+class CaterAbstractDataset(Dataset):
+    n_tracks = 6
+
+    def __init__(self, predictions_dir: str, label_dir: str):
+        self.predictions_dir = Path(predictions_dir)
+        self.labels_dir = Path(label_dir)
+        self.videos_names: List[str] = []
+        self.label_paths: Dict[str, str] = {}
+
+    def _init_dataset_if_not_initiated(self) -> None:
+        if len(self.videos_names) == 0:
+            self.videos_names = sorted(str(p.stem) for p in self.predictions_dir.glob("*.pkl"))   # datasets.py:70-74
+            for name in self.videos_names:
+                self.label_paths[name] = str(self.labels_dir / (name + "_bb.json"))
+
+    def __len__(self) -> int:
+        self._init_dataset_if_not_initiated()
+        return len(self.videos_names)
+
+    def _encode(self, idx: int):
+        self._init_dataset_if_not_initiated()
+        name = self.videos_names[idx]
+        labels = load_snitch_labels(self.label_paths[name])
+        with open(str(self.predictions_dir / (name + ".pkl")), "rb") as f:
+            data = pickle.load(f)
+        boxes = encode_boxes(data["bb"], data["labels"], self.n_tracks)
+        idx_vec = index_to_track(boxes)
+        return (torch.tensor(boxes, dtype=torch.float32), torch.tensor(idx_vec, dtype=torch.int64),
+                torch.tensor(labels, dtype=torch.float32), name)
+
+    def __getitem__(self, idx: int):
+        boxes, idx_vec, labels, name = self._encode(idx)
+        return (boxes, idx_vec), (labels, torch.tensor([])), name
+
+
+class _TrainingMixin:
+    def _init_mask(self, mask_annotations_path: str):
+        self.mask_annotations_path = mask_annotations_path
+        self.mask_frames: Dict[str, np.ndarray] = {}
+
+    def _init_dataset_if_not_initiated(self) -> None:
+        if len(self.videos_names) == 0:
+            super()._init_dataset_if_not_initiated()
+            self.mask_frames = read_mask_file(self.mask_annotations_path, self.videos_names)
+
+    def __getitem__(self, idx: int):
+        boxes, idx_vec, labels, name = self._encode(idx)
+        mask = np.zeros((VIDEO_NUM_FRAMES, 4), dtype=bool)
+        mask[self.mask_frames[name], :] = True                                                   # datasets.py:545-547
+        return (boxes, idx_vec), (labels, torch.tensor(mask)), name
+
+
+class Cater6TracksForObjectsInferenceDataset(CaterAbstractDataset):
+    n_tracks = 6
+
+
+class Cater5TracksForObjectsInferenceDataset(CaterAbstractDataset):
+    n_tracks = 5
+
+
+class Cater6TracksForObjectsTrainingDataset(_TrainingMixin, CaterAbstractDataset):
+    n_tracks = 6
+
+    def __init__(self, predictions_dir: str, label_dir: str, mask_annotations_path: str):
+        CaterAbstractDataset.__init__(self, predictions_dir, label_dir)
+        self._init_mask(mask_annotations_path)
+
+
+class Cater5TracksForObjectsTrainingDataset(_TrainingMixin, CaterAbstractDataset):
+    n_tracks = 5
+
+    def __init__(self, predictions_dir: str, label_dir: str, mask_annotations_path: str):
+        CaterAbstractDataset.__init__(self, predictions_dir, label_dir)
+        self._init_mask(mask_annotations_path)
+
+
+class DatasetsFactory(object):
+    """reference baselines/datasets_factory.py:8-23"""
+
+    @staticmethod
+    def get_training_dataset(model_name: str, samples_dir: str, labels_dir: str, mask_file_path: str):
+        if model_name in TRAINING_SUPPORTED_MODELS_5_TRACKS:
+            return Cater5TracksForObjectsTrainingDataset(samples_dir, labels_dir, mask_file_path)
+        elif model_name in TRAINING_SUPPORTED_MODELS_6_TRACKS:
+            return Cater6TracksForObjectsTrainingDataset(samples_dir, labels_dir, mask_file_path)
+
+    @staticmethod
+    def get_inference_dataset(model_name: str, samples_dir: str, labels_dir: str):
+        if model_name in TRAINING_SUPPORTED_MODELS_5_TRACKS:
+            return Cater5TracksForObjectsInferenceDataset(samples_dir, labels_dir)
+        if model_name in TRAINING_SUPPORTED_MODELS_6_TRACKS:
+            return Cater6TracksForObjectsInferenceDataset(samples_dir, labels_dir)

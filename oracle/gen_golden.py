@@ -143,6 +143,48 @@ def gen_siblings(lm):
     np.savez_compressed(os.path.join(OUT, "siblings.npz"), **out)
 
 
+def gen_datasets():
+    """Dataset-encode goldens: write synthetic <video>.pkl / <video>_bb.json files and run the
+    reference's own Cater{5,6}TracksForObjectsInferenceDataset.__getitem__ and the training variant's mask."""
+    import pickle
+    import tempfile
+    sys.path.insert(0, REF)
+    from baselines import datasets as rd
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        samples, labels_dir = os.path.join(tmp, "s"), os.path.join(tmp, "l")
+        os.makedirs(samples); os.makedirs(labels_dir)
+        variants = ["plain", "dups", "crowded", "nosnitch0"]
+        lines = []
+        for i, v in enumerate(variants):
+            name = f"vid_{i:02d}_{v}"
+            bb, lab, gt = synth.make_raw_video(i, v)
+            with open(os.path.join(samples, name + ".pkl"), "wb") as f:
+                pickle.dump({"bb": bb, "labels": lab}, f, pickle.HIGHEST_PROTOCOL)
+            with open(os.path.join(labels_dir, name + "_bb.json"), "w") as f:
+                json.dump(gt, f)
+            frames = sorted(set(int(x) for x in np.random.default_rng(i).integers(0, 300, size=20 * i)))
+            lines.append(name + "\t" + ",".join(str(x) for x in frames) + "\n")
+        mask_file = os.path.join(tmp, "containment.txt")
+        with open(mask_file, "w") as f:
+            f.writelines(lines)
+        for tracks, cls_inf, cls_tr in ((6, rd.Cater6TracksForObjectsInferenceDataset, rd.Cater6TracksForObjectsTrainingDataset),
+                                        (5, rd.Cater5TracksForObjectsInferenceDataset, rd.Cater5TracksForObjectsTrainingDataset)):
+            ds = cls_inf(samples, labels_dir)
+            dt = cls_tr(samples, labels_dir, mask_file)
+            assert len(ds) == len(variants)
+            for i in range(len(ds)):
+                (boxes, idx), (lab, _), name = ds[i]
+                out[f"t{tracks}/{i}/name"] = np.array(name)
+                out[f"t{tracks}/{i}/boxes"] = boxes.numpy()
+                out[f"t{tracks}/{i}/index"] = idx.numpy()
+                out[f"t{tracks}/{i}/labels"] = lab.numpy()
+                (_, _), (_, mask), _ = dt[i]
+                out[f"t{tracks}/{i}/mask"] = mask.numpy()
+    np.savez_compressed(os.path.join(OUT, "datasets.npz"), **out)
+    print("datasets: ", {k: out[k].shape for k in list(out)[:5]})
+
+
 def sample_indices(name, n, k=4096):
     """deterministic sample of flat indices of a tensor (same helper used by the tests)"""
     if n <= k:
@@ -232,6 +274,7 @@ def main():
     y, labels = gen_opnet(lm, real, n_clips=4, t_frames=300, tag="real", keep_intermediates=False)
     gen_metric(tu, y, labels)
     gen_siblings(lm)
+    gen_datasets()
     gen_train(lm, tiny, n_clips=3, t_frames=12, tag="tiny", full=True, adam_steps=3)
     gen_train(lm, real, n_clips=4, t_frames=300, tag="real", full=False, adam_steps=2)
 

@@ -228,3 +228,47 @@ def make_clip(c: int, t_frames: int = T_FRAMES) -> Tuple[np.ndarray, np.ndarray]
 def make_batch(first_clip: int, n_clips: int, t_frames: int = T_FRAMES) -> Tuple[np.ndarray, np.ndarray]:
     bs, ls = zip(*(make_clip(first_clip + i, t_frames) for i in range(n_clips)))
     return np.stack(bs), np.stack(ls)
+
+
+# --------------------------------------------------------------------------------------
+# synthetic on-disk samples (formats of SURVEY.md section 10: <video>.pkl and <video>_bb.json)
+# --------------------------------------------------------------------------------------
+SNITCH_NAME = "small_gold_spl_metal_Spl_0"   # datasets.py:13
+
+
+def make_raw_video(c: int, variant: str = "plain", t_frames: int = T_FRAMES):
+    """Raw perception sample as the detector / "perfect perception" tools write it:
+    returns (bb list[T] of int64 [n_f,4] xyxy pixels, labels list[T] of int64 [n_f], gt dict name -> list[T] [x,y,w,h]).
+    variants: "plain" (10 objects, random drop-outs), "dups" (duplicate ids + shuffled order inside frames),
+    "crowded" (17 distinct objects -> the encoder truncates to 15 slots), "nosnitch0" (snitch absent at frame 0)."""
+    rng = np.random.default_rng(5000 + c)
+    ids = [SNITCH_ID] + list(CONE_IDS) + list(OTHER_IDS)
+    if variant == "crowded":
+        ids = ids + [8, 12, 16, 66, 67, 99, 134]         # three more cones (8, 12, 16) and four non-cones
+    n = len(ids)
+    w = rng.integers(8, 65, size=n); h = rng.integers(8, 65, size=n)
+    px = rng.uniform(0, 236, size=n); py = rng.uniform(0, 156, size=n)
+    vx = rng.normal(0, 1, size=n); vy = rng.normal(0, 1, size=n)
+    bbs, labels, gt = [], [], []
+    hidden = np.zeros(t_frames, dtype=bool)
+    for _ in range(int(rng.integers(2, 6))):
+        s = int(rng.integers(1 if variant != "nosnitch0" else 0, max(2, t_frames - 20)))
+        hidden[s:s + 15] = True
+    if variant == "nosnitch0":
+        hidden[:3] = True
+    for t in range(t_frames):
+        vx = 0.9 * vx + rng.normal(0, 0.6, size=n); vy = 0.9 * vy + rng.normal(0, 0.6, size=n)
+        px = np.clip(px + vx, 0, 235); py = np.clip(py + vy, 0, 155)
+        x1 = px.astype(np.int64); y1 = py.astype(np.int64)
+        box = np.stack([x1, y1, x1 + w, y1 + h], axis=1)
+        vis = rng.random(n) < 0.9
+        vis[0] = not hidden[t]
+        idx = np.flatnonzero(vis)
+        if variant == "dups" and len(idx) > 2:
+            extra = rng.choice(idx, size=2)                 # the perception model repeats two ids ...
+            idx = np.concatenate([idx, extra])
+            idx = idx[rng.permutation(len(idx))]            # ... and returns them in score order, not id order
+        bbs.append(box[idx] + (rng.integers(-2, 3, size=(len(idx), 4)) if variant == "dups" else 0))
+        labels.append(np.array([ids[i] for i in idx], dtype=np.int64))
+        gt.append([int(x1[0]), int(y1[0]), int(w[0]), int(h[0])])
+    return bbs, labels, {SNITCH_NAME: gt, "other_object_0": [[0, 0, 0, 0]] * t_frames}
