@@ -200,7 +200,7 @@ __device__ __forceinline__ void load_a_chunk(float4 (&a)[OPNET_CH], const float4
 #pragma unroll
     for (int j = 0; j < OPNET_CH; ++j) {
         if (qb + j < q1) {
-#if defined(OPNET_TRACE) && OPNET_VARIANT == 2   /* probe: no weight loads */
+#if (defined(OPNET_TRACE) && OPNET_VARIANT == 2) || defined(OPNET_ABLATE_A)   /* probe: no weight loads */
             a[j] = make_float4(1.f, 2.f, 3.f, (float)(qb + j));
 #else
             a[j] = A[(qb + j) * 64 + lane];
@@ -221,7 +221,7 @@ __device__ __forceinline__ void mma_chunk(const float4 (&a)[OPNET_CH], const flo
         const int q = qb + j;
         if (q < q1) {  // wave-uniform
             const float4 *src = (q < nh0) ? (seg0 + q * 128) : (seg1 + (q - nh0) * 128);
-#if defined(OPNET_TRACE) && OPNET_VARIANT == 1   /* probe: no activation loads */
+#if (defined(OPNET_TRACE) && OPNET_VARIANT == 1) || defined(OPNET_ABLATE_B)   /* probe: no activation loads */
             b0[j] = make_float4(1.f, 2.f, 3.f, (float)q);
             b1[j] = make_float4(1.f, 2.f, 3.f, (float)lane);
 #else
@@ -232,6 +232,15 @@ __device__ __forceinline__ void mma_chunk(const float4 (&a)[OPNET_CH], const flo
     }
     TRACE_WAIT_LOADS();
     TRACE_STAMP(2);
+#ifdef OPNET_ABLATE_MFMA   /* probe: loads only (kept alive), no matrix work */
+#pragma unroll
+    for (int j = 0; j < OPNET_CH; ++j)
+        if (qb + j < q1) {
+            asm volatile("" ::"v"(a[j].x), "v"(b0[j].x), "v"(b1[j].x), "v"(a[j].w), "v"(b0[j].w), "v"(b1[j].w));
+            acc0[0] += a[j].x + b0[j].y; acc1[0] += b1[j].z;
+        }
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < OPNET_CH; ++j) {
         if (qb + j < q1) {
