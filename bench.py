@@ -5,9 +5,10 @@
 
 One "step" = one pass of the hot path (OPNet.forward through libopnet_hip.so) over one batch of
 `--batch` synthetic CATER clips (300 frames x 15 slots x 6 features, fp32) that is already resident in
-HBM, followed by the device-side post-processing to int32 pixel boxes.  With N > 1 every rank runs
-its own batch (clips are independent: weak scaling, no data-path collective inside the forward) and
-the per-clip predictions are all-gathered over RCCL on a side stream, overlapped with the next step.
+HBM, followed by the device-side post-processing to int32 pixel boxes.  Independent steps are spread over
+S HIP streams (several forwards in flight).  With N > 1 every rank runs its own batch (clips are independent:
+weak scaling, no data-path collective inside the forward) and the per-clip predictions are all-gathered
+over RCCL; only the issuing step's stream waits for the collective, the other forwards keep running.
 
 Rank 0 prints ONE JSON line: BASELINE.json's metric (clips/s, whole job), plus
   roofline     - the dominant kernel (opnet_step) against the HBM roofline under SURVEY.md 8-d4's
@@ -169,9 +170,7 @@ def main():
     # S <= 4 created streams and keeps the null stream out of it: stream 0 doubles as the timing stream.
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     main_stream = streams[0]
-    side = torch.cuda.Stream(device=dev) if world > 1 else None    # RCCL all-gather of predictions
     gathered = [torch.empty((world * B, T_FRAMES, 4), dtype=torch.int32, device=dev) for _ in range(len(streams))] if world > 1 else None
-    pending = [None] * len(streams)
 
     if args.mode == "train":
         return bench_train(args, model, boxes, labels, world, rank, dev, dist)
@@ -185,22 +184,14 @@ def main():
                 y, _logits = model(boxes)
             pred_px, _, _ = metrics.postprocess_and_iou(y)
             if world > 1:
-                # prediction all-gather on the comm stream, overlapped with the following steps
-                if pending[k] is not None:
-                    pending[k].wait()
-                side.wait_stream(streams[k])
-                with torch.cuda.stream(side):
-                    pred_px.record_stream(side)
-                    pending[k] = dist.all_gather_into_tensor(gathered[k], pred_px, async_op=True)
+                # inference exchange: all-gather of the int32 predictions (4.8 KB/clip) over RCCL.  The
+                # collective runs on the process group's own stream and only THIS step's stream waits for
+                # it, so it overlaps with the forwards in flight on the other streams.
+                dist.all_gather_into_tensor(gathered[k], pred_px)
         return y, pred_px
 
     def drain():
-        for k in range(len(streams)):
-            if pending[k] is not None:
-                with torch.cuda.stream(streams[k]):
-                    pending[k].wait()
-                pending[k] = None
-        for st in streams[1:] + ([side] if side is not None else []):
+        for st in streams[1:]:
             main_stream.wait_stream(st)
 
     if args.streams <= 0 and args.mode == "infer":

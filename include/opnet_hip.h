@@ -118,6 +118,11 @@ int opseq_lstm_stack_pack_weights_f32(const float *const *w_ih, const float *con
                                       float *packed, size_t packed_bytes, int L, int KX, int H, void *stream);
 int opseq_lstm_stack_forward_f32(const float *x, const float *packed, float *y, void *workspace,
                                  size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream);
+/* same, with the T+L step launches replayed from a hipGraph cached per (workspace, packed, shape) inside
+ * the library (host-side objects; opseq_graph_cache_clear() releases them). Bit-identical results. */
+int opseq_lstm_stack_forward_graph_f32(const float *x, const float *packed, float *y, void *workspace,
+                                       size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream);
+void opseq_graph_cache_clear(void);
 /* relu(boxes_linear(x)) (:138,:178): x [ntok,15,5], W [F,5] -> out [ntok, nslots_out, F];
  * nslots_out = 15 (all slots) or 1 (slot 0 only - the live path of TransformerLstm). */
 int opseq_slot_embed_relu_f32(const float *x, const float *W, float *out, long ntok, int nslots_out, int F,

@@ -68,6 +68,10 @@ def _declare(lib):
                                                       c_int, c_int, c_int, c_void_p]
     lib.opseq_lstm_stack_forward_f32.restype = c_int
     lib.opseq_lstm_stack_forward_f32.argtypes = [fp, fp, fp, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.opseq_lstm_stack_forward_graph_f32.restype = c_int
+    lib.opseq_lstm_stack_forward_graph_f32.argtypes = lib.opseq_lstm_stack_forward_f32.argtypes
+    lib.opseq_graph_cache_clear.restype = None
+    lib.opseq_graph_cache_clear.argtypes = []
     lib.opseq_slot_embed_relu_f32.restype = c_int
     lib.opseq_slot_embed_relu_f32.argtypes = [fp, fp, fp, ctypes.c_long, c_int, c_int, c_void_p]
     lib.opseq_encoder_workspace_bytes.restype = c_size_t
@@ -97,7 +101,8 @@ EXPORTS = [
     "opnet_train_forward_f32", "opnet_train_backward_f32", "opnet_l1_loss_f32", "opnet_adam_step_f32",
     "opnet_mlp_pack_weights_f32", "opnet_mlp_forward_f32",
     "opseq_lstm_stack_packed_bytes", "opseq_lstm_stack_workspace_bytes", "opseq_lstm_stack_pack_weights_f32",
-    "opseq_lstm_stack_forward_f32", "opseq_slot_embed_relu_f32", "opseq_encoder_workspace_bytes",
+    "opseq_lstm_stack_forward_f32", "opseq_lstm_stack_forward_graph_f32", "opseq_graph_cache_clear",
+    "opseq_slot_embed_relu_f32", "opseq_encoder_workspace_bytes",
     "opseq_encoder_layer_f32",
     "opdet_conv2d_f32", "opdet_maxpool3x3s2_f32", "opdet_subsample2_f32", "opdet_upsample_add_f32",
     "opdet_preprocess_frame_f32",

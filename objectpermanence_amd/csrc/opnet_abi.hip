@@ -10,6 +10,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -694,8 +696,45 @@ extern "C" int opseq_lstm_stack_pack_weights_f32(const float *const *w_ih, const
     return OPNET_OK;
 }
 
+// The T+L step launches of a stacked-LSTM forward as one cached hipGraph per (workspace, packed, shape):
+// every argument of the step kernel is fixed for that key, the caller-dependent boundary kernels
+// (rows_to_packed, copy_y_out) stay eager on the same stream.
+struct StackGraphKey {
+    const void *ws, *packed;
+    int B, T, L, KX, H;
+    bool operator<(const StackGraphKey &o) const
+    {
+        return memcmp(this, &o, sizeof(*this)) < 0;
+    }
+};
+static std::map<StackGraphKey, hipGraphExec_t> g_stack_graphs;
+static std::mutex g_stack_graphs_mu;
+
+static int stack_forward_impl(const float *x, const float *packed, float *y, void *workspace,
+                              size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream, bool graph);
+
 extern "C" int opseq_lstm_stack_forward_f32(const float *x, const float *packed, float *y, void *workspace,
                                             size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream)
+{
+    return stack_forward_impl(x, packed, y, workspace, workspace_bytes, B, T, L, KX, H, stream, false);
+}
+
+extern "C" int opseq_lstm_stack_forward_graph_f32(const float *x, const float *packed, float *y, void *workspace,
+                                                  size_t workspace_bytes, int B, int T, int L, int KX, int H,
+                                                  void *stream)
+{
+    return stack_forward_impl(x, packed, y, workspace, workspace_bytes, B, T, L, KX, H, stream, true);
+}
+
+extern "C" void opseq_graph_cache_clear(void)
+{
+    std::lock_guard<std::mutex> lk(g_stack_graphs_mu);
+    for (auto &kv : g_stack_graphs) (void)hipGraphExecDestroy(kv.second);
+    g_stack_graphs.clear();
+}
+
+static int stack_forward_impl(const float *x, const float *packed, float *y, void *workspace,
+                              size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream, bool graph)
 {
     if (int rc = check_stack(B, T, L, KX, H)) return rc;
     if (!x || !packed || !y || !workspace) return fail(OPNET_EINVAL, "null pointer");
@@ -725,7 +764,44 @@ extern "C" int opseq_lstm_stack_forward_f32(const float *x, const float *packed,
     rows_to_packed<<<2048, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, RB, KX, P.nhx[0] * 16,
                                           (float4 *)(w + W.state), (long)((W.state_end - W.state) / 16));
     const dim3 grid(ntiles, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
-    for (int s = 0; s < T + L; ++s) lstm_stack_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    if (!graph) {
+        for (int s = 0; s < T + L; ++s) lstm_stack_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    } else {
+        StackGraphKey key;
+        memset(&key, 0, sizeof(key));
+        key.ws = workspace; key.packed = packed; key.B = B; key.T = T; key.L = L; key.KX = KX; key.H = H;
+        hipGraphExec_t exec = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_stack_graphs_mu);
+            auto it = g_stack_graphs.find(key);
+            if (it != g_stack_graphs.end()) exec = it->second;
+        }
+        if (!exec) {
+            hipGraph_t g = nullptr;
+            HIP_TRY(hipGraphCreate(&g, 0));
+            hipGraphNode_t prev = nullptr, node = nullptr;
+            for (int s = 0; s < T + L; ++s) {
+                StackArgs av = a;
+                int step = s;
+                void *args[] = {(void *)&av, (void *)&step};
+                hipKernelNodeParams kp;
+                memset(&kp, 0, sizeof(kp));
+                kp.func = (void *)lstm_stack_step;
+                kp.gridDim = grid;
+                kp.blockDim = dim3(OPNET_THREADS, 1, 1);
+                kp.kernelParams = args;
+                hipError_t e = hipGraphAddKernelNode(&node, g, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
+                if (e != hipSuccess) { (void)hipGraphDestroy(g); return fail(OPNET_EHIP, "hipGraphAddKernelNode: %s", hipGetErrorString(e)); }
+                prev = node;
+            }
+            hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) return fail(OPNET_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+            std::lock_guard<std::mutex> lk(g_stack_graphs_mu);
+            g_stack_graphs[key] = exec;
+        }
+        HIP_TRY(hipGraphLaunch(exec, st));
+    }
     const long ny = (long)B * T;
     copy_y_out<<<(unsigned)((ny + 255) / 256 > 1024 ? 1024 : (ny + 255) / 256), 256, 0, st>>>(a.ystage, (float4 *)y, ny);
     HIP_TRY(hipGetLastError());

@@ -209,9 +209,11 @@ __device__ __forceinline__ void load_a_chunk(float4 (&a)[OPNET_CH], const float4
     }
 }
 
+// two_halves = false: the row block holds <= 16 clips, so the second accumulator chain (clips 16..31,
+// all padding) is skipped - half the loads and MFMAs for small batches (B <= 16, e.g. one 300-frame clip).
 __device__ __forceinline__ void mma_chunk(const float4 (&a)[OPNET_CH], const float4 *__restrict__ seg0, int nh0,
                                           const float4 *__restrict__ seg1, int qb, int q1,
-                                          f32x4 &acc0, f32x4 &acc1, const int s)
+                                          f32x4 &acc0, f32x4 &acc1, const int s, const bool two_halves)
 {
     const int lane = threadIdx.x & 63;
     const int boff = (lane >> 4) * 32 + (lane & 15);
@@ -226,7 +228,7 @@ __device__ __forceinline__ void mma_chunk(const float4 (&a)[OPNET_CH], const flo
             b1[j] = make_float4(1.f, 2.f, 3.f, (float)lane);
 #else
             b0[j] = src[boff];
-            b1[j] = src[boff + 16];
+            if (two_halves) b1[j] = src[boff + 16];
 #endif
         }
     }
@@ -241,6 +243,18 @@ __device__ __forceinline__ void mma_chunk(const float4 (&a)[OPNET_CH], const flo
         }
     return;
 #endif
+    if (!two_halves) {
+#pragma unroll
+        for (int j = 0; j < OPNET_CH; ++j) {
+            if (qb + j < q1) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0[j].x, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b0[j].y, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b0[j].z, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b0[j].w, acc0, 0, 0, 0);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < OPNET_CH; ++j) {
         if (qb + j < q1) {
@@ -261,15 +275,15 @@ __device__ __forceinline__ void mma_chunk(const float4 (&a)[OPNET_CH], const flo
 __device__ __forceinline__ void gemm16_rb(const float4 (&a0)[OPNET_CH], const float4 *__restrict__ A,
                                           const float4 *__restrict__ seg0, int nh0,
                                           const float4 *__restrict__ seg1, const KSlice ks,
-                                          float *__restrict__ part, const int s)
+                                          float *__restrict__ part, const int s, const bool two_halves = true)
 {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
-    mma_chunk(a0, seg0, nh0, seg1, ks.q0, ks.q1, acc0, acc1, s);
+    mma_chunk(a0, seg0, nh0, seg1, ks.q0, ks.q1, acc0, acc1, s, two_halves);
     for (int qb = ks.q0 + OPNET_CH; qb < ks.q1; qb += OPNET_CH) {
         float4 an[OPNET_CH];
         load_a_chunk(an, A, qb, ks.q1);
-        mma_chunk(an, seg0, nh0, seg1, qb, ks.q1, acc0, acc1, s);
+        mma_chunk(an, seg0, nh0, seg1, qb, ks.q1, acc0, acc1, s, two_halves);
     }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -403,7 +417,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
                 }
                 continue;
             }
-            gemm16_rb(a0, A, hprev, nh, hprev, ks, part, s);
+            gemm16_rb(a0, A, hprev, nh, hprev, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             TRACE_STAMP(4);
             if (tid < 128) {
@@ -444,7 +458,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
             const float4 *hprev = a.h1buf + (slot_prev(a, t) * a.RB + rb) * (H1 * 8);
             float c_old = 0.f;
             if (tid < 128) c_old = a.c1[((cslot_prev(a, t) * a.RB + rb) * H1 + unit) * 32 + clip];
-            gemm16_rb(a0, A, xsrc, OPNET_KXQ / 4, hprev, ks, part, s);
+            gemm16_rb(a0, A, xsrc, OPNET_KXQ / 4, hprev, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             TRACE_STAMP(4);
             if (tid < 128) {
@@ -480,7 +494,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
                     bxv[o] = xs[((k >> 2) * 32 + mc) * 4 + (k & 3)];
                 }
             }
-            gemm16_rb(a0, a.wselp, hcur, nh, hcur, ks, part, s);
+            gemm16_rb(a0, a.wselp, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             TRACE_STAMP(4);
             if (tid < 128) {
@@ -535,7 +549,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
         load_a_chunk(a0, a.woutp, ks.q0, ks.q1);
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
             const float4 *hcur = a.h2buf + (slot_out(a, t) * a.RB + rb) * (H2 * 8);
-            gemm16_rb(a0, a.woutp, hcur, nh, hcur, ks, part, s);
+            gemm16_rb(a0, a.woutp, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             TRACE_STAMP(4);
             if (tid < 128 && quarter == 0) {

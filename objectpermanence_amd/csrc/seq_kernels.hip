@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
             const float4 *hprev = ly.hbuf + ((long)((t + 1) & 1) * a.RB + rb) * ((long)H * 8);
             float c_old = 0.f;
             if (tid < 128) c_old = ly.c[((long)rb * H + unit) * 32 + clip];
-            gemm16_rb(a0, A, xseg, nhx, hprev, ks, part, s);
+            gemm16_rb(a0, A, xseg, nhx, hprev, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             if (tid < 128) {
                 float c = c_old;
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         load_a_chunk(a0, a.headA, ks.q0, ks.q1);
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
             const float4 *hcur = ly.hbuf + ((long)(t & 1) * a.RB + rb) * ((long)ly.H * 8);
-            gemm16_rb(a0, a.headA, hcur, nh, hcur, ks, part, s);
+            gemm16_rb(a0, a.headA, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             if (tid < 128 && quarter == 0) {
                 const long b = rb * 32 + clip;

@@ -291,8 +291,10 @@ class _LstmStackRunner:
             self.ws = {wkey: torch.empty(nb, dtype=torch.uint8, device=dev)}   # keep one shape at a time
         ws = self.ws[wkey]
         y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
-        rc = lib.opseq_lstm_stack_forward_f32(x.data_ptr(), self.packed.data_ptr(), y.data_ptr(), ws.data_ptr(),
-                                              ws.numel(), B, T, self.L, self.KX, self.H, stream)
+        fwd = lib.opseq_lstm_stack_forward_f32 if os.environ.get("OPNET_HIP_EAGER", "0") == "1" \
+            else lib.opseq_lstm_stack_forward_graph_f32
+        rc = fwd(x.data_ptr(), self.packed.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), B, T, self.L,
+                 self.KX, self.H, stream)
         _lib.check(rc, "opseq_lstm_stack_forward_f32")
         return y
 
