@@ -75,4 +75,7 @@ class FusedAdam(torch.optim.Optimizer):
                                                  float(group["grad_scale"]),
                                                  torch.cuda.current_stream(p.device).cuda_stream)
                 _lib.check(rc, "opnet_adam_step_f32")
+                # the update happened outside torch's view: bump the version counter so that consumers
+                # keyed on it (the modules' packed-weight caches) see the parameter as modified
+                torch.autograd.graph.increment_version(p)
         return loss

@@ -185,6 +185,40 @@ def gen_datasets():
     print("datasets: ", {k: out[k].shape for k in list(out)[:5]})
 
 
+def gen_trained(lm, tu, cfg):
+    """Reference forward + ResultsAnalyzer metrics with TRAINED weights (tests/golden/opnet_trained_fp16.npz:
+    OPNet trained for 40 epochs on synthetic clips by tools/train_synthetic.py on the MI355X with this repo's
+    own training path, stored rounded to fp16) on held-out synthetic clips: a non-vacuous mean-IoU / mAP@0.5
+    parity target (north_star: mean-IoU within 1e-3)."""
+    path = os.path.join(OUT, "opnet_trained_fp16.npz")
+    if not os.path.exists(path):
+        print("gen_trained: no trained weights fixture, skipped")
+        return
+    w = np.load(path)
+    params = {k: w[k].astype(np.float32) for k in w.files}
+    model = lm.OPNet(cfg)
+    _load_params(model, params)
+    model.eval()
+    first, n = 200000, 16
+    boxes, labels = synth.make_batch(first, n, 300)
+    with torch.no_grad():
+        y, _ = model(torch.from_numpy(boxes))
+    y = y.numpy()
+    fs = np.array([320, 240, 320, 240])
+    pred_px = (np.array(list(y.reshape(-1, 4))) * fs).reshape((n, 300, 4)).astype(np.int32)       # inference_main.py:219
+    gt_px = (np.array(list(labels.reshape(-1, 4))) * fs).reshape((n, 300, 4)).astype(np.int32)
+    names = [str(i) for i in range(n)]
+    an = tu.ResultsAnalyzer(names, pred_px, gt_px, iou_thresh=[0.5])
+    an.compute_aggregated_metric("video_mean", np.mean)
+    an.compute_aggregated_metric("video_mean", np.mean, metric="map")
+    kept = list(an.get_videos_names())
+    vm = np.array([an.videos_metrics["video_mean_iou"][k] for k in kept])
+    vmap = np.array([an.videos_metrics["video_mean_map_0.5"][k] for k in kept])
+    np.savez_compressed(os.path.join(OUT, "opnet_trained_eval.npz"), first=first, n=n, y=y, pred_px=pred_px,
+                        kept=np.array([int(k) for k in kept]), video_mean_iou=vm, video_map50=vmap)
+    print(f"trained eval: reference mean-IoU {vm.mean():.4f}  mAP@0.5 {vmap.mean():.4f}  ({len(kept)}/{n} videos kept)")
+
+
 def sample_indices(name, n, k=4096):
     """deterministic sample of flat indices of a tensor (same helper used by the tests)"""
     if n <= k:
@@ -273,6 +307,7 @@ def main():
         real = json.load(f)
     y, labels = gen_opnet(lm, real, n_clips=4, t_frames=300, tag="real", keep_intermediates=False)
     gen_metric(tu, y, labels)
+    gen_trained(lm, tu, real)
     gen_siblings(lm)
     gen_datasets()
     gen_train(lm, tiny, n_clips=3, t_frames=12, tag="tiny", full=True, adam_steps=3)

@@ -142,3 +142,26 @@ def test_l1_mean_and_adam_match_torch():
         p1.grad, p2.grad = gr.clone(), gr.clone()
         o1.step(); o2.step()
     assert torch.allclose(p1, p2, rtol=0, atol=2e-7)
+
+
+def test_inference_after_fused_adam_uses_updated_weights():
+    """Regression: FusedAdam updates parameters outside torch's view; the inference path's packed-weight
+    cache is keyed on the parameter version and must notice."""
+    from objectpermanence_amd import FusedAdam, l1_mean
+    boxes, labels = synth.make_batch(9, 4, 20)
+    m = _model(REAL_CFG)
+    x, lab = torch.from_numpy(boxes).cuda(), torch.from_numpy(labels).cuda()
+    opt = FusedAdam(m.parameters(), lr=1e-2)
+    with torch.no_grad():
+        y0, _ = m(x)
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        y, _ = m(x)
+        l1_mean(y, lab).backward()
+        opt.step()
+    with torch.no_grad():
+        y1, _ = m(x)                      # inference path after training steps
+    yt, _ = m(x)                          # training path (always repacks)
+    torch.cuda.synchronize()
+    assert not torch.equal(y0, y1)
+    assert torch.equal(y1, yt.detach())
