@@ -50,6 +50,32 @@ def pmc_traffic(batch):
     return None if best is None else int(best["traffic_bytes_per_launch"])
 
 
+def accuracy_block(dev):
+    """mean-IoU / mAP@0.5 of the HIP path with TRAINED weights on 16 held-out synthetic clips, next to the
+    values the reference's own model + ResultsAnalyzer produce for the same weights and clips
+    (tests/golden/opnet_trained_*.npz; oracle/gen_golden.py).  Outside the timed region."""
+    from objectpermanence_amd import ModelsFactory, metrics
+    from oracle import synth
+    wpath = os.path.join(REPO, "tests", "golden", "opnet_trained_fp16.npz")
+    epath = os.path.join(REPO, "tests", "golden", "opnet_trained_eval.npz")
+    if not (os.path.exists(wpath) and os.path.exists(epath)):
+        return {}
+    w, g = np.load(wpath), np.load(epath)
+    m = ModelsFactory.get_model("opnet", CFG)
+    m.load_state_dict({k: torch.from_numpy(w[k].astype(np.float32)) for k in w.files})
+    m.eval().to(dev)
+    boxes, labels = synth.make_batch(int(g["first"]), int(g["n"]), T_FRAMES)
+    with torch.no_grad():
+        y, _ = m(torch.from_numpy(boxes).to(dev))
+    _, _, iou = metrics.postprocess_and_iou(y, torch.from_numpy(labels).to(dev))
+    miou, map50 = metrics.mean_iou_and_map(iou)
+    return {"accuracy": {"weights": "OPNet trained on MI355X by this repo's training path (tools/train_synthetic.py), fp16-rounded",
+                         "clips": int(g["n"]), "mean_iou": round(miou, 6), "map_0.5": round(map50, 6),
+                         "reference_mean_iou": round(float(g["video_mean_iou"].mean()), 6),
+                         "reference_map_0.5": round(float(g["video_map50"].mean()), 6),
+                         "max_abs_dy_vs_reference": float(np.abs(y.cpu().numpy() - g["y"]).max())}}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +298,7 @@ def main():
                          "kernel": "opnet_step", "launch_us": round(launch_us, 3), "launches_in_flight": S,
                          "alg_bytes_per_launch": int(alg_bytes_per_launch)},
         }
+        out.update(accuracy_block(dev))
         if world == 1 and not args.no_cpu_baseline:
             cb, y_cpu = cpu_baseline(boxes_np, params, args.cpu_seconds)
             out["cpu_baseline"] = cb

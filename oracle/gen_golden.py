@@ -219,6 +219,28 @@ def gen_trained(lm, tu, cfg):
     print(f"trained eval: reference mean-IoU {vm.mean():.4f}  mAP@0.5 {vmap.mean():.4f}  ({len(kept)}/{n} videos kept)")
 
 
+def gen_detector_filter():
+    """CaterObjectDetector.remove_low_probability_object (detector.py:14-28) on synthetic detector outputs
+    (SURVEY.md 8-c3-vi), incl. an unsorted score list where the prefix rule keeps a low score."""
+    from baselines.detector import CaterObjectDetector
+    cases = []
+    for seed, sort_desc in ((0, True), (1, True), (2, False)):
+        rng = np.random.default_rng(seed)
+        n = int(rng.integers(3, 12))
+        scores = rng.random(n).astype(np.float32)
+        if sort_desc:
+            scores = np.sort(scores)[::-1].copy()
+        boxes = (rng.random((n, 4)) * 300).astype(np.float32)
+        labels = rng.integers(0, 193, size=n).astype(np.int64)
+        out = CaterObjectDetector.remove_low_probability_object(
+            {"boxes": torch.from_numpy(boxes), "labels": torch.from_numpy(labels), "scores": torch.from_numpy(scores)})
+        cases.append({"boxes": boxes.tolist(), "labels": labels.tolist(), "scores": scores.tolist(),
+                      "kept": int(out["scores"].shape[0]), "kept_boxes_int": out["boxes"].numpy().astype(int).tolist()})
+    with open(os.path.join(OUT, "detector_filter.json"), "w") as f:
+        json.dump(cases, f)
+    print("detector_filter:", [c["kept"] for c in cases])
+
+
 def sample_indices(name, n, k=4096):
     """deterministic sample of flat indices of a tensor (same helper used by the tests)"""
     if n <= k:
@@ -307,6 +329,7 @@ def main():
         real = json.load(f)
     y, labels = gen_opnet(lm, real, n_clips=4, t_frames=300, tag="real", keep_intermediates=False)
     gen_metric(tu, y, labels)
+    gen_detector_filter()
     gen_trained(lm, tu, real)
     gen_siblings(lm)
     gen_datasets()

@@ -145,3 +145,17 @@ def test_dp_gradient_allreduce_equals_single_process(tmp_path):
         got = np.load(os.path.join(str(tmp_path), f"g{r}.npz"))
         for k in ref:
             assert np.abs(got[k] - ref[k]).max() <= 1e-6 * max(1.0, np.abs(ref[k]).max()), k
+
+
+def test_detector_score_filter_matches_reference(golden_dir):
+    """detector.py:14-28 + the int cast of preprocess_perception_main.py:35 (row a11), vs goldens produced by the
+    reference's own static method (tests/golden/detector_filter.json)."""
+    import json
+    from objectpermanence_amd.detector import CaterObjectDetector
+    cases = json.load(open(os.path.join(golden_dir, "detector_filter.json")))
+    assert len(cases) == 3
+    for c in cases:
+        out = CaterObjectDetector.remove_low_probability_object(
+            {"boxes": torch.tensor(c["boxes"]), "labels": torch.tensor(c["labels"]), "scores": torch.tensor(c["scores"])})
+        assert out["scores"].shape[0] == c["kept"] == out["labels"].shape[0]
+        assert out["boxes"].numpy().astype(int).tolist() == c["kept_boxes_int"]
