@@ -189,3 +189,149 @@ __global__ void __launch_bounds__(256) preprocess_frame(const unsigned char *__r
         ((float4 *)Y)[idx] = out;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged tiled variant (the production conv / GEMM kernel)
+// ------------------------------------------------------------------------------------------------
+// Workgroup tile BM=128 output pixels x BN (128 or 64) output channels, K walked 16 at a time.
+// Per K step the workgroup stages the im2col patch slice A[128 x 16] and the weight slice W[BN x 16]
+// through LDS once (each thread: coalesced float4 global loads issued BEFORE the MFMA phase of the current
+// step, written to the other LDS buffer after it - the guide's issue-early / write-late split), and each
+// wave reads its fragments with conflict-free ds_read_b128 (layout [k/4][row][4]: the 16 lanes of a k-group
+// read 16 consecutive rows = one 256-B bank row).  BN=128: 2x2 waves of 64x64 (4x4 fragments, 64 MFMAs per
+// K step per wave); BN=64: 4x1 waves of 32x64.  Global traffic per MFMA drops 4x vs conv2d_nhwc.
+template <int BN>
+__global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
+{
+    constexpr int BM = 128;
+    constexpr int FM = (BN == 128) ? 4 : 2;   // 16-row fragments per wave along M
+    constexpr int FN = 4;                     // ... along N
+    constexpr int WROWS = BN;                 // weight rows staged per step
+    constexpr int WLD = BN / 64;              // weight float4 loads per thread per step (2 or 1)
+    __shared__ __attribute__((aligned(16))) float4 As[2][4][BM];
+    __shared__ __attribute__((aligned(16))) float4 Ws[2][4][WROWS];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    const int wm = (BN == 128) ? (w >> 1) : w, wn = (BN == 128) ? (w & 1) : 0;
+    const long M = (long)a.N * a.OH * a.OW;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int K = a.KH * a.KW * a.Cin;
+
+    // loader role: thread -> k-quad (tid & 3) of rows (tid >> 2) and (tid >> 2) + 64, so the 4 lanes of a row
+    // read one contiguous 64-byte run (16 rows x 64 B per wave load, like the fragment-shaped direct loads)
+    const int lkq = tid & 3, lr0 = tid >> 2;
+    int iy0[2], ix0[2];
+    const float *xn[2];
+    bool prow_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        long p = m0 + lr0 + 64 * j;
+        prow_ok[j] = p < M;
+        if (!prow_ok[j]) p = M - 1;
+        const int ox = p % a.OW;
+        const long tq = p / a.OW;
+        const int oy = tq % a.OH;
+        const int nimg = tq / a.OH;
+        iy0[j] = oy * a.stride - a.pad;
+        ix0[j] = ox * a.stride - a.pad;
+        xn[j] = a.X + (long)nimg * a.H * a.W * a.Cin;
+    }
+    bool wrow_ok[2];
+    const float4 *wsrc[2];
+#pragma unroll
+    for (int j = 0; j < WLD; ++j) {
+        const int r = n0 + lr0 + 64 * j;
+        wrow_ok[j] = r < a.Cout;
+        wsrc[j] = (const float4 *)(a.Wt + (long)min(r, a.Cout - 1) * a.KP) + lkq;
+    }
+
+    auto load_a2 = [&](int q, float4 (&ra)[2]) {
+        const int k4 = 16 * q + 4 * lkq;
+        const int tap = k4 / a.Cin, c = k4 - tap * a.Cin;
+        const int dy = tap / a.KW, dx = tap - dy * a.KW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int y = iy0[j] + dy, x = ix0[j] + dx;
+            const bool ok = prow_ok[j] && k4 < K && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            ra[j] = ok ? *(const float4 *)(xn[j] + ((long)y * a.W + x) * a.Cin + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto load_w2 = [&](int q, float4 (&rw)[2]) {
+#pragma unroll
+        for (int j = 0; j < WLD; ++j) rw[j] = wrow_ok[j] ? wsrc[j][q * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto park = [&](int buf, const float4 (&ra)[2], const float4 (&rw)[2]) {
+        As[buf][lkq][lr0] = ra[0];
+        As[buf][lkq][lr0 + 64] = ra[1];
+#pragma unroll
+        for (int j = 0; j < WLD; ++j) Ws[buf][lkq][lr0 + 64 * j] = rw[j];
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int x = 0; x < FM; ++x)
+#pragma unroll
+        for (int y = 0; y < FN; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nhex = a.KP >> 4;
+    float4 ra[2], rw[2];
+    load_a2(0, ra);
+    load_w2(0, rw);
+    park(0, ra, rw);
+    __syncthreads();
+
+    for (int q = 0; q < nhex; ++q) {
+        const int cur = q & 1;
+        const bool more = q + 1 < nhex;
+        if (more) {   // issue the next step's global loads before this step's MFMAs
+            load_a2(q + 1, ra);
+            load_w2(q + 1, rw);
+        }
+        float4 af[FM], bf[FN];
+#pragma unroll
+        for (int x = 0; x < FM; ++x) af[x] = As[cur][kk][wm * (FM * 16) + x * 16 + i];
+#pragma unroll
+        for (int y = 0; y < FN; ++y) bf[y] = Ws[cur][kk][wn * 64 + y * 16 + i];
+        // k element outermost: 8..16 independent accumulators between two uses of the same one (the
+        // 16x16x4 f32 MFMA has a 40-cycle dependent latency against a 32-cycle issue interval)
+#pragma unroll
+        for (int x = 0; x < FM; ++x)
+#pragma unroll
+            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[x].x, bf[y].x, acc[x][y], 0, 0, 0);
+#pragma unroll
+        for (int x = 0; x < FM; ++x)
+#pragma unroll
+            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[x].y, bf[y].y, acc[x][y], 0, 0, 0);
+#pragma unroll
+        for (int x = 0; x < FM; ++x)
+#pragma unroll
+            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[x].z, bf[y].z, acc[x][y], 0, 0, 0);
+#pragma unroll
+        for (int x = 0; x < FM; ++x)
+#pragma unroll
+            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[x].w, bf[y].w, acc[x][y], 0, 0, 0);
+        if (more) park(cur ^ 1, ra, rw);   // ... and park them in the other buffer after the MFMAs
+        __syncthreads();
+    }
+    // epilogue: D fragment lane = (channel column l&15, pixel rows 4*(l>>4)+r)
+#pragma unroll
+    for (int x = 0; x < FM; ++x)
+#pragma unroll
+        for (int y = 0; y < FN; ++y) {
+            const int co = n0 + wn * 64 + y * 16 + i;
+            if (co >= a.Cout) continue;
+            const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long pp = m0 + wm * (FM * 16) + x * 16 + kk * 4 + r;
+                if (pp < M) {
+                    float v = acc[x][y][r] + b;
+                    if (a.R) v += a.R[pp * a.Cout + co];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.Y[pp * a.Cout + co] = v;
+                }
+            }
+        }
+}

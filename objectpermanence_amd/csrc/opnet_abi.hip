@@ -859,8 +859,20 @@ extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float 
     float *z1 = proj + (size_t)S * E;
     float *hid = z1 + (size_t)S * E;
     const int M = (int)S, hd = E / nhead;
+    // C[M][N] = act(A[M][K] W[N][K]^T + b) = a 1x1 "convolution" over M pixels: the LDS-staged tiled kernel
     auto gemm = [&](const float *A, const float *Wt, const float *b, float *C, int N, int K, int act) {
-        gemm_bias_act<<<dim3((M + 63) / 64, (N + 63) / 64, 1), 256, 0, st>>>(A, Wt, b, C, M, N, K, act);
+        if ((long)((M + 127) / 128) * ((N + 127) / 128) < 256) {   // too few 128-tiles to fill the chip
+            gemm_bias_act<<<dim3((M + 63) / 64, (N + 63) / 64, 1), 256, 0, st>>>(A, Wt, b, C, M, N, K, act);
+            return;
+        }
+        ConvArgs c;
+        c.X = A; c.Wt = Wt; c.bias = b; c.R = nullptr; c.Y = C;
+        c.N = 1; c.H = 1; c.W = M; c.Cin = K; c.Cout = N; c.KH = 1; c.KW = 1; c.stride = 1; c.pad = 0;
+        c.OH = 1; c.OW = M; c.KP = K; c.relu = act;
+        if (N > 64)
+            conv2d_nhwc_tiled<128><<<dim3((M + 127) / 128, (N + 127) / 128, 1), 256, 0, st>>>(c);
+        else
+            conv2d_nhwc_tiled<64><<<dim3((M + 127) / 128, (N + 63) / 64, 1), 256, 0, st>>>(c);
     };
     gemm(z, in_w, in_b, qkv, 3 * E, E, 0);
     attention_f32<<<dim3((M + 63) / 64, nhead, 1), 256, 0, st>>>(qkv, att, M, E, hd, 1.0f / sqrtf((float)hd));
@@ -895,7 +907,15 @@ extern "C" int opdet_conv2d_f32(const float *x, const float *w, const float *bia
     a.KP = KP; a.relu = relu;
     if (a.OH <= 0 || a.OW <= 0) return fail(OPNET_ESHAPE, "empty conv output");
     const long M = (long)N * a.OH * a.OW;
-    conv2d_nhwc<<<dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, 1), 256, 0, (hipStream_t)stream>>>(a);
+    // LDS-staged 128 x {128, 64} tiles when they still give >= one workgroup per CU; the deep, spatially
+    // small layers (25x34 .. 50x68 maps at batch 1) keep the un-staged 64 x 64 tiles for parallelism
+    const long t128 = ((M + 127) / 128) * ((Cout + 127) / 128), t64 = ((M + 127) / 128) * ((Cout + 63) / 64);
+    if (Cout > 64 && t128 >= 256)
+        conv2d_nhwc_tiled<128><<<dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), 256, 0, (hipStream_t)stream>>>(a);
+    else if (Cout <= 64 && t64 >= 256)
+        conv2d_nhwc_tiled<64><<<dim3((unsigned)((M + 127) / 128), (Cout + 63) / 64, 1), 256, 0, (hipStream_t)stream>>>(a);
+    else
+        conv2d_nhwc<<<dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, 1), 256, 0, (hipStream_t)stream>>>(a);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

@@ -4,15 +4,19 @@ import numpy as np, torch
 from objectpermanence_amd.detector import ResNet50FPNBackbone, preprocess_frame
 from oracle import detector_oracle as do
 bb = ResNet50FPNBackbone(do.synth_backbone_params(), "cuda:0")
-frame = np.random.default_rng(0).integers(0, 256, size=(240, 320, 3), dtype=np.uint8)
-for _ in range(2):
-    f = bb.forward_nhwc(preprocess_frame(frame))
-torch.cuda.synchronize()
-n = 10
-t0 = time.perf_counter()
-for _ in range(n):
-    f = bb.forward_nhwc(preprocess_frame(frame))
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / n
-# MACs of ResNet-50 + FPN at 800x1088: count from layer shapes
-print(f"240x320 frame -> 800x1088: preprocess + ResNet-50-FPN backbone {dt*1e3:.2f} ms/frame ({1/dt:.1f} frames/s); maps:", {k: tuple(v.shape) for k, v in f.items()})
+frames = np.random.default_rng(0).integers(0, 256, size=(16, 240, 320, 3), dtype=np.uint8)
+for nb in [int(a) for a in sys.argv[1:]] or [1, 8]:
+    def run():
+        x = torch.cat([preprocess_frame(frames[i]) for i in range(nb)], dim=0)
+        return bb.forward_nhwc(x)
+    for _ in range(2):
+        f = run()
+    torch.cuda.synchronize()
+    n = max(2, 16 // nb)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        f = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"{nb} x (240x320 frame -> 800x1088): preprocess + ResNet-50-FPN backbone {dt*1e3:.2f} ms = {dt/nb*1e3:.2f} ms/frame "
+          f"({nb/dt:.1f} frames/s, ~{0.2*nb/dt:.1f} TFLOP/s); maps:", {k: tuple(v.shape) for k, v in f.items()}, flush=True)
