@@ -94,6 +94,10 @@ int opnet_train_backward_f32(const float *dy, const float *packed, void *workspa
  * = sign(y - labels) / n.  scratch: >= 4096 bytes of device memory. Deterministic reduction. */
 int opnet_l1_loss_f32(const float *y, const float *labels, float *loss, float *dy, long n, void *scratch,
                       size_t scratch_bytes, void *stream);
+/* torch.nn.SmoothL1Loss(beta) with mean reduction - the loss BASELINE.json's config text names; the
+ * reference itself trains with L1 (training_main.py:152). */
+int opnet_smooth_l1_loss_f32(const float *y, const float *labels, float *loss, float *dy, long n, float beta,
+                             void *scratch, size_t scratch_bytes, void *stream);
 /* One torch.optim.Adam step on one tensor (no weight decay / amsgrad); `step` counts from 1;
  * the gradient is multiplied by grad_scale first (1/world for data-parallel sums). */
 int opnet_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,

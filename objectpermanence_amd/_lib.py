@@ -52,6 +52,8 @@ def _declare(lib):
                                              c_int, c_int, c_int, c_int, c_void_p]
     lib.opnet_l1_loss_f32.restype = c_int
     lib.opnet_l1_loss_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_void_p, c_size_t, c_void_p]
+    lib.opnet_smooth_l1_loss_f32.restype = c_int
+    lib.opnet_smooth_l1_loss_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_float, c_void_p, c_size_t, c_void_p]
     lib.opnet_adam_step_f32.restype = c_int
     lib.opnet_adam_step_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_float, c_float, c_float, c_float,
                                         c_int, c_float, c_void_p]
@@ -98,7 +100,7 @@ EXPORTS = [
     "opnet_workspace_bytes", "opnet_forward_f32", "opnet_plan_create", "opnet_plan_forward",
     "opnet_plan_destroy", "opnet_postprocess_iou",
     "opnet_train_packed_weights_bytes", "opnet_train_pack_weights_f32", "opnet_train_workspace_bytes",
-    "opnet_train_forward_f32", "opnet_train_backward_f32", "opnet_l1_loss_f32", "opnet_adam_step_f32",
+    "opnet_train_forward_f32", "opnet_train_backward_f32", "opnet_l1_loss_f32", "opnet_smooth_l1_loss_f32", "opnet_adam_step_f32",
     "opnet_mlp_pack_weights_f32", "opnet_mlp_forward_f32",
     "opseq_lstm_stack_packed_bytes", "opseq_lstm_stack_workspace_bytes", "opseq_lstm_stack_pack_weights_f32",
     "opseq_lstm_stack_forward_f32", "opseq_lstm_stack_forward_graph_f32", "opseq_graph_cache_clear",

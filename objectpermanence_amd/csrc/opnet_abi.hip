@@ -587,15 +587,31 @@ extern "C" int opnet_train_backward_f32(const float *dy, const float *packed, vo
     return OPNET_OK;
 }
 
+static int l1_family(const float *y, const float *labels, float *loss, float *dy, long n, void *scratch,
+                     size_t scratch_bytes, float beta, void *stream);
+
 extern "C" int opnet_l1_loss_f32(const float *y, const float *labels, float *loss, float *dy, long n,
                                  void *scratch, size_t scratch_bytes, void *stream)
+{
+    return l1_family(y, labels, loss, dy, n, scratch, scratch_bytes, 0.f, stream);
+}
+
+extern "C" int opnet_smooth_l1_loss_f32(const float *y, const float *labels, float *loss, float *dy, long n,
+                                        float beta, void *scratch, size_t scratch_bytes, void *stream)
+{
+    if (!(beta > 0.f)) return fail(OPNET_EINVAL, "beta must be positive");
+    return l1_family(y, labels, loss, dy, n, scratch, scratch_bytes, beta, stream);
+}
+
+static int l1_family(const float *y, const float *labels, float *loss, float *dy, long n, void *scratch,
+                     size_t scratch_bytes, float beta, void *stream)
 {
     if (!y || !labels || !loss || !scratch) return fail(OPNET_EINVAL, "null pointer");
     if (n <= 0) return fail(OPNET_ESHAPE, "n must be positive");
     int nb = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
     if (scratch_bytes < (size_t)nb * 4) return fail(OPNET_EWORKSPACE, "scratch %zu B < %d B", scratch_bytes, nb * 4);
     hipStream_t st = (hipStream_t)stream;
-    opnet_l1_partial<<<nb, 256, 0, st>>>(y, labels, dy, (float *)scratch, n);
+    opnet_l1_partial<<<nb, 256, 0, st>>>(y, labels, dy, (float *)scratch, n, beta);
     opnet_l1_final<<<1, 64, 0, st>>>((const float *)scratch, nb, loss, n);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;

@@ -369,16 +369,25 @@ __global__ void __launch_bounds__(256) opnet_wgrad(const WgradBatch batch)
 // mean(|y - label|) (nn.L1Loss(reduction="none") then torch.mean, training_main.py:152,192,204) and
 // its gradient sign(y - label) / n.  Two-stage deterministic reduction: per-block partials, then
 // block 0... a second tiny launch sums them in fixed order.
+// beta <= 0: L1.  beta > 0: SmoothL1 (torch.nn.SmoothL1Loss, mean reduction): |d| < beta -> 0.5 d^2 / beta, else
+// |d| - 0.5 beta - the loss BASELINE.json's config text names; the reference itself trains with L1.
 __global__ void __launch_bounds__(256) opnet_l1_partial(const float *__restrict__ y, const float *__restrict__ lab,
-                                                        float *__restrict__ dy, float *__restrict__ partial, long n)
+                                                        float *__restrict__ dy, float *__restrict__ partial, long n,
+                                                        float beta)
 {
     __shared__ float red[256];
     const float inv = 1.0f / (float)n;
     float s = 0.f;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float d = y[i] - lab[i];
-        s += fabsf(d);
-        if (dy) dy[i] = d > 0.f ? inv : (d < 0.f ? -inv : 0.f);   // torch: sign(0) = 0
+        const float ad = fabsf(d);
+        if (beta > 0.f && ad < beta) {
+            s += 0.5f * d * d / beta;
+            if (dy) dy[i] = d / beta * inv;
+        } else {
+            s += beta > 0.f ? ad - 0.5f * beta : ad;
+            if (dy) dy[i] = d > 0.f ? inv : (d < 0.f ? -inv : 0.f);   // torch: sign(0) = 0
+        }
     }
     red[threadIdx.x] = s;
     __syncthreads();

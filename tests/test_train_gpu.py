@@ -165,3 +165,19 @@ def test_inference_after_fused_adam_uses_updated_weights():
     torch.cuda.synchronize()
     assert not torch.equal(y0, y1)
     assert torch.equal(y1, yt.detach())
+
+
+def test_smooth_l1_matches_torch():
+    from objectpermanence_amd.optim import smooth_l1_mean
+    torch.manual_seed(1)
+    y = (torch.randn(5, 11, 4, device="cuda") * 0.7).requires_grad_(True)
+    lab = torch.randn(5, 11, 4, device="cuda") * 0.7
+    for beta in (1.0, 0.25):
+        y.grad = None
+        loss = smooth_l1_mean(y, lab, beta)
+        loss.backward()
+        y2 = y.detach().clone().requires_grad_(True)
+        ref = torch.nn.SmoothL1Loss(beta=beta)(y2, lab)
+        ref.backward()
+        assert float(loss.detach()) == pytest.approx(float(ref.detach()), rel=2e-6)
+        assert torch.allclose(y.grad, y2.grad, rtol=1e-6, atol=1e-9)
