@@ -29,6 +29,14 @@ _REGISTRY = {
 class ModelsFactory(object):
 
     @staticmethod
+    def get_detector_model(model_name: str, model_weights: str = None):
+        """reference models_factory.py:36-39 - returns the detector front-end mirror (backbone only, see detector.py)"""
+        if model_name == "object_detector":
+            from .detector import CaterObjectDetector
+            from .object_indices import NUM_CLASSES
+            return CaterObjectDetector(model_weights, {str(i): i for i in range(NUM_CLASSES)})
+
+    @staticmethod
     def get_model(model_name: str, model_config: Dict[str, int], model_weights_path: str = None) -> lm.AbstractCaterModel:
         cls_name = _REGISTRY.get(model_name)
         if cls_name is None or not hasattr(lm, cls_name):

@@ -25,6 +25,15 @@ def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, min(n_items, lo + per)
 
 
+def shard_batches(n_items: int, batch_size: int, world: int, rank: int):
+    """Whole-batch sharding for TransformerLstm: its attention spans all clips of a minibatch (S = B*T, SURVEY.md
+    section 0), so results depend on batch composition and clips may only be sharded at REFERENCE-BATCH
+    granularity: the dataset is cut into the same consecutive batches the reference's DataLoader would form
+    and rank r takes batches r, r + world, ...  Returns the list of (lo, hi) clip ranges owned by `rank`."""
+    n_batches = (n_items + batch_size - 1) // batch_size
+    return [(b * batch_size, min(n_items, (b + 1) * batch_size)) for b in range(rank, n_batches, world)]
+
+
 def all_gather_predictions(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessGroup] = None,
                            async_op: bool = False):
     """local [n_local, ...] (this rank's shard, n_local may be short or zero on the last ranks) ->

@@ -159,3 +159,21 @@ def test_detector_score_filter_matches_reference(golden_dir):
             {"boxes": torch.tensor(c["boxes"]), "labels": torch.tensor(c["labels"]), "scores": torch.tensor(c["scores"])})
         assert out["scores"].shape[0] == c["kept"] == out["labels"].shape[0]
         assert out["boxes"].numpy().astype(int).tolist() == c["kept_boxes_int"]
+
+
+def test_batch_granular_sharding_for_transformer():
+    from objectpermanence_amd import parallel
+    for n, bs, w in ((37, 16, 2), (5, 16, 8), (64, 16, 4), (0, 4, 2)):
+        owned = [parallel.shard_batches(n, bs, w, r) for r in range(w)]
+        flat = sorted(x for part in owned for x in part)
+        # every reference batch appears exactly once, intact, in dataset order
+        assert flat == [(b * bs, min(n, (b + 1) * bs)) for b in range((n + bs - 1) // bs)]
+        for r, part in enumerate(owned):
+            assert all((lo // bs) % w == r for lo, _ in part)
+
+
+def test_detector_factory_entry():
+    from objectpermanence_amd import ModelsFactory
+    det = ModelsFactory.get_detector_model("object_detector", "detection_model.pth")
+    assert det.num_classes == 193 and det.saved_detector_path == "detection_model.pth"
+    assert ModelsFactory.get_detector_model("nope") is None
