@@ -241,6 +241,20 @@ def gen_detector_filter():
     print("detector_filter:", [c["kept"] for c in cases])
 
 
+def gen_analysis():
+    """analysis CSV golden: the reference's analyze_results (analyze_iou_offline.py:12-51) on synthetic files"""
+    import tempfile
+    from baselines.analyze_iou_offline import analyze_results
+    with tempfile.TemporaryDirectory() as tmp:
+        kw = synth.make_analysis_fixture(tmp)
+        out = os.path.join(tmp, "results.csv")
+        analyze_results(output_file=out, **kw)
+        text = open(out).read()
+    with open(os.path.join(OUT, "analysis_results.csv"), "w") as f:
+        f.write(text)
+    print("analysis csv:", len(text.splitlines()), "lines,", len(text.splitlines()[0].split(",")), "columns")
+
+
 def sample_indices(name, n, k=4096):
     """deterministic sample of flat indices of a tensor (same helper used by the tests)"""
     if n <= k:
@@ -330,6 +344,7 @@ def main():
     y, labels = gen_opnet(lm, real, n_clips=4, t_frames=300, tag="real", keep_intermediates=False)
     gen_metric(tu, y, labels)
     gen_detector_filter()
+    gen_analysis()
     gen_trained(lm, tu, real)
     gen_siblings(lm)
     gen_datasets()

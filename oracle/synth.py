@@ -272,3 +272,33 @@ def make_raw_video(c: int, variant: str = "plain", t_frames: int = T_FRAMES):
         labels.append(np.array([ids[i] for i in idx], dtype=np.int64))
         gt.append([int(x1[0]), int(y1[0]), int(w[0]), int(h[0])])
     return bbs, labels, {SNITCH_NAME: gt, "other_object_0": [[0, 0, 0, 0]] * t_frames}
+
+
+def make_analysis_fixture(root: str, n_videos: int = 6, t_frames: int = T_FRAMES):
+    """Synthetic analysis inputs in the reference's on-disk formats: prediction and label
+    `<video>_bb.json` directories plus six frame-list TSVs.  Returns the argument dict of analyze_results()."""
+    import json
+    import os
+    pred_dir, lab_dir = os.path.join(root, "pred"), os.path.join(root, "labels")
+    os.makedirs(pred_dir, exist_ok=True); os.makedirs(lab_dir, exist_ok=True)
+    names = [str(v) for v in (0, 1, 10, 11, 2, 3)][:n_videos]          # string sort differs from numeric order
+    files = {k: [] for k in ("containment", "static", "move", "vis0", "vis30", "vis99")}
+    for i, name in enumerate(names):
+        rng = np.random.default_rng(9000 + i)
+        _, _, gt = make_raw_video(i, "plain", t_frames)
+        xywh = np.array(gt[SNITCH_NAME])
+        xyxy = np.stack([xywh[:, 0], xywh[:, 1], xywh[:, 0] + xywh[:, 2], xywh[:, 1] + xywh[:, 3]], axis=1)
+        pred = xyxy + rng.integers(-10, 11, size=xyxy.shape)
+        json.dump(pred.tolist(), open(os.path.join(pred_dir, name + "_bb.json"), "w"))
+        json.dump(gt, open(os.path.join(lab_dir, name + "_bb.json"), "w"))
+        for j, k in enumerate(files):
+            frames = [] if (i == 1 and k == "static") else sorted(set(int(x) for x in rng.integers(0, t_frames, size=15 * (j + 1) + 7 * i)))
+            files[k].append(name + "\t" + ",".join(str(x) for x in frames) + "\n")
+    paths = {}
+    for k, lines in files.items():
+        paths[k] = os.path.join(root, k + ".txt")
+        open(paths[k], "w").writelines(lines)
+    return dict(predictions_dir=pred_dir, labels_dir=lab_dir, containment_annotations=paths["containment"],
+                containment_only_static=paths["static"], containment_with_movements=paths["move"],
+                visibility_gt_0=paths["vis0"], visibility_gt_30=paths["vis30"], visibility_gt_99=paths["vis99"],
+                iou_thresh=[0.5, 0.75])
