@@ -47,3 +47,41 @@ def test_inference_driver_end_to_end(tmp_path):
     miou, map50 = oo.mean_iou_and_map(px, gt_px)
     assert res["mean_iou"] == pytest.approx(miou, abs=1e-3)        # north_star: mean-IoU within 1e-3
     assert res["map_0.5"] == pytest.approx(map50, abs=2e-3)
+
+
+def test_training_driver_end_to_end(tmp_path):
+    """training_main mirror on synthetic files: loss falls, dev mean-IoU rises, the best checkpoint is a plain
+    state_dict that the inference driver loads back."""
+    from objectpermanence_amd.training_main import training_main
+    from objectpermanence_amd.inference_main import reasoning_inference_main
+    dirs = {}
+    for split, n, first in (("train", 24, 100), ("dev", 4, 100)):      # dev = the first 4 training clips
+        s, l = tmp_path / f"{split}_s", tmp_path / f"{split}_l"
+        s.mkdir(); l.mkdir()
+        lines = []
+        for i in range(n):
+            name = f"{split}{i:02d}"
+            bb, lab, gt = synth.make_raw_video(first + i, "plain")
+            pickle.dump({"bb": bb, "labels": lab}, open(s / (name + ".pkl"), "wb"), pickle.HIGHEST_PROTOCOL)
+            json.dump(gt, open(l / (name + "_bb.json"), "w"))
+            lines.append(name + "\t" + ",".join(str(x) for x in range(10 * i, 10 * i + 25)) + "\n")
+        open(tmp_path / f"{split}_mask.txt", "w").writelines(lines)
+        dirs[split] = (str(s), str(l), str(tmp_path / f"{split}_mask.txt"))
+    cfg = {"batch_size": 8, "inference_batch_size": 400, "num_workers": 0, "num_epochs": 40, "print_step": 100,
+           "learning_rate": 0.001, "lr_scheduler_patience": 2, "lr_scheduler_factor": 0.8, "device": "cuda:0",
+           "checkpoints_path": str(tmp_path / "ckpt"),
+           "train_sample_dir": dirs["train"][0], "train_labels_dir": dirs["train"][1], "train_containment_file": dirs["train"][2],
+           "dev_sample_dir": dirs["dev"][0], "dev_labels_dir": dirs["dev"][1], "dev_containment_file": dirs["dev"][2]}
+    torch.manual_seed(0)
+    res = training_main("opnet", cfg, CFG)
+    h = res["history"]
+    assert h[-1]["train_loss"] < 0.4 * h[0]["train_loss"]
+    assert res["best_dev_iou"] > 0.02 and res["checkpoint"] and os.path.exists(res["checkpoint"])
+    assert os.path.basename(res["checkpoint"]).endswith(f"_{round(res['best_dev_iou'], 3)}.pth")
+    sd = torch.load(res["checkpoint"])
+    assert set(sd) == set(synth.opnet_shapes(CFG))
+    json.dump(CFG, open(tmp_path / "model.json", "w"))
+    json.dump({"batch_size": 4, "num_workers": 0, "device": "cuda:0", "model_path": res["checkpoint"], "videos_dir": "unused",
+               "sample_dir": dirs["dev"][0], "labels_dir": dirs["dev"][1]}, open(tmp_path / "infer.json", "w"))
+    out = reasoning_inference_main("opnet", str(tmp_path / "out"), str(tmp_path / "infer.json"), str(tmp_path / "model.json"))
+    assert len(out["video_names"]) == 4 and np.isfinite(out["mean_iou"])
