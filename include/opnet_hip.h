@@ -127,6 +127,20 @@ int opseq_lstm_stack_forward_f32(const float *x, const float *packed, float *y, 
 int opseq_lstm_stack_forward_graph_f32(const float *x, const float *packed, float *y, void *workspace,
                                        size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream);
 void opseq_graph_cache_clear(void);
+/* training of the stacked LSTM: forward keeping the history in `workspace`, then BPTT + weight gradients.
+ * g_ih / g_hh: HOST arrays of L device pointers (state_dict layouts); dx0 (may be NULL): gradient of x [B,T,KX]. */
+size_t opseq_lstm_stack_train_packed_bytes(int L, int KX, int H);
+size_t opseq_lstm_stack_train_workspace_bytes(int B, int T, int L, int KX, int H);
+int opseq_lstm_stack_train_pack_weights_f32(const float *const *w_ih, const float *const *w_hh, const float *w_head,
+                                            float *packed, size_t packed_bytes, int L, int KX, int H, void *stream);
+int opseq_lstm_stack_train_forward_f32(const float *x, const float *packed, float *y, void *workspace,
+                                       size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream);
+int opseq_lstm_stack_train_backward_f32(const float *dy, const float *packed, void *workspace, size_t workspace_bytes,
+                                        float *const *g_ih, float *const *g_hh, float *g_head, float *dx0, int B,
+                                        int T, int L, int KX, int H, void *stream);
+/* gradient of boxes_linear.weight [F,5] given the saved forward output and its gradient */
+int opseq_slot_embed_relu_bwd_f32(const float *x, const float *out, const float *dout, float *dW, long ntok,
+                                  int nslots_out, int F, void *stream);
 /* relu(boxes_linear(x)) (:138,:178): x [ntok,15,5], W [F,5] -> out [ntok, nslots_out, F];
  * nslots_out = 15 (all slots) or 1 (slot 0 only - the live path of TransformerLstm). */
 int opseq_slot_embed_relu_f32(const float *x, const float *W, float *out, long ntok, int nslots_out, int F,

@@ -74,6 +74,19 @@ def _declare(lib):
     lib.opseq_lstm_stack_forward_graph_f32.argtypes = lib.opseq_lstm_stack_forward_f32.argtypes
     lib.opseq_graph_cache_clear.restype = None
     lib.opseq_graph_cache_clear.argtypes = []
+    lib.opseq_lstm_stack_train_packed_bytes.restype = c_size_t
+    lib.opseq_lstm_stack_train_packed_bytes.argtypes = [c_int, c_int, c_int]
+    lib.opseq_lstm_stack_train_workspace_bytes.restype = c_size_t
+    lib.opseq_lstm_stack_train_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    lib.opseq_lstm_stack_train_pack_weights_f32.restype = c_int
+    lib.opseq_lstm_stack_train_pack_weights_f32.argtypes = lib.opseq_lstm_stack_pack_weights_f32.argtypes
+    lib.opseq_lstm_stack_train_forward_f32.restype = c_int
+    lib.opseq_lstm_stack_train_forward_f32.argtypes = lib.opseq_lstm_stack_forward_f32.argtypes
+    lib.opseq_lstm_stack_train_backward_f32.restype = c_int
+    lib.opseq_lstm_stack_train_backward_f32.argtypes = [fp, fp, c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_void_p),
+                                                        fp, fp, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.opseq_slot_embed_relu_bwd_f32.restype = c_int
+    lib.opseq_slot_embed_relu_bwd_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_int, c_int, c_void_p]
     lib.opseq_slot_embed_relu_f32.restype = c_int
     lib.opseq_slot_embed_relu_f32.argtypes = [fp, fp, fp, ctypes.c_long, c_int, c_int, c_void_p]
     lib.opseq_encoder_workspace_bytes.restype = c_size_t
@@ -104,7 +117,11 @@ EXPORTS = [
     "opnet_mlp_pack_weights_f32", "opnet_mlp_forward_f32",
     "opseq_lstm_stack_packed_bytes", "opseq_lstm_stack_workspace_bytes", "opseq_lstm_stack_pack_weights_f32",
     "opseq_lstm_stack_forward_f32", "opseq_lstm_stack_forward_graph_f32", "opseq_graph_cache_clear",
-    "opseq_slot_embed_relu_f32", "opseq_encoder_workspace_bytes",
+    "opseq_slot_embed_relu_f32", "opseq_slot_embed_relu_bwd_f32",
+    "opseq_lstm_stack_train_packed_bytes", "opseq_lstm_stack_train_workspace_bytes",
+    "opseq_lstm_stack_train_pack_weights_f32", "opseq_lstm_stack_train_forward_f32",
+    "opseq_lstm_stack_train_backward_f32",
+    "opseq_encoder_workspace_bytes",
     "opseq_encoder_layer_f32",
     "opdet_conv2d_f32", "opdet_maxpool3x3s2_f32", "opdet_subsample2_f32", "opdet_upsample_add_f32",
     "opdet_preprocess_frame_f32",

@@ -824,6 +824,250 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
     return OPNET_OK;
 }
 
+// ---- training of the stacked LSTM ---------------------------------------------------------------------
+struct StackTrainPacked { size_t fwd_total, whh_t[SEQ_MAX_LAYERS], wih_t[SEQ_MAX_LAYERS], whead, wih0_t, total; };
+
+static StackTrainPacked stack_train_packed_layout(int L, int KX, int H)
+{
+    StackTrainPacked P;
+    size_t o = align_up(stack_packed_layout(L, KX, H).total, 4);
+    P.fwd_total = stack_packed_layout(L, KX, H).total;
+    for (int l = 0; l < L; ++l) {
+        P.whh_t[l] = o; o += (size_t)(H / 16) * (H / 4) * 256;
+        P.wih_t[l] = o; if (l >= 1) o += (size_t)(H / 16) * (H / 4) * 256;
+    }
+    P.whead = o; o += align_up((size_t)4 * H, 4);
+    P.wih0_t = o; o += align_up((size_t)(((KX + 15) / 16) * 16) * 4 * H, 4);   // W_ih0^T [KXP][4H], k = 4*unit + gate
+    P.total = o;
+    return P;
+}
+
+struct StackTrainWs {
+    size_t xp, state, hall[SEQ_MAX_LAYERS], call[SEQ_MAX_LAYERS], state_end, g[SEQ_MAX_LAYERS], ystage, dyp,
+        rpart[SEQ_MAX_LAYERS], dxpart[SEQ_MAX_LAYERS], dcz, dc[SEQ_MAX_LAYERS], dcz_end, darows, total;
+};
+
+static StackTrainWs stack_train_ws_layout(int B, int T, int L, int KX, int H)
+{
+    const size_t RB = (B + 31) / 32, KXP = (size_t)((KX + 15) / 16) * 16, TT = T;
+    StackTrainWs W;
+    size_t o = 0;
+    W.xp = o; o += TT * RB * (KXP / 4) * 32 * 16;
+    W.state = o;
+    for (int l = 0; l < L; ++l) {
+        W.hall[l] = o; o += (TT + 1) * RB * (size_t)H * 32 * 4;
+        W.call[l] = o; o += (TT + 1) * RB * (size_t)H * 32 * 4;
+    }
+    W.state_end = o;
+    for (int l = 0; l < L; ++l) { W.g[l] = o; o += TT * RB * (size_t)H * 32 * 16; }
+    W.ystage = o; o += RB * 32 * TT * 16;
+    W.dyp = o;    o += TT * RB * 32 * 16;
+    for (int l = 0; l < L; ++l) {
+        W.rpart[l] = o;  o += 4 * RB * (size_t)H * 32 * 4;
+        W.dxpart[l] = o; o += 4 * RB * (size_t)H * 32 * 4;
+    }
+    W.dcz = o;
+    for (int l = 0; l < L; ++l) { W.dc[l] = o; o += RB * (size_t)H * 32 * 4; }
+    W.dcz_end = o;
+    W.darows = o; o += (size_t)B * TT * 4 * H * 4;      // da0 as rows, for the input-gradient GEMM
+    W.total = align_up(o, 256);
+    return W;
+}
+
+extern "C" size_t opseq_lstm_stack_train_packed_bytes(int L, int KX, int H)
+{
+    if (check_stack(1, 1, L, KX, H)) return 0;
+    return stack_train_packed_layout(L, KX, H).total * sizeof(float);
+}
+
+extern "C" size_t opseq_lstm_stack_train_workspace_bytes(int B, int T, int L, int KX, int H)
+{
+    if (check_stack(B, T, L, KX, H)) return 0;
+    return stack_train_ws_layout(B, T, L, KX, H).total;
+}
+
+// W_ih0 [4H][KX] (torch gate-major rows) -> [KXP][4H] with column k = 4*unit + gate, zero rows beyond KX
+__global__ void pack_wih0_t(float *__restrict__ out, const float *__restrict__ w, int H, int KX, int KXP)
+{
+    const long n = (long)KXP * 4 * H;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const int k = idx % (4 * H);
+        const int x = idx / (4 * H);
+        const int unit = k >> 2, gate = k & 3;
+        out[idx] = x < KX ? w[((long)gate * H + unit) * KX + x] : 0.f;
+    }
+}
+
+extern "C" int opseq_lstm_stack_train_pack_weights_f32(const float *const *w_ih, const float *const *w_hh,
+                                                       const float *w_head, float *packed, size_t packed_bytes,
+                                                       int L, int KX, int H, void *stream)
+{
+    if (int rc = check_stack(1, 1, L, KX, H)) return rc;
+    const StackTrainPacked P = stack_train_packed_layout(L, KX, H);
+    if (packed_bytes < P.total * sizeof(float)) return fail(OPNET_EWORKSPACE, "packed buffer too small");
+    if (int rc = opseq_lstm_stack_pack_weights_f32(w_ih, w_hh, w_head, packed, P.fwd_total * sizeof(float), L, KX, H, stream))
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    auto blocks = [](size_t n) { return (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256); };
+    const size_t tile_f = (size_t)(H / 16) * (H / 4) * 256;
+    for (int l = 0; l < L; ++l) {
+        opnet_pack_tiles_t<<<blocks(tile_f), 256, 0, st>>>(packed + P.whh_t[l], w_hh[l], H, 0, 0, H / 16);
+        if (l >= 1) opnet_pack_tiles_t<<<blocks(tile_f), 256, 0, st>>>(packed + P.wih_t[l], w_ih[l], H, 0, 0, H / 16);
+    }
+    opnet_copy_f32<<<blocks((size_t)4 * H), 256, 0, st>>>(packed + P.whead, w_head, (long)4 * H);
+    const int KXP = ((KX + 15) / 16) * 16;
+    pack_wih0_t<<<blocks((size_t)KXP * 4 * H), 256, 0, st>>>(packed + P.wih0_t, w_ih[0], H, KX, KXP);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+static int make_stack_train_args(StackArgs *a, StackBwdArgs *b, const float *packed, void *workspace,
+                                 size_t workspace_bytes, int B, int T, int L, int KX, int H)
+{
+    if (int rc = check_stack(B, T, L, KX, H)) return rc;
+    if (!packed || !workspace) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(packed) || !aligned16(workspace)) return fail(OPNET_EINVAL, "packed/workspace must be 16-byte aligned");
+    const StackTrainWs W = stack_train_ws_layout(B, T, L, KX, H);
+    if (workspace_bytes < W.total) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", workspace_bytes, W.total);
+    const StackPackedLayout P = stack_packed_layout(L, KX, H);
+    const StackTrainPacked TP = stack_train_packed_layout(L, KX, H);
+    char *w = (char *)workspace;
+    const int RB = (B + 31) / 32;
+    memset(a, 0, sizeof(*a));
+    memset(b, 0, sizeof(*b));
+    a->B = B; a->T = T; a->RB = RB; a->L = L; a->train = 1;
+    a->xp = (const float4 *)(w + W.xp);
+    b->B = B; b->T = T; b->RB = RB; b->L = L; b->H = H;
+    for (int l = 0; l < L; ++l) {
+        a->layer[l].A = (const float4 *)(packed + P.layer[l]);
+        a->layer[l].H = H;
+        a->layer[l].nhx = P.nhx[l];
+        a->layer[l].hbuf = (float4 *)(w + W.hall[l]);
+        a->layer[l].c = (float *)(w + W.call[l]);
+        a->layer[l].gsave = (float4 *)(w + W.g[l]);
+        b->layer[l].whh_t = (const float4 *)(packed + TP.whh_t[l]);
+        b->layer[l].wih_t = l >= 1 ? (const float4 *)(packed + TP.wih_t[l]) : nullptr;
+        b->layer[l].g = (float4 *)(w + W.g[l]);
+        b->layer[l].call = (const float *)(w + W.call[l]);
+        b->layer[l].rpart = (float *)(w + W.rpart[l]);
+        b->layer[l].dxpart = (float *)(w + W.dxpart[l]);
+        b->layer[l].dc = (float *)(w + W.dc[l]);
+    }
+    a->headA = (const float4 *)(packed + P.head);
+    a->ystage = (float4 *)(w + W.ystage);
+    b->dyp = (const float4 *)(w + W.dyp);
+    b->whead = packed + TP.whead;
+    return OPNET_OK;
+}
+
+extern "C" int opseq_lstm_stack_train_forward_f32(const float *x, const float *packed, float *y, void *workspace,
+                                                  size_t workspace_bytes, int B, int T, int L, int KX, int H,
+                                                  void *stream)
+{
+    StackArgs a; StackBwdArgs b;
+    if (!x || !y) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(y)) return fail(OPNET_EINVAL, "y must be 16-byte aligned");
+    if (int rc = make_stack_train_args(&a, &b, packed, workspace, workspace_bytes, B, T, L, KX, H)) return rc;
+    const StackTrainWs W = stack_train_ws_layout(B, T, L, KX, H);
+    const StackPackedLayout P = stack_packed_layout(L, KX, H);
+    char *w = (char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    rows_to_packed<<<2048, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, a.RB, KX, P.nhx[0] * 16,
+                                          (float4 *)(w + W.state), (long)((W.state_end - W.state) / 16));
+    const dim3 grid(L * (H / 4) + 1, a.RB < OPNET_MAX_GY ? a.RB : OPNET_MAX_GY, 1);
+    for (int s = 0; s < T + L; ++s) lstm_stack_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    const long ny = (long)B * T;
+    copy_y_out<<<(unsigned)((ny + 255) / 256 > 1024 ? 1024 : (ny + 255) / 256), 256, 0, st>>>(a.ystage, (float4 *)y, ny);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+/* g_ih / g_hh: HOST arrays of L device pointers (gradients in the state_dict layouts); dx0 (nullable):
+ * gradient of the stack's input x [B,T,KX] (needed by models with trainable layers below the LSTM). */
+extern "C" int opseq_lstm_stack_train_backward_f32(const float *dy, const float *packed, void *workspace,
+                                                   size_t workspace_bytes, float *const *g_ih, float *const *g_hh,
+                                                   float *g_head, float *dx0, int B, int T, int L, int KX, int H,
+                                                   void *stream)
+{
+    StackArgs a; StackBwdArgs b;
+    if (!dy || !g_ih || !g_hh || !g_head) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(dy)) return fail(OPNET_EINVAL, "dy must be 16-byte aligned");
+    if (int rc = make_stack_train_args(&a, &b, packed, workspace, workspace_bytes, B, T, L, KX, H)) return rc;
+    const StackTrainWs W = stack_train_ws_layout(B, T, L, KX, H);
+    const StackTrainPacked TP = stack_train_packed_layout(L, KX, H);
+    const StackPackedLayout P = stack_packed_layout(L, KX, H);
+    char *w = (char *)workspace;
+    const int RB = a.RB;
+    hipStream_t st = (hipStream_t)stream;
+    opnet_pack_dy<<<256, 256, 0, st>>>((const float4 *)dy, (float4 *)(w + W.dyp), (float *)(w + W.dcz),
+                                        (long)((W.dcz_end - W.dcz) / 4), B, T, RB);
+    const int per = 4 * (H / 16);
+    const dim3 ggemm((2 * L - 1) * per, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
+    const dim3 gcell(L * (H / 8), RB, 1);
+    for (int n = 0; n < T + L - 1; ++n) {
+        stack_bwd_cell<<<gcell, 256, 0, st>>>(b, n);
+        stack_bwd_gemm<<<ggemm, OPNET_THREADS, 0, st>>>(b, n);
+    }
+    // weight gradients over the saved histories (same merged GEMM launch as OPNet's)
+    const long hs = (long)(H / 4) * 32;
+    std::vector<WgradArgs> jobs;
+    auto add = [&](const float4 *Pp, long ps, int MQ, const float4 *Q, long qs, int NQ, float *out, int ld,
+                   int mvalid, int nvalid, int rowmode) {
+        WgradArgs g;
+        memset(&g, 0, sizeof(g));
+        g.P = Pp; g.p_stride = ps; g.MQ = MQ; g.Q = Q; g.q_stride = qs; g.NQ = NQ;
+        g.out = out; g.ld = ld; g.mvalid = mvalid; g.nvalid = nvalid; g.rowmode = rowmode; g.H = H;
+        g.T = T; g.RB = RB;
+        g.tiles_m = (MQ + 15) / 16;
+        jobs.push_back(g);
+    };
+    for (int l = 0; l < L; ++l) {
+        if (!g_ih[l] || !g_hh[l]) return fail(OPNET_EINVAL, "null gradient pointer (layer %d)", l);
+        const float4 *hall = (const float4 *)(w + W.hall[l]);
+        add(b.layer[l].g, (long)H * 32, H, hall, hs, H / 4, g_hh[l], H, 4 * H, H, 1);                 // da_l x h_l(t-1)
+        if (l == 0)
+            add(b.layer[l].g, (long)H * 32, H, a.xp, (long)P.nhx[0] * 128, P.nhx[0] * 4, g_ih[0], KX, 4 * H, KX, 1);
+        else
+            add(b.layer[l].g, (long)H * 32, H, (const float4 *)(w + W.hall[l - 1]) + (long)RB * hs, hs, H / 4,
+                g_ih[l], H, 4 * H, H, 1);                                                                // da_l x h_{l-1}(t)
+    }
+    add(b.dyp, 32, 1, (const float4 *)(w + W.hall[L - 1]) + (long)RB * hs, hs, H / 4, g_head, H, 4, H, 0);
+    for (size_t j0 = 0; j0 < jobs.size(); j0 += OPNET_WGRAD_JOBS) {
+        WgradBatch wb;
+        int ntiles = 0;
+        for (int j = 0; j < OPNET_WGRAD_JOBS; ++j) {
+            if (j0 + j < jobs.size()) {
+                wb.job[j] = jobs[j0 + j];
+                wb.job[j].tile_begin = ntiles;
+                ntiles += wb.job[j].tiles_m * ((wb.job[j].NQ + 15) / 16);
+            } else {
+                memset(&wb.job[j], 0, sizeof(WgradArgs));
+                wb.job[j].tile_begin = 0x7fffffff;
+                wb.job[j].tiles_m = 1;
+            }
+        }
+        opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
+    }
+    if (dx0) {
+        // dx0 [B*T][KX] = da0 [B*T][4H] . W_ih0 [4H][KX]  (k = 4*unit + gate on both sides) via the tiled GEMM
+        float *rows = (float *)(w + W.darows);
+        const long nb = (long)B * T * H;
+        packed_da_to_rows<<<(unsigned)((nb + 255) / 256 > 8192 ? 8192 : (nb + 255) / 256), 256, 0, st>>>(
+            b.layer[0].g, rows, B, T, RB, H);
+        ConvArgs c;
+        c.X = rows; c.Wt = packed + TP.wih0_t; c.bias = nullptr; c.R = nullptr; c.Y = dx0;
+        c.N = 1; c.H = 1; c.W = B * T; c.Cin = 4 * H; c.Cout = KX; c.KH = 1; c.KW = 1; c.stride = 1; c.pad = 0;
+        c.OH = 1; c.OW = B * T; c.KP = 4 * H; c.relu = 0;
+        const int M = B * T;
+        if (KX > 64)
+            conv2d_nhwc_tiled<128><<<dim3((M + 127) / 128, (KX + 127) / 128, 1), 256, 0, st>>>(c);
+        else
+            conv2d_nhwc_tiled<64><<<dim3((M + 127) / 128, (KX + 63) / 64, 1), 256, 0, st>>>(c);
+    }
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
 extern "C" int opseq_slot_embed_relu_f32(const float *x, const float *W, float *out, long ntok, int nslots_out,
                                          int F, void *stream)
 {
@@ -833,6 +1077,16 @@ extern "C" int opseq_slot_embed_relu_f32(const float *x, const float *W, float *
     const long n = ntok * nslots_out * F;
     slot_embed_relu<<<(unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
         x, W, out, ntok, nslots_out, F);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opseq_slot_embed_relu_bwd_f32(const float *x, const float *out, const float *dout, float *dW, long ntok,
+                                             int nslots_out, int F, void *stream)
+{
+    if (!x || !out || !dout || !dW) return fail(OPNET_EINVAL, "null pointer");
+    if (ntok <= 0 || F <= 0 || (nslots_out != 1 && nslots_out != 15)) return fail(OPNET_ESHAPE, "bad shape");
+    slot_embed_relu_bwd<<<F, 256, 0, (hipStream_t)stream>>>(x, out, dout, dW, ntok, nslots_out, F);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

@@ -18,12 +18,14 @@ struct StackLayer {
     const float4 *A;       // [H/4 tiles][nhx + H/16][64]  A tiles: K = [x part (nhx hexadecets) | h part]
     int H;                 // hidden size
     int nhx;               // hexadecets of the x part (input width padded to 16)
-    float4 *hbuf;          // [2 parity][RB][H/4][32]
-    float *c;              // [RB][H][32]
+    float4 *hbuf;          // [2 parity | T+1][RB][H/4][32]
+    float *c;              // [1 | T+1][RB][H][32]
+    float4 *gsave;         // training: [T][RB][H][32] post-activation gates (i,f,g,o), later overwritten by da
 };
 
 struct StackArgs {
     int B, T, RB, L;
+    int train;             // 1: full-history buffers (slot t+1 = step t, slot 0 = zero state), gates saved
     const float4 *xp;      // layer 0 input, packed [T][RB][4*nhx0][32]
     StackLayer layer[SEQ_MAX_LAYERS];
     const float4 *headA;   // [H_last/16][64]  4 -> 16 rows
@@ -58,20 +60,24 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         load_a_chunk(a0, A, ks.q0, ks.q1);
         const int unit = tile * 4 + quarter;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            const long so = a.train ? t + 1 : (t & 1), sp = a.train ? t : ((t + 1) & 1);   // history slots
+            const long co = a.train ? t + 1 : 0, cp = a.train ? t : 0;
             const float4 *xseg = (l == 0)
                 ? a.xp + ((long)t * a.RB + rb) * ((long)nhx * 128)
-                : a.layer[l - 1].hbuf + ((long)(t & 1) * a.RB + rb) * ((long)a.layer[l - 1].H * 8);
-            const float4 *hprev = ly.hbuf + ((long)((t + 1) & 1) * a.RB + rb) * ((long)H * 8);
+                : a.layer[l - 1].hbuf + (so * a.RB + rb) * ((long)a.layer[l - 1].H * 8);
+            const float4 *hprev = ly.hbuf + (sp * a.RB + rb) * ((long)H * 8);
             float c_old = 0.f;
-            if (tid < 128) c_old = ly.c[((long)rb * H + unit) * 32 + clip];
+            if (tid < 128) c_old = ly.c[((cp * a.RB + rb) * H + unit) * 32 + clip];
             gemm16_rb(a0, A, xseg, nhx, hprev, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             if (tid < 128) {
                 float c = c_old;
-                const float h = lstm_cell(part_sum(part, half * 4 + 0, el), part_sum(part, half * 4 + 1, el),
-                                          part_sum(part, half * 4 + 2, el), part_sum(part, half * 4 + 3, el), &c);
-                ly.c[((long)rb * H + unit) * 32 + clip] = c;
-                float *hout = (float *)(ly.hbuf + ((long)(t & 1) * a.RB + rb) * ((long)H * 8));
+                float4 gs;
+                const float h = lstm_cell_g(part_sum(part, half * 4 + 0, el), part_sum(part, half * 4 + 1, el),
+                                            part_sum(part, half * 4 + 2, el), part_sum(part, half * 4 + 3, el), &c, &gs);
+                ly.c[((co * a.RB + rb) * H + unit) * 32 + clip] = c;
+                if (a.train) ly.gsave[(((long)t * a.RB + rb) * H + unit) * 32 + clip] = gs;
+                float *hout = (float *)(ly.hbuf + (so * a.RB + rb) * ((long)H * 8));
                 hout[((long)tile * 32 + clip) * 4 + quarter] = h;
             }
             if (rb + (int)gridDim.y < a.RB) __syncthreads();
@@ -85,7 +91,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         const KSlice ks = wave_slice(nh);
         load_a_chunk(a0, a.headA, ks.q0, ks.q1);
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
-            const float4 *hcur = ly.hbuf + ((long)(t & 1) * a.RB + rb) * ((long)ly.H * 8);
+            const float4 *hcur = ly.hbuf + ((a.train ? t + 1 : (long)(t & 1)) * a.RB + rb) * ((long)ly.H * 8);
             gemm16_rb(a0, a.headA, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             if (tid < 128 && quarter == 0) {
@@ -138,6 +144,122 @@ __global__ void __launch_bounds__(256) copy_y_out(const float4 *__restrict__ ys,
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = ys[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward through the stacked LSTM (BPTT) - generic counterpart of opnet_bwd_gemm / opnet_bwd_cell
+// ------------------------------------------------------------------------------------------------
+// Layer l (0 = bottom) lags the top layer by lam_l = L-1-l launch pairs.  Launch pair n:
+//   stack_bwd_cell(n): layer l, t = T-1-n+lam_l:   dh = [l == L-1 ? W_head^T dy_t : sum DX_{l+1} partials]
+//                                                      + [t < T-1 ? sum R_l partials : 0]  -> cell backward -> da_l(t)
+//   stack_bwd_gemm(n): for every layer at its t:   R_l  = W_hh_l^T da_l(t)   (split-K x4) -> dh_l(t-1) partials
+//                      for l >= 1:                 DX_l = W_ih_l^T da_l(t)   (split-K x4) -> dh_{l-1}(t) partials
+// da overwrites the saved gates in place (k = 4*unit + gate layout), exactly as in opnet_train_kernels.hip.
+struct StackBwdLayer {
+    const float4 *whh_t;   // [H/16][H/4][64]  W_hh^T tiles, k = 4*unit' + gate
+    const float4 *wih_t;   // l >= 1: [H/16][H/4][64]  W_ih^T tiles (rows = units of layer l-1)
+    float4 *g;             // [T][RB][H][32]  gates in / da out
+    const float *call;     // [T+1][RB][H][32]
+    float *rpart;          // [4][RB][H][32]
+    float *dxpart;         // l >= 1: [4][RB][H][32] partials of dh_{l-1}
+    float *dc;             // [RB][H][32]
+};
+
+struct StackBwdArgs {
+    int B, T, RB, L, H;
+    StackBwdLayer layer[SEQ_MAX_LAYERS];
+    const float4 *dyp;     // [T][RB][32]
+    const float *whead;    // [4][H] raw
+};
+
+// grid.x = L * 4*(H/16) R tiles + (L-1) * 4*(H/16) DX tiles ; grid.y <= RB
+__global__ void __launch_bounds__(OPNET_THREADS) stack_bwd_gemm(const StackBwdArgs a, const int n)
+{
+    __shared__ __attribute__((aligned(16))) float part[OPNET_NW * 8 * 64];
+    const int s = n;
+    const int H = a.H, per = 4 * (H >> 4);
+    int bx = blockIdx.x;
+    const int kind = bx >= a.L * per;               // 0: R product, 1: DX product
+    if (kind) bx -= a.L * per;
+    const int l = kind ? 1 + bx / per : bx / per;
+    bx -= (kind ? l - 1 : l) * per;
+    const int tile = bx >> 2, ks = bx & 3;
+    const int t = a.T - 1 - n + (a.L - 1 - l);
+    if (t < 0 || t >= a.T) return;
+    const StackBwdLayer &ly = a.layer[l];
+    const float4 *A = (kind ? ly.wih_t : ly.whh_t) + ((long)tile * (H >> 2) + ks * (H >> 4)) * 64;
+    float *dst = kind ? ly.dxpart : ly.rpart;
+    const int tid = threadIdx.x, el = tid & 63, half = tid >> 6;
+    const int clip = half * 16 + (el & 15), quarter = el >> 4;
+    float4 a0[OPNET_CH];
+    const int nh = H >> 4;
+    const KSlice ksl = wave_slice(nh);
+    load_a_chunk(a0, A, ksl.q0, ksl.q1);
+    for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+        const float4 *seg = ly.g + (((long)t * a.RB + rb) * H + (long)ks * (H >> 2)) * 32;
+        gemm16_rb(a0, A, seg, nh, seg, ksl, part, s, a.B - rb * 32 > 16);
+        __syncthreads();
+        if (tid < 128) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = tile * 16 + quarter * 4 + r;
+                dst[(((long)ks * a.RB + rb) * H + row) * 32 + clip] = part_sum(part, half * 4 + r, el);
+            }
+        }
+        if (rb + (int)gridDim.y < a.RB) __syncthreads();
+    }
+}
+
+// grid.x = L * H/8 ; grid.y = RB
+__global__ void __launch_bounds__(256) stack_bwd_cell(const StackBwdArgs a, const int n)
+{
+    const int H = a.H, per = H >> 3;
+    const int l = blockIdx.x / per, chunk = blockIdx.x - l * per;
+    const int rb = blockIdx.y;
+    const int t = a.T - 1 - n + (a.L - 1 - l);
+    if (t < 0 || t >= a.T) return;
+    const StackBwdLayer &ly = a.layer[l];
+    const int tid = threadIdx.x, clip = tid & 31;
+    const int u = chunk * 8 + (tid >> 5);
+    const long e = ((long)rb * H + u) * 32 + clip;
+    const long ps = (long)a.RB * H * 32;
+    float dh;
+    if (l == a.L - 1) {
+        const float4 dy = a.dyp[((long)t * a.RB + rb) * 32 + clip];
+        dh = a.whead[u] * dy.x;
+        dh = fmaf(a.whead[H + u], dy.y, dh);
+        dh = fmaf(a.whead[2 * H + u], dy.z, dh);
+        dh = fmaf(a.whead[3 * H + u], dy.w, dh);
+    } else {
+        const float *dx = a.layer[l + 1].dxpart;
+        dh = ((dx[e] + dx[ps + e]) + dx[2 * ps + e]) + dx[3 * ps + e];
+    }
+    float dcc = 0.f;
+    if (t < a.T - 1) {
+        dh += ((ly.rpart[e] + ly.rpart[ps + e]) + ly.rpart[2 * ps + e]) + ly.rpart[3 * ps + e];
+        dcc = ly.dc[e];
+    }
+    const long ge = (((long)t * a.RB + rb) * H + u) * 32 + clip;
+    const float c_t = ly.call[(((long)(t + 1)) * a.RB + rb) * H * 32 + (long)u * 32 + clip];
+    const float c_p = ly.call[((long)t * a.RB + rb) * H * 32 + (long)u * 32 + clip];
+    float dco;
+    ly.g[ge] = cell_backward(dh, dcc, ly.g[ge], c_t, c_p, &dco);
+    ly.dc[e] = dco;
+}
+
+// da0 in the packed layout [T][RB][H][32] float4 (k = 4*unit + gate) -> row-major [B*T][4H] with the SAME k order,
+// the A operand of the input-gradient GEMM  dx0 = da0 . W_ih0  (boxes_linear / encoder backward)
+__global__ void __launch_bounds__(256) packed_da_to_rows(const float4 *__restrict__ g, float *__restrict__ out, int B,
+                                                         int T, int RB, int H)
+{
+    const long n = (long)B * T * H;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const int u = idx % H;
+        const long bt = idx / H;
+        const int t = bt % T;
+        const int b = bt / T;
+        ((float4 *)out)[idx] = g[(((long)t * RB + (b >> 5)) * H + u) * 32 + (b & 31)];
+    }
+}
+
 // out[(b*T+t)*nslots_out + slot][f] = relu(sum_k W[f][k] * x[b][t][slot][k]), k < 5
 // nslots_out = 15 (NonLinearLstm, learned_models.py:138) or 1 = slot 0 only (TransformerLstm's live path).
 __global__ void __launch_bounds__(256) slot_embed_relu(const float *__restrict__ x, const float *__restrict__ W,
@@ -158,6 +280,37 @@ __global__ void __launch_bounds__(256) slot_embed_relu(const float *__restrict__
         acc = fmaf(w[4], xi[4], acc);
         out[idx] = fmaxf(acc, 0.f);
     }
+}
+
+// gradient of boxes_linear.weight [F][5] through relu: dW[f][k] = sum_{tok,slot} [out > 0] * dout * x[tok][slot][k]
+// one workgroup per output feature f; fixed-order block reduction (deterministic)
+__global__ void __launch_bounds__(256) slot_embed_relu_bwd(const float *__restrict__ x, const float *__restrict__ out,
+                                                           const float *__restrict__ dout, float *__restrict__ dW,
+                                                           long ntok, int nslots_out, int F)
+{
+    __shared__ float red[5][256];
+    const int f = blockIdx.x;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const long n = ntok * nslots_out;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const long tok = i / nslots_out;
+        const int slot = i - tok * nslots_out;
+        const long o = i * F + f;
+        const float g = out[o] > 0.f ? dout[o] : 0.f;
+        const float *xi = x + (tok * 15 + slot) * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k] = fmaf(g, xi[k], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 5) dW[f * 5 + threadIdx.x] = red[threadIdx.x][0];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -235,6 +235,106 @@ class OPNet(AbstractCaterModel):
 # ------------------------------------------------------------------------------------------------
 # sibling reasoners (reference learned_models.py:55-197) - inference through the HIP library
 # ------------------------------------------------------------------------------------------------
+def _check_input(module: nn.Module, x: torch.Tensor, feat: int):
+    if not x.is_cuda:
+        raise RuntimeError(f"objectpermanence_amd.{type(module).__name__} runs on MI355X only: move the input "
+                           "(and the model) to a ROCm device; there is no CPU fallback")
+    if x.dim() != 4 or x.shape[2] != 15 or x.shape[3] != feat:
+        raise ValueError(f"input must be [B, T, 15, {feat}], got {tuple(x.shape)}")
+
+
+def _wants_grad(module: nn.Module) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+class _StackTrainFunction(torch.autograd.Function):
+    """autograd bridge of the stacked LSTM: opseq_lstm_stack_train_forward_f32 / _backward_f32"""
+
+    @staticmethod
+    def forward(ctx, runner, x, *weights):
+        lib = _lib.load()
+        L, KX, H = runner.L, runner.KX, runner.H
+        B, T, dev = int(x.shape[0]), int(x.shape[1]), x.device
+        stream = _stream_ptr(dev)
+        nbytes = lib.opseq_lstm_stack_train_packed_bytes(L, KX, H)
+        if nbytes == 0:
+            _lib.check(-2, "opseq_lstm_stack_train_packed_bytes")
+        if runner.tpacked is None or runner.tpacked.device != dev:
+            runner.tpacked = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        arr = _lib.c_void_p * L
+        ih = arr(*[w.data_ptr() for w in weights[:L]])
+        hh = arr(*[w.data_ptr() for w in weights[L:2 * L]])
+        _lib.check(lib.opseq_lstm_stack_train_pack_weights_f32(ih, hh, weights[2 * L].data_ptr(), runner.tpacked.data_ptr(),
+                                                               nbytes, L, KX, H, stream), "opseq_lstm_stack_train_pack_weights_f32")
+        key = (B, T, str(dev))
+        if runner.tws_key != key:
+            wsb = lib.opseq_lstm_stack_train_workspace_bytes(B, T, L, KX, H)
+            if wsb == 0:
+                _lib.check(-2, "opseq_lstm_stack_train_workspace_bytes")
+            runner.tws = None
+            runner.tws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            runner.tws_key = key
+        y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+        _lib.check(lib.opseq_lstm_stack_train_forward_f32(x.data_ptr(), runner.tpacked.data_ptr(), y.data_ptr(),
+                                                          runner.tws.data_ptr(), runner.tws.numel(), B, T, L, KX, H, stream),
+                   "opseq_lstm_stack_train_forward_f32")
+        runner.train_gen += 1
+        ctx.runner, ctx.gen, ctx.shape = runner, runner.train_gen, (B, T)
+        ctx.wshapes = [tuple(w.shape) for w in weights]
+        ctx.need_dx = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        runner = ctx.runner
+        if ctx.gen != runner.train_gen:
+            raise RuntimeError("backward() after another training forward - the saved history has been overwritten")
+        lib = _lib.load()
+        L, KX, H = runner.L, runner.KX, runner.H
+        B, T = ctx.shape
+        dev = grad_y.device
+        grad_y = grad_y.contiguous().float()
+        grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.wshapes]
+        dx = torch.empty((B, T, KX), dtype=torch.float32, device=dev) if ctx.need_dx else None
+        arr = _lib.c_void_p * L
+        gih = arr(*[g.data_ptr() for g in grads[:L]])
+        ghh = arr(*[g.data_ptr() for g in grads[L:2 * L]])
+        with torch.cuda.device(dev):
+            rc = lib.opseq_lstm_stack_train_backward_f32(grad_y.data_ptr(), runner.tpacked.data_ptr(), runner.tws.data_ptr(),
+                                                         runner.tws.numel(), gih, ghh, grads[2 * L].data_ptr(),
+                                                         None if dx is None else dx.data_ptr(), B, T, L, KX, H,
+                                                         _stream_ptr(dev))
+        _lib.check(rc, "opseq_lstm_stack_train_backward_f32")
+        return (None, dx) + tuple(grads)
+
+
+class _SlotEmbedFunction(torch.autograd.Function):
+    """relu(boxes_linear(x)) per slot with its weight gradient (the input boxes never need a gradient)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, nslots_out):
+        lib = _lib.load()
+        ntok, F = int(x.shape[0] * x.shape[1]), int(weight.shape[0])
+        out = torch.empty((x.shape[0], x.shape[1], nslots_out * F), dtype=torch.float32, device=x.device)
+        _lib.check(lib.opseq_slot_embed_relu_f32(x.data_ptr(), weight.data_ptr(), out.data_ptr(), ntok, nslots_out, F,
+                                                 _stream_ptr(x.device)), "opseq_slot_embed_relu_f32")
+        ctx.save_for_backward(x, out)
+        ctx.dims = (ntok, nslots_out, F)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, out = ctx.saved_tensors
+        ntok, nslots_out, F = ctx.dims
+        dW = torch.empty((F, 5), dtype=torch.float32, device=x.device)
+        dout = dout.contiguous().float()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.opseq_slot_embed_relu_bwd_f32(x.data_ptr(), out.data_ptr(), dout.data_ptr(), dW.data_ptr(), ntok,
+                                                         nslots_out, F, _stream_ptr(x.device)), "opseq_slot_embed_relu_bwd_f32")
+        return None, dW, None
+
+
 def _require_inference(module: nn.Module, x: torch.Tensor, feat: int):
     if not x.is_cuda:
         raise RuntimeError(f"objectpermanence_amd.{type(module).__name__} runs on MI355X only: move the input "
@@ -258,6 +358,15 @@ class _LstmStackRunner:
         self.packed = None
         self.key = None
         self.ws = {}
+        self.tpacked, self.tws, self.tws_key, self.train_gen = None, None, None, 0
+
+    def run_train(self, x: torch.Tensor, lstm: "LSTMWeights", head: "LinearWeight") -> torch.Tensor:
+        ws_list = [getattr(lstm, f"weight_ih_l{l}") for l in range(self.L)] + \
+                  [getattr(lstm, f"weight_hh_l{l}") for l in range(self.L)] + [head.weight]
+        for w in ws_list:
+            if w.device != x.device or w.dtype != torch.float32 or not w.is_contiguous():
+                raise RuntimeError("parameters must be contiguous fp32 on the input's device")
+        return _StackTrainFunction.apply(self, x.contiguous(), *ws_list)
 
     def run(self, x: torch.Tensor, lstm: "LSTMWeights", head: "LinearWeight") -> torch.Tensor:
         lib = _lib.load()
@@ -310,10 +419,13 @@ class BaselineLstm(AbstractCaterModel):
         self._runner = _LstmStackRunner(1, self.max_objects_in_frame * self.bb_in_dim, h)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        _require_inference(self, x, 5)
+        _check_input(self, x, 5)
         x = x.contiguous().float()
         with torch.cuda.device(x.device):
-            return self._runner.run(x.view(x.shape[0], x.shape[1], -1), self.video_LSTM, self.predictions_layer)
+            flat = x.view(x.shape[0], x.shape[1], -1)
+            if _wants_grad(self):
+                return self._runner.run_train(flat, self.video_LSTM, self.predictions_layer)
+            return self._runner.run(flat, self.video_LSTM, self.predictions_layer)
 
 
 class NonLinearLstm(AbstractCaterModel):
@@ -329,11 +441,14 @@ class NonLinearLstm(AbstractCaterModel):
         self._runner = _LstmStackRunner(2, self.max_objects_in_frame * f, h)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        _require_inference(self, x, 5)
+        _check_input(self, x, 5)
         lib = _lib.load()
         x = x.contiguous().float()
         B, T = int(x.shape[0]), int(x.shape[1])
         with torch.cuda.device(x.device):
+            if _wants_grad(self):
+                feats = _SlotEmbedFunction.apply(x, self.boxes_linear.weight, 15)
+                return self._runner.run_train(feats, self.video_LSTM, self.predictions_layer)
             feats = torch.empty((B, T, 15 * self._f), dtype=torch.float32, device=x.device)
             rc = lib.opseq_slot_embed_relu_f32(x.data_ptr(), self.boxes_linear.weight.data_ptr(), feats.data_ptr(),
                                                B * T, 15, self._f, _stream_ptr(x.device))

@@ -305,6 +305,34 @@ def gen_train(lm, cfg, n_clips, t_frames, tag, full, adam_steps):
     print(f"opnet_train_{tag}: losses {losses}")
 
 
+def gen_sibling_train(lm):
+    """one training step (L1 mean, torch autograd) of the reference's BaselineLstm / NonLinearLstm: loss + gradients"""
+    out = {}
+    cases = [("baseline_lstm", lm.BaselineLstm, synth.baseline_lstm_synth_params, "tiny", {"videos_hidden_dim": 32}, 3, 10),
+             ("baseline_lstm", lm.BaselineLstm, synth.baseline_lstm_synth_params, "real", {"videos_hidden_dim": 512}, 3, 120),
+             ("non_linear_lstm", lm.NonLinearLstm, synth.non_linear_lstm_synth_params, "tiny",
+              {"boxes_features_dim": 16, "videos_hidden_dim": 32}, 3, 10),
+             ("non_linear_lstm", lm.NonLinearLstm, synth.non_linear_lstm_synth_params, "real",
+              {"boxes_features_dim": 256, "videos_hidden_dim": 512}, 2, 40)]
+    for name, cls, pfn, tag, cfg, n, t in cases:
+        model = cls(cfg)
+        _load_params(model, pfn(cfg))
+        model.train(True)
+        boxes, labels = synth.make_batch(0, n, t)
+        y = model(torch.from_numpy(synth.boxes5(boxes)))
+        loss = torch.mean(torch.nn.L1Loss(reduction="none")(y, torch.from_numpy(labels)))
+        loss.backward()
+        pre = f"{name}/{tag}/"
+        out[pre + "cfg"] = np.array(json.dumps(cfg)); out[pre + "shape"] = np.array([n, t]); out[pre + "loss"] = np.float64(loss.item())
+        for k, v in model.named_parameters():
+            g = v.grad.detach().numpy()
+            out[pre + "gnorm/" + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            idx = sample_indices(k, g.size)
+            out[pre + "gval/" + k] = g.reshape(-1)[idx].copy()
+        print(f"sibling train {name}/{tag}: loss {loss.item():.5f}")
+    np.savez_compressed(os.path.join(OUT, "siblings_train.npz"), **out)
+
+
 def gen_metric(tu, y, labels):
     """ResultsAnalyzer goldens on integer boxes (tracking_utils.py:137-159, 251-256, 278-288)."""
     frame_shapes = np.array([320, 240, 320, 240])
@@ -347,6 +375,7 @@ def main():
     gen_analysis()
     gen_trained(lm, tu, real)
     gen_siblings(lm)
+    gen_sibling_train(lm)
     gen_datasets()
     gen_train(lm, tiny, n_clips=3, t_frames=12, tag="tiny", full=True, adam_steps=3)
     gen_train(lm, real, n_clips=4, t_frames=300, tag="real", full=False, adam_steps=2)

@@ -71,3 +71,28 @@ def adam_step(params: Dict[str, np.ndarray], grads: Dict[str, np.ndarray], state
         v *= np.float32(b2); v += np.float32(1.0 - b2) * g * g
         denom = np.sqrt(v) / np.float32(np.sqrt(bc2)) + np.float32(eps)
         params[k] -= np.float32(lr / bc1) * (m / denom)
+
+
+def baseline_lstm_forward(x: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """BaselineLstm.forward (learned_models.py:104-118)"""
+    B, T = x.shape[:2]
+    h = lstm_seq(x.reshape(B, T, -1), p["video_LSTM.weight_ih_l0"], p["video_LSTM.weight_hh_l0"])
+    return h @ p["predictions_layer.weight"].t()
+
+
+def non_linear_lstm_forward(x: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """NonLinearLstm.forward (learned_models.py:134-151)"""
+    B, T = x.shape[:2]
+    h = torch.relu(x @ p["boxes_linear.weight"].t()).reshape(B, T, -1)
+    for l in range(2):
+        h = lstm_seq(h, p[f"video_LSTM.weight_ih_l{l}"], p[f"video_LSTM.weight_hh_l{l}"])
+    return h @ p["predictions_layer.weight"].t()
+
+
+def sibling_loss_and_grads(name: str, x: np.ndarray, labels: np.ndarray, params: Dict[str, np.ndarray], dtype=torch.float32):
+    fwd = {"baseline_lstm": baseline_lstm_forward, "non_linear_lstm": non_linear_lstm_forward}[name]
+    p = {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in params.items()}
+    y = fwd(torch.tensor(x, dtype=dtype), p)
+    loss = l1_mean(y, torch.tensor(labels, dtype=dtype))
+    loss.backward()
+    return float(loss.item()), {k: v.grad.numpy() for k, v in p.items()}, y.detach().numpy()

@@ -1,0 +1,86 @@
+"""Training parity of the stacked-LSTM reasoners (BaselineLstm, NonLinearLstm): gradients of the L1 loss against
+the reference's own models under torch autograd (tests/golden/siblings_train.npz); oracle/torch_port.py pinned
+against the same fixtures on CPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import synth, torch_port
+
+PARAMS = {"baseline_lstm": synth.baseline_lstm_synth_params, "non_linear_lstm": synth.non_linear_lstm_synth_params}
+CASES = [("baseline_lstm", "tiny"), ("baseline_lstm", "real"), ("non_linear_lstm", "tiny"), ("non_linear_lstm", "real")]
+
+
+def sample_indices(name, n, k=4096):
+    if n <= k:
+        return np.arange(n)
+    u = synth.counter_uniform(synth.name_seed(name, 99), k)
+    return np.unique((u * n).astype(np.int64))
+
+
+def _case(g, name, tag):
+    pre = f"{name}/{tag}/"
+    cfg = json.loads(str(g[pre + "cfg"]))
+    n, t = (int(v) for v in g[pre + "shape"])
+    boxes, labels = synth.make_batch(0, n, t)
+    return pre, cfg, synth.boxes5(boxes), labels
+
+
+def _check(g, pre, loss, grads, rel):
+    assert loss == pytest.approx(float(g[pre + "loss"]), abs=5e-6)
+    for k, gr in grads.items():
+        ref = g[pre + "gval/" + k]
+        got = gr.reshape(-1)[sample_indices(k, gr.size)]
+        scale = max(1e-3, np.abs(ref).max())
+        assert np.abs(got - ref).max() <= rel * scale, k
+        assert np.sqrt((gr.astype(np.float64) ** 2).sum()) == pytest.approx(float(g[pre + "gnorm/" + k]), rel=5e-4), k
+
+
+@pytest.mark.parametrize("name,tag", CASES)
+def test_torch_port_matches_reference(golden_dir, name, tag):
+    g = np.load(os.path.join(golden_dir, "siblings_train.npz"))
+    pre, cfg, x, labels = _case(g, name, tag)
+    loss, grads, _ = torch_port.sibling_loss_and_grads(name, x, labels, PARAMS[name](cfg))
+    _check(g, pre, loss, grads, 2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,tag", CASES)
+def test_hip_gradients_match_reference(golden_dir, name, tag):
+    import torch
+    from objectpermanence_amd import ModelsFactory, l1_mean
+    g = np.load(os.path.join(golden_dir, "siblings_train.npz"))
+    pre, cfg, x, labels = _case(g, name, tag)
+    m = ModelsFactory.get_model(name, cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in PARAMS[name](cfg).items()})
+    m.to("cuda:0").train(True)
+    y = m(torch.from_numpy(x).cuda())
+    loss = l1_mean(y, torch.from_numpy(labels).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    _check(g, pre, float(loss.detach()), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}, 5e-4)
+    with torch.no_grad():
+        y_inf = m(torch.from_numpy(x).cuda())
+    assert torch.equal(y_inf, y.detach())          # train-mode forward == inference forward, bit for bit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B,T", [("baseline_lstm", 33, 5), ("non_linear_lstm", 2, 3)])
+def test_hip_gradients_ragged_vs_torch_port(name, B, T):
+    import torch
+    from objectpermanence_amd import ModelsFactory, l1_mean
+    cfg = {"videos_hidden_dim": 64} if name == "baseline_lstm" else {"boxes_features_dim": 16, "videos_hidden_dim": 48}
+    boxes, labels = synth.make_batch(77, B, T)
+    x = synth.boxes5(boxes)
+    p = PARAMS[name](cfg)
+    m = ModelsFactory.get_model(name, cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+    m.to("cuda:0").train(True)
+    loss = l1_mean(m(torch.from_numpy(x).cuda()), torch.from_numpy(labels).cuda())
+    loss.backward()
+    ref_loss, ref, _ = torch_port.sibling_loss_and_grads(name, x, labels, p, dtype=torch.float64)
+    assert float(loss.detach()) == pytest.approx(ref_loss, abs=2e-6)
+    for k, prm in m.named_parameters():
+        assert np.abs(prm.grad.cpu().numpy() - ref[k]).max() <= 1e-4 * max(1e-2, np.abs(ref[k]).max()), k
