@@ -111,6 +111,20 @@ int opnet_mlp_pack_weights_f32(const float *w_ih1, const float *w_hh1, const flo
                                size_t packed_bytes, int H1, int H2, void *stream);
 int opnet_mlp_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
                           void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2, void *stream);
+
+/* OPNetLstmMlp training (reference learned_models.py:55-89 under training.py:17-150): same history workspace,
+ * sizes and conventions as the opnet_train_* entry points (opnet_train_packed_weights_bytes /
+ * opnet_train_workspace_bytes give the sizes).  hidden_layer.weight [H2,6] rides in the gate-0 rows of the
+ * OPNet "W_ih2" block, so `scratch` (>= 4*H2*6 floats, device) is needed by pack and receives the padded
+ * gradient in backward: rows [0,H2) of g_hidden_scratch are d hidden_layer.weight, the rest is zero. */
+int opnet_mlp_train_pack_weights_f32(const float *w_ih1, const float *w_hh1, const float *w_sel,
+                                     const float *w_hidden, const float *w_out, float *packed, size_t packed_bytes,
+                                     float *scratch4h2x6, int H1, int H2, void *stream);
+int opnet_mlp_train_forward_f32(const float *boxes, const float *packed, float *y, float *logits, void *workspace,
+                                size_t workspace_bytes, int B, int T, int H1, int H2, void *stream);
+int opnet_mlp_train_backward_f32(const float *dy, const float *packed, void *workspace, size_t workspace_bytes,
+                                 float *g_ih1, float *g_hh1, float *g_sel, float *g_hidden_scratch, float *g_out,
+                                 int B, int T, int H1, int H2, void *stream);
 /* L (1..3) stacked bias-free LSTM layers (input width KX, hidden H each) + Linear H->4:
  *   x [B,T,KX] -> y [B,T,4].  BaselineLstm (:92-118): L=1, KX=75.  NonLinearLstm (:121-151): L=2,
  *   KX=15*F after opseq_slot_embed_relu_f32.  TransformerLstm's LSTM half (:170-172,192-195): L=2, KX=E.

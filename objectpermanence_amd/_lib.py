@@ -61,6 +61,13 @@ def _declare(lib):
     lib.opnet_mlp_pack_weights_f32.argtypes = [fp, fp, fp, fp, fp, fp, c_size_t, c_int, c_int, c_void_p]
     lib.opnet_mlp_forward_f32.restype = c_int
     lib.opnet_mlp_forward_f32.argtypes = [fp, fp, fp, fp, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]
+    lib.opnet_mlp_train_pack_weights_f32.restype = c_int
+    lib.opnet_mlp_train_pack_weights_f32.argtypes = [fp, fp, fp, fp, fp, fp, c_size_t, fp, c_int, c_int, c_void_p]
+    lib.opnet_mlp_train_forward_f32.restype = c_int
+    lib.opnet_mlp_train_forward_f32.argtypes = [fp, fp, fp, fp, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]
+    lib.opnet_mlp_train_backward_f32.restype = c_int
+    lib.opnet_mlp_train_backward_f32.argtypes = [fp, fp, c_void_p, c_size_t, fp, fp, fp, fp, fp,
+                                                 c_int, c_int, c_int, c_int, c_void_p]
     lib.opseq_lstm_stack_packed_bytes.restype = c_size_t
     lib.opseq_lstm_stack_packed_bytes.argtypes = [c_int, c_int, c_int]
     lib.opseq_lstm_stack_workspace_bytes.restype = c_size_t
@@ -115,6 +122,7 @@ EXPORTS = [
     "opnet_train_packed_weights_bytes", "opnet_train_pack_weights_f32", "opnet_train_workspace_bytes",
     "opnet_train_forward_f32", "opnet_train_backward_f32", "opnet_l1_loss_f32", "opnet_smooth_l1_loss_f32", "opnet_adam_step_f32",
     "opnet_mlp_pack_weights_f32", "opnet_mlp_forward_f32",
+    "opnet_mlp_train_pack_weights_f32", "opnet_mlp_train_forward_f32", "opnet_mlp_train_backward_f32",
     "opseq_lstm_stack_packed_bytes", "opseq_lstm_stack_workspace_bytes", "opseq_lstm_stack_pack_weights_f32",
     "opseq_lstm_stack_forward_f32", "opseq_lstm_stack_forward_graph_f32", "opseq_graph_cache_clear",
     "opseq_slot_embed_relu_f32", "opseq_slot_embed_relu_bwd_f32",

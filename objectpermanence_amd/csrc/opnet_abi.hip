@@ -536,13 +536,36 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
     return OPNET_OK;
 }
 
+static int train_backward_impl(const float *dy, const float *packed, void *workspace, size_t workspace_bytes,
+                               float *g_ih1, float *g_hh1, float *g_sel, float *g_ih2, float *g_hh2, float *g_out,
+                               int B, int T, int H1, int H2, void *stream, int mlp);
+
 extern "C" int opnet_train_backward_f32(const float *dy, const float *packed, void *workspace,
                                         size_t workspace_bytes, float *g_ih1, float *g_hh1, float *g_sel,
                                         float *g_ih2, float *g_hh2, float *g_out, int B, int T, int H1, int H2,
                                         void *stream)
 {
+    if (!g_hh2) return fail(OPNET_EINVAL, "null pointer");
+    return train_backward_impl(dy, packed, workspace, workspace_bytes, g_ih1, g_hh1, g_sel, g_ih2, g_hh2, g_out, B, T,
+                               H1, H2, stream, 0);
+}
+
+/* OPNetLstmMlp: g_hidden [H2,6] takes the place of g_ih2; there is no g_hh2.  g_ih2_scratch: >= 4*H2*6 floats. */
+extern "C" int opnet_mlp_train_backward_f32(const float *dy, const float *packed, void *workspace,
+                                            size_t workspace_bytes, float *g_ih1, float *g_hh1, float *g_sel,
+                                            float *g_hidden_scratch, float *g_out, int B, int T, int H1, int H2,
+                                            void *stream)
+{
+    return train_backward_impl(dy, packed, workspace, workspace_bytes, g_ih1, g_hh1, g_sel, g_hidden_scratch, nullptr,
+                               g_out, B, T, H1, H2, stream, 1);
+}
+
+static int train_backward_impl(const float *dy, const float *packed, void *workspace, size_t workspace_bytes,
+                               float *g_ih1, float *g_hh1, float *g_sel, float *g_ih2, float *g_hh2, float *g_out,
+                               int B, int T, int H1, int H2, void *stream, int mlp)
+{
     StepArgs a; OpnetIO io; BwdArgs bw;
-    if (!dy || !g_ih1 || !g_hh1 || !g_sel || !g_ih2 || !g_hh2 || !g_out) return fail(OPNET_EINVAL, "null pointer");
+    if (!dy || !g_ih1 || !g_hh1 || !g_sel || !g_ih2 || !g_out) return fail(OPNET_EINVAL, "null pointer");
     if (!aligned16(dy)) return fail(OPNET_EINVAL, "dy must be 16-byte aligned");
     if (int rc = make_train_args(&a, &io, &bw, nullptr, packed, nullptr, nullptr, workspace, workspace_bytes, B, T, H1, H2))
         return rc;
@@ -552,6 +575,8 @@ extern "C" int opnet_train_backward_f32(const float *dy, const float *packed, vo
     char *w = (char *)workspace;
     opnet_pack_dy<<<256, 256, 0, st>>>((const float4 *)dy, (float4 *)(w + W.dyp), (float *)(w + W.dcz),
                                         (long)((W.dcz_end - W.dcz) / 4), B, T, RB);
+    bw.mlp = mlp;
+    if (mlp) opnet_mlp_dhid<<<4096, 256, 0, st>>>(bw);
     const dim3 gcell(H2 / 8 + H1 / 8, RB, 1);
     const dim3 ggemm(4 * (H2 / 16) + 4 * (H1 / 16) + 4, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
     for (int n = 0; n <= T; ++n) {
@@ -573,7 +598,7 @@ extern "C" int opnet_train_backward_f32(const float *dy, const float *packed, vo
     };
     const long h1s = (long)(H1 / 4) * 32, h2s = (long)(H2 / 4) * 32;
     // video_LSTM.weight_hh_l0 [4H2][H2]: da2_t x h2_{t-1} (slot t) ; weight_ih_l0 [4H2][6]: da2_t x frames_boxes_t
-    wgrad(bw.g2, (long)H2 * 32, H2, bw.h2all, h2s, H2 / 4, g_hh2, H2, 4 * H2, H2, 1, H2);
+    if (!mlp) wgrad(bw.g2, (long)H2 * 32, H2, bw.h2all, h2s, H2 / 4, g_hh2, H2, 4 * H2, H2, 1, H2);
     wgrad(bw.g2, (long)H2 * 32, H2, bw.x2all, 64, 2, g_ih2, OPNET_FEATS, 4 * H2, OPNET_FEATS, 1, H2);
     // object_to_track_LSTM.weight_hh_l0 [4H1][H1], weight_ih_l0 [4H1][90]
     wgrad(bw.g1, (long)H1 * 32, H1, bw.h1all, h1s, H1 / 4, g_hh1, H1, 4 * H1, H1, 1, H1);
@@ -582,7 +607,59 @@ extern "C" int opnet_train_backward_f32(const float *dy, const float *packed, vo
     wgrad(bw.dlall, 128, 4, bw.h1all + (long)RB * h1s, h1s, H1 / 4, g_sel, H1, OPNET_SLOTS, H1, 0, 0);
     // prediction_layer.weight [4][H2]: dy_t x h2_t (slot t+1)
     wgrad(bw.dyp, 32, 1, bw.h2all + (long)RB * h2s, h2s, H2 / 4, g_out, H2, 4, H2, 0, 0);
+    for (int j = njobs; j < OPNET_WGRAD_JOBS; ++j) {   // unused slots never match a block
+        memset(&wb.job[j], 0, sizeof(WgradArgs));
+        wb.job[j].tile_begin = 0x7fffffff;
+        wb.job[j].tiles_m = 1;
+    }
     opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+/* OPNetLstmMlp training weights: the OPNet training layout with hidden_layer.weight [H2,6] in the gate-0 rows of
+ * "W_ih2" and no recurrent video weights.  scratch4h2x6: caller scratch of 4*H2*6 floats. */
+extern "C" int opnet_mlp_train_pack_weights_f32(const float *w_ih1, const float *w_hh1, const float *w_sel,
+                                                const float *w_hidden, const float *w_out, float *packed,
+                                                size_t packed_bytes, float *scratch4h2x6, int H1, int H2, void *stream)
+{
+    if (int rc = check_dims(1, 1, H1, H2)) return rc;
+    if (!scratch4h2x6) return fail(OPNET_EINVAL, "null pointer");
+    const TrainPackedLayout L = train_packed_layout(H1, H2);
+    if (packed_bytes < L.total * sizeof(float)) return fail(OPNET_EWORKSPACE, "packed buffer too small");
+    if (int rc = opnet_mlp_pack_weights_f32(w_ih1, w_hh1, w_sel, w_hidden, w_out, packed, L.fwd_total * sizeof(float), H1, H2, stream))
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    auto blocks = [](size_t n) { return (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256); };
+    // "W_ih2" [4H2][6] = [hidden_layer.weight ; 0 ; 0 ; 0]
+    HIP_TRY(hipMemsetAsync(scratch4h2x6, 0, (size_t)4 * H2 * OPNET_FEATS * sizeof(float), st));
+    opnet_copy_f32<<<blocks((size_t)H2 * OPNET_FEATS), 256, 0, st>>>(scratch4h2x6, w_hidden, (long)H2 * OPNET_FEATS);
+    opnet_pack_tiles_t<<<blocks((size_t)(H1 / 16) * (H1 / 4) * 256), 256, 0, st>>>(packed + L.w1bt, w_hh1, H1, 0, 0, H1 / 16);
+    opnet_pack_tiles_t<<<blocks((size_t)(H2 / 4) * 256), 256, 0, st>>>(packed + L.wih2t, scratch4h2x6, H2, OPNET_FEATS, 1, 1);
+    opnet_copy_f32<<<blocks((size_t)OPNET_SLOTS * H1), 256, 0, st>>>(packed + L.wsel, w_sel, (long)OPNET_SLOTS * H1);
+    opnet_copy_f32<<<blocks((size_t)4 * H2), 256, 0, st>>>(packed + L.wout, w_out, (long)4 * H2);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opnet_mlp_train_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
+                                           void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
+                                           void *stream)
+{
+    StepArgs a; OpnetIO io; BwdArgs bw;
+    if (!boxes || !y || !logits) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(y) || (((uintptr_t)boxes) & 7u)) return fail(OPNET_EINVAL, "y must be 16-byte and boxes 8-byte aligned");
+    if (int rc = make_train_args(&a, &io, &bw, boxes, packed, y, logits, workspace, workspace_bytes, B, T, H1, H2))
+        return rc;
+    a.mlp = 1;
+    const TrainWorkspaceLayout W = train_workspace_layout(B, T, H1, H2);
+    hipStream_t st = (hipStream_t)stream;
+    OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
+    opnet_set_io<<<1, 1, 0, st>>>(dio, io);
+    opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
+    const dim3 grid = step_grid(a.RB, H1, H2);
+    for (int s = 0; s < T + 3; ++s) opnet_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

@@ -23,6 +23,7 @@
 
 struct BwdArgs {
     int B, T, RB, H1, H2;
+    int mlp;                // OPNetLstmMlp: no video LSTM - g2 holds (d hidden, 0, 0, 0), filled by opnet_mlp_dhid
     // saved by the training forward
     const float4 *xp;       // [T][RB][24][32]
     const float4 *h1all;    // [T+1][RB][H1/4][32]   slot t+1 = h1_t, slot 0 = 0
@@ -124,6 +125,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_bwd_gemm(const BwdArgs a,
     const float4 *da;
     float *dst;
     if (bx < n2) {
+        if (a.mlp) return;   // relu(Linear) has no recurrence
         t = T - 1 - n; H = H2; tile = bx >> 2; ks = bx & 3;
         A = a.w2bt + ((long)tile * (H2 >> 2) + ks * (H2 >> 4)) * 64;   // tile has 4H/16 = H/4 hexadecets
         da = a.g2; dst = a.dhpart2; nrows_out = H2;
@@ -186,7 +188,7 @@ __global__ void __launch_bounds__(256) opnet_bwd_cell(const BwdArgs a, const int
     if (bx < nc2) {
         // ---------------- LSTM2 at t = T-1-n ----------------
         const int t = T - 1 - n;
-        if (t < 0) return;
+        if (t < 0 || a.mlp) return;
         const int u = bx * 8 + (tid >> 5);
         const long e = ((long)rb * H2 + u) * 32 + clip;
         // upstream: prediction_layer (learned_models.py:47): dh += W_out^T dy_t
@@ -272,6 +274,31 @@ __global__ void __launch_bounds__(256) opnet_bwd_cell(const BwdArgs a, const int
         float dco;
         a.g1[ge] = cell_backward(dh, dcc, a.g1[ge], c_t, c_p, &dco);
         a.dc1[e] = dco;
+    }
+}
+
+// OPNetLstmMlp (learned_models.py:83-84): hidden = relu(hidden_layer(frames_boxes)), y = prediction_layer(hidden).
+// d hidden = [hidden > 0] * W_out^T dy for every (t, clip, unit) at once (no recurrence), stored as (d hidden, 0,0,0)
+// in the gate-gradient layout so the W_ih2^T product, the head backward and the weight-gradient GEMMs of the
+// OPNet path apply unchanged (the packed "W_ih2" carries hidden_layer.weight in its gate-0 rows).
+__global__ void __launch_bounds__(256) opnet_mlp_dhid(const BwdArgs a)
+{
+    const int H2 = a.H2;
+    const long n = (long)a.T * a.RB * H2 * 32;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const int clip = idx & 31;
+        long r = idx >> 5;
+        const int u = r % H2; r /= H2;
+        const int rb = r % a.RB;
+        const int t = r / a.RB;
+        const float4 dy = a.dyp[((long)t * a.RB + rb) * 32 + clip];
+        float dh = a.wout[u] * dy.x;
+        dh = fmaf(a.wout[H2 + u], dy.y, dh);
+        dh = fmaf(a.wout[2 * H2 + u], dy.z, dh);
+        dh = fmaf(a.wout[3 * H2 + u], dy.w, dh);
+        // hidden_t sits in the h2 history slot t+1, kq-major: [(u/4)][clip][u%4]
+        const float hid = ((const float *)(a.h2all + (((long)(t + 1)) * a.RB + rb) * ((long)H2 * 8)))[((long)(u >> 2) * 32 + clip) * 4 + (u & 3)];
+        a.g2[idx] = make_float4(hid > 0.f ? dh : 0.f, 0.f, 0.f, 0.f);
     }
 }
 

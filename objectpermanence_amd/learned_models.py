@@ -124,6 +124,71 @@ class _OPNetTrainFunction(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class _OPNetMlpTrainFunction(torch.autograd.Function):
+    """OPNetLstmMlp training: the OPNet history/BPTT machinery with relu(hidden_layer) in the video role."""
+
+    @staticmethod
+    def forward(ctx, module, boxes, *weights):
+        lib = _lib.load()
+        B, T = int(boxes.shape[0]), int(boxes.shape[1])
+        dev = boxes.device
+        h1, h2 = module._h1, module._h2
+        with torch.cuda.device(dev):
+            stream = _stream_ptr(dev)
+            nbytes = lib.opnet_train_packed_weights_bytes(h1, h2)
+            if nbytes == 0:
+                _lib.check(-2, "opnet_train_packed_weights_bytes")
+            if module._tpacked is None or module._tpacked.device != dev:
+                module._tpacked = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
+                module._tscratch = torch.empty(4 * h2 * 6, dtype=torch.float32, device=dev)
+            rc = lib.opnet_mlp_train_pack_weights_f32(*(w.data_ptr() for w in weights), module._tpacked.data_ptr(),
+                                                      nbytes, module._tscratch.data_ptr(), h1, h2, stream)
+            _lib.check(rc, "opnet_mlp_train_pack_weights_f32")
+            key = (B, T, str(dev))
+            if module._tws_key != key:
+                wsb = lib.opnet_train_workspace_bytes(B, T, h1, h2)
+                if wsb == 0:
+                    _lib.check(-2, "opnet_train_workspace_bytes")
+                module._tws = None
+                module._tws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                module._tws_key = key
+            y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+            logits = torch.empty((B, 15, T), dtype=torch.float32, device=dev)
+            rc = lib.opnet_mlp_train_forward_f32(boxes.data_ptr(), module._tpacked.data_ptr(), y.data_ptr(),
+                                                 logits.data_ptr(), module._tws.data_ptr(), module._tws.numel(),
+                                                 B, T, h1, h2, stream)
+            _lib.check(rc, "opnet_mlp_train_forward_f32")
+        module._train_gen += 1
+        ctx.module, ctx.gen, ctx.shape = module, module._train_gen, (B, T)
+        ctx.wshapes = [tuple(w.shape) for w in weights]
+        ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)
+        return y, logits
+
+    @staticmethod
+    def backward(ctx, grad_y, grad_logits):
+        module = ctx.module
+        if ctx.gen != module._train_gen:
+            raise RuntimeError("OPNetLstmMlp: backward() after another training forward - the saved history of "
+                               "this forward has been overwritten (one history per module)")
+        n_in = 2 + len(ctx.wshapes)
+        if grad_y is None:
+            return (None,) * n_in
+        lib = _lib.load()
+        B, T = ctx.shape
+        dev = grad_y.device
+        grad_y = grad_y.contiguous().float()
+        g_ih1, g_hh1, g_sel, _, g_out = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.wshapes]
+        g_hid4 = torch.empty((4 * module._h2, 6), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.opnet_mlp_train_backward_f32(grad_y.data_ptr(), module._tpacked.data_ptr(),
+                                                  module._tws.data_ptr(), module._tws.numel(), g_ih1.data_ptr(),
+                                                  g_hh1.data_ptr(), g_sel.data_ptr(), g_hid4.data_ptr(),
+                                                  g_out.data_ptr(), B, T, module._h1, module._h2, _stream_ptr(dev))
+        _lib.check(rc, "opnet_mlp_train_backward_f32")
+        return (None, None, g_ih1, g_hh1, g_sel, g_hid4[:module._h2].contiguous(), g_out)
+
+
 class OPNet(AbstractCaterModel):
     """reference learned_models.py:18-52.  forward(boxes [B,T,15,6]) -> (y_boxes [B,T,4],
     object_to_track_prediction [B,15,T])."""
@@ -342,7 +407,7 @@ def _require_inference(module: nn.Module, x: torch.Tensor, feat: int):
     if x.dim() != 4 or x.shape[2] != 15 or x.shape[3] != feat:
         raise ValueError(f"input must be [B, T, 15, {feat}], got {tuple(x.shape)}")
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise RuntimeError(f"{type(module).__name__}: training through the HIP path is implemented for OPNet only; "
+        raise RuntimeError(f"{type(module).__name__}: training through the HIP path is not implemented for this model; "
                            "wrap inference in torch.no_grad()")
 
 
@@ -553,14 +618,20 @@ class OPNetLstmMlp(AbstractCaterModel):
         self.prediction_layer = LinearWeight(h2, self.bb_out_dim)
         self._h1, self._h2 = h1, h2
         self._packed, self._key, self._ws = None, None, {}
+        self._tpacked, self._tscratch, self._tws, self._tws_key, self._train_gen = None, None, None, None, 0
 
     def forward(self, boxes: torch.Tensor):
-        _require_inference(self, boxes, 6)
+        _check_input(self, boxes, 6)
         lib = _lib.load()
         boxes = boxes.contiguous().float()
         B, T, dev = int(boxes.shape[0]), int(boxes.shape[1]), boxes.device
         ws_list = [self.object_to_track_LSTM.weight_ih_l0, self.object_to_track_LSTM.weight_hh_l0,
                    self.object_to_track_prediction.weight, self.hidden_layer.weight, self.prediction_layer.weight]
+        if _wants_grad(self):
+            for w in ws_list:
+                if w.device != dev or w.dtype != torch.float32 or not w.is_contiguous():
+                    raise RuntimeError("OPNetLstmMlp parameters must be contiguous fp32 on the input's device")
+            return _OPNetMlpTrainFunction.apply(self, boxes, *ws_list)
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
             key = _weights_key(ws_list, dev)

@@ -313,13 +313,20 @@ def gen_sibling_train(lm):
              ("non_linear_lstm", lm.NonLinearLstm, synth.non_linear_lstm_synth_params, "tiny",
               {"boxes_features_dim": 16, "videos_hidden_dim": 32}, 3, 10),
              ("non_linear_lstm", lm.NonLinearLstm, synth.non_linear_lstm_synth_params, "real",
-              {"boxes_features_dim": 256, "videos_hidden_dim": 512}, 2, 40)]
+              {"boxes_features_dim": 256, "videos_hidden_dim": 512}, 2, 40),
+             ("opnet_lstm_mlp", lm.OPNetLstmMlp, synth.opnet_lstm_mlp_synth_params, "tiny",
+              {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 32, "videos_hidden_dim": 32}, 3, 10),
+             ("opnet_lstm_mlp", lm.OPNetLstmMlp, synth.opnet_lstm_mlp_synth_params, "real",
+              {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}, 3, 60)]
     for name, cls, pfn, tag, cfg, n, t in cases:
         model = cls(cfg)
         _load_params(model, pfn(cfg))
         model.train(True)
         boxes, labels = synth.make_batch(0, n, t)
-        y = model(torch.from_numpy(synth.boxes5(boxes)))
+        if name == "opnet_lstm_mlp":
+            y, _ = model(torch.from_numpy(boxes))
+        else:
+            y = model(torch.from_numpy(synth.boxes5(boxes)))
         loss = torch.mean(torch.nn.L1Loss(reduction="none")(y, torch.from_numpy(labels)))
         loss.backward()
         pre = f"{name}/{tag}/"

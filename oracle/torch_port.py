@@ -89,8 +89,18 @@ def non_linear_lstm_forward(x: torch.Tensor, p: Dict[str, torch.Tensor]) -> torc
     return h @ p["predictions_layer.weight"].t()
 
 
+def opnet_lstm_mlp_forward(x: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """OPNetLstmMlp.forward (learned_models.py:72-89): OPNet's selection stage, then relu(Linear 6->H2) -> Linear"""
+    B, T = x.shape[:2]
+    h1 = lstm_seq(x.reshape(B, T, -1), p["object_to_track_LSTM.weight_ih_l0"], p["object_to_track_LSTM.weight_hh_l0"])
+    probs = torch.softmax(h1 @ p["object_to_track_prediction.weight"].t(), dim=-1)
+    frames_boxes = torch.einsum("bfot,bfo->bft", x, probs)
+    return torch.relu(frames_boxes @ p["hidden_layer.weight"].t()) @ p["prediction_layer.weight"].t()
+
+
 def sibling_loss_and_grads(name: str, x: np.ndarray, labels: np.ndarray, params: Dict[str, np.ndarray], dtype=torch.float32):
-    fwd = {"baseline_lstm": baseline_lstm_forward, "non_linear_lstm": non_linear_lstm_forward}[name]
+    fwd = {"baseline_lstm": baseline_lstm_forward, "non_linear_lstm": non_linear_lstm_forward,
+           "opnet_lstm_mlp": opnet_lstm_mlp_forward}[name]
     p = {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in params.items()}
     y = fwd(torch.tensor(x, dtype=dtype), p)
     loss = l1_mean(y, torch.tensor(labels, dtype=dtype))

@@ -1,4 +1,4 @@
-"""Training parity of the stacked-LSTM reasoners (BaselineLstm, NonLinearLstm): gradients of the L1 loss against
+"""Training parity of the sibling reasoners (BaselineLstm, NonLinearLstm, OPNetLstmMlp): gradients of the L1 loss against
 the reference's own models under torch autograd (tests/golden/siblings_train.npz); oracle/torch_port.py pinned
 against the same fixtures on CPU."""
 import json
@@ -9,8 +9,18 @@ import pytest
 
 from oracle import synth, torch_port
 
-PARAMS = {"baseline_lstm": synth.baseline_lstm_synth_params, "non_linear_lstm": synth.non_linear_lstm_synth_params}
-CASES = [("baseline_lstm", "tiny"), ("baseline_lstm", "real"), ("non_linear_lstm", "tiny"), ("non_linear_lstm", "real")]
+PARAMS = {"baseline_lstm": synth.baseline_lstm_synth_params, "non_linear_lstm": synth.non_linear_lstm_synth_params,
+          "opnet_lstm_mlp": synth.opnet_lstm_mlp_synth_params}
+CASES = [("baseline_lstm", "tiny"), ("baseline_lstm", "real"), ("non_linear_lstm", "tiny"), ("non_linear_lstm", "real"),
+         ("opnet_lstm_mlp", "tiny"), ("opnet_lstm_mlp", "real")]
+
+
+def _features(name, boxes):
+    return boxes if name == "opnet_lstm_mlp" else synth.boxes5(boxes)
+
+
+def _y(out):
+    return out[0] if isinstance(out, tuple) else out
 
 
 def sample_indices(name, n, k=4096):
@@ -25,7 +35,7 @@ def _case(g, name, tag):
     cfg = json.loads(str(g[pre + "cfg"]))
     n, t = (int(v) for v in g[pre + "shape"])
     boxes, labels = synth.make_batch(0, n, t)
-    return pre, cfg, synth.boxes5(boxes), labels
+    return pre, cfg, _features(name, boxes), labels
 
 
 def _check(g, pre, loss, grads, rel):
@@ -56,29 +66,30 @@ def test_hip_gradients_match_reference(golden_dir, name, tag):
     m = ModelsFactory.get_model(name, cfg)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in PARAMS[name](cfg).items()})
     m.to("cuda:0").train(True)
-    y = m(torch.from_numpy(x).cuda())
+    y = _y(m(torch.from_numpy(x).cuda()))
     loss = l1_mean(y, torch.from_numpy(labels).cuda())
     loss.backward()
     torch.cuda.synchronize()
     _check(g, pre, float(loss.detach()), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}, 5e-4)
     with torch.no_grad():
-        y_inf = m(torch.from_numpy(x).cuda())
+        y_inf = _y(m(torch.from_numpy(x).cuda()))
     assert torch.equal(y_inf, y.detach())          # train-mode forward == inference forward, bit for bit
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,B,T", [("baseline_lstm", 33, 5), ("non_linear_lstm", 2, 3)])
+@pytest.mark.parametrize("name,B,T", [("baseline_lstm", 33, 5), ("non_linear_lstm", 2, 3), ("opnet_lstm_mlp", 37, 4)])
 def test_hip_gradients_ragged_vs_torch_port(name, B, T):
     import torch
     from objectpermanence_amd import ModelsFactory, l1_mean
-    cfg = {"videos_hidden_dim": 64} if name == "baseline_lstm" else {"boxes_features_dim": 16, "videos_hidden_dim": 48}
+    cfg = {"baseline_lstm": {"videos_hidden_dim": 64}, "non_linear_lstm": {"boxes_features_dim": 16, "videos_hidden_dim": 48},
+           "opnet_lstm_mlp": {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 48, "videos_hidden_dim": 64}}[name]
     boxes, labels = synth.make_batch(77, B, T)
-    x = synth.boxes5(boxes)
+    x = _features(name, boxes)
     p = PARAMS[name](cfg)
     m = ModelsFactory.get_model(name, cfg)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
     m.to("cuda:0").train(True)
-    loss = l1_mean(m(torch.from_numpy(x).cuda()), torch.from_numpy(labels).cuda())
+    loss = l1_mean(_y(m(torch.from_numpy(x).cuda())), torch.from_numpy(labels).cuda())
     loss.backward()
     ref_loss, ref, _ = torch_port.sibling_loss_and_grads(name, x, labels, p, dtype=torch.float64)
     assert float(loss.detach()) == pytest.approx(ref_loss, abs=2e-6)
