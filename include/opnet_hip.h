@@ -188,6 +188,36 @@ int opdet_upsample_add_f32(const float *lateral, const float *top, float *y, int
 int opdet_preprocess_frame_f32(const unsigned char *frame_bgr, float *y, int H, int W, int RH, int RW, int PH,
                                int PW, const float *mean3_host, const float *std3_host, void *stream);
 
+/* ---- detector back half: RPN proposals, MultiScaleRoIAlign, detections (the non-conv stages of the
+ *      torchvision fasterrcnn_resnet50_fpn call at reference detector.py:84; PARITY UNPINNED).
+ * The dense stages (RPNHead convs, TwoMLPHead, FastRCNNPredictor) run on opdet_conv2d_f32.
+ *
+ * opdet_rpn_proposals_f32: head_out = HOST array of n_levels DEVICE pointers, level l = [gh[l], gw[l], 16] fp32 NHWC
+ * with channels 0..2 the objectness logits of the 3 anchors, 3..14 their deltas (anchor-major dx,dy,dw,dh), 15 unused.
+ * AnchorGenerator(sizes = anchor_sizes[l], ratios 0.5/1/2, strides int(padded/grid)), per-level top pre_nms_top_n on
+ * the logits, decode (weights 1), clip to [image_h, image_w], drop sides < min_size, per-level NMS, best
+ * post_nms_top_n.  Out: proposals [post_nms_top_n, 4] xyxy (rows >= *count zero), scores (may be NULL), count
+ * (DEVICE int).  Nothing is copied to the host; gh / gw / anchor_sizes are HOST arrays. */
+size_t opdet_rpn_workspace_bytes(int n_levels, const int *gh, const int *gw, const int *anchor_sizes, int padded_h,
+                                 int padded_w, int pre_nms_top_n);
+int opdet_rpn_proposals_f32(const float *const *head_out, int n_levels, const int *gh, const int *gw,
+                            const int *anchor_sizes, int image_h, int image_w, int padded_h, int padded_w,
+                            int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float min_size, float *proposals,
+                            float *scores, int *count, void *workspace, size_t workspace_bytes, void *stream);
+/* MultiScaleRoIAlign(["0".."3"], 7, sampling_ratio 2): feats = HOST array of 4 DEVICE pointers [fh[l], fw[l], C] NHWC,
+ * rois [max_rois, 4] in resized-image pixels, count DEVICE int; out [max_rois, 7, 7, C] (rows >= *count zero). */
+int opdet_roi_align_f32(const float *const *feats, const int *fh, const int *fw, int C, int image_h, const float *rois,
+                        const int *count, int max_rois, float *out, void *stream);
+/* RoIHeads.postprocess_detections + the transform's rescale to the original frame: softmax, per-class decode
+ * (weights 10,10,5,5), clip, drop background, score > score_thresh (>= 0.05), sides >= 1e-2, per-class NMS, best
+ * max_det.  class_logits [max_rois, NC], box_regression [max_rois, 4 NC]; out boxes [max_det, 4] xyxy in original-frame
+ * pixels, scores [max_det] descending, labels [max_det] int64, n_det DEVICE int (rows >= *n_det zero). */
+size_t opdet_detections_workspace_bytes(int max_rois, int num_classes);
+int opdet_detections_f32(const float *class_logits, const float *box_regression, const float *proposals,
+                         const int *count, int max_rois, int num_classes, int image_h, int image_w, int orig_h,
+                         int orig_w, float score_thresh, float nms_thresh, int max_det, float *boxes, float *scores,
+                         long long *labels, int *n_det, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- output post-processing + metric (replaces inference_main.py:219 and
  *      tracking_utils.py:137-159,251-256,278-288) ------------------------------------------------
  * y, labels [N, T, 4] fp32 normalised -> pred_px, gt_px [N, T, 4] int32 (float64 multiply by

@@ -111,6 +111,19 @@ def _declare(lib):
     lib.opdet_preprocess_frame_f32.restype = c_int
     lib.opdet_preprocess_frame_f32.argtypes = [fp, fp, c_int, c_int, c_int, c_int, c_int, c_int,
                                                POINTER(c_float), POINTER(c_float), c_void_p]
+    ip = POINTER(c_int)
+    lib.opdet_rpn_workspace_bytes.restype = c_size_t
+    lib.opdet_rpn_workspace_bytes.argtypes = [c_int, ip, ip, ip, c_int, c_int, c_int]
+    lib.opdet_rpn_proposals_f32.restype = c_int
+    lib.opdet_rpn_proposals_f32.argtypes = [POINTER(c_void_p), c_int, ip, ip, ip, c_int, c_int, c_int, c_int, c_int, c_int,
+                                            c_float, c_float, fp, fp, fp, c_void_p, c_size_t, c_void_p]
+    lib.opdet_roi_align_f32.restype = c_int
+    lib.opdet_roi_align_f32.argtypes = [POINTER(c_void_p), ip, ip, c_int, c_int, fp, fp, c_int, fp, c_void_p]
+    lib.opdet_detections_workspace_bytes.restype = c_size_t
+    lib.opdet_detections_workspace_bytes.argtypes = [c_int, c_int]
+    lib.opdet_detections_f32.restype = c_int
+    lib.opdet_detections_f32.argtypes = [fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
+                                         fp, fp, fp, fp, c_void_p, c_size_t, c_void_p]
     lib.opnet_postprocess_iou.restype = c_int
     lib.opnet_postprocess_iou.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_void_p]
 
@@ -132,7 +145,8 @@ EXPORTS = [
     "opseq_encoder_workspace_bytes",
     "opseq_encoder_layer_f32",
     "opdet_conv2d_f32", "opdet_maxpool3x3s2_f32", "opdet_subsample2_f32", "opdet_upsample_add_f32",
-    "opdet_preprocess_frame_f32",
+    "opdet_preprocess_frame_f32", "opdet_rpn_workspace_bytes", "opdet_rpn_proposals_f32", "opdet_roi_align_f32",
+    "opdet_detections_workspace_bytes", "opdet_detections_f32",
 ]
 
 

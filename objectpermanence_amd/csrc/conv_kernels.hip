@@ -200,7 +200,12 @@ __global__ void __launch_bounds__(256) preprocess_frame(const unsigned char *__r
 // wave reads its fragments with conflict-free ds_read_b128 (layout [k/4][row][4]: the 16 lanes of a k-group
 // read 16 consecutive rows = one 256-B bank row).  BN=128: 2x2 waves of 64x64 (4x4 fragments, 64 MFMAs per
 // K step per wave); BN=64: 4x1 waves of 32x64.  Global traffic per MFMA drops 4x vs conv2d_nhwc.
-template <int BN>
+// ALIGNED (Cin % 16 == 0, every layer but the stem): a 16-wide K step lies inside one tap, so the tap walk
+// (c0, dx, dy) is wave-uniform and lives on the scalar unit; per row the loader is one offset add and the
+// bounds test - the VALU slots left between MFMAs (7 per 16x16x4) no longer go to integer division.
+// The MFMA is issued with the weight fragment as the A operand: D rows = channels, so a lane ends up with 4
+// consecutive channels of one pixel and the epilogue moves float4s (bias, residual, store).
+template <int BN, bool ALIGNED>
 __global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
 {
     constexpr int BM = 128;
@@ -237,6 +242,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
         iy0[j] = oy * a.stride - a.pad;
         ix0[j] = ox * a.stride - a.pad;
         xn[j] = a.X + (long)nimg * a.H * a.W * a.Cin;
+        if (ALIGNED) xn[j] += ((long)iy0[j] * a.W + ix0[j]) * a.Cin + 4 * lkq;   // + tap offset per step
     }
     bool wrow_ok[2];
     const float4 *wsrc[2];
@@ -247,15 +253,32 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
         wsrc[j] = (const float4 *)(a.Wt + (long)min(r, a.Cout - 1) * a.KP) + lkq;
     }
 
+    // wave-uniform tap walk of the NEXT step to load (ALIGNED only)
+    int t_c0 = 0, t_dx = 0, t_dy = 0;
     auto load_a2 = [&](int q, float4 (&ra)[2]) {
-        const int k4 = 16 * q + 4 * lkq;
-        const int tap = k4 / a.Cin, c = k4 - tap * a.Cin;
-        const int dy = tap / a.KW, dx = tap - dy * a.KW;
+        if (ALIGNED) {
+            const long toff = ((long)t_dy * a.W + t_dx) * a.Cin + t_c0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int y = iy0[j] + dy, x = ix0[j] + dx;
-            const bool ok = prow_ok[j] && k4 < K && y >= 0 && y < a.H && x >= 0 && x < a.W;
-            ra[j] = ok ? *(const float4 *)(xn[j] + ((long)y * a.W + x) * a.Cin + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < 2; ++j) {
+                const bool ok = prow_ok[j] && (unsigned)(iy0[j] + t_dy) < (unsigned)a.H &&
+                                (unsigned)(ix0[j] + t_dx) < (unsigned)a.W;
+                ra[j] = ok ? *(const float4 *)(xn[j] + toff) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            t_c0 += 16;
+            if (t_c0 == a.Cin) {
+                t_c0 = 0;
+                if (++t_dx == a.KW) { t_dx = 0; ++t_dy; }
+            }
+        } else {
+            const int k4 = 16 * q + 4 * lkq;
+            const int tap = k4 / a.Cin, c = k4 - tap * a.Cin;
+            const int dy = tap / a.KW, dx = tap - dy * a.KW;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int y = iy0[j] + dy, x = ix0[j] + dx;
+                const bool ok = prow_ok[j] && k4 < K && y >= 0 && y < a.H && x >= 0 && x < a.W;
+                ra[j] = ok ? *(const float4 *)(xn[j] + ((long)y * a.W + x) * a.Cin + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto load_w2 = [&](int q, float4 (&rw)[2]) {
@@ -299,39 +322,54 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
 #pragma unroll
         for (int x = 0; x < FM; ++x)
 #pragma unroll
-            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[x].x, bf[y].x, acc[x][y], 0, 0, 0);
+            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[y].x, af[x].x, acc[x][y], 0, 0, 0);
 #pragma unroll
         for (int x = 0; x < FM; ++x)
 #pragma unroll
-            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[x].y, bf[y].y, acc[x][y], 0, 0, 0);
+            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[y].y, af[x].y, acc[x][y], 0, 0, 0);
 #pragma unroll
         for (int x = 0; x < FM; ++x)
 #pragma unroll
-            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[x].z, bf[y].z, acc[x][y], 0, 0, 0);
+            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[y].z, af[x].z, acc[x][y], 0, 0, 0);
 #pragma unroll
         for (int x = 0; x < FM; ++x)
 #pragma unroll
-            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[x].w, bf[y].w, acc[x][y], 0, 0, 0);
+            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[y].w, af[x].w, acc[x][y], 0, 0, 0);
         if (more) park(cur ^ 1, ra, rw);   // ... and park them in the other buffer after the MFMAs
         __syncthreads();
     }
-    // epilogue: D fragment lane = (channel column l&15, pixel rows 4*(l>>4)+r)
+    // epilogue: D fragment lane = (pixel column l&15, channel rows 4*(l>>4)+r)
+    const bool vec = (a.Cout & 3) == 0;
 #pragma unroll
-    for (int x = 0; x < FM; ++x)
+    for (int x = 0; x < FM; ++x) {
+        const long pp = m0 + wm * (FM * 16) + x * 16 + i;
+        if (pp >= M) continue;
 #pragma unroll
         for (int y = 0; y < FN; ++y) {
-            const int co = n0 + wn * 64 + y * 16 + i;
+            const int co = n0 + wn * 64 + y * 16 + 4 * kk;
             if (co >= a.Cout) continue;
-            const float b = a.bias ? a.bias[co] : 0.f;
+            if (vec) {
+                float4 v = make_float4(acc[x][y][0], acc[x][y][1], acc[x][y][2], acc[x][y][3]);
+                if (a.bias) {
+                    const float4 b = *(const float4 *)(a.bias + co);
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                if (a.R) {
+                    const float4 r = *(const float4 *)(a.R + pp * a.Cout + co);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (a.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                *(float4 *)(a.Y + pp * a.Cout + co) = v;
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long pp = m0 + wm * (FM * 16) + x * 16 + kk * 4 + r;
-                if (pp < M) {
-                    float v = acc[x][y][r] + b;
-                    if (a.R) v += a.R[pp * a.Cout + co];
+                for (int r = 0; r < 4; ++r) {
+                    if (co + r >= a.Cout) break;
+                    float v = acc[x][y][r] + (a.bias ? a.bias[co + r] : 0.f);
+                    if (a.R) v += a.R[pp * a.Cout + co + r];
                     if (a.relu) v = fmaxf(v, 0.f);
-                    a.Y[pp * a.Cout + co] = v;
+                    a.Y[pp * a.Cout + co + r] = v;
                 }
             }
         }
+    }
 }

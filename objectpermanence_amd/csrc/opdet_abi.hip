@@ -1,0 +1,278 @@
+// opdet_abi.hip - host side of the detector's proposal / RoI / detection stages (second translation unit of
+// libopnet_hip.so; the radix sorts come from hipCUB, everything else is det_head_kernels.hip).
+#include "det_head_kernels.hip"
+
+#include <hipcub/hipcub.hpp>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/opnet_hip.h"
+
+int opnet_set_error(int code, const char *msg);   // opnet_abi.hip
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return opnet_set_error(code, buf);
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(OPNET_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+static const float kBoxClip = 4.135166556742356f;   // log(1000 / 16), BoxCoder.bbox_xform_clip
+
+// ---- shared NMS stage: sorted boxes -> kept indices -------------------------------------------------
+struct NmsBuffers { float4 *sbox; int *sgroup; float *sscore; unsigned long long *mask; int *kept; int *n_kept; };
+
+static size_t nms_bytes(int cap)
+{
+    const size_t nw = (cap + 63) / 64;
+    return up256((size_t)cap * 16) + up256((size_t)cap * 4) * 2 + up256((size_t)cap * nw * 8) + up256((size_t)cap * 4) + 256;
+}
+
+static char *carve_nms(char *p, int cap, NmsBuffers *b)
+{
+    const size_t nw = (cap + 63) / 64;
+    b->sbox = (float4 *)p;  p += up256((size_t)cap * 16);
+    b->sgroup = (int *)p;   p += up256((size_t)cap * 4);
+    b->sscore = (float *)p; p += up256((size_t)cap * 4);
+    b->mask = (unsigned long long *)p; p += up256((size_t)cap * nw * 8);
+    b->kept = (int *)p;     p += up256((size_t)cap * 4);
+    b->n_kept = (int *)p;   p += 256;
+    return p;
+}
+
+static int run_nms(const NmsBuffers &b, const int *n_valid, int cap, float thresh, int max_keep, hipStream_t st)
+{
+    const int nb = (cap + 63) / 64;
+    if (nb > 512) return fail(OPNET_ESHAPE, "NMS over more than 32768 candidates is not supported (%d)", cap);
+    nms_mask<<<dim3(nb, nb), 64, 0, st>>>(b.sbox, b.sgroup, n_valid, cap, thresh, b.mask, nb);
+    const int threads = ((nb + 63) / 64) * 64;
+    nms_scan<<<1, threads, 0, st>>>(b.mask, nb, n_valid, cap, max_keep, b.kept, b.n_kept);
+    return OPNET_OK;
+}
+
+// ---- RPN proposals ---------------------------------------------------------------------------------
+struct RpnPlan { RpnLevels L; int total, ncand, nb; size_t sort1, sort2; };
+
+static int rpn_plan(RpnPlan *P, int n_levels, const int *gh, const int *gw, const int *anchor_sizes, int padded_h,
+                    int padded_w, int pre_nms_top_n)
+{
+    if (n_levels < 1 || n_levels > DET_MAX_LEVELS || !gh || !gw || !anchor_sizes)
+        return fail(OPNET_ESHAPE, "1..%d feature levels", DET_MAX_LEVELS);
+    if (pre_nms_top_n <= 0 || padded_h <= 0 || padded_w <= 0) return fail(OPNET_ESHAPE, "bad RPN sizes");
+    RpnLevels &L = P->L;
+    memset(&L, 0, sizeof(L));
+    L.n_levels = n_levels;
+    int off = 0, coff = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        if (gh[l] <= 0 || gw[l] <= 0) return fail(OPNET_ESHAPE, "empty feature level %d", l);
+        L.gh[l] = gh[l]; L.gw[l] = gw[l];
+        L.sh[l] = padded_h / gh[l];       // int(image / grid), AnchorGenerator.forward
+        L.sw[l] = padded_w / gw[l];
+        L.off[l] = off; L.coff[l] = coff;
+        const int na = gh[l] * gw[l] * DET_ANCHORS;
+        off += na;
+        coff += na < pre_nms_top_n ? na : pre_nms_top_n;
+        // AnchorGenerator.generate_anchors in fp32, aspect ratios (0.5, 1, 2), round half to even
+        const float ratios[DET_ANCHORS] = {0.5f, 1.0f, 2.0f};
+        for (int a = 0; a < DET_ANCHORS; ++a) {
+            const float hr = sqrtf(ratios[a]), wr = 1.0f / hr;
+            const float ws = wr * (float)anchor_sizes[l], hs = hr * (float)anchor_sizes[l];
+            L.base[l][a][0] = rintf(-ws / 2.0f); L.base[l][a][1] = rintf(-hs / 2.0f);
+            L.base[l][a][2] = rintf(ws / 2.0f);  L.base[l][a][3] = rintf(hs / 2.0f);
+        }
+    }
+    L.off[n_levels] = off; L.coff[n_levels] = coff;
+    P->total = off; P->ncand = coff;
+    int nmax = 0;
+    for (int l = 0; l < n_levels; ++l) nmax = L.coff[l + 1] - L.coff[l] > nmax ? L.coff[l + 1] - L.coff[l] : nmax;
+    P->nb = (nmax + 63) / 64;
+    if (P->nb > 64) return fail(OPNET_ESHAPE, "pre_nms_top_n above 4096 is not supported");
+    size_t t1 = 0, t2 = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                       (unsigned *)nullptr, (unsigned *)nullptr, off, 0, 35, (hipStream_t)0);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr,
+                                       (unsigned *)nullptr, coff, 0, 32, (hipStream_t)0);
+    P->sort1 = t1; P->sort2 = t2;
+    return OPNET_OK;
+}
+
+static size_t rpn_bytes(const RpnPlan &P)
+{
+    const size_t n = P.total, c = P.ncand;
+    return up256(n * 8) * 2 + up256(n * 4) * 2 + up256(P.sort1) + up256(c * 16) + up256(c * 4) * 7 + up256(P.sort2) + 256 +
+           up256(c * P.nb * 8);
+}
+
+extern "C" size_t opdet_rpn_workspace_bytes(int n_levels, const int *gh, const int *gw, const int *anchor_sizes,
+                                            int padded_h, int padded_w, int pre_nms_top_n)
+{
+    RpnPlan P;
+    if (rpn_plan(&P, n_levels, gh, gw, anchor_sizes, padded_h, padded_w, pre_nms_top_n)) return 0;
+    return rpn_bytes(P);
+}
+
+extern "C" int opdet_rpn_proposals_f32(const float *const *head_out, int n_levels, const int *gh, const int *gw,
+                                       const int *anchor_sizes, int image_h, int image_w, int padded_h, int padded_w,
+                                       int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float min_size,
+                                       float *proposals, float *scores, int *count, void *workspace,
+                                       size_t workspace_bytes, void *stream)
+{
+    if (!head_out || !proposals || !count || !workspace) return fail(OPNET_EINVAL, "null pointer");
+    if ((((uintptr_t)proposals) & 15u) || (((uintptr_t)workspace) & 255u))
+        return fail(OPNET_EINVAL, "proposals must be 16-byte and workspace 256-byte aligned");
+    if (post_nms_top_n <= 0 || image_h <= 0 || image_w <= 0) return fail(OPNET_ESHAPE, "bad RPN sizes");
+    RpnPlan P;
+    if (int rc = rpn_plan(&P, n_levels, gh, gw, anchor_sizes, padded_h, padded_w, pre_nms_top_n)) return rc;
+    if (workspace_bytes < rpn_bytes(P)) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", workspace_bytes, rpn_bytes(P));
+    for (int l = 0; l < n_levels; ++l) {
+        if (!head_out[l]) return fail(OPNET_EINVAL, "null pointer");
+        P.L.head[l] = head_out[l];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = P.total, c = P.ncand;
+    char *p = (char *)workspace;
+    unsigned long long *k_in = (unsigned long long *)p;  p += up256(n * 8);
+    unsigned long long *k_out = (unsigned long long *)p; p += up256(n * 8);
+    unsigned *v_in = (unsigned *)p;  p += up256(n * 4);
+    unsigned *v_out = (unsigned *)p; p += up256(n * 4);
+    void *tmp1 = p; p += up256(P.sort1);
+    float4 *cbox = (float4 *)p; p += up256(c * 16);
+    int *cgroup = (int *)p;     p += up256(c * 4);
+    float *cscore = (float *)p; p += up256(c * 4);
+    unsigned *ck_in = (unsigned *)p;  p += up256(c * 4);
+    unsigned *ck_out = (unsigned *)p; p += up256(c * 4);
+    unsigned *cv_in = (unsigned *)p;  p += up256(c * 4);
+    unsigned *cv_out = (unsigned *)p; p += up256(c * 4);
+    void *tmp2 = p; p += up256(P.sort2);
+    unsigned *fkeys = (unsigned *)p; p += up256(c * 4);
+    int *counters = (int *)p; p += 256;      // [0] boxes that pass the size test, [1] boxes kept by NMS
+    unsigned long long *mask = (unsigned long long *)p;
+
+    HIP_TRY(hipMemsetAsync(counters, 0, 8, st));
+    HIP_TRY(hipMemsetAsync(fkeys, 0xff, c * 4, st));
+    rpn_make_keys<<<(unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256), 256, 0, st>>>(P.L, k_in, v_in);
+    size_t t1 = P.sort1, t2 = P.sort2;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp1, t1, k_in, k_out, v_in, v_out, (int)n, 0, 35, st));
+    rpn_decode_topk<<<(unsigned)((c + 255) / 256), 256, 0, st>>>(P.L, v_out, cbox, cgroup, cscore, ck_in, cv_in, counters,
+                                                                (float)image_w, (float)image_h, min_size, kBoxClip);
+    // per-level NMS on the level-major, score-descending candidates, then ONE sort of the survivors by score
+    rpn_nms_mask<<<dim3(P.nb, P.nb, n_levels), 64, 0, st>>>(P.L, cbox, ck_in, nms_thresh, mask, P.nb);
+    rpn_nms_scan<<<n_levels, 64, 0, st>>>(P.L, mask, P.nb, ck_in, post_nms_top_n, fkeys, counters + 1);
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp2, t2, fkeys, ck_out, cv_in, cv_out, (int)c, 0, 32, st));
+    rpn_emit_sorted<<<(post_nms_top_n + 255) / 256, 256, 0, st>>>(cv_out, counters + 1, post_nms_top_n, cbox, cscore,
+                                                                  (float4 *)proposals, scores, count);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+// ---- MultiScaleRoIAlign ----------------------------------------------------------------------------
+extern "C" int opdet_roi_align_f32(const float *const *feats, const int *fh, const int *fw, int C, int image_h,
+                                   const float *rois, const int *count, int max_rois, float *out, void *stream)
+{
+    if (!feats || !fh || !fw || !rois || !count || !out) return fail(OPNET_EINVAL, "null pointer");
+    if ((((uintptr_t)rois) & 15u) || (((uintptr_t)out) & 15u)) return fail(OPNET_EINVAL, "rois / out must be 16-byte aligned");
+    if (C <= 0 || (C & 3) || C > 1024 || 256 % (C / 4)) return fail(OPNET_ESHAPE, "C=%d: C/4 must divide 256", C);
+    if (max_rois <= 0 || image_h <= 0) return fail(OPNET_ESHAPE, "bad roi_align sizes");
+    RoiLevels L;
+    L.C = C;
+    for (int l = 0; l < 4; ++l) {
+        if (!feats[l] || fh[l] <= 0 || fw[l] <= 0) return fail(OPNET_EINVAL, "bad feature level %d", l);
+        L.feat[l] = feats[l]; L.fh[l] = fh[l]; L.fw[l] = fw[l];
+        // MultiScaleRoIAlign.infer_scale: 2 ** round(log2(feature / image)) from the heights
+        L.scale[l] = exp2f(rintf(log2f((float)fh[l] / (float)image_h)));
+    }
+    roi_align_levels<<<max_rois, 256, 0, (hipStream_t)stream>>>(L, (const float4 *)rois, count, (float4 *)out);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+// ---- detections ------------------------------------------------------------------------------------
+struct DetPlan { size_t ncand; int cap; size_t sort; };
+
+static int det_plan(DetPlan *P, int max_rois, int num_classes)
+{
+    if (max_rois <= 0 || num_classes < 2) return fail(OPNET_ESHAPE, "bad detection sizes");
+    P->ncand = (size_t)max_rois * (num_classes - 1);
+    // scores of one roi sum to 1, so at most 19 classes per roi can clear any threshold >= 0.05
+    size_t cap = (size_t)max_rois * 19 < P->ncand ? (size_t)max_rois * 19 : P->ncand;
+    if (cap > 32768) cap = 32768;
+    P->cap = (int)cap;
+    size_t t = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr,
+                                       (unsigned *)nullptr, (int)P->ncand, 0, 32, (hipStream_t)0);
+    P->sort = t;
+    return OPNET_OK;
+}
+
+static size_t det_bytes(const DetPlan &P)
+{
+    return up256(P.ncand * 16) + up256(P.ncand * 4) * 6 + up256(P.sort) + 256 + nms_bytes(P.cap);
+}
+
+extern "C" size_t opdet_detections_workspace_bytes(int max_rois, int num_classes)
+{
+    DetPlan P;
+    if (det_plan(&P, max_rois, num_classes)) return 0;
+    return det_bytes(P);
+}
+
+extern "C" int opdet_detections_f32(const float *class_logits, const float *box_regression, const float *proposals,
+                                    const int *count, int max_rois, int num_classes, int image_h, int image_w,
+                                    int orig_h, int orig_w, float score_thresh, float nms_thresh, int max_det,
+                                    float *boxes, float *scores, long long *labels, int *n_det, void *workspace,
+                                    size_t workspace_bytes, void *stream)
+{
+    if (!class_logits || !box_regression || !proposals || !count || !boxes || !scores || !labels || !n_det || !workspace)
+        return fail(OPNET_EINVAL, "null pointer");
+    if ((((uintptr_t)proposals) & 15u) || (((uintptr_t)boxes) & 15u) || (((uintptr_t)workspace) & 255u))
+        return fail(OPNET_EINVAL, "proposals / boxes must be 16-byte and workspace 256-byte aligned");
+    if (image_h <= 0 || image_w <= 0 || orig_h <= 0 || orig_w <= 0 || max_det <= 0) return fail(OPNET_ESHAPE, "bad sizes");
+    if (score_thresh < 0.05f) return fail(OPNET_ESHAPE, "score_thresh below 0.05 is not supported (candidate bound)");
+    DetPlan P;
+    if (int rc = det_plan(&P, max_rois, num_classes)) return rc;
+    if (workspace_bytes < det_bytes(P)) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", workspace_bytes, det_bytes(P));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t c = P.ncand;
+    char *p = (char *)workspace;
+    float4 *cbox = (float4 *)p; p += up256(c * 16);
+    int *cgroup = (int *)p;     p += up256(c * 4);
+    float *cscore = (float *)p; p += up256(c * 4);
+    unsigned *ck_in = (unsigned *)p;  p += up256(c * 4);
+    unsigned *ck_out = (unsigned *)p; p += up256(c * 4);
+    unsigned *cv_in = (unsigned *)p;  p += up256(c * 4);
+    unsigned *cv_out = (unsigned *)p; p += up256(c * 4);
+    void *tmp = p; p += up256(P.sort);
+    int *n_valid = (int *)p; p += 256;
+    NmsBuffers nb;
+    carve_nms(p, P.cap, &nb);
+
+    HIP_TRY(hipMemsetAsync(n_valid, 0, 4, st));
+    det_score_boxes<<<max_rois, 256, 0, st>>>(class_logits, box_regression, (const float4 *)proposals, count, num_classes,
+                                              (float)image_w, (float)image_h, score_thresh, 1e-2f, kBoxClip, cbox, cgroup,
+                                              cscore, ck_in, cv_in, n_valid);
+    size_t t = P.sort;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, t, ck_in, ck_out, cv_in, cv_out, (int)c, 0, 32, st));
+    det_gather_sorted<<<(unsigned)((P.cap + 255) / 256), 256, 0, st>>>(cv_out, cbox, cgroup, cscore, nb.sbox, nb.sgroup,
+                                                                      nb.sscore, n_valid, P.cap);
+    if (int rc = run_nms(nb, n_valid, P.cap, nms_thresh, max_det, st)) return rc;
+    // GeneralizedRCNNTransform.postprocess: boxes back to the original frame, ratio = float(orig) / float(resized)
+    const float rw = (float)((double)orig_w / (double)image_w), rh = (float)((double)orig_h / (double)image_h);
+    det_emit<<<1, 128, 0, st>>>(nb.kept, nb.n_kept, max_det, nb.sbox, nb.sgroup, nb.sscore, rw, rh, (float4 *)boxes, scores,
+                                labels, n_det);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}

@@ -28,6 +28,13 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// error text set from the detector-head translation unit (opdet_abi.hip)
+__attribute__((visibility("hidden"))) int opnet_set_error(int code, const char *msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
         hipError_t e_ = (expr);                                                            \
@@ -35,6 +42,22 @@ static int fail(int code, const char *fmt, ...)
             return fail(OPNET_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                         __FILE__, __LINE__);                                               \
     } while (0)
+
+// the LDS-staged conv / GEMM kernel: 128 x {128, 64} tiles; the scalar tap walk needs Cin % 16 == 0
+static void launch_conv_tiled(const ConvArgs &c, long M, hipStream_t st)
+{
+    const bool al = (c.Cin & 15) == 0;
+    const unsigned gx = (unsigned)((M + 127) / 128);
+    if (c.Cout > 64) {
+        const dim3 g(gx, (c.Cout + 127) / 128, 1);
+        if (al) conv2d_nhwc_tiled<128, true><<<g, 256, 0, st>>>(c);
+        else conv2d_nhwc_tiled<128, false><<<g, 256, 0, st>>>(c);
+    } else {
+        const dim3 g(gx, (c.Cout + 63) / 64, 1);
+        if (al) conv2d_nhwc_tiled<64, true><<<g, 256, 0, st>>>(c);
+        else conv2d_nhwc_tiled<64, false><<<g, 256, 0, st>>>(c);
+    }
+}
 
 static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1136,10 +1159,7 @@ extern "C" int opseq_lstm_stack_train_backward_f32(const float *dy, const float 
         c.N = 1; c.H = 1; c.W = B * T; c.Cin = 4 * H; c.Cout = KX; c.KH = 1; c.KW = 1; c.stride = 1; c.pad = 0;
         c.OH = 1; c.OW = B * T; c.KP = 4 * H; c.relu = 0;
         const int M = B * T;
-        if (KX > 64)
-            conv2d_nhwc_tiled<128><<<dim3((M + 127) / 128, (KX + 127) / 128, 1), 256, 0, st>>>(c);
-        else
-            conv2d_nhwc_tiled<64><<<dim3((M + 127) / 128, (KX + 63) / 64, 1), 256, 0, st>>>(c);
+        launch_conv_tiled(c, M, st);
     }
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
@@ -1216,10 +1236,7 @@ extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float 
         c.X = A; c.Wt = Wt; c.bias = b; c.R = nullptr; c.Y = C;
         c.N = 1; c.H = 1; c.W = M; c.Cin = K; c.Cout = N; c.KH = 1; c.KW = 1; c.stride = 1; c.pad = 0;
         c.OH = 1; c.OW = M; c.KP = K; c.relu = act;
-        if (N > 64)
-            conv2d_nhwc_tiled<128><<<dim3((M + 127) / 128, (N + 127) / 128, 1), 256, 0, st>>>(c);
-        else
-            conv2d_nhwc_tiled<64><<<dim3((M + 127) / 128, (N + 63) / 64, 1), 256, 0, st>>>(c);
+        launch_conv_tiled(c, M, st);
     };
     gemm(z, in_w, in_b, qkv, 3 * E, E, 0);
     attention_f32<<<dim3((M + 63) / 64, nhead, 1), 256, 0, st>>>(qkv, att, M, E, hd, 1.0f / sqrtf((float)hd));
@@ -1257,10 +1274,8 @@ extern "C" int opdet_conv2d_f32(const float *x, const float *w, const float *bia
     // LDS-staged 128 x {128, 64} tiles when they still give >= one workgroup per CU; the deep, spatially
     // small layers (25x34 .. 50x68 maps at batch 1) keep the un-staged 64 x 64 tiles for parallelism
     const long t128 = ((M + 127) / 128) * ((Cout + 127) / 128), t64 = ((M + 127) / 128) * ((Cout + 63) / 64);
-    if (Cout > 64 && t128 >= 256)
-        conv2d_nhwc_tiled<128><<<dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), 256, 0, (hipStream_t)stream>>>(a);
-    else if (Cout <= 64 && t64 >= 256)
-        conv2d_nhwc_tiled<64><<<dim3((unsigned)((M + 127) / 128), (Cout + 63) / 64, 1), 256, 0, (hipStream_t)stream>>>(a);
+    if ((Cout > 64 && t128 >= 256) || (Cout <= 64 && t64 >= 256))
+        launch_conv_tiled(a, M, (hipStream_t)stream);
     else
         conv2d_nhwc<<<dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, 1), 256, 0, (hipStream_t)stream>>>(a);
     HIP_TRY(hipGetLastError());
