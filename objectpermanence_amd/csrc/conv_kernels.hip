@@ -205,6 +205,22 @@ __global__ void __launch_bounds__(256) preprocess_frame(const unsigned char *__r
 // bounds test - the VALU slots left between MFMAs (7 per 16x16x4) no longer go to integer division.
 // The MFMA is issued with the weight fragment as the A operand: D rows = channels, so a lane ends up with 4
 // consecutive channels of one pixel and the epilogue moves float4s (bias, residual, store).
+#ifndef CONV_XCD
+#define CONV_XCD 1
+#endif
+typedef unsigned conv_u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte load through a buffer descriptor: offsets past num_records (0xffffffff = "masked") return zeros, so
+// padding taps, rows past M and channels past Cout need no branch - straight-line loads that the compiler can
+// keep in flight across K steps with counted waits
+__device__ __forceinline__ float4 conv_bload(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    const conv_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// X and the packed weights must each be < 2 GiB (32-bit byte offsets, top bit = masked); the host falls back to
+// conv2d_nhwc otherwise.
 template <int BN, bool ALIGNED>
 __global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
 {
@@ -220,15 +236,33 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
     const int i = lane & 15, kk = lane >> 4;
     const int wm = (BN == 128) ? (w >> 1) : w, wn = (BN == 128) ? (w & 1) : 0;
     const long M = (long)a.N * a.OH * a.OW;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.
+    // Give every XCD one contiguous run of tiles, N-tiles of a pixel tile adjacent, so the 3x3 halo rows and the
+    // pixel tile shared by the N-tiles are fetched into ONE L2 (and the neighbour's fetch acts as a prefetch).
+#if CONV_XCD
+    const unsigned nt = gridDim.x * gridDim.y;
+    unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const unsigned per = nt >> 3, rem = nt & 7u, xcd = lin & 7u, slot = lin >> 3;
+        lin = xcd * per + min(xcd, rem) + slot;          // XCDs < rem own one extra tile
+    }
+    const long m0 = (long)(lin / gridDim.y) * BM;
+    const int n0 = (lin % gridDim.y) * BN;
+#else
     const long m0 = (long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
+#endif
     const int K = a.KH * a.KW * a.Cin;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a.X, 0, (unsigned)((long)a.N * a.H * a.W * a.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a.Wt, 0, (unsigned)((long)a.Cout * a.KP * 4), 0x00020000);
 
     // loader role: thread -> k-quad (tid & 3) of rows (tid >> 2) and (tid >> 2) + 64, so the 4 lanes of a row
     // read one contiguous 64-byte run (16 rows x 64 B per wave load, like the fragment-shaped direct loads)
     const int lkq = tid & 3, lr0 = tid >> 2;
     int iy0[2], ix0[2];
-    const float *xn[2];
+    int xoff[2];          // byte offset of (image, iy0, ix0, channel 4*lkq); may be negative at the border
     bool prow_ok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -241,28 +275,25 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
         const int nimg = tq / a.OH;
         iy0[j] = oy * a.stride - a.pad;
         ix0[j] = ox * a.stride - a.pad;
-        xn[j] = a.X + (long)nimg * a.H * a.W * a.Cin;
-        if (ALIGNED) xn[j] += ((long)iy0[j] * a.W + ix0[j]) * a.Cin + 4 * lkq;   // + tap offset per step
+        xoff[j] = (int)(((((long)nimg * a.H + iy0[j]) * a.W + ix0[j]) * a.Cin + (ALIGNED ? 4 * lkq : 0)) * 4);
     }
-    bool wrow_ok[2];
-    const float4 *wsrc[2];
+    unsigned woff[2];
 #pragma unroll
     for (int j = 0; j < WLD; ++j) {
         const int r = n0 + lr0 + 64 * j;
-        wrow_ok[j] = r < a.Cout;
-        wsrc[j] = (const float4 *)(a.Wt + (long)min(r, a.Cout - 1) * a.KP) + lkq;
+        woff[j] = r < a.Cout ? (unsigned)(((long)r * a.KP + 4 * lkq) * 4) : 0xffffffffu;
     }
 
     // wave-uniform tap walk of the NEXT step to load (ALIGNED only)
     int t_c0 = 0, t_dx = 0, t_dy = 0;
     auto load_a2 = [&](int q, float4 (&ra)[2]) {
         if (ALIGNED) {
-            const long toff = ((long)t_dy * a.W + t_dx) * a.Cin + t_c0;
+            const int toff = ((t_dy * a.W + t_dx) * a.Cin + t_c0) * 4;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const bool ok = prow_ok[j] && (unsigned)(iy0[j] + t_dy) < (unsigned)a.H &&
                                 (unsigned)(ix0[j] + t_dx) < (unsigned)a.W;
-                ra[j] = ok ? *(const float4 *)(xn[j] + toff) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[j] = conv_bload(rx, ok ? (unsigned)(xoff[j] + toff) : 0xffffffffu);
             }
             t_c0 += 16;
             if (t_c0 == a.Cin) {
@@ -277,13 +308,13 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
             for (int j = 0; j < 2; ++j) {
                 const int y = iy0[j] + dy, x = ix0[j] + dx;
                 const bool ok = prow_ok[j] && k4 < K && y >= 0 && y < a.H && x >= 0 && x < a.W;
-                ra[j] = ok ? *(const float4 *)(xn[j] + ((long)y * a.W + x) * a.Cin + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[j] = conv_bload(rx, ok ? (unsigned)(xoff[j] + ((dy * a.W + dx) * a.Cin + c) * 4) : 0xffffffffu);
             }
         }
     };
     auto load_w2 = [&](int q, float4 (&rw)[2]) {
 #pragma unroll
-        for (int j = 0; j < WLD; ++j) rw[j] = wrow_ok[j] ? wsrc[j][q * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < WLD; ++j) rw[j] = conv_bload(rwt, woff[j] == 0xffffffffu ? woff[j] : woff[j] + q * 64);
     };
     auto park = [&](int buf, const float4 (&ra)[2], const float4 (&rw)[2]) {
         As[buf][lkq][lr0] = ra[0];
@@ -337,6 +368,187 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
             for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[y].w, af[x].w, acc[x][y], 0, 0, 0);
         if (more) park(cur ^ 1, ra, rw);   // ... and park them in the other buffer after the MFMAs
         __syncthreads();
+    }
+    // epilogue: D fragment lane = (pixel column l&15, channel rows 4*(l>>4)+r)
+    const bool vec = (a.Cout & 3) == 0;
+#pragma unroll
+    for (int x = 0; x < FM; ++x) {
+        const long pp = m0 + wm * (FM * 16) + x * 16 + i;
+        if (pp >= M) continue;
+#pragma unroll
+        for (int y = 0; y < FN; ++y) {
+            const int co = n0 + wn * 64 + y * 16 + 4 * kk;
+            if (co >= a.Cout) continue;
+            if (vec) {
+                float4 v = make_float4(acc[x][y][0], acc[x][y][1], acc[x][y][2], acc[x][y][3]);
+                if (a.bias) {
+                    const float4 b = *(const float4 *)(a.bias + co);
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                if (a.R) {
+                    const float4 r = *(const float4 *)(a.R + pp * a.Cout + co);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (a.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                *(float4 *)(a.Y + pp * a.Cout + co) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (co + r >= a.Cout) break;
+                    float v = acc[x][y][r] + (a.bias ? a.bias[co + r] : 0.f);
+                    if (a.R) v += a.R[pp * a.Cout + co + r];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.Y[pp * a.Cout + co + r] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (Cin % 16 == 0): the staged slices go global -> LDS directly (buffer_load_dwordx4 ... lds),
+// NS stages deep, with counted vmcnt waits and one raw s_barrier per K step.  No staging VGPRs, no ds_write pass,
+// and the prefetch distance (NS-1 steps) is no longer tied to a register ring the compiler will not build.
+// LDS image per stage: row-major [row][4 k-quads] float4 with the quad position XOR-swizzled by (row >> 2) & 3 -
+// the DMA destination is lane-linear (lane l -> 16 B at M0 + 16 l), so the swizzle is applied on the SOURCE side
+// (which k-quad a lane fetches); 4 lanes still fetch one contiguous 64-B run of a row, and the 16 lanes of a
+// fragment read (16 consecutive rows, one k-quad) hit 16 distinct 16-B bank groups.
+// Masked lanes (padding taps, rows past M, channels past Cout) use an offset past num_records: the DMA writes zeros.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void conv_glds16(conv_u32x4 rsrc, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+
+template <int BN, int NS>
+__global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
+{
+    constexpr int BM = 128;
+    constexpr int FM = (BN == 128) ? 4 : 2;
+    constexpr int FN = 4;
+    constexpr int WLD = BN / 64;                       // weight DMA instructions per wave per stage
+    constexpr int LPS = 2 + WLD;                       // DMA instructions per wave per stage
+    constexpr int STAGE_F4 = (BM + BN) * 4;            // float4 slots per stage: A rows then W rows
+    __shared__ __attribute__((aligned(1024))) float4 smem[NS * STAGE_F4];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kk = lane >> 4;
+    const int wm = (BN == 128) ? (w >> 1) : w, wn = (BN == 128) ? (w & 1) : 0;
+    const long M = (long)a.N * a.OH * a.OW;
+    const unsigned nt = gridDim.x * gridDim.y;
+    unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    {   // XCD-aware tile order, see conv2d_nhwc_tiled
+        const unsigned per = nt >> 3, rem = nt & 7u, xcd = lin & 7u, slot = lin >> 3;
+        lin = xcd * per + min(xcd, rem) + slot;
+    }
+    const long m0 = (long)(lin / gridDim.y) * BM;
+    const int n0 = (lin % gridDim.y) * BN;
+
+    conv_u32x4 rx, rwt;
+    {
+        const unsigned long long bx = (unsigned long long)a.X, bw = (unsigned long long)a.Wt;
+        rx.x = (unsigned)bx; rx.y = (unsigned)(bx >> 32);
+        rx.z = (unsigned)((long)a.N * a.H * a.W * a.Cin * 4); rx.w = 0x00020000u;
+        rwt.x = (unsigned)bw; rwt.y = (unsigned)(bw >> 32);
+        rwt.z = (unsigned)((long)a.Cout * a.KP * 4); rwt.w = 0x00020000u;
+    }
+    const unsigned lds0 = (unsigned)(unsigned long long)(const void *)smem;   // LDS byte address of the staging area
+
+    // DMA role: wave w, instruction j covers rows 32w+16j .. +15 (A) / (BN/4)w+16j .. (W); lane l -> row + (l >> 2),
+    // quad position l & 3, which holds k-quad (l & 3) ^ ((row >> 2) & 3) = (l & 3) ^ ((l >> 4) & 3)
+    const int lkq = (lane & 3) ^ ((lane >> 4) & 3), lr = lane >> 2;
+    int iy0[2], ix0[2], xoff[2];
+    bool prow_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        long p = m0 + 32 * w + 16 * j + lr;
+        prow_ok[j] = p < M;
+        if (!prow_ok[j]) p = M - 1;
+        const int ox = p % a.OW;
+        const long tq = p / a.OW;
+        const int oy = tq % a.OH;
+        const int nimg = tq / a.OH;
+        iy0[j] = oy * a.stride - a.pad;
+        ix0[j] = ox * a.stride - a.pad;
+        xoff[j] = (int)(((((long)nimg * a.H + iy0[j]) * a.W + ix0[j]) * a.Cin + 4 * lkq) * 4);
+    }
+    unsigned woff[WLD];
+#pragma unroll
+    for (int j = 0; j < WLD; ++j) {
+        const int r = n0 + (BN / 4) * w + 16 * j + lr;
+        woff[j] = r < a.Cout ? (unsigned)(((long)r * a.KP + 4 * lkq) * 4) : 0x80000000u;
+    }
+
+    int t_c0 = 0, t_dx = 0, t_dy = 0;   // wave-uniform tap walk of the next stage to issue
+    auto issue = [&](int q) {
+        const unsigned sbase = lds0 + (unsigned)(q % NS) * (STAGE_F4 * 16);
+        const int toff = ((t_dy * a.W + t_dx) * a.Cin + t_c0) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = prow_ok[j] && (unsigned)(iy0[j] + t_dy) < (unsigned)a.H && (unsigned)(ix0[j] + t_dx) < (unsigned)a.W;
+            conv_glds16(rx, ok ? (unsigned)(xoff[j] + toff) : 0x80000000u, sbase + (32 * w + 16 * j) * 64);
+        }
+#pragma unroll
+        for (int j = 0; j < WLD; ++j)
+            conv_glds16(rwt, woff[j] == 0x80000000u ? woff[j] : woff[j] + q * 64, sbase + BM * 64 + ((BN / 4) * w + 16 * j) * 64);
+        t_c0 += 16;
+        if (t_c0 == a.Cin) {
+            t_c0 = 0;
+            if (++t_dx == a.KW) { t_dx = 0; ++t_dy; }
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int x = 0; x < FM; ++x)
+#pragma unroll
+        for (int y = 0; y < FN; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nhex = a.KP >> 4;
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nhex) issue(s0);
+    // stage 0 landed (this wave's part) when at most the later prologue stages are outstanding
+    if (nhex >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPS * (NS - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int fsw = (i >> 2) & 3;                       // fragment rows are 16-aligned: (row >> 2) & 3 = (i >> 2) & 3
+    for (int q = 0; q < nhex; ++q) {
+        const bool steady = q + NS - 1 < nhex;
+        if (steady) issue(q + NS - 1);                  // into the buffer every wave finished reading at step q-1
+        const float4 *As = smem + (q % NS) * STAGE_F4;
+        const float4 *Ws = As + BM * 4;
+        float4 af[FM], bf[FN];
+#pragma unroll
+        for (int x = 0; x < FM; ++x) af[x] = As[(wm * (FM * 16) + x * 16 + i) * 4 + (kk ^ fsw)];
+#pragma unroll
+        for (int y = 0; y < FN; ++y) bf[y] = Ws[(wn * 64 + y * 16 + i) * 4 + (kk ^ fsw)];
+#pragma unroll
+        for (int x = 0; x < FM; ++x)
+#pragma unroll
+            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[y].x, af[x].x, acc[x][y], 0, 0, 0);
+#pragma unroll
+        for (int x = 0; x < FM; ++x)
+#pragma unroll
+            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[y].y, af[x].y, acc[x][y], 0, 0, 0);
+#pragma unroll
+        for (int x = 0; x < FM; ++x)
+#pragma unroll
+            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[y].z, af[x].z, acc[x][y], 0, 0, 0);
+#pragma unroll
+        for (int x = 0; x < FM; ++x)
+#pragma unroll
+            for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[y].w, af[x].w, acc[x][y], 0, 0, 0);
+        // stage q+1 must have landed before the barrier that lets every wave read it: in steady state NS-2 later
+        // stages stay in flight; in the tail (nothing new issued) simply drain
+        if (steady) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPS * (NS - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
     // epilogue: D fragment lane = (pixel column l&15, channel rows 4*(l>>4)+r)
     const bool vec = (a.Cout & 3) == 0;

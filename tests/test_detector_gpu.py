@@ -38,6 +38,32 @@ def test_conv2d_matches_torch(cin, cout, k, stride, pad, h, w):
     assert (got - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [
+    (32, 80, 3, 1, 1, 128, 130),     # >= 256 pixel tiles: the LDS-staged kernels (BN = 128), ragged M
+    (64, 48, 1, 1, 0, 131, 127),     # BN = 64
+    (16, 200, 3, 2, 1, 257, 255),    # stride 2, two channel tiles with a ragged second one
+    (48, 77, 3, 1, 1, 128, 129),     # Cout % 4 != 0: scalar epilogue
+    (4, 64, 7, 2, 3, 300, 260),      # stem-like (Cin = 4): the unaligned register-staged variant
+])
+def test_conv2d_tiled_matches_torch(cin, cout, k, stride, pad, h, w):
+    from objectpermanence_amd.detector import _Conv
+    sd = {"w": synth.synth_tensor(f"tw{cin}{cout}{k}", (cout, cin, k, k), float(np.sqrt(6.0 / (cin * k * k)))),
+          "b": synth.synth_tensor("tb", (cout,), 0.2)}
+    x = torch.from_numpy(synth.synth_tensor("tx", (2, cin, h, w), 1.0))
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    assert (2 * oh * ow + 127) // 128 >= 256
+    res = torch.from_numpy(synth.synth_tensor("tr", (2, cout, oh, ow), 1.0))
+    conv = _Conv(sd, "w", bias="b", stride=stride, pad=pad)
+    y = conv(_nhwc(x).cuda(), relu=True, residual=_nhwc(res).cuda())
+    y2 = conv(_nhwc(x).cuda(), relu=False)
+    torch.cuda.synchronize()
+    lin = F.conv2d(x.double(), torch.from_numpy(sd["w"]).double(), torch.from_numpy(sd["b"]).double(), stride=stride, padding=pad)
+    for got, ref in ((y, F.relu(lin + res.double())), (y2, lin)):
+        got = got.cpu().permute(0, 3, 1, 2).double()
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max())
+
+
 def test_preprocess_matches_oracle():
     from objectpermanence_amd.detector import preprocess_frame
     rng = np.random.default_rng(0)
