@@ -85,3 +85,56 @@ def test_training_driver_end_to_end(tmp_path):
                "sample_dir": dirs["dev"][0], "labels_dir": dirs["dev"][1]}, open(tmp_path / "infer.json", "w"))
     out = reasoning_inference_main("opnet", str(tmp_path / "out"), str(tmp_path / "infer.json"), str(tmp_path / "model.json"))
     assert len(out["video_names"]) == 4 and np.isfinite(out["mean_iou"])
+
+
+def test_perception_to_reasoner_end_to_end(tmp_path):
+    """config 4 plumbing: raw frames -> detector (HIP backbone + RPN + RoI heads) -> <video>.pkl -> dataset encoder ->
+    OPNet -> <video>_bb.json.  Synthetic detector weights: what is checked is the file formats, the 300-frame rule,
+    the 0.8 score cut / int truncation, and that batched passes give the per-frame call's detections."""
+    from oracle import detector_oracle as do
+    from objectpermanence_amd.detector import CaterObjectDetector
+    from objectpermanence_amd.inference_main import reasoning_inference_main
+    from objectpermanence_amd.preprocess_perception_main import preprocess_main
+    vids, res, lab, out = (tmp_path / d for d in ("videos", "perception", "labels", "out"))
+    for d in (vids, res, lab):
+        d.mkdir()
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, size=(300, 60, 80, 3), dtype=np.uint8)
+    np.save(vids / "cater_000.npy", frames)
+    np.save(vids / "cater_short.npy", frames[:299])                    # not 300 frames: must not be written
+    sd = {k: torch.from_numpy(v) for k, v in {**do.synth_backbone_params(), **do.synth_head_params()}.items()}
+    torch.save({"model_state_dict": sd}, tmp_path / "detection_model.pth")
+    json.dump({"videos_dir": str(vids), "od_model_weights": str(tmp_path / "detection_model.pth"), "device": "cuda:0"},
+              open(tmp_path / "preprocess.json", "w"))
+    assert preprocess_main(str(res), str(tmp_path / "preprocess.json"), frames_per_pass=12) == 1
+    assert sorted(os.listdir(res)) == ["cater_000.pkl"]
+    data = pickle.load(open(res / "cater_000.pkl", "rb"))
+    assert set(data) == {"bb", "labels"} and len(data["bb"]) == len(data["labels"]) == 300
+    for bb, lb in zip(data["bb"], data["labels"]):
+        assert bb.dtype.kind == "i" and lb.dtype.kind == "i" and bb.shape == (len(lb), 4)
+        assert len(lb) == 0 or (lb.min() >= 1 and lb.max() <= 192 and bb.min() >= 0 and bb[:, [0, 2]].max() <= 80
+                                and bb[:, [1, 3]].max() <= 60)
+    assert sum(len(lb) for lb in data["labels"]) > 300                 # the synthetic heads do clear 0.8 regularly
+    # frame-by-frame call (the reference's pattern, preprocess_perception_main.py:32-36) on a few frames
+    det = CaterObjectDetector(str(tmp_path / "detection_model.pth"))
+    det.load_model(torch.device("cuda:0"))
+    agree = total = 0
+    for t in (0, 11, 12, 150, 299):
+        one = det.remove_low_probability_object(det(frames[t], torch.device("cuda:0"))[0])
+        bb, lb = one["boxes"].cpu().numpy().astype(int), one["labels"].cpu().numpy().astype(int)
+        total += len(lb)
+        for b, l in zip(bb, lb):
+            cand = data["bb"][t][data["labels"][t] == l]
+            agree += bool(len(cand) and np.abs(cand - b).max(axis=1).min() <= 1)
+    assert total > 0 and agree >= 0.9 * total
+    # ... and on into the reasoner through the dataset encoder
+    _, _, gt = synth.make_raw_video(3, "plain")
+    json.dump(gt, open(lab / "cater_000_bb.json", "w"))
+    params = synth.opnet_synth_params(CFG)
+    torch.save({k: torch.from_numpy(v) for k, v in params.items()}, tmp_path / "opnet.pth")
+    json.dump(CFG, open(tmp_path / "model.json", "w"))
+    json.dump({"batch_size": 1, "num_workers": 0, "device": "cuda:0", "model_path": str(tmp_path / "opnet.pth"),
+               "videos_dir": str(vids), "sample_dir": str(res), "labels_dir": str(lab)}, open(tmp_path / "infer.json", "w"))
+    r = reasoning_inference_main("opnet", str(out), str(tmp_path / "infer.json"), str(tmp_path / "model.json"))
+    assert r["video_names"] == ["cater_000"] and r["predictions"].shape == (1, 300, 4)
+    assert len(json.load(open(out / "cater_000_bb.json"))) == 300
