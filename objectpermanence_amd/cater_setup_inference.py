@@ -1,0 +1,62 @@
+"""CATER snitch-localisation task: last-frame box -> 6x6 grid class per video -> class_pred_results.csv.
+
+Mirror of reference baselines/cater_setup_inference.py (transform_xyxy_to_w_h :18-20, get_classes_predictions :23-32,
+cater_setup_inference :35-105): the reasoner runs on the HIP path, only the LAST frame's prediction is used (:77),
+int32 pixel truncation (:91), box centre -> [-1, 1] image coordinates (:28) -> floor-plane homography -> class id.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+from typing import Dict, List
+
+import numpy as np
+import pandas as pd
+import torch
+from torch.utils import data
+
+from .datasets import DatasetsFactory
+from .models_factory import ModelsFactory
+from .proj_utils import get_class_predictions
+from .supported_models import DOUBLE_OUTPUT_MODELS
+
+W_FRAME = 320
+H_FRAME = 240
+
+
+def transform_xyxy_to_w_h(predictions: np.ndarray) -> np.ndarray:
+    p = np.asarray(predictions)
+    return np.stack([(p[:, 2] + p[:, 0]) / 2, (p[:, 3] + p[:, 1]) / 2], axis=1)
+
+
+def get_classes_predictions(predictions: np.ndarray) -> List[int]:
+    p = np.asarray(predictions, dtype=np.float64)
+    return get_class_predictions(p[:, 0] * 2 / W_FRAME - 1, p[:, 1] * 2 / H_FRAME - 1, nrows=3, ncols=3).tolist()
+
+
+def cater_setup_inference(model_name: str, results_dir: str, inference_config_path: str, model_config_path: str) -> pd.DataFrame:
+    with open(inference_config_path, "rb") as f:
+        config: Dict[str, str] = json.load(f)
+    with open(model_config_path, "rb") as f:
+        model_config: Dict[str, int] = json.load(f)
+    device = torch.device(config["device"])
+    dataset = DatasetsFactory.get_inference_dataset(model_name, config["sample_dir"], config["labels_dir"])
+    loader = data.DataLoader(dataset, batch_size=int(config["batch_size"]), num_workers=int(config["num_workers"]))
+    model = ModelsFactory.get_model(model_name, model_config, config["model_path"])
+    model.eval()
+    model.to(device)
+    names: List[str] = []
+    last: List[np.ndarray] = []
+    with torch.no_grad():
+        for (boxes, _index_to_track), _y, video_names in loader:
+            out = model(boxes.to(device))
+            output = out[0] if model_name in DOUBLE_OUTPUT_MODELS else out
+            last.append(output[:, -1, :].cpu().numpy().reshape(-1, 4))                 # :77
+            names.extend(video_names)
+    frame_shapes = np.array([320, 240, 320, 240])
+    px = (np.concatenate(last) * frame_shapes).reshape((len(dataset), 4)).astype(np.int32)   # :91
+    classes = get_classes_predictions(transform_xyxy_to_w_h(px))
+    results = pd.DataFrame({"video_names": [f"{n}.avi" for n in names], "class_predictions": classes})
+    Path(results_dir).mkdir(parents=True, exist_ok=True)
+    results.to_csv(f"{results_dir}/class_pred_results.csv", index=False)
+    return results

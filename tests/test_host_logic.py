@@ -177,3 +177,18 @@ def test_detector_factory_entry():
     det = ModelsFactory.get_detector_model("object_detector", "detection_model.pth")
     assert det.num_classes == 193 and det.saved_detector_path == "detection_model.pth"
     assert ModelsFactory.get_detector_model("nope") is None
+
+
+def test_proj_utils_grid_classes():
+    """reference proj_utils.py:37-75 without cv2: the homography is the closed-form inverse of the floor->image map"""
+    from objectpermanence_amd import proj_utils as pu
+    pts = np.array([[-3, -3, pu.Z], [0, 3, pu.Z], [-3, 0, pu.Z], [0, 0, pu.Z]])          # the reference's 4 fit points
+    img = pu.project_3d_point(pts)
+    q = pu.H @ np.vstack([img.T, np.ones(4)])
+    assert np.abs((q[:2] / q[2]).T - pts[:, :2]).max() < 1e-9 and pu.H[2, 2] == 1.0
+    centres = np.array([[gx - 2.5, gy - 2.5, pu.Z] for gy in range(6) for gx in range(6)])
+    ic = pu.project_3d_point(centres)
+    assert pu.get_class_predictions(ic[:, 0], ic[:, 1]).tolist() == list(range(36))        # cls = y1 * 6 + x1
+    assert pu.get_class_prediction(float(ic[7, 0]), float(ic[7, 1])) == 7
+    far = pu.project_3d_point(np.array([[40.0, -40.0, pu.Z]]))                             # clipped into the grid
+    assert pu.get_class_prediction(far[0, 0], far[0, 1]) == 5

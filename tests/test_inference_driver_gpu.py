@@ -138,3 +138,35 @@ def test_perception_to_reasoner_end_to_end(tmp_path):
     r = reasoning_inference_main("opnet", str(out), str(tmp_path / "infer.json"), str(tmp_path / "model.json"))
     assert r["video_names"] == ["cater_000"] and r["predictions"].shape == (1, 300, 4)
     assert len(json.load(open(out / "cater_000_bb.json"))) == 300
+
+
+def test_cater_setup_inference_grid_classes(tmp_path):
+    """cater_setup_inference mirror: last-frame prediction -> 6x6 grid class -> class_pred_results.csv, against the
+    oracle pipeline (encode -> OPNet -> int32 last-frame box -> centre -> homography -> class)"""
+    import pandas as pd
+    from objectpermanence_amd.cater_setup_inference import cater_setup_inference, get_classes_predictions, transform_xyxy_to_w_h
+    from objectpermanence_amd.datasets import encode_boxes
+    s, l, out = tmp_path / "s", tmp_path / "l", tmp_path / "out"
+    s.mkdir(); l.mkdir()
+    raws = {}
+    for i in range(6):
+        name = f"CATER_new_{i:06d}"
+        bb, lab, gt = synth.make_raw_video(40 + i, "plain")
+        raws[name] = (bb, lab)
+        pickle.dump({"bb": bb, "labels": lab}, open(s / (name + ".pkl"), "wb"), pickle.HIGHEST_PROTOCOL)
+        json.dump(gt, open(l / (name + "_bb.json"), "w"))
+    params = synth.opnet_synth_params(CFG)
+    torch.save({k: torch.from_numpy(v) for k, v in params.items()}, tmp_path / "opnet.pth")
+    json.dump(CFG, open(tmp_path / "model.json", "w"))
+    json.dump({"batch_size": 4, "num_workers": 0, "device": "cuda:0", "model_path": str(tmp_path / "opnet.pth"),
+               "sample_dir": str(s), "labels_dir": str(l)}, open(tmp_path / "infer.json", "w"))
+    df = cater_setup_inference("opnet", str(out), str(tmp_path / "infer.json"), str(tmp_path / "model.json"))
+    on_disk = pd.read_csv(out / "class_pred_results.csv")
+    assert list(on_disk.columns) == ["video_names", "class_predictions"] and on_disk.equals(df)
+    assert df["video_names"].tolist() == [n + ".avi" for n in sorted(raws)]
+    boxes = np.stack([encode_boxes(*raws[n], 6).astype(np.float32) for n in sorted(raws)])
+    y, _ = oo.opnet_forward(boxes, params, np.float32)
+    px = oo.postprocess_to_pixels(y)[:, -1, :]
+    want = get_classes_predictions(transform_xyxy_to_w_h(px))
+    assert all(0 <= c < 36 for c in want)
+    assert df["class_predictions"].tolist() == want
