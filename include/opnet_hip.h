@@ -159,6 +159,9 @@ int opseq_slot_embed_relu_bwd_f32(const float *x, const float *out, const float 
  * nslots_out = 15 (all slots) or 1 (slot 0 only - the live path of TransformerLstm). */
 int opseq_slot_embed_relu_f32(const float *x, const float *W, float *out, long ntok, int nslots_out, int F,
                               void *stream);
+/* attention core of nn.MultiheadAttention (learned_models.py:166-168 via nn.TransformerEncoderLayer) over ONE sequence:
+ * qkv [S][3E] = (q | k | v) after the input projection -> out [S][E]; head size E/nhead a multiple of 16, <= 128. */
+int opseq_attention_f32(const float *qkv, float *out, long S, int E, int nhead, void *stream);
 /* One post-LN nn.TransformerEncoderLayer (eval mode, ReLU FFN, eps 1e-5; :166-168,184) applied IN PLACE
  * to ONE sequence z [S,E] (S = B*T: the reference's sequence-first call attends across all frames
  * of the minibatch). Parameters in state_dict layouts: in_proj [3E,E]+[3E], out_proj [E,E]+[E],

@@ -17,6 +17,7 @@
 //   upsample_add     FPN top-down: Y = lateral + nearest_upsample(top) to lateral's size
 //   preprocess_frame detector.py:74-80 (BGR->RGB, /256) + GeneralizedRCNNTransform (normalize, bilinear
 //                    resize align_corners=False, zero pad) -> NHWC with C = 4 (4th channel 0)
+#pragma once
 #include <hip/hip_runtime.h>
 
 struct ConvArgs {

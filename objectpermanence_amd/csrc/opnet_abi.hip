@@ -4,6 +4,7 @@
 #include "opnet_train_kernels.hip"
 #include "seq_kernels.hip"
 #include "conv_kernels.hip"
+#include "attn_kernels.hip"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -72,6 +73,31 @@ static void launch_conv_tiled(const ConvArgs &c, long M, hipStream_t st)
         if (al) conv2d_nhwc_tiled<64, true><<<g, 256, 0, st>>>(c);
 #endif
         else conv2d_nhwc_tiled<64, false><<<g, 256, 0, st>>>(c);
+    }
+}
+
+// self-attention over one sequence of S tokens: LDS-DMA flash kernel for power-of-two head sizes; two query
+// fragments per wave (K/V fragment reuse) once that still leaves >= one workgroup per CU
+template <int HD>
+static void launch_attention_hd(const float *qkv, float *att, int S, int E, int nhead, hipStream_t st)
+{
+    const float scale = 1.0f / sqrtf((float)HD);
+    if ((long)((S + 127) / 128) * nhead >= 256)
+        attention_glds<HD, 2><<<dim3((S + 127) / 128, nhead, 1), 256, 0, st>>>(qkv, att, S, E, scale);
+    else
+        attention_glds<HD, 1><<<dim3((S + 63) / 64, nhead, 1), 256, 0, st>>>(qkv, att, S, E, scale);
+}
+
+static void launch_attention(const float *qkv, float *att, int S, int E, int nhead, int hd, hipStream_t st)
+{
+    if ((long)S * 3 * E * 4 >= (1L << 31)) hd = 0;      // 32-bit buffer offsets: fall through to the direct kernel
+    switch (hd) {
+    case 16: launch_attention_hd<16>(qkv, att, S, E, nhead, st); break;
+    case 32: launch_attention_hd<32>(qkv, att, S, E, nhead, st); break;
+    case 64: launch_attention_hd<64>(qkv, att, S, E, nhead, st); break;
+    case 128: launch_attention_hd<128>(qkv, att, S, E, nhead, st); break;
+    default:
+        attention_f32<<<dim3((S + 63) / 64, nhead, 1), 256, 0, st>>>(qkv, att, S, E, E / nhead, 1.0f / sqrtf((float)(E / nhead)));
     }
 }
 
@@ -1221,6 +1247,20 @@ extern "C" size_t opseq_encoder_workspace_bytes(long S, int E, int nhead, int ff
     return align_up((size_t)S * (3 * E + 3 * E + ffn) * sizeof(float), 256);
 }
 
+/* the attention core of nn.MultiheadAttention over ONE sequence: qkv [S][3E] (q | k | v, already projected) ->
+ * out [S][E] = concat_h softmax(q_h k_h^T / sqrt(hd)) v_h */
+extern "C" int opseq_attention_f32(const float *qkv, float *out, long S, int E, int nhead, void *stream)
+{
+    if (!qkv || !out) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(qkv) || !aligned16(out)) return fail(OPNET_EINVAL, "qkv / out must be 16-byte aligned");
+    if (S <= 0 || S > 0x7fffffffL || E <= 0 || nhead <= 0 || E % nhead) return fail(OPNET_ESHAPE, "bad attention shape");
+    const int hd = E / nhead;
+    if ((hd & 15) || hd > 128) return fail(OPNET_ESHAPE, "head size %d: must be a multiple of 16, <= 128", hd);
+    launch_attention(qkv, out, (int)S, E, nhead, hd, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
 /* one post-LN nn.TransformerEncoderLayer (eval), in place on z [S][E] */
 extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float *in_b, const float *out_w,
                                        const float *out_b, const float *l1_w, const float *l1_b, const float *l2_w,
@@ -1255,7 +1295,7 @@ extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float 
         launch_conv_tiled(c, M, st);
     };
     gemm(z, in_w, in_b, qkv, 3 * E, E, 0);
-    attention_f32<<<dim3((M + 63) / 64, nhead, 1), 256, 0, st>>>(qkv, att, M, E, hd, 1.0f / sqrtf((float)hd));
+    launch_attention(qkv, att, M, E, nhead, hd, st);
     gemm(att, out_w, out_b, proj, E, E, 0);
     add_layernorm<<<(M + 3) / 4, 256, 0, st>>>(z, proj, n1_w, n1_b, z1, M, E, 1e-5f);
     gemm(z1, l1_w, l1_b, hid, ffn, E, 1);

@@ -84,3 +84,29 @@ def test_ragged_batches_vs_oracle(name, B, T):
         y_ref = fn(synth.boxes5(boxes), p)
         y = _run(_model(name, cfg), synth.boxes5(boxes)).cpu().numpy()
     assert np.abs(y - y_ref).max() < 3e-5
+
+
+@pytest.mark.parametrize("S,E,nhead", [
+    (300, 256, 2), (300, 256, 4),        # one clip, the JSON's 2 heads and BASELINE.json's 4 heads
+    (77, 32, 2), (130, 64, 2),           # head sizes 16 and 32, ragged last key tile
+    (200, 96, 2),                        # head size 48: not a power of two -> the direct (un-staged) kernel
+    (8400, 256, 4),                      # 28 clips: two query fragments per wave (>= 256 workgroups)
+    (16500, 256, 2),
+])
+def test_attention_core_matches_torch(S, E, nhead):
+    """opseq_attention_f32 (LDS-DMA flash kernel) vs softmax(q k^T / sqrt(hd)) v in torch on the CPU"""
+    from objectpermanence_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(S + E + nhead)
+    qkv = torch.randn((S, 3 * E), generator=g) * 1.5
+    x = qkv.cuda()
+    out = torch.empty((S, E), device="cuda:0")
+    _lib.check(lib.opseq_attention_f32(x.data_ptr(), out.data_ptr(), S, E, nhead, torch.cuda.current_stream().cuda_stream),
+               "opseq_attention_f32")
+    torch.cuda.synchronize()
+    dt = torch.float64 if S <= 1000 else torch.float32
+    hd = E // nhead
+    q, k, v = (qkv[:, j * E:(j + 1) * E].to(dt).view(S, nhead, hd).transpose(0, 1) for j in range(3))
+    ref = torch.cat([torch.softmax(q[h] @ k[h].T / hd ** 0.5, dim=-1) @ v[h] for h in range(nhead)], dim=1)
+    err = (out.cpu().to(dt) - ref).abs().max().item()
+    assert err < (2e-5 if S <= 1000 else 2e-4), err
