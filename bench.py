@@ -81,11 +81,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (BASELINE configs: 32)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="clips per GPU per step (default 32, the BASELINE configs); frames per pass for --mode detect (default 16)")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the independent steps are spread over (step i runs on stream i %% S); "
                          "0 = calibrate S in {1,2,3,4} on untimed steps before the warm-up and keep the fastest")
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+    ap.add_argument("--mode", choices=["infer", "train", "detect"], default="infer",
                     help="infer = the BASELINE metric (default); train = fwd + L1 + bwd + Adam step (configs 2/5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
@@ -154,6 +155,97 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist):
         dist.destroy_process_group()
 
 
+def detector_flops_per_frame(h=800, w=1088, rois=1000, classes=193):
+    """algorithmic FLOPs of one eval-mode fasterrcnn_resnet50_fpn call at the padded size: every conv / linear of the
+    backbone, FPN, RPN head and box heads, 2 * M * N * K each"""
+    total = 0
+
+    def conv(hh, ww, cin, cout, k, s, p):
+        nonlocal total
+        oh, ow = (hh + 2 * p - k) // s + 1, (ww + 2 * p - k) // s + 1
+        total += 2 * oh * ow * cout * k * k * cin
+        return oh, ow
+
+    hh, ww = conv(h, w, 3, 64, 7, 2, 3)
+    hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+    inpl, feats = 64, []
+    for li, (nb, pl) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512)), 1):
+        for b in range(nb):
+            st = 2 if (b == 0 and li > 1) else 1
+            if b == 0:
+                conv(hh, ww, inpl, pl * 4, 1, st, 0)
+            conv(hh, ww, inpl, pl, 1, 1, 0)
+            h2, w2 = conv(hh, ww, pl, pl, 3, st, 1)
+            conv(h2, w2, pl, pl * 4, 1, 1, 0)
+            hh, ww, inpl = h2, w2, pl * 4
+        feats.append((hh, ww, inpl))
+    levels = []
+    for fh, fw, c in feats:
+        conv(fh, fw, c, 256, 1, 1, 0)
+        conv(fh, fw, 256, 256, 3, 1, 1)
+        levels.append((fh, fw))
+    levels.append(((feats[3][0] - 1) // 2 + 1, (feats[3][1] - 1) // 2 + 1))
+    for fh, fw in levels:
+        conv(fh, fw, 256, 256, 3, 1, 1)
+        conv(fh, fw, 256, 15, 1, 1, 0)
+    total += 2 * rois * (12544 * 1024 + 1024 * 1024 + 1024 * classes * 5)
+    return total
+
+
+def bench_detect(args, world, rank, dev, dist):
+    """Detector throughput (config 4's front-end, not the BASELINE headline): one step = CaterObjectDetector.detect_batch
+    on `--batch` 240x320 frames per GPU (frames are independent: weak scaling, no collective)."""
+    from objectpermanence_amd.detector import CaterObjectDetector
+    from oracle import detector_oracle as do
+    params = {**do.synth_backbone_params(), **do.synth_head_params()}
+    det = CaterObjectDetector(None)
+    det.load_state_dict(params, dev)
+    nf = args.batch
+    frames = [f for f in np.random.default_rng(rank).integers(0, 256, size=(nf, 240, 320, 3), dtype=np.uint8)]
+    for _ in range(max(1, args.warmup)):
+        out = det.detect_batch(frames, dev)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = det.detect_batch(frames, dev)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        fl = detector_flops_per_frame()
+        tf = fl * nf * args.steps / elapsed / 1e12
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
+            t1 = time.perf_counter()
+            do.detector_forward(frames[0], params, dtype=torch.float32)
+            cpu = {"value": round(1.0 / (time.perf_counter() - t1), 3), "unit": "frames/s", "cores": torch.get_num_threads(),
+                   "kind": "port", "sample": "1 frame through oracle/detector_oracle.py (torch fp32 convs + numpy selection stages)"}
+        print(json.dumps({
+            "metric": "detector frames/sec (Faster-RCNN R50-FPN 193 classes, 240x320 frame -> 800x1066, eval)",
+            "value": round(world * nf * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"detector, {nf} frames per pass per GPU, synthetic weights", "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": round(tf / world, 2), "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": round(tf / world / 157.3, 4), "traffic": None,
+                         "kernel": "all dense launches of a pass (conv2d_nhwc_glds dominates); whole-step time incl. selection stages",
+                         "gflop_per_frame": round(fl / 1e9, 1)},
+            "cpu_baseline": cpu,
+            "detections_per_frame": [len(o["scores"]) for o in out][:4]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,9 +263,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.mode == "detect":
+        args.batch = args.batch or 16     # frames per pass
+        if args.steps == 200:
+            args.steps, args.warmup = 10, 2
+        return bench_detect(args, world, rank, dev, dist)
+
     from objectpermanence_amd import ModelsFactory, metrics
     from oracle import synth
 
+    args.batch = args.batch or 32
     B = args.batch
     params = synth.opnet_synth_params(CFG)
     model = ModelsFactory.get_model("opnet", CFG)
