@@ -112,10 +112,12 @@ class FasterRCNNHeads:
         self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms_thresh = pre_nms_top_n, post_nms_top_n, rpn_nms_thresh
         self.score_thresh, self.nms_thresh, self.detections_per_img = score_thresh, nms_thresh, detections_per_img
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self._side = None
 
     def _workspace(self, key, nbytes: int, what: str) -> torch.Tensor:
         if nbytes == 0:
             _lib.check(-2, what)
+        key = key + (_stream(self.device),)              # one workspace per (shape, stream): images overlap on side streams
         if key not in self._ws:
             self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws[key]
@@ -200,14 +202,42 @@ class FasterRCNNHeads:
         maps = list(feats.values())
         r = self.post_nms_top_n
         pooled = torch.empty((n * r, 7, 7, int(maps[0].shape[3])), dtype=torch.float32, device=self.device)
-        props = []
+        # the per-image stages are ~45 small launches that leave most of the chip idle: images are independent, so
+        # they go round-robin over a few side streams (each with its own workspaces) and overlap one another
+        cur = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(4)]
+        sides = self._side[:max(1, min(len(self._side), n))]
+        props = [None] * n
+
+        def fork():
+            for st in sides:
+                st.wait_stream(cur)
+
+        def join():
+            for st in sides:
+                cur.wait_stream(st)
+
+        fork()
         for i in range(n):
-            p, _, count = self.proposals([h[i:i + 1] for h in head], image_sizes[i], padded_size)
-            self.roi_align([m[i:i + 1] for m in maps], p, count, image_sizes[i], out=pooled[i * r:(i + 1) * r])
-            props.append((p, count))
+            with torch.cuda.stream(sides[i % len(sides)]):
+                p, _, count = self.proposals([h[i:i + 1] for h in head], image_sizes[i], padded_size)
+                self.roi_align([m[i:i + 1] for m in maps], p, count, image_sizes[i], out=pooled[i * r:(i + 1) * r])
+                p.record_stream(cur); count.record_stream(cur)
+                props[i] = (p, count)
+        join()
         cls, reg = self.box_heads(pooled)
-        return [self.detections(cls[i * r:(i + 1) * r], reg[i * r:(i + 1) * r], props[i][0], props[i][1], image_sizes[i],
-                                original_sizes[i]) for i in range(n)]
+        outs = [None] * n
+        fork()
+        for i in range(n):
+            with torch.cuda.stream(sides[i % len(sides)]):
+                o = self.detections(cls[i * r:(i + 1) * r], reg[i * r:(i + 1) * r], props[i][0], props[i][1], image_sizes[i],
+                                    original_sizes[i])
+                for t in o:
+                    t.record_stream(cur)
+                outs[i] = o
+        join()
+        return outs
 
 
 class ResNet50FPNBackbone:
