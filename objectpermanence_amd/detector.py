@@ -365,11 +365,18 @@ class CaterObjectDetector(object):
         with torch.cuda.device(x.device):
             return self.backbone.forward_nhwc(x)
 
+    MAX_FRAMES_PER_PASS = 32      # keeps every activation under the 2 GiB the conv kernel's 32-bit offsets address
+
     def _detect(self, frames, compute_device):
         if self.backbone is None:
             raise RuntimeError("load_model() first")
         if len({f.shape for f in frames}) != 1:
             raise ValueError("frames of one call must share a shape")
+        if len(frames) > self.MAX_FRAMES_PER_PASS:
+            out = []
+            for i in range(0, len(frames), self.MAX_FRAMES_PER_PASS):
+                out.extend(self._detect(frames[i:i + self.MAX_FRAMES_PER_PASS], compute_device))
+            return out
         x = torch.cat([preprocess_frame(f, compute_device, self.min_size, self.max_size) for f in frames], dim=0)
         hw = [tuple(f.shape[:2]) for f in frames]
         sizes = [resized_size(h, w, self.min_size, self.max_size) for h, w in hw]
