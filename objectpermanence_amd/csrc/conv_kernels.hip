@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) preprocess_frame(const unsigned char *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS-staged tiled variant (the production conv / GEMM kernel)
+// LDS-staged tile kernels: register-staged variant first (stem only), the LDS-DMA production kernel below
 // ------------------------------------------------------------------------------------------------
 // Workgroup tile BM=128 output pixels x BN (128 or 64) output channels, K walked 16 at a time.
 // Per K step the workgroup stages the im2col patch slice A[128 x 16] and the weight slice W[BN x 16]
@@ -201,11 +201,11 @@ __global__ void __launch_bounds__(256) preprocess_frame(const unsigned char *__r
 // wave reads its fragments with conflict-free ds_read_b128 (layout [k/4][row][4]: the 16 lanes of a k-group
 // read 16 consecutive rows = one 256-B bank row).  BN=128: 2x2 waves of 64x64 (4x4 fragments, 64 MFMAs per
 // K step per wave); BN=64: 4x1 waves of 32x64.  Global traffic per MFMA drops 4x vs conv2d_nhwc.
-// ALIGNED (Cin % 16 == 0, every layer but the stem): a 16-wide K step lies inside one tap, so the tap walk
-// (c0, dx, dy) is wave-uniform and lives on the scalar unit; per row the loader is one offset add and the
-// bounds test - the VALU slots left between MFMAs (7 per 16x16x4) no longer go to integer division.
-// The MFMA is issued with the weight fragment as the A operand: D rows = channels, so a lane ends up with 4
-// consecutive channels of one pixel and the epilogue moves float4s (bias, residual, store).
+//
+// conv2d_nhwc_tiled is the register-staged variant of the tile kernel for Cin % 16 != 0 (the stem, Cin = 4): a
+// 16-wide K step straddles taps, so each lane derives (tap, channel) of its k-quad itself; everything else is
+// served by conv2d_nhwc_glds below.  The MFMA is issued with the weight fragment as the A operand: D rows =
+// channels, so a lane ends up with 4 consecutive channels of one pixel and the epilogue moves float4s.
 #ifndef CONV_XCD
 #define CONV_XCD 1
 #endif
@@ -222,7 +222,7 @@ __device__ __forceinline__ float4 conv_bload(__amdgpu_buffer_rsrc_t r, unsigned 
 
 // X and the packed weights must each be < 2 GiB (32-bit byte offsets, top bit = masked); the host falls back to
 // conv2d_nhwc otherwise.
-template <int BN, bool ALIGNED>
+template <int BN>
 __global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
 {
     constexpr int BM = 128;
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
         const int nimg = tq / a.OH;
         iy0[j] = oy * a.stride - a.pad;
         ix0[j] = ox * a.stride - a.pad;
-        xoff[j] = (int)(((((long)nimg * a.H + iy0[j]) * a.W + ix0[j]) * a.Cin + (ALIGNED ? 4 * lkq : 0)) * 4);
+        xoff[j] = (int)((((long)nimg * a.H + iy0[j]) * a.W + ix0[j]) * a.Cin * 4);
     }
     unsigned woff[2];
 #pragma unroll
@@ -285,32 +285,15 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_tiled(const ConvArgs a)
         woff[j] = r < a.Cout ? (unsigned)(((long)r * a.KP + 4 * lkq) * 4) : 0xffffffffu;
     }
 
-    // wave-uniform tap walk of the NEXT step to load (ALIGNED only)
-    int t_c0 = 0, t_dx = 0, t_dy = 0;
     auto load_a2 = [&](int q, float4 (&ra)[2]) {
-        if (ALIGNED) {
-            const int toff = ((t_dy * a.W + t_dx) * a.Cin + t_c0) * 4;
+        const int k4 = 16 * q + 4 * lkq;
+        const int tap = k4 / a.Cin, c = k4 - tap * a.Cin;
+        const int dy = tap / a.KW, dx = tap - dy * a.KW;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool ok = prow_ok[j] && (unsigned)(iy0[j] + t_dy) < (unsigned)a.H &&
-                                (unsigned)(ix0[j] + t_dx) < (unsigned)a.W;
-                ra[j] = conv_bload(rx, ok ? (unsigned)(xoff[j] + toff) : 0xffffffffu);
-            }
-            t_c0 += 16;
-            if (t_c0 == a.Cin) {
-                t_c0 = 0;
-                if (++t_dx == a.KW) { t_dx = 0; ++t_dy; }
-            }
-        } else {
-            const int k4 = 16 * q + 4 * lkq;
-            const int tap = k4 / a.Cin, c = k4 - tap * a.Cin;
-            const int dy = tap / a.KW, dx = tap - dy * a.KW;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int y = iy0[j] + dy, x = ix0[j] + dx;
-                const bool ok = prow_ok[j] && k4 < K && y >= 0 && y < a.H && x >= 0 && x < a.W;
-                ra[j] = conv_bload(rx, ok ? (unsigned)(xoff[j] + ((dy * a.W + dx) * a.Cin + c) * 4) : 0xffffffffu);
-            }
+        for (int j = 0; j < 2; ++j) {
+            const int y = iy0[j] + dy, x = ix0[j] + dx;
+            const bool ok = prow_ok[j] && k4 < K && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            ra[j] = conv_bload(rx, ok ? (unsigned)(xoff[j] + ((dy * a.W + dx) * a.Cin + c) * 4) : 0xffffffffu);
         }
     };
     auto load_w2 = [&](int q, float4 (&rw)[2]) {

@@ -70,7 +70,7 @@ __device__ __forceinline__ float4 det_clip(float4 b, float width, float height)
 // per-level top-k candidates: decode against the anchor, clip to the resized image, drop boxes below min_size.
 // ckeys = ~orderable(score) (0xffffffff for dropped candidates: they sort last), cvals = candidate index
 __global__ void __launch_bounds__(256) rpn_decode_topk(const RpnLevels L, const unsigned *sorted_vals, float4 *cbox,
-                                                       int *cgroup, float *cscore, unsigned *ckeys, unsigned *cvals,
+                                                       float *cscore, unsigned *ckeys, unsigned *cvals,
                                                        int *n_valid, float img_w, float img_h, float min_size, float clipv)
 {
     const int total = L.coff[L.n_levels];
@@ -91,7 +91,6 @@ __global__ void __launch_bounds__(256) rpn_decode_topk(const RpnLevels L, const 
     const float score = o[a];
     const bool ok = __fsub_rn(b.z, b.x) >= min_size && __fsub_rn(b.w, b.y) >= min_size;
     cbox[c] = b;
-    cgroup[c] = l;
     cscore[c] = score;
     ckeys[c] = ok ? ~det_orderable(score) : 0xffffffffu;
     cvals[c] = (unsigned)c;

@@ -113,7 +113,7 @@ static int rpn_plan(RpnPlan *P, int n_levels, const int *gh, const int *gw, cons
 static size_t rpn_bytes(const RpnPlan &P)
 {
     const size_t n = P.total, c = P.ncand;
-    return up256(n * 8) * 2 + up256(n * 4) * 2 + up256(P.sort1) + up256(c * 16) + up256(c * 4) * 7 + up256(P.sort2) + 256 +
+    return up256(n * 8) * 2 + up256(n * 4) * 2 + up256(P.sort1) + up256(c * 16) + up256(c * 4) * 6 + up256(P.sort2) + 256 +
            up256(c * P.nb * 8);
 }
 
@@ -151,7 +151,6 @@ extern "C" int opdet_rpn_proposals_f32(const float *const *head_out, int n_level
     unsigned *v_out = (unsigned *)p; p += up256(n * 4);
     void *tmp1 = p; p += up256(P.sort1);
     float4 *cbox = (float4 *)p; p += up256(c * 16);
-    int *cgroup = (int *)p;     p += up256(c * 4);
     float *cscore = (float *)p; p += up256(c * 4);
     unsigned *ck_in = (unsigned *)p;  p += up256(c * 4);
     unsigned *ck_out = (unsigned *)p; p += up256(c * 4);
@@ -167,7 +166,7 @@ extern "C" int opdet_rpn_proposals_f32(const float *const *head_out, int n_level
     rpn_make_keys<<<(unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256), 256, 0, st>>>(P.L, k_in, v_in);
     size_t t1 = P.sort1, t2 = P.sort2;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp1, t1, k_in, k_out, v_in, v_out, (int)n, 0, 35, st));
-    rpn_decode_topk<<<(unsigned)((c + 255) / 256), 256, 0, st>>>(P.L, v_out, cbox, cgroup, cscore, ck_in, cv_in, counters,
+    rpn_decode_topk<<<(unsigned)((c + 255) / 256), 256, 0, st>>>(P.L, v_out, cbox, cscore, ck_in, cv_in, counters,
                                                                 (float)image_w, (float)image_h, min_size, kBoxClip);
     // per-level NMS on the level-major, score-descending candidates, then ONE sort of the survivors by score
     rpn_nms_mask<<<dim3(P.nb, P.nb, n_levels), 64, 0, st>>>(P.L, cbox, ck_in, nms_thresh, mask, P.nb);

@@ -44,7 +44,7 @@ __attribute__((visibility("hidden"))) int opnet_set_error(int code, const char *
                         __FILE__, __LINE__);                                               \
     } while (0)
 
-// the LDS-staged conv / GEMM kernel: 128 x {128, 64} tiles; the scalar tap walk needs Cin % 16 == 0
+// the LDS-staged conv / GEMM kernels: 128 x {128, 64} tiles; LDS-DMA staging (3 stages) needs Cin % 16 == 0
 static void launch_conv_tiled(const ConvArgs &c, long M, hipStream_t st)
 {
     // the tiled kernel addresses X and W with 32-bit byte offsets through buffer descriptors
@@ -54,25 +54,14 @@ static void launch_conv_tiled(const ConvArgs &c, long M, hipStream_t st)
     }
     const bool al = (c.Cin & 15) == 0;
     const unsigned gx = (unsigned)((M + 127) / 128);
-#ifndef CONV_GLDS
-#define CONV_GLDS 3        // LDS-DMA stages of the aligned path (0 = register-staged kernel)
-#endif
     if (c.Cout > 64) {
         const dim3 g(gx, (c.Cout + 127) / 128, 1);
-#if CONV_GLDS
-        if (al) conv2d_nhwc_glds<128, CONV_GLDS><<<g, 256, 0, st>>>(c);
-#else
-        if (al) conv2d_nhwc_tiled<128, true><<<g, 256, 0, st>>>(c);
-#endif
-        else conv2d_nhwc_tiled<128, false><<<g, 256, 0, st>>>(c);
+        if (al) conv2d_nhwc_glds<128, 3><<<g, 256, 0, st>>>(c);
+        else conv2d_nhwc_tiled<128><<<g, 256, 0, st>>>(c);
     } else {
         const dim3 g(gx, (c.Cout + 63) / 64, 1);
-#if CONV_GLDS
-        if (al) conv2d_nhwc_glds<64, CONV_GLDS><<<g, 256, 0, st>>>(c);
-#else
-        if (al) conv2d_nhwc_tiled<64, true><<<g, 256, 0, st>>>(c);
-#endif
-        else conv2d_nhwc_tiled<64, false><<<g, 256, 0, st>>>(c);
+        if (al) conv2d_nhwc_glds<64, 3><<<g, 256, 0, st>>>(c);
+        else conv2d_nhwc_tiled<64><<<g, 256, 0, st>>>(c);
     }
 }
 
