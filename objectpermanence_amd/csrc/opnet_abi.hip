@@ -774,7 +774,12 @@ static int check_stack(int B, int T, int L, int KX, int H)
     return OPNET_OK;
 }
 
-struct StackPackedLayout { size_t layer[SEQ_MAX_LAYERS], head, total; int nhx[SEQ_MAX_LAYERS]; };
+// A wide layer-0 input (NonLinearLstm: 15 x 256 = 3840 features against H = 512) makes W_ih x_t 88 % of every step's
+// weight stream; it does not depend on the recurrence, so inference computes it for all t in ONE GEMM on the conv kernel
+// ("hoisting") and the steps walk only W_hh.
+static bool stack_hoists_input(int KX, int H) { return (KX & 15) == 0 && KX >= 2 * H; }
+
+struct StackPackedLayout { size_t layer[SEQ_MAX_LAYERS], head, wih0g, total; int nhx[SEQ_MAX_LAYERS]; };
 
 static StackPackedLayout stack_packed_layout(int L, int KX, int H)
 {
@@ -786,18 +791,21 @@ static StackPackedLayout stack_packed_layout(int L, int KX, int H)
         o += (size_t)(H / 4) * (P.nhx[l] + H / 16) * 256;
     }
     P.head = o; o += (size_t)(H / 16) * 256;
+    P.wih0g = o;                                   // [4H][KX] rows unit*4+gate: weight operand of the hoisted GEMM
+    if (stack_hoists_input(KX, H)) o += (size_t)4 * H * KX;
     P.total = o;
     return P;
 }
 
-struct StackWorkspaceLayout { size_t xp, state, hbuf[SEQ_MAX_LAYERS], c[SEQ_MAX_LAYERS], state_end, ystage, total; };
+struct StackWorkspaceLayout { size_t xp, state, hbuf[SEQ_MAX_LAYERS], c[SEQ_MAX_LAYERS], state_end, ystage, gemm, xg, total; };
 
 static StackWorkspaceLayout stack_workspace_layout(int B, int T, int L, int KX, int H)
 {
     const size_t RB = (B + 31) / 32, KXP = (size_t)((KX + 15) / 16) * 16;
     StackWorkspaceLayout W;
     size_t o = 0;
-    W.xp = o; o += (size_t)T * RB * (KXP / 4) * 32 * 16;
+    W.xp = o;
+    if (!stack_hoists_input(KX, H)) o += (size_t)T * RB * (KXP / 4) * 32 * 16;     // packed x: only when the steps read it
     W.state = o;
     for (int l = 0; l < L; ++l) {
         W.hbuf[l] = o; o += 2 * RB * (size_t)H * 32 * 4;
@@ -805,6 +813,12 @@ static StackWorkspaceLayout stack_workspace_layout(int B, int T, int L, int KX, 
     }
     W.state_end = o;
     W.ystage = o; o += RB * 32 * (size_t)T * 16;
+    o = align_up(o, 256);
+    W.gemm = W.xg = o;
+    if (stack_hoists_input(KX, H)) {
+        W.gemm = o; o += align_up((size_t)B * T * 4 * H * 4, 256);       // G [B*T][4H]
+        W.xg = o;   o += (size_t)T * RB * H * 32 * 16;                     // xg [T][RB][H][32] float4
+    }
     W.total = align_up(o, 256);
     return W;
 }
@@ -839,6 +853,8 @@ extern "C" int opseq_lstm_stack_pack_weights_f32(const float *const *w_ih, const
             packed + P.layer[l], w_ih[l], w_hh[l], kx, P.nhx[l] * 16, H, H, 0, 0, H / 4);
     }
     opnet_pack_tiles<<<blocks((size_t)(H / 16) * 256), 256, 0, st>>>(packed + P.head, nullptr, w_head, 0, 0, H, 0, 4, 1, 1);
+    if (stack_hoists_input(KX, H))
+        stack_pack_wih_rows<<<blocks((size_t)4 * H * KX), 256, 0, st>>>(w_ih[0], packed + P.wih0g, H, KX, KX);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }
@@ -908,8 +924,26 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
     a.headA = (const float4 *)(packed + P.head);
     a.ystage = (float4 *)(w + W.ystage);
     hipStream_t st = (hipStream_t)stream;
-    rows_to_packed<<<2048, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, RB, KX, P.nhx[0] * 16,
-                                          (float4 *)(w + W.state), (long)((W.state_end - W.state) / 16));
+    if (stack_hoists_input(KX, H)) {
+        if (!aligned16(x)) return fail(OPNET_EINVAL, "x must be 16-byte aligned");
+        // G [B*T][4H] = x [B*T][KX] . W_ih0^T  (a 1x1 "conv" over B*T pixels), then into the step kernel's layout
+        ConvArgs c;
+        c.X = x; c.Wt = packed + P.wih0g; c.bias = nullptr; c.R = nullptr; c.Y = (float *)(w + W.gemm);
+        c.N = 1; c.H = 1; c.W = B * T; c.Cin = KX; c.Cout = 4 * H; c.KH = 1; c.KW = 1; c.stride = 1; c.pad = 0;
+        c.OH = 1; c.OW = B * T; c.KP = KX; c.relu = 0;
+        launch_conv_tiled(c, (long)B * T, st);
+        const long nx = (long)T * RB * 32 * H;
+        stack_xg_repack<<<(unsigned)((nx + 255) / 256 > 8192 ? 8192 : (nx + 255) / 256), 256, 0, st>>>(
+            (const float4 *)(w + W.gemm), (float4 *)(w + W.xg), B, T, RB, H);
+        a.layer[0].xg = (const float4 *)(w + W.xg);
+        a.layer[0].a_skip = P.nhx[0];
+        a.layer[0].nhx = 0;
+        rows_to_packed<<<2048, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, RB, 0, 0, (float4 *)(w + W.state),
+                                              (long)((W.state_end - W.state) / 16));      // zero the state only
+    } else {
+        rows_to_packed<<<2048, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, RB, KX, P.nhx[0] * 16,
+                                              (float4 *)(w + W.state), (long)((W.state_end - W.state) / 16));
+    }
     const dim3 grid(ntiles, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
     if (!graph) {
         for (int s = 0; s < T + L; ++s) lstm_stack_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
@@ -1105,6 +1139,23 @@ extern "C" int opseq_lstm_stack_train_forward_f32(const float *x, const float *p
     hipStream_t st = (hipStream_t)stream;
     rows_to_packed<<<2048, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, a.RB, KX, P.nhx[0] * 16,
                                           (float4 *)(w + W.state), (long)((W.state_end - W.state) / 16));
+    if (stack_hoists_input(KX, H)) {
+        // same hoisted input product as the inference forward (bit-identical y); the packed x above is still needed
+        // by the weight-gradient GEMM.  Scratch: G lives in the da-rows buffer (used by backward only), xg in layer
+        // 0's gate-save buffer - every thread reads its xg element before it overwrites it with the saved gates.
+        if (!aligned16(x)) return fail(OPNET_EINVAL, "x must be 16-byte aligned");
+        ConvArgs c;
+        c.X = x; c.Wt = packed + P.wih0g; c.bias = nullptr; c.R = nullptr; c.Y = (float *)(w + W.darows);
+        c.N = 1; c.H = 1; c.W = B * T; c.Cin = KX; c.Cout = 4 * H; c.KH = 1; c.KW = 1; c.stride = 1; c.pad = 0;
+        c.OH = 1; c.OW = B * T; c.KP = KX; c.relu = 0;
+        launch_conv_tiled(c, (long)B * T, st);
+        const long nx = (long)T * a.RB * 32 * H;
+        stack_xg_repack<<<(unsigned)((nx + 255) / 256 > 8192 ? 8192 : (nx + 255) / 256), 256, 0, st>>>(
+            (const float4 *)(w + W.darows), (float4 *)(w + W.g[0]), B, T, a.RB, H);
+        a.layer[0].xg = (const float4 *)(w + W.g[0]);
+        a.layer[0].a_skip = P.nhx[0];
+        a.layer[0].nhx = 0;
+    }
     const dim3 grid(L * (H / 4) + 1, a.RB < OPNET_MAX_GY ? a.RB : OPNET_MAX_GY, 1);
     for (int s = 0; s < T + L; ++s) lstm_stack_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     const long ny = (long)B * T;

@@ -21,6 +21,10 @@ struct StackLayer {
     float4 *hbuf;          // [2 parity | T+1][RB][H/4][32]
     float *c;              // [1 | T+1][RB][H][32]
     float4 *gsave;         // training: [T][RB][H][32] post-activation gates (i,f,g,o), later overwritten by da
+    // hoisted input product (inference, wide layer-0 inputs): xg [T][RB][H][32] = W_ih x_t for every t, computed by ONE
+    // GEMM before the recurrence; the step then walks only the h part of the A tiles (a_skip = hexadecets to skip)
+    const float4 *xg;
+    int a_skip;
 };
 
 struct StackArgs {
@@ -56,7 +60,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         const int H = ly.H, nhh = H >> 4, nhx = ly.nhx;
         const int tile = bx;
         const KSlice ks = wave_slice(nhx + nhh);
-        const float4 *A = ly.A + (long)tile * (nhx + nhh) * 64;
+        const float4 *A = ly.A + ((long)tile * (ly.a_skip + nhx + nhh) + ly.a_skip) * 64;
         load_a_chunk(a0, A, ks.q0, ks.q1);
         const int unit = tile * 4 + quarter;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
@@ -67,14 +71,18 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
                 : a.layer[l - 1].hbuf + (so * a.RB + rb) * ((long)a.layer[l - 1].H * 8);
             const float4 *hprev = ly.hbuf + (sp * a.RB + rb) * ((long)H * 8);
             float c_old = 0.f;
-            if (tid < 128) c_old = ly.c[((cp * a.RB + rb) * H + unit) * 32 + clip];
+            float4 xg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < 128) {
+                c_old = ly.c[((cp * a.RB + rb) * H + unit) * 32 + clip];
+                if (ly.xg) xg = ly.xg[(((long)t * a.RB + rb) * H + unit) * 32 + clip];
+            }
             gemm16_rb(a0, A, xseg, nhx, hprev, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             if (tid < 128) {
                 float c = c_old;
                 float4 gs;
-                const float h = lstm_cell_g(part_sum(part, half * 4 + 0, el), part_sum(part, half * 4 + 1, el),
-                                            part_sum(part, half * 4 + 2, el), part_sum(part, half * 4 + 3, el), &c, &gs);
+                const float h = lstm_cell_g(part_sum(part, half * 4 + 0, el) + xg.x, part_sum(part, half * 4 + 1, el) + xg.y,
+                                            part_sum(part, half * 4 + 2, el) + xg.z, part_sum(part, half * 4 + 3, el) + xg.w, &c, &gs);
                 ly.c[((co * a.RB + rb) * H + unit) * 32 + clip] = c;
                 if (a.train) ly.gsave[(((long)t * a.RB + rb) * H + unit) * 32 + clip] = gs;
                 float *hout = (float *)(ly.hbuf + (so * a.RB + rb) * ((long)H * 8));
@@ -135,6 +143,36 @@ __global__ void __launch_bounds__(256) rows_to_packed(const float *__restrict__ 
                 if (kq * 4 + e < K) v[e] = src[e];
         }
         xp[(((long)t * RB + rb) * KQ + kq) * 32 + clip] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// W_ih [4H][K] (torch gate-major rows: gate*H + unit) -> [4H][KP] with row unit*4 + gate, zero-padded columns:
+// the weight operand of the hoisted input GEMM, whose output columns are then (unit, gate) = one float4 per unit
+__global__ void __launch_bounds__(256) stack_pack_wih_rows(const float *__restrict__ w, float *__restrict__ out, int H,
+                                                           int K, int KP)
+{
+    const long n = 4L * H * KP;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const int k = idx % KP;
+        const int row = idx / KP;
+        const int unit = row >> 2, gate = row & 3;
+        out[idx] = k < K ? w[((long)gate * H + unit) * K + k] : 0.f;
+    }
+}
+
+// G [B*T][H] float4 (row b*T + t: the GEMM's pixel order over x [B][T][K]) -> xg [T][RB][H][32], clips past B zero
+__global__ void __launch_bounds__(256) stack_xg_repack(const float4 *__restrict__ G, float4 *__restrict__ xg, int B, int T,
+                                                       int RB, int H)
+{
+    const long n = (long)T * RB * 32 * H;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const int unit = idx % H;            // consecutive threads walk the units of one (t, clip): coalesced reads
+        long r = idx / H;
+        const int clip = r & 31; r >>= 5;
+        const int rb = r % RB;
+        const int t = r / RB;
+        const int b = rb * 32 + clip;
+        xg[(((long)t * RB + rb) * H + unit) * 32 + clip] = b < B ? G[((long)b * T + t) * H + unit] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
