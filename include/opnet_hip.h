@@ -161,7 +161,10 @@ int opseq_slot_embed_relu_f32(const float *x, const float *W, float *out, long n
                               void *stream);
 /* attention core of nn.MultiheadAttention (learned_models.py:166-168 via nn.TransformerEncoderLayer) over ONE sequence:
  * qkv [S][3E] = (q | k | v) after the input projection -> out [S][E]; head size E/nhead a multiple of 16, <= 128. */
-int opseq_attention_f32(const float *qkv, float *out, long S, int E, int nhead, void *stream);
+size_t opseq_attention_workspace_bytes(long S, int E, int nhead);
+/* workspace (nullable): scratch for the key-split partials; without it the kernel runs unsplit */
+int opseq_attention_f32(const float *qkv, float *out, long S, int E, int nhead, void *workspace,
+                        size_t workspace_bytes, void *stream);
 /* One post-LN nn.TransformerEncoderLayer (eval mode, ReLU FFN, eps 1e-5; :166-168,184) applied IN PLACE
  * to ONE sequence z [S,E] (S = B*T: the reference's sequence-first call attends across all frames
  * of the minibatch). Parameters in state_dict layouts: in_proj [3E,E]+[3E], out_proj [E,E]+[E],

@@ -28,9 +28,14 @@ __device__ __forceinline__ int att_kswz(int row)
     return PPR >= 16 ? (row & 15) : ((row / (16 / PPR)) & (PPR - 1));
 }
 
+// Key split (gridDim.z = KS > 1): workgroup z sweeps key tiles [z*per, (z+1)*per) and leaves an UNNORMALISED partial
+// (O, running max m, running sum l) per query and head; attention_merge combines them.  Wave-tasks come in units of
+// "16 QF queries x all keys"; when their number is a small non-multiple of the SIMD count (S = 9600, 2 heads: 1200
+// tasks on 1024 SIMDs) the busiest SIMD carries twice the average - splitting the keys makes the units 1/KS the size.
 template <int HD, int QF>
 __global__ void __launch_bounds__(256) attention_glds(const float *__restrict__ qkv, float *__restrict__ out, int S,
-                                                      int E, float scale)
+                                                      int E, float scale, float *__restrict__ opart,
+                                                      float2 *__restrict__ ml)
 {
     constexpr int NS = 3;                                     // LDS stages
     constexpr int PPR = HD / 4;                               // pieces per row
@@ -107,16 +112,19 @@ __global__ void __launch_bounds__(256) attention_glds(const float *__restrict__ 
 #pragma unroll
     for (int f = 0; f < QF; ++f) { m_run[f] = -INFINITY; l_run[f] = 0.f; }
 
-    const int nblk = (S + 15) >> 4;
+    const int nall = (S + 15) >> 4;
+    const int per = (nall + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int blk0 = (int)blockIdx.z * per;
+    const int nblk = min(nall, blk0 + per);          // this workgroup sweeps key tiles [blk0, nblk)
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0)
-        if (s0 < nblk) issue(s0);
-    if (nblk >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPS * (NS - 2)) : "memory");
+        if (blk0 + s0 < nblk) issue(blk0 + s0);
+    if (nblk - blk0 >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPS * (NS - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     const int ksw = att_kswz<HD>(i);
-    for (int blk = 0; blk < nblk; ++blk) {
+    for (int blk = blk0; blk < nblk; ++blk) {
         const bool steady = blk + NS - 1 < nblk;
         if (steady) issue(blk + NS - 1);
         const float4 *Kt = smem + (blk % NS) * (2 * TILE_F4);
@@ -199,8 +207,10 @@ __global__ void __launch_bounds__(256) attention_glds(const float *__restrict__ 
     for (int f = 0; f < QF; ++f) {
         const int q = q0 + 16 * f + i;
         if (q >= S) continue;
-        const float inv = 1.0f / l_run[f];
-        float *op = out + (long)q * E + (long)head * HD;
+        const bool partial = gridDim.z > 1;
+        const float inv = partial ? 1.0f : 1.0f / l_run[f];
+        float *op = (partial ? opart + ((long)blockIdx.z * S + q) * E : out + (long)q * E) + (long)head * HD;
+        if (partial && kk == 0) ml[((long)blockIdx.z * S + q) * gridDim.y + head] = make_float2(m_run[f], l_run[f]);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -209,5 +219,32 @@ __global__ void __launch_bounds__(256) attention_glds(const float *__restrict__ 
                 if (d < HD)
                     *(float4 *)(op + d) = make_float4(o[f][c][0][r] * inv, o[f][c][1][r] * inv, o[f][c][2][r] * inv, o[f][c][3][r] * inv);
             }
+    }
+}
+
+// out[q][head*hd + d] = sum_z w_z O_z / sum_z w_z l_z,  w_z = exp(m_z - max_z m_z)   (one thread per float4 of out)
+__global__ void __launch_bounds__(256) attention_merge(const float *__restrict__ opart, const float2 *__restrict__ ml,
+                                                       float *__restrict__ out, int S, int E, int nhead, int KS)
+{
+    const int hd = E / nhead;
+    const long n = (long)S * (E >> 2);
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const int e4 = idx % (E >> 2);
+        const long q = idx / (E >> 2);
+        const int head = (e4 * 4) / hd;
+        float m = -INFINITY;
+        for (int z = 0; z < KS; ++z) m = fmaxf(m, ml[((long)z * S + q) * nhead + head].x);
+        float l = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < KS; ++z) {
+            const float2 s = ml[((long)z * S + q) * nhead + head];
+            if (s.y == 0.f) continue;                       // an empty split (no keys)
+            const float wz = __expf(s.x - m);
+            const float4 v = *(const float4 *)(opart + ((long)z * S + q) * E + e4 * 4);
+            l += wz * s.y;
+            acc.x += wz * v.x; acc.y += wz * v.y; acc.z += wz * v.z; acc.w += wz * v.w;
+        }
+        const float inv = 1.0f / l;
+        *(float4 *)(out + q * E + e4 * 4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
     }
 }

@@ -66,25 +66,55 @@ static void launch_conv_tiled(const ConvArgs &c, long M, hipStream_t st)
 }
 
 // self-attention over one sequence of S tokens: LDS-DMA flash kernel for power-of-two head sizes; two query
-// fragments per wave (K/V fragment reuse) once that still leaves >= one workgroup per CU
-template <int HD>
-static void launch_attention_hd(const float *qkv, float *att, int S, int E, int nhead, hipStream_t st)
+// fragments per wave (K/V fragment reuse) once that still leaves >= one workgroup per CU; a key split when the
+// workgroup count is a small non-multiple of the CU count (needs scratch: KS partial outputs + their softmax stats)
+static size_t attention_scratch_bytes(long S, int E, int nhead, int KS)
 {
-    const float scale = 1.0f / sqrtf((float)HD);
-    if ((long)((S + 127) / 128) * nhead >= 256)
-        attention_glds<HD, 2><<<dim3((S + 127) / 128, nhead, 1), 256, 0, st>>>(qkv, att, S, E, scale);
-    else
-        attention_glds<HD, 1><<<dim3((S + 63) / 64, nhead, 1), 256, 0, st>>>(qkv, att, S, E, scale);
+    return KS <= 1 ? 0 : (size_t)KS * S * E * 4 + (size_t)KS * S * nhead * 8;
 }
 
-static void launch_attention(const float *qkv, float *att, int S, int E, int nhead, int hd, hipStream_t st)
+static int attention_key_split(long S, int nhead, int QF)
+{
+    const long W = ((S + 64 * QF - 1) / (64 * QF)) * nhead;
+    if (W >= 8 * 256 || (S + 15) / 16 < 64) return 1;         // enough workgroups / too few key tiles to split
+    int best = 1;
+    double best_cost = (double)((W + 255) / 256);              // rounds of 256 CUs, in units of one full sweep
+    for (int ks = 2; ks <= 4; ++ks) {
+        const double cost = (double)((W * ks + 255) / 256) / ks * 1.03;    // +3 % per split for the merge pass
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = ks; }
+    }
+    return best;
+}
+
+template <int HD>
+static void launch_attention_hd(const float *qkv, float *att, int S, int E, int nhead, void *scratch,
+                                size_t scratch_bytes, hipStream_t st)
+{
+    const float scale = 1.0f / sqrtf((float)HD);
+    const int QF = (long)((S + 127) / 128) * nhead >= 256 ? 2 : 1;
+    int KS = attention_key_split(S, nhead, QF);
+    while (KS > 1 && (!scratch || attention_scratch_bytes(S, E, nhead, KS) > scratch_bytes)) --KS;
+    float *opart = KS > 1 ? (float *)scratch : nullptr;
+    float2 *ml = KS > 1 ? (float2 *)((char *)scratch + (size_t)KS * S * E * 4) : nullptr;
+    if (QF == 2)
+        attention_glds<HD, 2><<<dim3((S + 127) / 128, nhead, KS), 256, 0, st>>>(qkv, att, S, E, scale, opart, ml);
+    else
+        attention_glds<HD, 1><<<dim3((S + 63) / 64, nhead, KS), 256, 0, st>>>(qkv, att, S, E, scale, opart, ml);
+    if (KS > 1) {
+        const long n = (long)S * (E / 4);
+        attention_merge<<<(unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), 256, 0, st>>>(opart, ml, att, S, E, nhead, KS);
+    }
+}
+
+static void launch_attention(const float *qkv, float *att, int S, int E, int nhead, int hd, void *scratch,
+                             size_t scratch_bytes, hipStream_t st)
 {
     if ((long)S * 3 * E * 4 >= (1L << 31)) hd = 0;      // 32-bit buffer offsets: fall through to the direct kernel
     switch (hd) {
-    case 16: launch_attention_hd<16>(qkv, att, S, E, nhead, st); break;
-    case 32: launch_attention_hd<32>(qkv, att, S, E, nhead, st); break;
-    case 64: launch_attention_hd<64>(qkv, att, S, E, nhead, st); break;
-    case 128: launch_attention_hd<128>(qkv, att, S, E, nhead, st); break;
+    case 16: launch_attention_hd<16>(qkv, att, S, E, nhead, scratch, scratch_bytes, st); break;
+    case 32: launch_attention_hd<32>(qkv, att, S, E, nhead, scratch, scratch_bytes, st); break;
+    case 64: launch_attention_hd<64>(qkv, att, S, E, nhead, scratch, scratch_bytes, st); break;
+    case 128: launch_attention_hd<128>(qkv, att, S, E, nhead, scratch, scratch_bytes, st); break;
     default:
         attention_f32<<<dim3((S + 63) / 64, nhead, 1), 256, 0, st>>>(qkv, att, S, E, E / nhead, 1.0f / sqrtf((float)(E / nhead)));
     }
@@ -1289,14 +1319,22 @@ extern "C" size_t opseq_encoder_workspace_bytes(long S, int E, int nhead, int ff
 
 /* the attention core of nn.MultiheadAttention over ONE sequence: qkv [S][3E] (q | k | v, already projected) ->
  * out [S][E] = concat_h softmax(q_h k_h^T / sqrt(hd)) v_h */
-extern "C" int opseq_attention_f32(const float *qkv, float *out, long S, int E, int nhead, void *stream)
+extern "C" size_t opseq_attention_workspace_bytes(long S, int E, int nhead)
+{
+    if (S <= 0 || E <= 0 || nhead <= 0) return 0;
+    return align_up(attention_scratch_bytes(S, E, nhead, 4), 256);
+}
+
+extern "C" int opseq_attention_f32(const float *qkv, float *out, long S, int E, int nhead, void *workspace,
+                                   size_t workspace_bytes, void *stream)
 {
     if (!qkv || !out) return fail(OPNET_EINVAL, "null pointer");
+    if (workspace && !aligned16(workspace)) return fail(OPNET_EINVAL, "workspace must be 16-byte aligned");
     if (!aligned16(qkv) || !aligned16(out)) return fail(OPNET_EINVAL, "qkv / out must be 16-byte aligned");
     if (S <= 0 || S > 0x7fffffffL || E <= 0 || nhead <= 0 || E % nhead) return fail(OPNET_ESHAPE, "bad attention shape");
     const int hd = E / nhead;
     if ((hd & 15) || hd > 128) return fail(OPNET_ESHAPE, "head size %d: must be a multiple of 16, <= 128", hd);
-    launch_attention(qkv, out, (int)S, E, nhead, hd, (hipStream_t)stream);
+    launch_attention(qkv, out, (int)S, E, nhead, hd, workspace, workspace ? workspace_bytes : 0, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }
@@ -1335,7 +1373,7 @@ extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float 
         launch_conv_tiled(c, M, st);
     };
     gemm(z, in_w, in_b, qkv, 3 * E, E, 0);
-    launch_attention(qkv, att, M, E, nhead, hd, st);
+    launch_attention(qkv, att, M, E, nhead, hd, hid, (size_t)S * ffn * sizeof(float), st);   // hid is free until the FFN
     gemm(att, out_w, out_b, proj, E, E, 0);
     add_layernorm<<<(M + 3) / 4, 256, 0, st>>>(z, proj, n1_w, n1_b, z1, M, E, 1e-5f);
     gemm(z1, l1_w, l1_b, hid, ffn, E, 1);

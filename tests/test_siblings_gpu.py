@@ -92,6 +92,7 @@ def test_ragged_batches_vs_oracle(name, B, T):
     (200, 96, 2),                        # head size 48: not a power of two -> the direct (un-staged) kernel
     (8400, 256, 4),                      # 28 clips: two query fragments per wave (>= 256 workgroups)
     (16500, 256, 2),
+    (9600, 256, 2), (5000, 256, 4),      # workgroup counts that trigger the key split
 ])
 def test_attention_core_matches_torch(S, E, nhead):
     """opseq_attention_f32 (LDS-DMA flash kernel) vs softmax(q k^T / sqrt(hd)) v in torch on the CPU"""
@@ -101,9 +102,13 @@ def test_attention_core_matches_torch(S, E, nhead):
     qkv = torch.randn((S, 3 * E), generator=g) * 1.5
     x = qkv.cuda()
     out = torch.empty((S, E), device="cuda:0")
-    _lib.check(lib.opseq_attention_f32(x.data_ptr(), out.data_ptr(), S, E, nhead, torch.cuda.current_stream().cuda_stream),
-               "opseq_attention_f32")
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(lib.opseq_attention_workspace_bytes(S, E, nhead), dtype=torch.uint8, device="cuda:0")
+    _lib.check(lib.opseq_attention_f32(x.data_ptr(), out.data_ptr(), S, E, nhead, ws.data_ptr(), ws.numel(), st), "opseq_attention_f32")
+    out1 = torch.empty_like(out)                      # without scratch the kernel must run unsplit and agree
+    _lib.check(lib.opseq_attention_f32(x.data_ptr(), out1.data_ptr(), S, E, nhead, None, 0, st), "opseq_attention_f32")
     torch.cuda.synchronize()
+    assert (out - out1).abs().max().item() < 5e-5      # fp32 reassociation of the key sum
     dt = torch.float64 if S <= 1000 else torch.float32
     hd = E // nhead
     q, k, v = (qkv[:, j * E:(j + 1) * E].to(dt).view(S, nhead, hd).transpose(0, 1) for j in range(3))

@@ -9,7 +9,8 @@ for S, E, nh in cases:
     qkv = torch.randn((S, 3 * E), device="cuda:0")
     out = torch.empty((S, E), device="cuda:0")
     st = torch.cuda.current_stream().cuda_stream
-    run = lambda: _lib.check(lib.opseq_attention_f32(qkv.data_ptr(), out.data_ptr(), S, E, nh, st), "att")
+    ws = torch.empty(lib.opseq_attention_workspace_bytes(S, E, nh) if os.environ.get("NOSPLIT") is None else 16, dtype=torch.uint8, device="cuda:0")
+    run = lambda: _lib.check(lib.opseq_attention_f32(qkv.data_ptr(), out.data_ptr(), S, E, nh, ws.data_ptr() if ws.numel() > 16 else None, ws.numel(), st), "att")
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 20 if S < 5000 else 5
