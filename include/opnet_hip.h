@@ -194,6 +194,29 @@ int opdet_upsample_add_f32(const float *lateral, const float *top, float *y, int
 int opdet_preprocess_frame_f32(const unsigned char *frame_bgr, float *y, int H, int W, int RH, int RW, int PH,
                                int PW, const float *mean3_host, const float *std3_host, void *stream);
 
+/* ---- transformer encoder layer, TRAINING (reference learned_models.py:166-168 under training_main.py:183-217) --------
+ * forward keeps the layer's activations (incl. the nhead S x S softmax matrices) in `saved` for the backward call;
+ * `scratch` is shared by all layers / both calls.  Dropout sites of nn.TransformerEncoderLayer (attention weights,
+ * after out_proj, after ReLU, after linear2) use a counter-based generator keyed by (seed, site, index); p_drop = 0
+ * disables them (the only configuration that can be pinned against the reference - torch's masks are not reproducible).
+ * backward OVERWRITES dz_in and the 12 gradients (state_dict layouts).  E, ffn multiples of 16, E <= 512,
+ * S x roundup(S,16) x 4 B < 2 GiB. */
+size_t opseq_encoder_train_saved_bytes(long S, int E, int nhead, int ffn);
+size_t opseq_encoder_train_scratch_bytes(long S, int E, int nhead, int ffn);
+int opseq_encoder_layer_train_forward_f32(const float *z_in, float *z_out, const float *in_w, const float *in_b,
+                                          const float *out_w, const float *out_b, const float *l1_w, const float *l1_b,
+                                          const float *l2_w, const float *l2_b, const float *n1_w, const float *n1_b,
+                                          const float *n2_w, const float *n2_b, void *saved, size_t saved_bytes,
+                                          void *scratch, size_t scratch_bytes, long S, int E, int nhead, int ffn,
+                                          float p_drop, unsigned long long seed, void *stream);
+int opseq_encoder_layer_train_backward_f32(const float *dz_out, float *dz_in, const float *in_w, const float *out_w,
+                                           const float *l1_w, const float *l2_w, const float *n1_w, const float *n2_w,
+                                           float *g_in_w, float *g_in_b, float *g_out_w, float *g_out_b, float *g_l1_w,
+                                           float *g_l1_b, float *g_l2_w, float *g_l2_b, float *g_n1_w, float *g_n1_b,
+                                           float *g_n2_w, float *g_n2_b, const void *saved, size_t saved_bytes,
+                                           void *scratch, size_t scratch_bytes, long S, int E, int nhead, int ffn,
+                                           float p_drop, unsigned long long seed, void *stream);
+
 /* ---- detector back half: RPN proposals, MultiScaleRoIAlign, detections (the non-conv stages of the
  *      torchvision fasterrcnn_resnet50_fpn call at reference detector.py:84; PARITY UNPINNED).
  * The dense stages (RPNHead convs, TwoMLPHead, FastRCNNPredictor) run on opdet_conv2d_f32.

@@ -102,6 +102,16 @@ def _declare(lib):
     lib.opseq_attention_f32.argtypes = [fp, fp, ctypes.c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]
     lib.opseq_attention_workspace_bytes.restype = c_size_t
     lib.opseq_attention_workspace_bytes.argtypes = [ctypes.c_long, c_int, c_int]
+    lib.opseq_encoder_train_saved_bytes.restype = c_size_t
+    lib.opseq_encoder_train_saved_bytes.argtypes = [ctypes.c_long, c_int, c_int, c_int]
+    lib.opseq_encoder_train_scratch_bytes.restype = c_size_t
+    lib.opseq_encoder_train_scratch_bytes.argtypes = [ctypes.c_long, c_int, c_int, c_int]
+    lib.opseq_encoder_layer_train_forward_f32.restype = c_int
+    lib.opseq_encoder_layer_train_forward_f32.argtypes = [fp] * 14 + [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.c_long,
+                                                          c_int, c_int, c_int, c_float, ctypes.c_ulonglong, c_void_p]
+    lib.opseq_encoder_layer_train_backward_f32.restype = c_int
+    lib.opseq_encoder_layer_train_backward_f32.argtypes = [fp] * 20 + [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.c_long,
+                                                           c_int, c_int, c_int, c_float, ctypes.c_ulonglong, c_void_p]
     lib.opseq_encoder_layer_f32.restype = c_int
     lib.opseq_encoder_layer_f32.argtypes = [fp] * 13 + [c_void_p, c_size_t, ctypes.c_long, c_int, c_int, c_int, c_void_p]
     lib.opdet_conv2d_f32.restype = c_int
@@ -148,6 +158,8 @@ EXPORTS = [
     "opseq_lstm_stack_train_backward_f32",
     "opseq_encoder_workspace_bytes",
     "opseq_encoder_layer_f32", "opseq_attention_f32", "opseq_attention_workspace_bytes",
+    "opseq_encoder_train_saved_bytes", "opseq_encoder_train_scratch_bytes", "opseq_encoder_layer_train_forward_f32",
+    "opseq_encoder_layer_train_backward_f32",
     "opdet_conv2d_f32", "opdet_maxpool3x3s2_f32", "opdet_subsample2_f32", "opdet_upsample_add_f32",
     "opdet_preprocess_frame_f32", "opdet_rpn_workspace_bytes", "opdet_rpn_proposals_f32", "opdet_roi_align_f32",
     "opdet_detections_workspace_bytes", "opdet_detections_f32",

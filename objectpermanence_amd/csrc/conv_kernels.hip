@@ -27,6 +27,9 @@ struct ConvArgs {
     const float *R;     // residual [N][OH][OW][Cout] or null
     float *Y;           // [N][OH][OW][Cout]
     int N, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, KP, relu;
+    // row strides in floats, 0 = dense (XS = Cin, WS = KP, YS = Cout).  Honoured by conv2d_nhwc_glds only: they let
+    // the GEMMs of the encoder backward read / write column slices of wider matrices (one head of qkv, d qkv ...)
+    int XS, WS, YS;
 };
 
 __global__ void __launch_bounds__(256) conv2d_nhwc(const ConvArgs a)
@@ -422,6 +425,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
     const int i = lane & 15, kk = lane >> 4;
     const int wm = (BN == 128) ? (w >> 1) : w, wn = (BN == 128) ? (w & 1) : 0;
     const long M = (long)a.N * a.OH * a.OW;
+    const int XS = a.XS ? a.XS : a.Cin, WS = a.WS ? a.WS : a.KP, YS = a.YS ? a.YS : a.Cout;
     const unsigned nt = gridDim.x * gridDim.y;
     unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
     {   // XCD-aware tile order, see conv2d_nhwc_tiled
@@ -435,9 +439,9 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
     {
         const unsigned long long bx = (unsigned long long)a.X, bw = (unsigned long long)a.Wt;
         rx.x = (unsigned)bx; rx.y = (unsigned)(bx >> 32);
-        rx.z = (unsigned)((long)a.N * a.H * a.W * a.Cin * 4); rx.w = 0x00020000u;
+        rx.z = (unsigned)((long)a.N * a.H * a.W * XS * 4); rx.w = 0x00020000u;
         rwt.x = (unsigned)bw; rwt.y = (unsigned)(bw >> 32);
-        rwt.z = (unsigned)((long)a.Cout * a.KP * 4); rwt.w = 0x00020000u;
+        rwt.z = (unsigned)((long)a.Cout * WS * 4); rwt.w = 0x00020000u;
     }
     const unsigned lds0 = (unsigned)(unsigned long long)(const void *)smem;   // LDS byte address of the staging area
 
@@ -457,19 +461,19 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
         const int nimg = tq / a.OH;
         iy0[j] = oy * a.stride - a.pad;
         ix0[j] = ox * a.stride - a.pad;
-        xoff[j] = (int)(((((long)nimg * a.H + iy0[j]) * a.W + ix0[j]) * a.Cin + 4 * lkq) * 4);
+        xoff[j] = (int)(((((long)nimg * a.H + iy0[j]) * a.W + ix0[j]) * XS + 4 * lkq) * 4);
     }
     unsigned woff[WLD];
 #pragma unroll
     for (int j = 0; j < WLD; ++j) {
         const int r = n0 + (BN / 4) * w + 16 * j + lr;
-        woff[j] = r < a.Cout ? (unsigned)(((long)r * a.KP + 4 * lkq) * 4) : 0x80000000u;
+        woff[j] = r < a.Cout ? (unsigned)(((long)r * WS + 4 * lkq) * 4) : 0x80000000u;
     }
 
     int t_c0 = 0, t_dx = 0, t_dy = 0;   // wave-uniform tap walk of the next stage to issue
     auto issue = [&](int q) {
         const unsigned sbase = lds0 + (unsigned)(q % NS) * (STAGE_F4 * 16);
-        const int toff = ((t_dy * a.W + t_dx) * a.Cin + t_c0) * 4;
+        const int toff = ((t_dy * a.W + t_dx) * XS + t_c0) * 4;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool ok = prow_ok[j] && (unsigned)(iy0[j] + t_dy) < (unsigned)a.H && (unsigned)(ix0[j] + t_dx) < (unsigned)a.W;
@@ -535,7 +539,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
         __builtin_amdgcn_s_barrier();
     }
     // epilogue: D fragment lane = (pixel column l&15, channel rows 4*(l>>4)+r)
-    const bool vec = (a.Cout & 3) == 0;
+    const bool vec = (a.Cout & 3) == 0 && (YS & 3) == 0;
 #pragma unroll
     for (int x = 0; x < FM; ++x) {
         const long pp = m0 + wm * (FM * 16) + x * 16 + i;
@@ -551,19 +555,19 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
                     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
                 }
                 if (a.R) {
-                    const float4 r = *(const float4 *)(a.R + pp * a.Cout + co);
+                    const float4 r = *(const float4 *)(a.R + pp * YS + co);
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }
                 if (a.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                *(float4 *)(a.Y + pp * a.Cout + co) = v;
+                *(float4 *)(a.Y + pp * YS + co) = v;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (co + r >= a.Cout) break;
                     float v = acc[x][y][r] + (a.bias ? a.bias[co + r] : 0.f);
-                    if (a.R) v += a.R[pp * a.Cout + co + r];
+                    if (a.R) v += a.R[pp * YS + co + r];
                     if (a.relu) v = fmaxf(v, 0.f);
-                    a.Y[pp * a.Cout + co + r] = v;
+                    a.Y[pp * YS + co + r] = v;
                 }
             }
         }

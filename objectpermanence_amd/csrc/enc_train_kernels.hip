@@ -1,0 +1,283 @@
+// enc_train_kernels.hip - the small kernels around the GEMMs of the transformer encoder layer's TRAINING step
+// (reference learned_models.py:166-168 nn.TransformerEncoderLayer under training_main.py:183-217).
+// Every matrix product of the layer's forward and backward runs on conv2d_nhwc_glds (strided NT GEMM); what is left
+// is row softmax / its backward, LayerNorm forward-with-stats / backward, dropout, ReLU masks, column sums and
+// transposes (a product that contracts over tokens is fed as two transposed operands).
+//
+// Dropout (p = 0.1 in the reference's train mode, four sites per layer) uses a counter-based generator keyed by
+// (seed, site, element index): masks are regenerated in the backward pass instead of stored.  The reference's own
+// masks come from torch's generator and cannot be reproduced, so parity is pinned with p = 0 and the p > 0 path is
+// checked statistically.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define ENC_LN_MAX_PER_LANE 8     // E <= 512
+
+__device__ __forceinline__ unsigned enc_hash(unsigned long long seed, unsigned site, unsigned long long idx)
+{
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((unsigned long long)site << 56);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+
+// multiplier of element idx at a dropout site: 0 (dropped) or 1/(1-p); thresh = p * 2^32 (0 => always 1)
+__device__ __forceinline__ float enc_keep(unsigned long long seed, unsigned site, unsigned long long idx, unsigned thresh,
+                                          float inv_keep)
+{
+    if (thresh == 0u) return 1.0f;
+    return enc_hash(seed, site, idx) >= thresh ? inv_keep : 0.0f;
+}
+
+// dst[c][r] = src[r * sld + c]  (r < R, c < C); dst rows have length dld >= R, columns R..dld-1 are zeroed
+__global__ void __launch_bounds__(256) enc_transpose(const float *__restrict__ src, long sld, float *__restrict__ dst,
+                                                     long dld, int R, int C)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        tile[ty + 8 * j][tx] = (r < R && c < C) ? src[(long)r * sld + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j, r = r0 + tx;
+        if (c < C && r < dld) dst[(long)c * dld + r] = tile[tx][ty + 8 * j];
+    }
+}
+
+// rows of scores -> softmax(scale * row) in place (Psoft, saved); optionally Pdrop = Psoft * dropout multiplier.
+// One workgroup per row of n valid columns (row stride ld, padding columns zeroed).
+__global__ void __launch_bounds__(256) enc_softmax_rows(float *__restrict__ P, float *__restrict__ Pdrop, long ld, int n,
+                                                        float scale, unsigned long long seed, unsigned site,
+                                                        unsigned long long idx0, unsigned thresh, float inv_keep)
+{
+    __shared__ float red[256];
+    const long row = blockIdx.x;
+    float *p = P + row * ld;
+    const int tid = threadIdx.x;
+    float m = -INFINITY;
+    for (int k = tid; k < n; k += 256) m = fmaxf(m, p[k] * scale);
+    red[tid] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    m = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int k = tid; k < n; k += 256) sum += __expf(p[k] * scale - m);
+    red[tid] = sum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const float inv = 1.0f / red[0];
+    for (int k = tid; k < ld; k += 256) {
+        const float v = k < n ? __expf(p[k] * scale - m) * inv : 0.f;
+        p[k] = v;
+        if (Pdrop) Pdrop[row * ld + k] = k < n ? v * enc_keep(seed, site, idx0 + row * n + k, thresh, inv_keep) : 0.f;
+    }
+}
+
+// dS = scale * Psoft * (dPs - sum_k dPs Psoft), dPs = dP * dropout multiplier; in place on dP.  One workgroup per row.
+__global__ void __launch_bounds__(256) enc_softmax_bwd_rows(const float *__restrict__ P, float *__restrict__ dP, long ld,
+                                                            int n, float scale, unsigned long long seed, unsigned site,
+                                                            unsigned long long idx0, unsigned thresh, float inv_keep)
+{
+    __shared__ float red[256];
+    const long row = blockIdx.x;
+    const float *p = P + row * ld;
+    float *d = dP + row * ld;
+    const int tid = threadIdx.x;
+    float dot = 0.f;
+    for (int k = tid; k < n; k += 256) dot += d[k] * enc_keep(seed, site, idx0 + row * n + k, thresh, inv_keep) * p[k];
+    red[tid] = dot;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    dot = red[0];
+    for (int k = tid; k < ld; k += 256)
+        d[k] = k < n ? scale * p[k] * (d[k] * enc_keep(seed, site, idx0 + row * n + k, thresh, inv_keep) - dot) : 0.f;
+}
+
+// u = x + y * dropout multiplier ; out = LayerNorm(u) * g + b ; saves u and (mean, rstd).  One wave per row.
+__global__ void __launch_bounds__(256) enc_add_drop_ln(const float *__restrict__ x, const float *__restrict__ y,
+                                                       const float *__restrict__ g, const float *__restrict__ b,
+                                                       float *__restrict__ u_out, float2 *__restrict__ stats,
+                                                       float *__restrict__ out, int rows, int E, float eps,
+                                                       unsigned long long seed, unsigned site, unsigned thresh, float inv_keep)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[ENC_LN_MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < ENC_LN_MAX_PER_LANE; ++j) {
+        const int e = j * 64 + lane;
+        v[j] = 0.f;
+        if (e < E) {
+            const long idx = (long)row * E + e;
+            v[j] = x[idx] + y[idx] * enc_keep(seed, site, idx, thresh, inv_keep);
+            u_out[idx] = v[j];
+            s += v[j];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mu = s / (float)E;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < ENC_LN_MAX_PER_LANE; ++j) {
+        const int e = j * 64 + lane;
+        const float d = e < E ? v[j] - mu : 0.f;
+        var += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var / (float)E + eps);
+    if (lane == 0) stats[row] = make_float2(mu, rstd);
+#pragma unroll
+    for (int j = 0; j < ENC_LN_MAX_PER_LANE; ++j) {
+        const int e = j * 64 + lane;
+        if (e < E) out[(long)row * E + e] = (v[j] - mu) * rstd * g[e] + b[e];
+    }
+}
+
+// LayerNorm backward for one row per wave:  du = rstd * (gd - mean(gd) - xhat * mean(gd * xhat)),  gd = dout * g.
+// du (+= du_add if given) is written; per-workgroup partial sums of dg = dout * xhat and db = dout go to
+// part[blockIdx.x][2][E] (reduced by enc_colsum_final in fixed order).
+__global__ void __launch_bounds__(256) enc_ln_bwd(const float *__restrict__ dout, const float *__restrict__ u,
+                                                  const float2 *__restrict__ stats, const float *__restrict__ g,
+                                                  const float *__restrict__ du_add, float *__restrict__ du,
+                                                  float *__restrict__ part, int rows, int E, int rows_per_block)
+{
+    __shared__ float acc[4][2][ENC_LN_MAX_PER_LANE * 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float dg[ENC_LN_MAX_PER_LANE], db[ENC_LN_MAX_PER_LANE];
+#pragma unroll
+    for (int j = 0; j < ENC_LN_MAX_PER_LANE; ++j) dg[j] = db[j] = 0.f;
+    const int r_begin = blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
+    for (int row = r_begin + w; row < r_end; row += 4) {
+        const float2 st = stats[row];
+        float xh[ENC_LN_MAX_PER_LANE], gd[ENC_LN_MAX_PER_LANE];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < ENC_LN_MAX_PER_LANE; ++j) {
+            const int e = j * 64 + lane;
+            xh[j] = gd[j] = 0.f;
+            if (e < E) {
+                const long idx = (long)row * E + e;
+                const float d = dout[idx];
+                xh[j] = (u[idx] - st.x) * st.y;
+                gd[j] = d * g[e];
+                dg[j] += d * xh[j];
+                db[j] += d;
+                s1 += gd[j];
+                s2 += gd[j] * xh[j];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        s1 /= (float)E;
+        s2 /= (float)E;
+#pragma unroll
+        for (int j = 0; j < ENC_LN_MAX_PER_LANE; ++j) {
+            const int e = j * 64 + lane;
+            if (e < E) {
+                const long idx = (long)row * E + e;
+                const float v = st.y * (gd[j] - s1 - xh[j] * s2);
+                du[idx] = du_add ? v + du_add[idx] : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < ENC_LN_MAX_PER_LANE; ++j) {
+        acc[w][0][j * 64 + lane] = dg[j];
+        acc[w][1][j * 64 + lane] = db[j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += 256) {
+        part[((long)blockIdx.x * 2 + 0) * E + e] = acc[0][0][e] + acc[1][0][e] + acc[2][0][e] + acc[3][0][e];
+        part[((long)blockIdx.x * 2 + 1) * E + e] = acc[0][1][e] + acc[1][1][e] + acc[2][1][e] + acc[3][1][e];
+    }
+}
+
+// out[j][e] = sum_b part[b][j][e]   (j < J slices of width E), fixed order
+__global__ void __launch_bounds__(256) enc_colsum_final(const float *__restrict__ part, float *__restrict__ out0,
+                                                        float *__restrict__ out1, int nblocks, int E)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int j = blockIdx.y;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[((long)b * gridDim.y + j) * E + e];
+    (j == 0 ? out0 : out1)[e] = s;
+}
+
+// partial column sums of X [rows][N] (row stride ld): part[blockIdx.y][n]
+__global__ void __launch_bounds__(256) enc_colsum_part(const float *__restrict__ X, long ld, float *__restrict__ part,
+                                                       int rows, int N, int rows_per_block)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += X[(long)r * ld + n];
+    part[(long)blockIdx.y * N + n] = s;
+}
+
+// out[row][k] = P[row][k] * attention-dropout multiplier (the operand of P V and of dV = P^T dO when p > 0)
+__global__ void __launch_bounds__(256) enc_attn_drop(const float *__restrict__ P, float *__restrict__ out, long ld, int n,
+                                                     long rows, unsigned long long seed, unsigned site,
+                                                     unsigned long long idx0, unsigned thresh, float inv_keep)
+{
+    const long total = rows * ld;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / ld;
+        const int k = (int)(i - row * ld);
+        out[i] = k < n ? P[i] * enc_keep(seed, site, idx0 + row * n + k, thresh, inv_keep) : 0.f;
+    }
+}
+
+// x *= dropout multiplier (forward sites after ReLU; backward of the residual-branch dropouts)
+__global__ void __launch_bounds__(256) enc_dropout(float *__restrict__ x, long n, unsigned long long seed, unsigned site,
+                                                   unsigned thresh, float inv_keep)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        x[i] *= enc_keep(seed, site, i, thresh, inv_keep);
+}
+
+// out = src * dropout multiplier
+__global__ void __launch_bounds__(256) enc_dropout_copy(const float *__restrict__ src, float *__restrict__ out, long n,
+                                                        unsigned long long seed, unsigned site, unsigned thresh,
+                                                        float inv_keep)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = src[i] * enc_keep(seed, site, i, thresh, inv_keep);
+}
+
+// d pre-activation of the FFN: dh * [hid > 0] * dropout multiplier (hid is saved AFTER ReLU and dropout, so hid > 0
+// means "active and kept")
+__global__ void __launch_bounds__(256) enc_relu_drop_bwd(float *__restrict__ dh, const float *__restrict__ hid, long n,
+                                                         float inv_keep)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        dh[i] = hid[i] > 0.f ? dh[i] * inv_keep : 0.f;
+}
+
+__global__ void __launch_bounds__(256) enc_add_inplace(float *__restrict__ a, const float *__restrict__ b, long n)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) a[i] += b[i];
+}

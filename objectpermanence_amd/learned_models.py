@@ -521,6 +521,54 @@ class NonLinearLstm(AbstractCaterModel):
             return self._runner.run(feats, self.video_LSTM, self.predictions_layer)
 
 
+class _EncoderLayerTrainFunction(torch.autograd.Function):
+    """autograd bridge of one nn.TransformerEncoderLayer in training: opseq_encoder_layer_train_forward_f32 /
+    _backward_f32.  The layer's activations live in a per-call `saved` buffer, the scratch is the owner module's."""
+
+    @staticmethod
+    def forward(ctx, z, owner, p_drop, seed, *weights):
+        lib = _lib.load()
+        S, E = int(z.shape[0]), int(z.shape[1])
+        nhead, ffn, dev = owner._nhead, owner.FFN, z.device
+        nsaved = lib.opseq_encoder_train_saved_bytes(S, E, nhead, ffn)
+        nscr = lib.opseq_encoder_train_scratch_bytes(S, E, nhead, ffn)
+        if nsaved == 0 or nscr == 0:
+            _lib.check(-2, "opseq_encoder_train_saved_bytes")
+        if owner._tscratch is None or owner._tscratch.numel() < nscr or owner._tscratch.device != dev:
+            owner._tscratch = None
+            owner._tscratch = torch.empty(nscr, dtype=torch.uint8, device=dev)
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=dev)
+        z = z.contiguous()
+        z_out = torch.empty_like(z)
+        with torch.cuda.device(dev):
+            rc = lib.opseq_encoder_layer_train_forward_f32(
+                z.data_ptr(), z_out.data_ptr(), *(w.data_ptr() for w in weights), saved.data_ptr(), nsaved,
+                owner._tscratch.data_ptr(), owner._tscratch.numel(), S, E, nhead, ffn, float(p_drop), int(seed), _stream_ptr(dev))
+        _lib.check(rc, "opseq_encoder_layer_train_forward_f32")
+        ctx.save_for_backward(*weights)
+        ctx.owner, ctx.saved, ctx.meta = owner, saved, (S, E, nhead, ffn, float(p_drop), int(seed))
+        return z_out
+
+    @staticmethod
+    def backward(ctx, dz_out):
+        lib = _lib.load()
+        weights = ctx.saved_tensors
+        S, E, nhead, ffn, p_drop, seed = ctx.meta
+        owner, dev = ctx.owner, dz_out.device
+        dz_out = dz_out.contiguous().float()
+        dz_in = torch.empty_like(dz_out)
+        grads = [torch.empty_like(w) for w in weights]
+        in_w, _in_b, out_w, _out_b, l1_w, _l1_b, l2_w, _l2_b, n1_w, _n1_b, n2_w, _n2_b = weights
+        with torch.cuda.device(dev):
+            rc = lib.opseq_encoder_layer_train_backward_f32(
+                dz_out.data_ptr(), dz_in.data_ptr(), in_w.data_ptr(), out_w.data_ptr(), l1_w.data_ptr(), l2_w.data_ptr(),
+                n1_w.data_ptr(), n2_w.data_ptr(), *(g.data_ptr() for g in grads), ctx.saved.data_ptr(), ctx.saved.numel(),
+                owner._tscratch.data_ptr(), owner._tscratch.numel(), S, E, nhead, ffn, p_drop, seed, _stream_ptr(dev))
+        _lib.check(rc, "opseq_encoder_layer_train_backward_f32")
+        ctx.saved = None
+        return (dz_in, None, None, None) + tuple(grads)
+
+
 class _EncoderLayerWeights(nn.Module):
     """Parameter holder with nn.TransformerEncoderLayer's parameter names (torch defaults for init)."""
 
@@ -554,12 +602,18 @@ class _EncoderWeights(nn.Module):
 
 
 class TransformerLstm(AbstractCaterModel):
-    """reference learned_models.py:154-197 (eval mode).  The reference hands [B*T, 15, E] to a
-    sequence-first encoder: attention spans the S = B*T frame axis (all clips of the minibatch,
-    non-causal) independently per slot, and only slot 0 is kept - so only slot 0 is evaluated here
-    (bit-for-bit the same function).  dim_feedforward is torch's default 2048."""
+    """reference learned_models.py:154-197.  The reference hands [B*T, 15, E] to a sequence-first encoder:
+    attention spans the S = B*T frame axis (all clips of the minibatch, non-causal) independently per slot, and
+    only slot 0 is kept - so only slot 0 is evaluated here (the same function, and the same gradients: slots 1..14
+    never reach the loss).  dim_feedforward is torch's default 2048.
+
+    Training: nn.TransformerEncoderLayer's dropout (default 0.1, active under model.train()) is drawn from a
+    counter-based generator (`dropout_seed`, advanced every forward) - the reference's torch masks cannot be
+    reproduced, so gradient parity is pinned with `dropout = 0.0`."""
 
     FFN = 2048
+    dropout = 0.1
+    dropout_seed = 0x5EED
 
     def __init__(self, config: Dict[str, int]):
         super().__init__(config)
@@ -573,13 +627,32 @@ class TransformerLstm(AbstractCaterModel):
         self.predictions_layer = LinearWeight(h, self.bb_out_dim)
         self._runner = _LstmStackRunner(ll, e, h)
         self._ews = None
+        self._tscratch = None
+        self._calls = 0
+
+    def _forward_train(self, x: torch.Tensor) -> torch.Tensor:
+        B, T = int(x.shape[0]), int(x.shape[1])
+        p = float(self.dropout) if self.training else 0.0
+        self._calls += 1
+        z = _SlotEmbedFunction.apply(x, self.boxes_linear.weight, 1).view(B * T, self._e)
+        for li, layer in enumerate(self.attention_encoder.layers):
+            ts = layer.tensors()
+            for t_ in ts:
+                if t_.device != x.device or not t_.is_contiguous() or t_.dtype != torch.float32:
+                    raise RuntimeError("parameters must be contiguous fp32 on the input's device")
+            seed = (int(self.dropout_seed) + 1000003 * self._calls + 7919 * li) & 0xFFFFFFFFFFFF
+            z = _EncoderLayerTrainFunction.apply(z, self, p, seed, *ts)
+        return self._runner.run_train(z.view(B, T, self._e), self.video_LSTM, self.predictions_layer)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        _require_inference(self, x, 5)
-        if self.training:
-            raise RuntimeError("TransformerLstm: only eval mode is implemented (train mode adds dropout 0.1)")
-        lib = _lib.load()
+        _check_input(self, x, 5)
         x = x.contiguous().float()
+        if _wants_grad(self):
+            return self._forward_train(x)
+        if self.training and self.dropout > 0:
+            raise RuntimeError("TransformerLstm: train mode without gradients would still apply dropout; call eval() "
+                               "for inference")
+        lib = _lib.load()
         B, T = int(x.shape[0]), int(x.shape[1])
         S, e, dev = B * T, self._e, x.device
         with torch.cuda.device(dev):

@@ -317,11 +317,25 @@ def gen_sibling_train(lm):
              ("opnet_lstm_mlp", lm.OPNetLstmMlp, synth.opnet_lstm_mlp_synth_params, "tiny",
               {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 32, "videos_hidden_dim": 32}, 3, 10),
              ("opnet_lstm_mlp", lm.OPNetLstmMlp, synth.opnet_lstm_mlp_synth_params, "real",
-              {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}, 3, 60)]
+              {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}, 3, 60),
+             # transformer_lstm with its dropout probabilities set to 0 (torch's masks are not reproducible): the
+             # reference class in train mode, only the p attributes of its Dropout / MultiheadAttention modules touched
+             ("transformer_lstm", lm.TransformerLstm, synth.transformer_lstm_synth_params, "tiny",
+              {"boxes_features_dim": 32, "num_attention_heads": 2, "num_attention_layers": 2, "num_lstm_layers": 2,
+               "lstm_hidden_dim": 32}, 2, 10),
+             ("transformer_lstm", lm.TransformerLstm, synth.transformer_lstm_synth_params, "real",
+              {"boxes_features_dim": 256, "num_attention_heads": 2, "num_attention_layers": 2, "num_lstm_layers": 2,
+               "lstm_hidden_dim": 512}, 2, 50)]
     for name, cls, pfn, tag, cfg, n, t in cases:
         model = cls(cfg)
         _load_params(model, pfn(cfg))
         model.train(True)
+        if name == "transformer_lstm":
+            for mod in model.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+                if isinstance(mod, torch.nn.MultiheadAttention):
+                    mod.dropout = 0.0
         boxes, labels = synth.make_batch(0, n, t)
         if name == "opnet_lstm_mlp":
             y, _ = model(torch.from_numpy(boxes))

@@ -98,11 +98,44 @@ def opnet_lstm_mlp_forward(x: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch
     return torch.relu(frames_boxes @ p["hidden_layer.weight"].t()) @ p["prediction_layer.weight"].t()
 
 
-def sibling_loss_and_grads(name: str, x: np.ndarray, labels: np.ndarray, params: Dict[str, np.ndarray], dtype=torch.float32):
+def transformer_lstm_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], nhead: int) -> torch.Tensor:
+    """TransformerLstm.forward (learned_models.py:175-197) without dropout, slot 0 only (the only slot that reaches
+    the output; attention runs over the S = B*T tokens of the whole minibatch, as the reference's layout makes it)"""
+    B, T = x.shape[:2]
+    z = torch.relu(x[:, :, 0, :] @ p["boxes_linear.weight"].t()).reshape(B * T, -1)
+    E = z.shape[1]
+    hd = E // nhead
+    li = 0
+    while f"attention_encoder.layers.{li}.linear1.weight" in p:
+        pre = f"attention_encoder.layers.{li}."
+        qkv = z @ p[pre + "self_attn.in_proj_weight"].t() + p[pre + "self_attn.in_proj_bias"]
+        q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+        heads = []
+        for h in range(nhead):
+            sl = slice(h * hd, (h + 1) * hd)
+            heads.append(torch.softmax((q[:, sl] * hd ** -0.5) @ k[:, sl].t(), dim=-1) @ v[:, sl])
+        a = torch.cat(heads, dim=1) @ p[pre + "self_attn.out_proj.weight"].t() + p[pre + "self_attn.out_proj.bias"]
+        z = torch.nn.functional.layer_norm(z + a, (E,), p[pre + "norm1.weight"], p[pre + "norm1.bias"])
+        f = torch.relu(z @ p[pre + "linear1.weight"].t() + p[pre + "linear1.bias"])
+        f = f @ p[pre + "linear2.weight"].t() + p[pre + "linear2.bias"]
+        z = torch.nn.functional.layer_norm(z + f, (E,), p[pre + "norm2.weight"], p[pre + "norm2.bias"])
+        li += 1
+    h = z.reshape(B, T, E)
+    l = 0
+    while f"video_LSTM.weight_ih_l{l}" in p:
+        h = lstm_seq(h, p[f"video_LSTM.weight_ih_l{l}"], p[f"video_LSTM.weight_hh_l{l}"])
+        l += 1
+    return h @ p["predictions_layer.weight"].t()
+
+
+def sibling_loss_and_grads(name: str, x: np.ndarray, labels: np.ndarray, params: Dict[str, np.ndarray], dtype=torch.float32,
+                           nhead: int = 2):
     fwd = {"baseline_lstm": baseline_lstm_forward, "non_linear_lstm": non_linear_lstm_forward,
-           "opnet_lstm_mlp": opnet_lstm_mlp_forward}[name]
+           "opnet_lstm_mlp": opnet_lstm_mlp_forward,
+           "transformer_lstm": lambda xx, pp: transformer_lstm_forward(xx, pp, nhead)}[name]
     p = {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in params.items()}
     y = fwd(torch.tensor(x, dtype=dtype), p)
     loss = l1_mean(y, torch.tensor(labels, dtype=dtype))
     loss.backward()
-    return float(loss.item()), {k: v.grad.numpy() for k, v in p.items()}, y.detach().numpy()
+    return float(loss.item()), {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape, v.detach().numpy().dtype))
+                                for k, v in p.items()}, y.detach().numpy()

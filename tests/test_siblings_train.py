@@ -10,9 +10,11 @@ import pytest
 from oracle import synth, torch_port
 
 PARAMS = {"baseline_lstm": synth.baseline_lstm_synth_params, "non_linear_lstm": synth.non_linear_lstm_synth_params,
-          "opnet_lstm_mlp": synth.opnet_lstm_mlp_synth_params}
+          "opnet_lstm_mlp": synth.opnet_lstm_mlp_synth_params, "transformer_lstm": synth.transformer_lstm_synth_params}
+# transformer_lstm: the reference in train mode with its dropout probabilities set to 0 (its torch masks cannot be
+# reproduced); the HIP model is run with dropout = 0.0 accordingly
 CASES = [("baseline_lstm", "tiny"), ("baseline_lstm", "real"), ("non_linear_lstm", "tiny"), ("non_linear_lstm", "real"),
-         ("opnet_lstm_mlp", "tiny"), ("opnet_lstm_mlp", "real")]
+         ("opnet_lstm_mlp", "tiny"), ("opnet_lstm_mlp", "real"), ("transformer_lstm", "tiny"), ("transformer_lstm", "real")]
 
 
 def _features(name, boxes):
@@ -52,7 +54,8 @@ def _check(g, pre, loss, grads, rel):
 def test_torch_port_matches_reference(golden_dir, name, tag):
     g = np.load(os.path.join(golden_dir, "siblings_train.npz"))
     pre, cfg, x, labels = _case(g, name, tag)
-    loss, grads, _ = torch_port.sibling_loss_and_grads(name, x, labels, PARAMS[name](cfg))
+    loss, grads, _ = torch_port.sibling_loss_and_grads(name, x, labels, PARAMS[name](cfg),
+                                                       nhead=cfg.get("num_attention_heads", 2))
     _check(g, pre, loss, grads, 2e-4)
 
 
@@ -66,6 +69,8 @@ def test_hip_gradients_match_reference(golden_dir, name, tag):
     m = ModelsFactory.get_model(name, cfg)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in PARAMS[name](cfg).items()})
     m.to("cuda:0").train(True)
+    if name == "transformer_lstm":
+        m.dropout = 0.0
     y = _y(m(torch.from_numpy(x).cuda()))
     loss = l1_mean(y, torch.from_numpy(labels).cuda())
     loss.backward()
@@ -73,7 +78,10 @@ def test_hip_gradients_match_reference(golden_dir, name, tag):
     _check(g, pre, float(loss.detach()), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}, 5e-4)
     with torch.no_grad():
         y_inf = _y(m(torch.from_numpy(x).cuda()))
-    assert torch.equal(y_inf, y.detach())          # train-mode forward == inference forward, bit for bit
+    if name == "transformer_lstm":      # materialised-softmax training kernels vs the flash inference kernel
+        assert (y_inf - y.detach()).abs().max().item() < 1e-4
+    else:
+        assert torch.equal(y_inf, y.detach())          # train-mode forward == inference forward, bit for bit
 
 
 @pytest.mark.gpu
@@ -95,3 +103,79 @@ def test_hip_gradients_ragged_vs_torch_port(name, B, T):
     assert float(loss.detach()) == pytest.approx(ref_loss, abs=2e-6)
     for k, prm in m.named_parameters():
         assert np.abs(prm.grad.cpu().numpy() - ref[k]).max() <= 1e-4 * max(1e-2, np.abs(ref[k]).max()), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,E,nhead", [(3, 7, 64, 4), (1, 33, 32, 2)])
+def test_transformer_gradients_ragged_vs_torch_port(B, T, E, nhead):
+    """S = B*T not a multiple of 16, 4 heads / head size 16: encoder + LSTM + embedding gradients vs fp64 autograd"""
+    import torch
+    from objectpermanence_amd import ModelsFactory, l1_mean
+    cfg = {"boxes_features_dim": E, "num_attention_heads": nhead, "num_attention_layers": 2, "num_lstm_layers": 2,
+           "lstm_hidden_dim": 48}
+    boxes, labels = synth.make_batch(55, B, T)
+    x = synth.boxes5(boxes)
+    p = synth.transformer_lstm_synth_params(cfg)
+    m = ModelsFactory.get_model("transformer_lstm", cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+    m.to("cuda:0").train(True)
+    m.dropout = 0.0
+    loss = l1_mean(m(torch.from_numpy(x).cuda()), torch.from_numpy(labels).cuda())
+    loss.backward()
+    ref_loss, ref, _ = torch_port.sibling_loss_and_grads("transformer_lstm", x, labels, p, dtype=torch.float64, nhead=nhead)
+    assert float(loss.detach()) == pytest.approx(ref_loss, abs=3e-6)
+    for k, prm in m.named_parameters():
+        assert np.abs(prm.grad.cpu().numpy() - ref[k]).max() <= 2e-4 * max(1e-2, np.abs(ref[k]).max()), k
+
+
+@pytest.mark.gpu
+def test_transformer_dropout_masks_and_backward_consistency():
+    """train mode with the reference's dropout 0.1: masks come from a counter generator (not torch's, so no parity):
+    same seed -> same output, another call -> another mask, about 10 % of the FFN activations dropped in expectation,
+    and the backward uses the SAME masks as the forward (directional derivative of the fixed-mask loss)"""
+    import torch
+    from objectpermanence_amd import ModelsFactory, l1_mean
+    cfg = {"boxes_features_dim": 32, "num_attention_heads": 2, "num_attention_layers": 2, "num_lstm_layers": 2,
+           "lstm_hidden_dim": 32}
+    boxes, labels = synth.make_batch(5, 2, 12)
+    x, lab = torch.from_numpy(synth.boxes5(boxes)).cuda(), torch.from_numpy(labels).cuda()
+    m = ModelsFactory.get_model("transformer_lstm", cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.transformer_lstm_synth_params(cfg).items()})
+    m.to("cuda:0").train(True)
+    assert m.dropout == pytest.approx(0.1)
+
+    def loss_at(calls):
+        m._calls = calls                       # the mask stream is keyed by (dropout_seed, call counter, layer)
+        return l1_mean(m(x), lab)
+
+    l0, l0b, l1 = loss_at(7), loss_at(7), loss_at(8)
+    assert float(l0.detach()) == float(l0b.detach()) and float(l0.detach()) != float(l1.detach())
+    m.eval()
+    with torch.no_grad():
+        y_eval = m(x)
+    m.train(True)
+    m._calls = 7
+    assert (m(x).detach() - y_eval).abs().max().item() > 1e-4          # dropout does change the output
+    # directional derivative with the masks frozen (same call counter)
+    m.zero_grad()
+    loss_at(7).backward()
+    prm = m.attention_encoder.layers[0].linear1.weight
+    g = prm.grad.detach().clone()
+    d = torch.randn_like(prm)
+    d /= d.norm()
+    eps = 2e-2
+    def shifted(step):
+        with torch.no_grad():
+            prm.add_(step * d)
+        try:
+            return float(loss_at(7).detach())
+        finally:
+            with torch.no_grad():
+                prm.sub_(step * d)
+
+    lp, lm_ = shifted(eps), shifted(-eps)
+    num, ana = (lp - lm_) / (2 * eps), float((g * d).sum())
+    assert abs(num - ana) <= 0.15 * max(abs(ana), 1e-3) + 2e-4, (num, ana)
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            m(x)                               # train mode without gradients would silently apply dropout: refuse

@@ -1,0 +1,27 @@
+"""transformer_lstm training step (fwd + L1 + bwd + Adam) timing: python tools/transformer_train_time.py [B ...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from objectpermanence_amd import ModelsFactory, FusedAdam
+from objectpermanence_amd.training import train_step
+from oracle import synth
+cfg = {"boxes_features_dim": 256, "num_attention_heads": 2, "num_attention_layers": 2, "num_lstm_layers": 2, "lstm_hidden_dim": 512}
+for B in [int(a) for a in sys.argv[1:]] or [1, 8, 32]:
+    m = ModelsFactory.get_model("transformer_lstm", cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.transformer_lstm_synth_params(cfg).items()})
+    m.to("cuda:0").train(True)
+    opt = FusedAdam(m.parameters(), lr=1e-4)
+    b, l = synth.make_batch(0, min(B, 4), 300)
+    x = torch.from_numpy(np.tile(synth.boxes5(b), ((B + 3) // 4, 1, 1, 1))[:B].copy()).cuda()
+    y = torch.from_numpy(np.tile(l, ((B + 3) // 4, 1, 1))[:B].copy()).cuda()
+    for _ in range(2):
+        loss = train_step("transformer_lstm", m, opt, x, y)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        loss = train_step("transformer_lstm", m, opt, x, y)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    print(f"transformer_lstm train B={B} (S={B*300}): {dt*1e3:.2f} ms/step  {B/dt:.0f} clips/s  loss {float(loss):.4f}  "
+          f"peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB", flush=True)
+    del m, opt
+    torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
