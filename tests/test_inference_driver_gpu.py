@@ -170,3 +170,34 @@ def test_cater_setup_inference_grid_classes(tmp_path):
     want = get_classes_predictions(transform_xyxy_to_w_h(px))
     assert all(0 <= c < 36 for c in want)
     assert df["class_predictions"].tolist() == want
+
+
+def test_training_driver_transformer_lstm(tmp_path):
+    """the training driver on transformer_lstm (train mode = dropout 0.1 from the counter generator, eval per epoch on
+    the flash inference path): the loss falls and a checkpoint is written"""
+    from objectpermanence_amd.training_main import training_main
+    dirs = {}
+    for split, n in (("train", 8), ("dev", 4)):
+        s, l = tmp_path / f"{split}_s", tmp_path / f"{split}_l"
+        s.mkdir(); l.mkdir()
+        lines = []
+        for i in range(n):
+            name = f"{split}{i:02d}"
+            bb, lab, gt = synth.make_raw_video(100 + i, "plain")
+            pickle.dump({"bb": bb, "labels": lab}, open(s / (name + ".pkl"), "wb"), pickle.HIGHEST_PROTOCOL)
+            json.dump(gt, open(l / (name + "_bb.json"), "w"))
+            lines.append(name + "\t" + ",".join(str(x) for x in range(10 * i, 10 * i + 25)) + "\n")
+        open(tmp_path / f"{split}_mask.txt", "w").writelines(lines)
+        dirs[split] = (str(s), str(l), str(tmp_path / f"{split}_mask.txt"))
+    cfg = {"batch_size": 4, "inference_batch_size": 4, "num_workers": 0, "num_epochs": 4, "print_step": 100,
+           "learning_rate": 0.0005, "lr_scheduler_patience": 2, "lr_scheduler_factor": 0.8, "device": "cuda:0",
+           "checkpoints_path": str(tmp_path / "ckpt"),
+           "train_sample_dir": dirs["train"][0], "train_labels_dir": dirs["train"][1], "train_containment_file": dirs["train"][2],
+           "dev_sample_dir": dirs["dev"][0], "dev_labels_dir": dirs["dev"][1], "dev_containment_file": dirs["dev"][2]}
+    mcfg = {"boxes_features_dim": 64, "num_attention_heads": 2, "num_attention_layers": 2, "num_lstm_layers": 2,
+            "lstm_hidden_dim": 64}
+    torch.manual_seed(0)
+    res = training_main("transformer_lstm", cfg, mcfg)
+    losses = [h["train_loss"] for h in res["history"]]
+    assert len(losses) == 4 and losses[-1] < 0.85 * losses[0]
+    assert res["checkpoint"] and os.path.exists(res["checkpoint"])
