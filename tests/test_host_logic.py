@@ -1,6 +1,7 @@
 """CPU-side checks: the C ABI library loads and exports every symbol include/opnet_hip.h declares, host
 argument validation (no GPU work is launched), and the data-parallel sharding logic over gloo."""
 import ctypes
+import json
 import os
 import re
 
@@ -192,3 +193,32 @@ def test_proj_utils_grid_classes():
     assert pu.get_class_prediction(float(ic[7, 0]), float(ic[7, 1])) == 7
     far = pu.project_3d_point(np.array([[40.0, -40.0, pu.Z]]))                             # clipped into the grid
     assert pu.get_class_prediction(far[0, 0], far[0, 1]) == 5
+
+
+def test_cli_mirrors_reference_subcommands(tmp_path):
+    """python -m objectpermanence_amd: the reference's five sub-commands with its flags (main.py:13-84); the analysis
+    command runs end to end on CPU (the others need the GPU)"""
+    from objectpermanence_amd.__main__ import build_parser, main
+    p = build_parser()
+    a = p.parse_args(["training", "--model_type", "opnet", "--model_config", "m.json", "--training_config", "t.json"])
+    assert (a.mode, a.model_type, a.model_config, a.training_config) == ("training", "opnet", "m.json", "t.json")
+    a = p.parse_args(["inference", "--model_type", "transformer_lstm", "--results_dir", "r", "--inference_config", "i.json"])
+    assert a.model_config is None
+    a = p.parse_args(["cater_inference", "--results_dir", "r", "--inference_config", "i.json", "--model_config", "m.json"])
+    assert a.mode == "cater_inference"
+    assert p.parse_args(["preprocess", "--results_dir", "r", "--config", "c.json"]).config == "c.json"
+    with pytest.raises(SystemExit):
+        p.parse_args(["inference", "--model_type", "DaSiamRPN", "--results_dir", "r", "--inference_config", "i.json"])
+    pred, lab = tmp_path / "pred", tmp_path / "lab"
+    pred.mkdir(); lab.mkdir()
+    rng = np.random.default_rng(0)
+    for v in ("v0", "v1"):
+        gt = np.tile(np.array([[50, 60, 30, 40]]), (300, 1))                       # xywh labels
+        json.dump({"small_gold_spl_metal_Spl_0": gt.tolist()}, open(lab / f"{v}_bb.json", "w"))
+        box = np.tile(np.array([[50, 60, 80, 100]]), (300, 1)) + rng.integers(-3, 4, size=(300, 4))
+        json.dump(box.tolist(), open(pred / f"{v}_bb.json", "w"))
+    out = tmp_path / "res.csv"
+    assert main(["analysis", "--predictions_dir", str(pred), "--labels_dir", str(lab), "--iou_thresholds", "0.5,0.9",
+                 "--output_file", str(out)]) == 0
+    rows = open(out).read().strip().splitlines()
+    assert len(rows) >= 3 and "overall" in rows[0]
