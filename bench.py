@@ -15,6 +15,10 @@ Rank 0 prints ONE JSON line: BASELINE.json's metric (clips/s, whole job), plus
                  per-time-step weight-streaming model, timed live with HIP events on the launch stream;
   cpu_baseline - oracle/opnet_oracle.c (a C/OpenMP port of the reference algorithm) timed on this
                  host's cores on a bounded sample of the same workload (N=1 only).
+
+`oracle/` is used here for exactly three things, none inside a timed region: the seeded synthetic clips / weights
+(`oracle/synth.py` - data, shared with the tests so the in-bench parity assert sees the same inputs), that parity
+assert, and the cpu_baseline leg.  The measured path is libopnet_hip.so only.
 """
 from __future__ import annotations
 
