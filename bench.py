@@ -206,15 +206,27 @@ def bench_detect(args, world, rank, dev, dist):
     det.load_state_dict(params, dev)
     nf = args.batch
     frames = [f for f in np.random.default_rng(rank).integers(0, 256, size=(nf, 240, 320, 3), dtype=np.uint8)]
-    for _ in range(max(1, args.warmup)):
-        out = det.detect_batch(frames, dev)
+    # two passes in flight on alternating streams, as preprocess_perception_main runs a video: the per-image selection
+    # kernels of pass k overlap the conv GEMMs of pass k+1
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+
+    def run(n):
+        prev, out = None, None
+        for k in range(n):
+            with torch.cuda.stream(streams[k % 2]):
+                h = det.detect_batch_async(frames, dev)
+            if prev is not None:
+                out = prev()
+            prev = h
+        return prev() if prev is not None else out
+
+    out = run(max(2, args.warmup))
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = det.detect_batch(frames, dev)
+    out = run(args.steps)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()

@@ -367,24 +367,44 @@ class CaterObjectDetector(object):
 
     MAX_FRAMES_PER_PASS = 32      # keeps every activation under the 2 GiB the conv kernel's 32-bit offsets address
 
-    def _detect(self, frames, compute_device):
+    def _enqueue(self, frames, compute_device):
+        """everything of one pass enqueued on the current stream (and the heads' side streams); no host sync"""
         if self.backbone is None:
             raise RuntimeError("load_model() first")
         if len({f.shape for f in frames}) != 1:
             raise ValueError("frames of one call must share a shape")
-        if len(frames) > self.MAX_FRAMES_PER_PASS:
-            out = []
-            for i in range(0, len(frames), self.MAX_FRAMES_PER_PASS):
-                out.extend(self._detect(frames[i:i + self.MAX_FRAMES_PER_PASS], compute_device))
-            return out
         x = torch.cat([preprocess_frame(f, compute_device, self.min_size, self.max_size) for f in frames], dim=0)
         hw = [tuple(f.shape[:2]) for f in frames]
         sizes = [resized_size(h, w, self.min_size, self.max_size) for h, w in hw]
         with torch.cuda.device(x.device):
             feats = self.backbone.forward_nhwc(x)
-            outs = self.heads.forward_images(feats, sizes, x.shape[1:3], hw)
-            counts = torch.cat([o[3] for o in outs]).tolist()          # the one host sync
+            return self.heads.forward_images(feats, sizes, x.shape[1:3], hw)
+
+    def _finish(self, outs):
+        counts = torch.cat([o[3] for o in outs]).tolist()              # the one host sync of a pass
         return [self._to_dict(o[0], o[1], o[2], int(n)) for o, n in zip(outs, counts)]
+
+    def _detect(self, frames, compute_device):
+        if len(frames) > self.MAX_FRAMES_PER_PASS:
+            out = []
+            for i in range(0, len(frames), self.MAX_FRAMES_PER_PASS):
+                out.extend(self._detect(frames[i:i + self.MAX_FRAMES_PER_PASS], compute_device))
+            return out
+        return self._finish(self._enqueue(frames, compute_device))
+
+    def detect_batch_async(self, frames, compute_device):
+        """enqueue one pass (<= MAX_FRAMES_PER_PASS frames) on the CURRENT stream and return a handle; `handle()` waits
+        for that pass only and returns the detections.  Two passes in flight on two streams let the small per-image
+        selection kernels of one pass run in the shadow of the other pass's conv GEMMs (preprocess_perception_main)."""
+        if len(frames) > self.MAX_FRAMES_PER_PASS:
+            raise ValueError(f"at most {self.MAX_FRAMES_PER_PASS} frames per pass")
+        stream = torch.cuda.current_stream(torch.device(compute_device))
+        outs = self._enqueue(list(frames), compute_device)
+
+        def result():
+            with torch.cuda.stream(stream):
+                return self._finish(outs)
+        return result
 
     @staticmethod
     def _to_dict(boxes, scores, labels, n: int) -> Dict[str, torch.Tensor]:

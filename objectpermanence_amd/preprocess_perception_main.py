@@ -74,21 +74,38 @@ def output_video_predictions(video, detector: CaterObjectDetector, compute_devic
     """reference :16-45.  -> (bb_predictions, labels): one int array [n_t, 4] / [n_t] per frame"""
     bb_predictions: List[np.ndarray] = []
     labels: List[np.ndarray] = []
+    device = torch.device(compute_device)
+    streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+    frames_per_pass = min(frames_per_pass, detector.MAX_FRAMES_PER_PASS)
 
-    def flush(frames: Sequence[np.ndarray]):
-        for det in detector.detect_batch(frames, compute_device):
+    def collect(handle):
+        for det in handle():
             det = detector.remove_low_probability_object(det, accuracy_threshold)
             bb_predictions.append(det["boxes"].cpu().numpy().astype(int))          # :35 (np.int truncation)
             labels.append(det["labels"].cpu().numpy().astype(int))                 # :36
 
+    # two passes in flight on alternating streams: pass k's results are collected after pass k+1 has been enqueued
+    in_flight, n_pass = None, 0
     pending: List[np.ndarray] = []
+
+    def submit():
+        nonlocal in_flight, n_pass, pending
+        with torch.cuda.stream(streams[n_pass % 2]):
+            handle = detector.detect_batch_async(pending, device)
+        n_pass += 1
+        pending = []
+        if in_flight is not None:
+            collect(in_flight)
+        in_flight = handle
+
     for frame in read_video_frames(video):
         pending.append(np.array(frame, dtype=np.uint8, order="C", copy=True))    # memmapped stacks are read-only
         if len(pending) == frames_per_pass:
-            flush(pending)
-            pending = []
+            submit()
     if pending:
-        flush(pending)
+        submit()
+    if in_flight is not None:
+        collect(in_flight)
     return bb_predictions, labels
 
 
