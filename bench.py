@@ -92,6 +92,9 @@ def parse():
                          "0 = calibrate S in {1,2,3,4} on untimed steps before the warm-up and keep the fastest")
     ap.add_argument("--mode", choices=["infer", "train", "detect"], default="infer",
                     help="infer = the BASELINE metric (default); train = fwd + L1 + bwd + Adam step (configs 2/5)")
+    ap.add_argument("--gather-every", type=int, default=16,
+                    help="N > 1: steps of a stream whose predictions are all-gathered in ONE collective (fewer, larger messages)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the N > 1 exchange path even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
@@ -274,10 +277,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    exchange = dist is not None
 
     if args.mode == "detect":
         args.batch = args.batch or 16     # frames per pass
@@ -315,7 +320,20 @@ def main():
     pool = [torch.cuda.Stream(device=dev) for _ in range(8)]
     streams = pool[:S]
     main_stream = streams[0]
-    gathered = [torch.empty((world * B, T_FRAMES, 4), dtype=torch.int32, device=dev) for _ in range(4)] if world > 1 else None
+    # inference exchange (N > 1): every stream collects the int32 predictions of G of its steps and all-gathers them in
+    # ONE collective (G x 154 KB per rank instead of G latency-bound 154 KB messages); xGMI is point-to-point, so the
+    # per-call latency of a small all-gather is what would otherwise cap the scaling
+    G = max(1, args.gather_every)
+    local_acc = [torch.empty((G, B, T_FRAMES, 4), dtype=torch.int32, device=dev) for _ in range(4)] if exchange else None
+    gathered = [torch.empty((world * G * B, T_FRAMES, 4), dtype=torch.int32, device=dev) for _ in range(4)] if exchange else None
+    filled = [0, 0, 0, 0]
+
+    def flush(k):
+        n = filled[k]
+        if n:
+            with torch.cuda.stream(streams[k]):
+                dist.all_gather_into_tensor(gathered[k][:world * n * B], local_acc[k][:n].view(n * B, T_FRAMES, 4))
+            filled[k] = 0
 
     if args.mode == "train":
         return bench_train(args, model, boxes, labels, world, rank, dev, dist)
@@ -328,14 +346,19 @@ def main():
             with torch.no_grad():
                 y, _logits = model(boxes)
             pred_px, _, _ = metrics.postprocess_and_iou(y)
-            if world > 1:
-                # inference exchange: all-gather of the int32 predictions (4.8 KB/clip) over RCCL.  The
-                # collective runs on the process group's own stream and only THIS step's stream waits for
-                # it, so it overlaps with the forwards in flight on the other streams.
-                dist.all_gather_into_tensor(gathered[k], pred_px)
+            if exchange:
+                # the collective runs on the process group's own stream and only THIS stream waits for it, so it
+                # overlaps with the forwards in flight on the other streams
+                local_acc[k][filled[k]].copy_(pred_px)
+                filled[k] += 1
+        if exchange and filled[k] == G:
+            flush(k)
         return y, pred_px
 
     def drain():
+        if exchange:
+            for k in range(len(streams)):
+                flush(k)
         for st in pool:
             if st is not main_stream:
                 main_stream.wait_stream(st)
@@ -434,7 +457,7 @@ def main():
             if not err < 1e-4 and not os.environ.get("OPNET_HIP_LIB"):
                 raise SystemExit(f"bench: HIP output of the last timed step differs from the CPU port by {err}")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
 
 
