@@ -828,7 +828,7 @@ static StackPackedLayout stack_packed_layout(int L, int KX, int H)
     return P;
 }
 
-struct StackWorkspaceLayout { size_t xp, state, hbuf[SEQ_MAX_LAYERS], c[SEQ_MAX_LAYERS], state_end, ystage, gemm, xg, total; };
+struct StackWorkspaceLayout { size_t xp, state, hbuf[SEQ_MAX_LAYERS], c[SEQ_MAX_LAYERS], state_end, ystage, gemm, xg, xgl[SEQ_MAX_LAYERS], total; };
 
 static StackWorkspaceLayout stack_workspace_layout(int B, int T, int L, int KX, int H)
 {
@@ -849,6 +849,10 @@ static StackWorkspaceLayout stack_workspace_layout(int B, int T, int L, int KX, 
     if (stack_hoists_input(KX, H)) {
         W.gemm = o; o += align_up((size_t)B * T * 4 * H * 4, 256);       // G [B*T][4H]
         W.xg = o;   o += (size_t)T * RB * H * 32 * 16;                     // xg [T][RB][H][32] float4
+    }
+    for (int l = 0; l < L; ++l) {                                          // x-projection of layers >= 1
+        W.xgl[l] = o;
+        if (l >= 1) o += (size_t)T * RB * H * 32 * 16;
     }
     W.total = align_up(o, 256);
     return W;
@@ -951,7 +955,14 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
         a.layer[l].hbuf = (float4 *)(w + W.hbuf[l]);
         a.layer[l].c = (float *)(w + W.c[l]);
         ntiles += H / 4;
+        if (l >= 1) {   // upper layers: the input product runs in its own role one launch earlier
+            a.layer[l].xg = (float4 *)(w + W.xgl[l]);
+            a.layer[l].a_skip = P.nhx[l];
+            a.layer[l].nhx = 0;
+            ntiles += H / 4;
+        }
     }
+    const int nlaunch = T + 2 * L - 1;
     a.headA = (const float4 *)(packed + P.head);
     a.ystage = (float4 *)(w + W.ystage);
     hipStream_t st = (hipStream_t)stream;
@@ -966,7 +977,7 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
         const long nx = (long)T * RB * 32 * H;
         stack_xg_repack<<<(unsigned)((nx + 255) / 256 > 8192 ? 8192 : (nx + 255) / 256), 256, 0, st>>>(
             (const float4 *)(w + W.gemm), (float4 *)(w + W.xg), B, T, RB, H);
-        a.layer[0].xg = (const float4 *)(w + W.xg);
+        a.layer[0].xg = (float4 *)(w + W.xg);
         a.layer[0].a_skip = P.nhx[0];
         a.layer[0].nhx = 0;
         rows_to_packed<<<2048, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, RB, 0, 0, (float4 *)(w + W.state),
@@ -977,7 +988,7 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
     }
     const dim3 grid(ntiles, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
     if (!graph) {
-        for (int s = 0; s < T + L; ++s) lstm_stack_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+        for (int s = 0; s < nlaunch; ++s) lstm_stack_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     } else {
         StackGraphKey key;
         memset(&key, 0, sizeof(key));
@@ -992,7 +1003,7 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
             hipGraph_t g = nullptr;
             HIP_TRY(hipGraphCreate(&g, 0));
             hipGraphNode_t prev = nullptr, node = nullptr;
-            for (int s = 0; s < T + L; ++s) {
+            for (int s = 0; s < nlaunch; ++s) {
                 StackArgs av = a;
                 int step = s;
                 void *args[] = {(void *)&av, (void *)&step};
@@ -1141,6 +1152,11 @@ static int make_stack_train_args(StackArgs *a, StackBwdArgs *b, const float *pac
         a->layer[l].hbuf = (float4 *)(w + W.hall[l]);
         a->layer[l].c = (float *)(w + W.call[l]);
         a->layer[l].gsave = (float4 *)(w + W.g[l]);
+        if (l >= 1) {   // x-projection role; its output shares the gate-save buffer (read before overwritten, same thread)
+            a->layer[l].xg = (float4 *)(w + W.g[l]);
+            a->layer[l].a_skip = P.nhx[l];
+            a->layer[l].nhx = 0;
+        }
         b->layer[l].whh_t = (const float4 *)(packed + TP.whh_t[l]);
         b->layer[l].wih_t = l >= 1 ? (const float4 *)(packed + TP.wih_t[l]) : nullptr;
         b->layer[l].g = (float4 *)(w + W.g[l]);
@@ -1183,12 +1199,12 @@ extern "C" int opseq_lstm_stack_train_forward_f32(const float *x, const float *p
         const long nx = (long)T * a.RB * 32 * H;
         stack_xg_repack<<<(unsigned)((nx + 255) / 256 > 8192 ? 8192 : (nx + 255) / 256), 256, 0, st>>>(
             (const float4 *)(w + W.darows), (float4 *)(w + W.g[0]), B, T, a.RB, H);
-        a.layer[0].xg = (const float4 *)(w + W.g[0]);
+        a.layer[0].xg = (float4 *)(w + W.g[0]);
         a.layer[0].a_skip = P.nhx[0];
         a.layer[0].nhx = 0;
     }
-    const dim3 grid(L * (H / 4) + 1, a.RB < OPNET_MAX_GY ? a.RB : OPNET_MAX_GY, 1);
-    for (int s = 0; s < T + L; ++s) lstm_stack_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    const dim3 grid((2 * L - 1) * (H / 4) + 1, a.RB < OPNET_MAX_GY ? a.RB : OPNET_MAX_GY, 1);
+    for (int s = 0; s < T + 2 * L - 1; ++s) lstm_stack_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     const long ny = (long)B * T;
     copy_y_out<<<(unsigned)((ny + 255) / 256 > 1024 ? 1024 : (ny + 255) / 256), 256, 0, st>>>(a.ystage, (float4 *)y, ny);
     HIP_TRY(hipGetLastError());

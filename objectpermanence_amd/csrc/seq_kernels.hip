@@ -21,9 +21,14 @@ struct StackLayer {
     float4 *hbuf;          // [2 parity | T+1][RB][H/4][32]
     float *c;              // [1 | T+1][RB][H][32]
     float4 *gsave;         // training: [T][RB][H][32] post-activation gates (i,f,g,o), later overwritten by da
-    // hoisted input product (inference, wide layer-0 inputs): xg [T][RB][H][32] = W_ih x_t for every t, computed by ONE
-    // GEMM before the recurrence; the step then walks only the h part of the A tiles (a_skip = hexadecets to skip)
-    const float4 *xg;
+    // input product kept out of the recurrent role: xg [T][RB][H][32] = W_ih x_t (gate float4 per unit and clip).
+    // Layer 0 with a wide input: ONE GEMM before the recurrence ("hoisted").  Layers >= 1: the x-projection role of
+    // the launch BEFORE the recurrent role's (W_ih h_{l-1,t} only needs the lower layer's h_t), so every role walks
+    // 32 hexadecets - one register chunk per wave, no second fetch round trip inside a launch.
+    // The recurrent role then walks only the h part of the A tiles (a_skip = x hexadecets to skip).
+    // (Giving layer 0's narrow x part its own role as well was measured: the extra workgroups cost more than the
+    // second chunk they remove - transformer_lstm B=1 2.06 -> 2.35 ms.)
+    float4 *xg;
     int a_skip;
 };
 
@@ -36,7 +41,9 @@ struct StackArgs {
     float4 *ystage;        // [RB*32][T]
 };
 
-// grid.x = sum_l H_l/4 + 1 ; grid.y <= RB.  Launch s: layer l runs step t = s - l, the head t = s - L.
+// grid.x = L * H/4 recurrent tiles + (L-1) * H/4 x-projection tiles + 1 ; grid.y <= RB.
+// Launch s: layer l's recurrent role runs step t = s - 2l, its x-projection role (l >= 1) step t = s - (2l - 1) -
+// one launch after layer l-1 produced h_t, one before the recurrent role consumes it - and the head t = s - (2L - 1).
 __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs a, const int s)
 {
     __shared__ __attribute__((aligned(16))) float part[OPNET_NW * 8 * 64];
@@ -47,15 +54,46 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
 
     int bx = blockIdx.x;
     int l = 0;
-    // deepest layer first in block order: it has the longest K when the input is another layer's h
     for (l = a.L - 1; l >= 0; --l) {
         const int nt = a.layer[l].H >> 2;
         if (bx < nt) break;
         bx -= nt;
     }
+    if (l < 0) {
+        // ---- x-projection role of an upper layer: xg_l[t] = W_ih_l h_{l-1,t} ----
+        int lx = 0;
+        for (lx = a.L - 1; lx >= 1; --lx) {
+            const int nt = a.layer[lx].H >> 2;
+            if (bx < nt) break;
+            bx -= nt;
+        }
+        if (lx >= 1) {
+            const StackLayer &ly = a.layer[lx];
+            const int t = s - (2 * lx - 1);
+            if (t < 0 || t >= a.T) return;
+            const int H = ly.H, nhh = H >> 4, nhx = ly.a_skip;
+            const int tile = bx;
+            const KSlice ks = wave_slice(nhx);
+            const float4 *A = ly.A + (long)tile * (nhx + nhh) * 64;           // the x part leads every tile
+            load_a_chunk(a0, A, ks.q0, ks.q1);
+            const int unit = tile * 4 + quarter;
+            for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+                const long so = a.train ? t + 1 : (t & 1);
+                const float4 *xseg = a.layer[lx - 1].hbuf + (so * a.RB + rb) * ((long)a.layer[lx - 1].H * 8);
+                gemm16_rb(a0, A, xseg, nhx, xseg, ks, part, s, a.B - rb * 32 > 16);
+                __syncthreads();
+                if (tid < 128)
+                    ly.xg[(((long)t * a.RB + rb) * H + unit) * 32 + clip] =
+                        make_float4(part_sum(part, half * 4 + 0, el), part_sum(part, half * 4 + 1, el),
+                                    part_sum(part, half * 4 + 2, el), part_sum(part, half * 4 + 3, el));
+                if (rb + (int)gridDim.y < a.RB) __syncthreads();
+            }
+            return;
+        }
+    }
     if (l >= 0) {
         const StackLayer &ly = a.layer[l];
-        const int t = s - l;
+        const int t = s - 2 * l;
         if (t < 0 || t >= a.T) return;
         const int H = ly.H, nhh = H >> 4, nhx = ly.nhx;
         const int tile = bx;
@@ -66,9 +104,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
             const long so = a.train ? t + 1 : (t & 1), sp = a.train ? t : ((t + 1) & 1);   // history slots
             const long co = a.train ? t + 1 : 0, cp = a.train ? t : 0;
-            const float4 *xseg = (l == 0)
-                ? a.xp + ((long)t * a.RB + rb) * ((long)nhx * 128)
-                : a.layer[l - 1].hbuf + (so * a.RB + rb) * ((long)a.layer[l - 1].H * 8);
+            const float4 *xseg = a.xp + ((long)t * a.RB + rb) * ((long)nhx * 128);      // layer 0 only (nhx = 0 above it)
             const float4 *hprev = ly.hbuf + (sp * a.RB + rb) * ((long)H * 8);
             float c_old = 0.f;
             float4 xg = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -92,7 +128,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         }
     } else {
         // head: predictions_layer (learned_models.py:101,113 / 137,148 / 172,195)
-        const int t = s - a.L;
+        const int t = s - (2 * a.L - 1);
         if (t < 0 || t >= a.T) return;
         const StackLayer &ly = a.layer[a.L - 1];
         const int nh = ly.H >> 4;
