@@ -95,6 +95,8 @@ def parse():
     ap.add_argument("--gather-every", type=int, default=16,
                     help="N > 1: steps of a stream whose predictions are all-gathered in ONE collective (fewer, larger messages)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the N > 1 exchange path even with one rank")
+    ap.add_argument("--loss", choices=["l1", "smooth_l1"], default="smooth_l1",
+                    help="--mode train: BASELINE.json config 2 names SmoothL1; the reference's own training uses l1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
@@ -122,9 +124,9 @@ def cpu_baseline(boxes_np, params, seconds):
     }, y
 
 
-def bench_train(args, model, boxes, labels, world, rank, dev, dist):
-    """Training throughput (not the BASELINE headline): one step = forward + L1 + backward + Adam on
-    `--batch` clips per GPU, gradients all-reduced over RCCL when N > 1."""
+def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
+    """Training throughput (BASELINE.json configs 2 / 5; not the headline metric): one step = forward + loss + backward +
+    Adam on `--batch` clips per GPU, gradients all-reduced over RCCL when N > 1."""
     from objectpermanence_amd import FusedAdam
     from objectpermanence_amd.training import train_step
     model.train(True)
@@ -132,33 +134,75 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist):
     comm = torch.cuda.Stream(device=dev)
     B = int(boxes.shape[0])
     for _ in range(args.warmup):
-        train_step("opnet", model, opt, boxes, labels, n_global=world * B, comm_stream=comm)
+        train_step("opnet", model, opt, boxes, labels, n_global=world * B, comm_stream=comm, loss_kind=args.loss)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
-        loss = train_step("opnet", model, opt, boxes, labels, n_global=world * B, comm_stream=comm)
+        loss = train_step("opnet", model, opt, boxes, labels, n_global=world * B, comm_stream=comm, loss_kind=args.loss)
+    ev1.record()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank == 0:
+        # algorithmic bytes of one training step under the per-time-step streaming model: the
+        # forward streams the weights once per step and moves each clip's state (+ the saved history: gates 4x, h, c per
+        # unit), the backward streams W_hh^T / W_ih2^T / the heads once per reverse step and reads the history back
+        hist = B * (256 + 512) * (4 + 1 + 1) * 4                     # gates, h, c of both LSTMs per clip per step
+        per_t = 2 * (W_BYTES + B * STATE_BYTES_PER_CLIP) + 2 * hist
+        alg = per_t * T_FRAMES + 2 * W_BYTES * 3                     # + weight gradients written, Adam read/write
+        achieved = alg * args.steps / (gpu_ms * 1e-3) / 1e9
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import torch_port
+            torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
+            cpu_model = torch_port.OPNetTorch(params)
+            cpu_opt = torch.optim.Adam(cpu_model.parameters(), lr=1e-3)
+            xb, lb = boxes.cpu(), labels.cpu()
+            loss_fn = torch.nn.SmoothL1Loss() if args.loss == "smooth_l1" else torch.nn.L1Loss()
+
+            def cpu_step():
+                cpu_opt.zero_grad()
+                loss_fn(cpu_model(xb), lb).backward()
+                cpu_opt.step()
+
+            cpu_step()                                                   # warm-up
+            t1 = time.perf_counter()
+            n_cpu = 0
+            while time.perf_counter() - t1 < args.cpu_seconds:
+                cpu_step()
+                n_cpu += 1
+            dt = time.perf_counter() - t1
+            cpu = {"value": round(n_cpu * B / dt, 2), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": f"{n_cpu} x (forward + {args.loss} + backward + Adam) of {B} clips x 300 frames, "
+                             f"oracle/torch_port.OPNetTorch (the graph on torch's CPU LSTM op, fp32), {dt:.1f} s"}
         print(json.dumps({
-            "metric": "CATER clips/sec OPNet training step (fwd + L1 + bwd + Adam)",
+            "metric": "CATER clips/sec OPNet training step (fwd + loss + bwd + Adam)",
             "value": round(world * B * args.steps / elapsed, 1), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"opnet training, batch={B} clips/GPU x 300 frames x 15 slots, L1 loss, Adam lr 1e-3",
-                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "config": {"workload": f"opnet training, batch={B} clips/GPU x 300 frames x 15 slots (10 objects), "
+                                   f"{args.loss} bbox loss, Adam lr 1e-3", "global_batch": world * B,
+                       "parallelism": f"dp{world}", "loss": args.loss},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "opnet_step + opnet_bwd_gemm + opnet_bwd_cell (the 3 launches of a time step); "
+                                   "algorithmic bytes of the whole step / GPU time",
+                         "alg_bytes_per_step": alg},
+            "cpu_baseline": cpu,
             "final_loss": float(loss.item())}), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
@@ -336,7 +380,7 @@ def main():
             filled[k] = 0
 
     if args.mode == "train":
-        return bench_train(args, model, boxes, labels, world, rank, dev, dist)
+        return bench_train(args, model, boxes, labels, world, rank, dev, dist, params)
 
     def step(i):
         # independent batches: step i is enqueued on stream i % S, so up to S forwards are in flight

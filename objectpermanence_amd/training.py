@@ -17,28 +17,31 @@ import torch
 import torch.distributed as dist
 
 from . import parallel
-from .optim import l1_mean
+from .optim import l1_mean, smooth_l1_mean
 from .supported_models import DOUBLE_OUTPUT_MODELS, NO_LABELS_MODELS
 
 
-def compute_loss(model_name: str, output: torch.Tensor, labels: torch.Tensor, mask: Optional[torch.Tensor] = None):
-    """Returns (loss, pred_loss, consistency_loss) as training_main.py:192-210 does."""
+def compute_loss(model_name: str, output: torch.Tensor, labels: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                 loss_kind: str = "l1"):
+    """Returns (loss, pred_loss, consistency_loss) as training_main.py:192-210 does.  loss_kind "smooth_l1" swaps the
+    supervised L1 for torch.nn.SmoothL1Loss (BASELINE.json config 2 names it; the reference itself trains with L1)."""
     nxt, cur = output[:, 1:, :], output[:, :-1, :]
     consistency = torch.mean(torch.norm(nxt - cur, p=2, dim=-1)) if output.shape[1] > 1 else output.new_zeros(())
     if model_name in NO_LABELS_MODELS:
         pred = torch.mean(torch.abs(output - labels) * mask)
         return pred + 0.5 * consistency, pred, consistency
-    pred = l1_mean(output, labels)
+    pred = smooth_l1_mean(output, labels) if loss_kind == "smooth_l1" else l1_mean(output, labels)
     return pred, pred, consistency.detach()
 
 
 def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.Optimizer, boxes: torch.Tensor,
                labels: torch.Tensor, mask: Optional[torch.Tensor] = None, group: Optional[dist.ProcessGroup] = None,
-               n_global: Optional[int] = None, comm_stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+               n_global: Optional[int] = None, comm_stream: Optional[torch.cuda.Stream] = None,
+               loss_kind: str = "l1") -> torch.Tensor:
     optimizer.zero_grad(set_to_none=True)
     out = model(boxes)
     output = out[0] if model_name in DOUBLE_OUTPUT_MODELS else out
-    loss, _, _ = compute_loss(model_name, output, labels, mask)
+    loss, _, _ = compute_loss(model_name, output, labels, mask, loss_kind)
     loss.backward()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         params = [p for p in model.parameters() if p.grad is not None]

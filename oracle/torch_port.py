@@ -43,6 +43,36 @@ def opnet_forward(boxes: torch.Tensor, p: Dict[str, torch.Tensor]):
     return y, logits.permute(0, 2, 1).contiguous()
 
 
+class OPNetTorch(torch.nn.Module):
+    """the same graph on torch's own CPU LSTM op (oneDNN / native) - what the reference's nn.LSTM calls run on
+    (learned_models.py:29,32); used as the timed CPU baseline of the TRAINING step, where the explicit python time loop
+    of `lstm_seq` above would measure the interpreter rather than the arithmetic"""
+
+    def __init__(self, params: Dict[str, np.ndarray]):
+        super().__init__()
+        h1 = params["object_to_track_LSTM.weight_hh_l0"].shape[1]
+        h2 = params["video_LSTM.weight_hh_l0"].shape[1]
+        self.lstm1 = torch.nn.LSTM(90, h1, batch_first=True, bias=False)
+        self.lstm2 = torch.nn.LSTM(6, h2, batch_first=True, bias=False)
+        self.sel = torch.nn.Linear(h1, 15, bias=False)
+        self.out = torch.nn.Linear(h2, 4, bias=False)
+        with torch.no_grad():
+            self.lstm1.weight_ih_l0.copy_(torch.from_numpy(params["object_to_track_LSTM.weight_ih_l0"]))
+            self.lstm1.weight_hh_l0.copy_(torch.from_numpy(params["object_to_track_LSTM.weight_hh_l0"]))
+            self.lstm2.weight_ih_l0.copy_(torch.from_numpy(params["video_LSTM.weight_ih_l0"]))
+            self.lstm2.weight_hh_l0.copy_(torch.from_numpy(params["video_LSTM.weight_hh_l0"]))
+            self.sel.weight.copy_(torch.from_numpy(params["object_to_track_prediction.weight"]))
+            self.out.weight.copy_(torch.from_numpy(params["prediction_layer.weight"]))
+
+    def forward(self, boxes: torch.Tensor) -> torch.Tensor:
+        B, T = boxes.shape[:2]
+        h1, _ = self.lstm1(boxes.reshape(B, T, 90))
+        probs = torch.softmax(self.sel(h1), dim=-1)
+        frames_boxes = torch.einsum("bfot,bfo->bft", boxes, probs)
+        h2, _ = self.lstm2(frames_boxes)
+        return self.out(h2)
+
+
 def l1_mean(y: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     """training_main.py:152,192,204 for the supervised models: mean(|y - label|)."""
     return (y - labels).abs().mean()

@@ -48,3 +48,20 @@ def test_real_gradients_match_reference(golden_dir):
         scale = max(1e-3, np.abs(ref).max())
         assert np.abs(gr.reshape(-1)[idx] - ref).max() <= 2e-4 * scale, k
         assert np.sqrt((gr.astype(np.float64) ** 2).sum()) == pytest.approx(float(g["gnorm/" + k]), rel=1e-4)
+
+
+def test_torch_lstm_port_matches_explicit_port():
+    """OPNetTorch (torch's CPU LSTM op; the timed CPU baseline of bench.py --mode train) == the explicit restatement"""
+    import torch
+    from oracle import synth, torch_port
+    cfg = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 32, "videos_hidden_dim": 48}
+    p = synth.opnet_synth_params(cfg)
+    boxes, labels = synth.make_batch(3, 3, 9)
+    loss, grads, y = torch_port.loss_and_grads(boxes, labels, p)
+    m = torch_port.OPNetTorch(p)
+    y2 = m(torch.from_numpy(boxes))
+    l2 = torch_port.l1_mean(y2, torch.from_numpy(labels))
+    l2.backward()
+    assert float(l2) == pytest.approx(loss, abs=1e-6) and np.abs(y2.detach().numpy() - y).max() < 1e-5
+    assert np.abs(m.lstm2.weight_hh_l0.grad.numpy() - grads["video_LSTM.weight_hh_l0"]).max() < 1e-5
+    assert np.abs(m.lstm1.weight_ih_l0.grad.numpy() - grads["object_to_track_LSTM.weight_ih_l0"]).max() < 1e-5
