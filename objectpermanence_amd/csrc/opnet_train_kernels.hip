@@ -277,6 +277,191 @@ __global__ void __launch_bounds__(256) opnet_bwd_cell(const BwdArgs a, const int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward step, fused: ONE launch per reverse time step (replaces the opnet_bwd_cell / opnet_bwd_gemm pair)
+// ------------------------------------------------------------------------------------------------
+// The pair existed because dh_{t-1} = W_hh^T da_t contracts over 4H gate columns: split-K over 4 workgroups kept a
+// workgroup's MFMA chain as short as the forward's, and the partials met in the next launch.  Here a workgroup owns
+// COMPLETE dh rows instead - 16 units x 16 clips (one clip half), K = 4H walked by its 4 waves in double-buffered
+// register chunks with two accumulator chains each - so the cell backward of those (unit, clip) pairs runs in the
+// same launch's epilogue and the reverse step costs one kernel boundary, not two.
+//   launch n:  LSTM2 cell at t = T-1-n          (recurrent product on da2_{t+1}, written by launch n-1)
+//              W_ih2^T da2 + selection-head backward at t = T-n   (da2_t from launch n-1)  -> dl_t
+//              LSTM1 cell at t = T+1-n          (product on da1_{t+1}; dl_t from launch n-1)
+// grid.x = 2 * (H2/16 + H1/16 + 1) workgroups (tile x clip half), grid.y <= RB.  Deterministic (fixed-order sums).
+#define FUSED_NW 8          // waves per workgroup: K = 4H split 8 ways
+#define FUSED_CH 16         // hexadecets a wave fetches up front (H2 = 512: its whole slice, one round trip)
+#define FUSED_THREADS (64 * FUSED_NW)
+
+// D[16 rows x 16 clips] = A[16 x 16 nq] . da^T over hexadecets [0, nq) split over the FUSED_NW waves - every wave
+// issues ALL its fragment loads before its first MFMA and keeps two accumulator chains - summed in fixed wave order
+// through `part` ([FUSED_NW][4][64] floats); returns this thread's element (tid < 256): row tid >> 4, clip tid & 15
+__device__ __forceinline__ float fused_product(const float4 *__restrict__ A, const float4 *__restrict__ seg, int nq,
+                                               int hf, float *__restrict__ part)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q0 = (w * nq) / FUSED_NW, q1 = ((w + 1) * nq) / FUSED_NW;
+    const int boff = (lane >> 4) * 32 + (lane & 15) + 16 * hf;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int qb = q0; qb < q1; qb += FUSED_CH) {
+        float4 fa[FUSED_CH], fb[FUSED_CH];
+#pragma unroll
+        for (int j = 0; j < FUSED_CH; ++j)
+            if (qb + j < q1) {
+                fa[j] = A[(qb + j) * 64 + lane];
+                fb[j] = seg[(qb + j) * 128 + boff];
+            }
+#pragma unroll
+        for (int j = 0; j < FUSED_CH; j += 2) {
+            if (qb + j < q1) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j].x, fb[j].x, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j].y, fb[j].y, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j].z, fb[j].z, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j].w, fb[j].w, acc0, 0, 0, 0);
+            }
+            if (qb + j + 1 < q1) {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j + 1].x, fb[j + 1].x, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j + 1].y, fb[j + 1].y, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j + 1].z, fb[j + 1].z, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j + 1].w, fb[j + 1].w, acc1, 0, 0, 0);
+            }
+        }
+    }
+    float *p = part + (w * 4) * 64 + lane;
+    p[0 * 64] = acc0[0] + acc1[0]; p[1 * 64] = acc0[1] + acc1[1];
+    p[2 * 64] = acc0[2] + acc1[2]; p[3 * 64] = acc0[3] + acc1[3];
+    __syncthreads();
+    // D element (row, clip) sits in lane clip + 16 (row >> 2), register row & 3
+    const int t256 = tid & 255;
+    const int row = t256 >> 4, cl = t256 & 15;
+    const int src = (row & 3) * 64 + cl + 16 * (row >> 2);
+    float sum = part[src];
+#pragma unroll
+    for (int k = 1; k < FUSED_NW; ++k) sum += part[k * 256 + src];
+    return sum;
+}
+
+__global__ void __launch_bounds__(FUSED_THREADS) opnet_bwd_fused(const BwdArgs a, const int n)
+{
+    __shared__ __attribute__((aligned(16))) float part[FUSED_NW * 4 * 64];
+    __shared__ float dxs[OPNET_FEATS_][16];
+    const int T = a.T, H1 = a.H1, H2 = a.H2;
+    const int n2 = 2 * (H2 >> 4), n1 = 2 * (H1 >> 4);
+    const int bx = blockIdx.x, tid = threadIdx.x;
+    const int row = (tid & 255) >> 4, cl = tid & 15;
+    const bool owner = tid < 256;          // one thread per (unit, clip) of the 16 x 16 tile does the cell backward
+    if (bx < n2) {
+        // ---------------- LSTM2 at t = T-1-n ----------------
+        const int t = T - 1 - n;
+        if (t < 0 || a.mlp) return;
+        const int tile = bx >> 1, hf = bx & 1;
+        const int u = tile * 16 + row, clip = hf * 16 + cl;
+        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            float rec = 0.f;
+            if (t < T - 1)
+                rec = fused_product(a.w2bt + (long)tile * (H2 >> 2) * 64, a.g2 + (((long)(t + 1)) * a.RB + rb) * H2 * 32,
+                                    H2 >> 2, hf, part);
+            if (owner) {
+                // upstream: prediction_layer (learned_models.py:47): dh += W_out^T dy_t
+                const float4 dy = a.dyp[((long)t * a.RB + rb) * 32 + clip];
+                float dh = a.wout[u] * dy.x;
+                dh = fmaf(a.wout[H2 + u], dy.y, dh);
+                dh = fmaf(a.wout[2 * H2 + u], dy.z, dh);
+                dh = fmaf(a.wout[3 * H2 + u], dy.w, dh);
+                dh += rec;
+                const long e = ((long)rb * H2 + u) * 32 + clip;
+                const float dcc = t < T - 1 ? a.dc2[e] : 0.f;
+                const long ge = (((long)t * a.RB + rb) * H2 + u) * 32 + clip;
+                const float c_t = a.c2all[(((long)(t + 1)) * a.RB + rb) * H2 * 32 + (long)u * 32 + clip];
+                const float c_p = a.c2all[((long)t * a.RB + rb) * H2 * 32 + (long)u * 32 + clip];
+                float dco;
+                a.g2[ge] = cell_backward(dh, dcc, a.g2[ge], c_t, c_p, &dco);
+                a.dc2[e] = dco;
+            }
+            if (rb + (int)gridDim.y < a.RB) __syncthreads();
+        }
+    } else if (bx < n2 + 2) {
+        // ---------------- d frames_boxes = W_ih2^T da2_t, then einsum / softmax backward, t = T-n ----------------
+        const int t = T - n;
+        if (t < 0 || t >= T) return;
+        const int hf = bx - n2, clip = hf * 16 + cl;
+        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            const float dx = fused_product(a.wih2t, a.g2 + ((long)t * a.RB + rb) * H2 * 32, H2 >> 2, hf, part);
+            if (owner && row < OPNET_FEATS_) dxs[row][cl] = dx;
+            __syncthreads();
+            if (tid < 16) {
+                // einsum backward: dp[o] = sum_f boxes[o][f] dx[f]; softmax backward: dl = p * (dp - <p, dp>)
+                const int c = hf * 16 + tid;
+                const float *xs = (const float *)(a.xp + ((long)t * a.RB + rb) * (OPNET_KXQ * 32));
+                const float4 *pp = a.psave + ((long)t * a.RB + rb) * 128 + c;
+                float p[16], dp[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = pp[q * 32];
+                    p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+                }
+                float dot = 0.f;
+#pragma unroll
+                for (int o = 0; o < OPNET_SLOTS_; ++o) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int f = 0; f < OPNET_FEATS_; ++f) {
+                        const int k = o * OPNET_FEATS_ + f;
+                        acc = fmaf(xs[((k >> 2) * 32 + c) * 4 + (k & 3)], dxs[f][tid], acc);
+                    }
+                    dp[o] = acc;
+                    dot = fmaf(p[o], acc, dot);
+                }
+                float dl[16];
+#pragma unroll
+                for (int o = 0; o < 16; ++o) dl[o] = o < OPNET_SLOTS_ ? p[o] * (dp[o] - dot) : 0.f;
+                float4 *dst = a.dlall + ((long)t * a.RB + rb) * 128 + c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q * 32] = make_float4(dl[4 * q], dl[4 * q + 1], dl[4 * q + 2], dl[4 * q + 3]);
+            }
+            if (rb + (int)gridDim.y < a.RB) __syncthreads();
+        }
+        (void)clip;
+    } else {
+        // ---------------- LSTM1 at t = T+1-n ----------------
+        const int t = T + 1 - n;
+        if (t < 0 || t >= T) return;
+        const int b1 = bx - n2 - 2;
+        const int tile = b1 >> 1, hf = b1 & 1;
+        const int u = tile * 16 + row, clip = hf * 16 + cl;
+        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            float rec = 0.f;
+            if (t < T - 1)
+                rec = fused_product(a.w1bt + (long)tile * (H1 >> 2) * 64, a.g1 + (((long)(t + 1)) * a.RB + rb) * H1 * 32,
+                                    H1 >> 2, hf, part);
+            if (owner) {
+                // upstream: object_to_track_prediction (learned_models.py:40): dh += W_sel^T dl_t
+                const float4 *dlp = a.dlall + ((long)t * a.RB + rb) * 128 + clip;
+                float dh = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = dlp[q * 32];
+                    dh = fmaf(a.wsel[(4 * q) * H1 + u], v.x, dh);
+                    dh = fmaf(a.wsel[(4 * q + 1) * H1 + u], v.y, dh);
+                    dh = fmaf(a.wsel[(4 * q + 2) * H1 + u], v.z, dh);
+                    if (4 * q + 3 < OPNET_SLOTS_) dh = fmaf(a.wsel[(4 * q + 3) * H1 + u], v.w, dh);
+                }
+                dh += rec;
+                const long e = ((long)rb * H1 + u) * 32 + clip;
+                const float dcc = t < T - 1 ? a.dc1[e] : 0.f;
+                const long ge = (((long)t * a.RB + rb) * H1 + u) * 32 + clip;
+                const float c_t = a.c1all[(((long)(t + 1)) * a.RB + rb) * H1 * 32 + (long)u * 32 + clip];
+                const float c_p = a.c1all[((long)t * a.RB + rb) * H1 * 32 + (long)u * 32 + clip];
+                float dco;
+                a.g1[ge] = cell_backward(dh, dcc, a.g1[ge], c_t, c_p, &dco);
+                a.dc1[e] = dco;
+            }
+            if (rb + (int)gridDim.y < a.RB) __syncthreads();
+        }
+    }
+}
+
 // OPNetLstmMlp (learned_models.py:83-84): hidden = relu(hidden_layer(frames_boxes)), y = prediction_layer(hidden).
 // d hidden = [hidden > 0] * W_out^T dy for every (t, clip, unit) at once (no recurrence), stored as (d hidden, 0,0,0)
 // in the gate-gradient layout so the W_ih2^T product, the head backward and the weight-gradient GEMMs of the

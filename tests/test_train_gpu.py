@@ -181,3 +181,31 @@ def test_smooth_l1_matches_torch():
         ref.backward()
         assert float(loss.detach()) == pytest.approx(float(ref.detach()), rel=2e-6)
         assert torch.allclose(y.grad, y2.grad, rtol=1e-6, atol=1e-9)
+
+
+def test_fused_and_split_backward_agree(monkeypatch):
+    """the two reverse-recurrence schedules (one fused launch per step for <= 2 row blocks, the split-K pair above) give
+    the same gradients; B = 70 (3 row blocks) exercises the automatic choice of the pair"""
+    from objectpermanence_amd import ModelsFactory, l1_mean
+    cfg = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 48, "videos_hidden_dim": 64}
+    p = synth.opnet_synth_params(cfg)
+
+    def grads(B, mode):
+        if mode:
+            monkeypatch.setenv("OPNET_BWD_MODE", mode)
+        else:
+            monkeypatch.delenv("OPNET_BWD_MODE", raising=False)
+        boxes, labels = synth.make_batch(31, B, 6)
+        m = ModelsFactory.get_model("opnet", cfg)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+        m.to("cuda:0").train(True)
+        l1_mean(m(torch.from_numpy(boxes).cuda())[0], torch.from_numpy(labels).cuda()).backward()
+        torch.cuda.synchronize()
+        return {k: v.grad.cpu().numpy() for k, v in m.named_parameters()}
+
+    for B in (5, 70):
+        gf, gs, ga = grads(B, "fused"), grads(B, "split"), grads(B, None)
+        for k in gf:
+            scale = max(1e-3, np.abs(gs[k]).max())
+            assert np.abs(gf[k] - gs[k]).max() <= 2e-5 * scale, (B, k)
+            assert np.array_equal(ga[k], gf[k] if B == 5 else gs[k]), (B, k)       # the automatic choice
