@@ -128,6 +128,15 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 extern "C" int opnet_hip_abi_version(void) { return 1; }
 extern "C" const char *opnet_last_error(void) { return g_err; }
 
+// the step kernel comes in two register-chunk sizes (opnet_kernels.hip, load_a_chunk): 8 for one row block, 4 beyond
+typedef void (*opnet_step_fn)(const StepArgs, const int);
+static opnet_step_fn step_kernel(int RB)
+{
+    const char *force = getenv("OPNET_STEP_CH");          // "4" / "8": measurement override
+    const bool small_chunks = force ? atoi(force) == 4 : RB >= 2;
+    return small_chunks ? opnet_step<4> : opnet_step<8>;
+}
+
 // ------------------------------------------------------------------------------------------------
 // shapes and buffer carving
 // ------------------------------------------------------------------------------------------------
@@ -293,7 +302,8 @@ extern "C" int opnet_forward_f32(const float *boxes, const float *packed, float 
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     const dim3 grid = step_grid(a.RB, H1, H2);
-    for (int s = 0; s < T + 3; ++s) opnet_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    const opnet_step_fn stepk = step_kernel(a.RB);
+    for (int s = 0; s < T + 3; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
@@ -344,7 +354,8 @@ extern "C" int opnet_mlp_forward_f32(const float *boxes, const float *packed, fl
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     const dim3 grid = step_grid(a.RB, H1, H2);
-    for (int s = 0; s < T + 3; ++s) opnet_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    const opnet_step_fn stepk = step_kernel(a.RB);
+    for (int s = 0; s < T + 3; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
@@ -416,7 +427,7 @@ static int plan_build(opnet_plan *p, const StepArgs &a, void *ws)
         void *args[] = {(void *)&av, (void *)&step};
         hipKernelNodeParams kp;
         memset(&kp, 0, sizeof(kp));
-        kp.func = (void *)opnet_step;
+        kp.func = (void *)step_kernel(a.RB);
         kp.gridDim = step_grid(a.RB, p->H1, p->H2);
         kp.blockDim = dim3(OPNET_THREADS, 1, 1);
         kp.kernelParams = args;
@@ -616,7 +627,8 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     const dim3 grid = step_grid(a.RB, H1, H2);
-    for (int s = 0; s < T + 3; ++s) opnet_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    const opnet_step_fn stepk = step_kernel(a.RB);
+    for (int s = 0; s < T + 3; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
@@ -755,7 +767,8 @@ extern "C" int opnet_mlp_train_forward_f32(const float *boxes, const float *pack
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     const dim3 grid = step_grid(a.RB, H1, H2);
-    for (int s = 0; s < T + 3; ++s) opnet_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    const opnet_step_fn stepk = step_kernel(a.RB);
+    for (int s = 0; s < T + 3; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;

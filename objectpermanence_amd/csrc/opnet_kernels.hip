@@ -194,11 +194,15 @@ __device__ __forceinline__ KSlice wave_slice(int nhex)
     return k;
 }
 
-__device__ __forceinline__ void load_a_chunk(float4 (&a)[OPNET_CH], const float4 *__restrict__ A, int qb, int q1)
+// CH = hexadecets of a register chunk, deduced from the caller's fragment array.  8 covers a wave's whole K slice of the
+// OPNet roles in one fetch round trip (best at B <= 32); 4 keeps the step kernel at 140 instead of 204 VGPRs, i.e. 3
+// resident waves per SIMD - which wins once several row blocks make the launch compute-bound (B >= 64).
+template <int CH>
+__device__ __forceinline__ void load_a_chunk(float4 (&a)[CH], const float4 *__restrict__ A, int qb, int q1)
 {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int j = 0; j < OPNET_CH; ++j) {
+    for (int j = 0; j < CH; ++j) {
         if (qb + j < q1) {
 #if (defined(OPNET_TRACE) && OPNET_VARIANT == 2) || defined(OPNET_ABLATE_A)   /* probe: no weight loads */
             a[j] = make_float4(1.f, 2.f, 3.f, (float)(qb + j));
@@ -211,15 +215,16 @@ __device__ __forceinline__ void load_a_chunk(float4 (&a)[OPNET_CH], const float4
 
 // two_halves = false: the row block holds <= 16 clips, so the second accumulator chain (clips 16..31,
 // all padding) is skipped - half the loads and MFMAs for small batches (B <= 16, e.g. one 300-frame clip).
-__device__ __forceinline__ void mma_chunk(const float4 (&a)[OPNET_CH], const float4 *__restrict__ seg0, int nh0,
+template <int CH>
+__device__ __forceinline__ void mma_chunk(const float4 (&a)[CH], const float4 *__restrict__ seg0, int nh0,
                                           const float4 *__restrict__ seg1, int qb, int q1,
                                           f32x4 &acc0, f32x4 &acc1, const int s, const bool two_halves)
 {
     const int lane = threadIdx.x & 63;
     const int boff = (lane >> 4) * 32 + (lane & 15);
-    float4 b0[OPNET_CH], b1[OPNET_CH];
+    float4 b0[CH], b1[CH];
 #pragma unroll
-    for (int j = 0; j < OPNET_CH; ++j) {
+    for (int j = 0; j < CH; ++j) {
         const int q = qb + j;
         if (q < q1) {  // wave-uniform
             const float4 *src = (q < nh0) ? (seg0 + q * 128) : (seg1 + (q - nh0) * 128);
@@ -236,7 +241,7 @@ __device__ __forceinline__ void mma_chunk(const float4 (&a)[OPNET_CH], const flo
     TRACE_STAMP(2);
 #ifdef OPNET_ABLATE_MFMA   /* probe: loads only (kept alive), no matrix work */
 #pragma unroll
-    for (int j = 0; j < OPNET_CH; ++j)
+    for (int j = 0; j < CH; ++j)
         if (qb + j < q1) {
             asm volatile("" ::"v"(a[j].x), "v"(b0[j].x), "v"(b1[j].x), "v"(a[j].w), "v"(b0[j].w), "v"(b1[j].w));
             acc0[0] += a[j].x + b0[j].y; acc1[0] += b1[j].z;
@@ -245,7 +250,7 @@ __device__ __forceinline__ void mma_chunk(const float4 (&a)[OPNET_CH], const flo
 #endif
     if (!two_halves) {
 #pragma unroll
-        for (int j = 0; j < OPNET_CH; ++j) {
+        for (int j = 0; j < CH; ++j) {
             if (qb + j < q1) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0[j].x, acc0, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b0[j].y, acc0, 0, 0, 0);
@@ -256,7 +261,7 @@ __device__ __forceinline__ void mma_chunk(const float4 (&a)[OPNET_CH], const flo
         return;
     }
 #pragma unroll
-    for (int j = 0; j < OPNET_CH; ++j) {
+    for (int j = 0; j < CH; ++j) {
         if (qb + j < q1) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b0[j].x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b1[j].x, acc1, 0, 0, 0);
@@ -272,7 +277,8 @@ __device__ __forceinline__ void mma_chunk(const float4 (&a)[OPNET_CH], const flo
 
 // One row block.  `a0` holds the wave's first A chunk already (loaded by the caller, possibly for
 // an earlier row block); further chunks - only when the K slice exceeds CH - are reloaded here.
-__device__ __forceinline__ void gemm16_rb(const float4 (&a0)[OPNET_CH], const float4 *__restrict__ A,
+template <int CH>
+__device__ __forceinline__ void gemm16_rb(const float4 (&a0)[CH], const float4 *__restrict__ A,
                                           const float4 *__restrict__ seg0, int nh0,
                                           const float4 *__restrict__ seg1, const KSlice ks,
                                           float *__restrict__ part, const int s, const bool two_halves = true)
@@ -280,8 +286,8 @@ __device__ __forceinline__ void gemm16_rb(const float4 (&a0)[OPNET_CH], const fl
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
     mma_chunk(a0, seg0, nh0, seg1, ks.q0, ks.q1, acc0, acc1, s, two_halves);
-    for (int qb = ks.q0 + OPNET_CH; qb < ks.q1; qb += OPNET_CH) {
-        float4 an[OPNET_CH];
+    for (int qb = ks.q0 + CH; qb < ks.q1; qb += CH) {
+        float4 an[CH];
         load_a_chunk(an, A, qb, ks.q1);
         mma_chunk(an, seg0, nh0, seg1, qb, ks.q1, acc0, acc1, s, two_halves);
     }
@@ -354,6 +360,7 @@ __device__ __forceinline__ float lstm_cell_g(float gi, float gf, float gg, float
 // grid.x = n2 (LSTM2 tiles, longest K first) + n1 (LSTM1 tiles) + 2 heads ; grid.y <= row blocks
 // (a workgroup walks row blocks rb = blockIdx.y, blockIdx.y + gridDim.y, ... with its weights held
 // in registers).
+template <int CH>
 __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, const int s)
 {
     __shared__ __attribute__((aligned(16))) float lds[OPNET_NW * 8 * 64 + 32 * 16];
@@ -373,7 +380,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
     const int half = tid >> 6;
     const int clip = half * 16 + (el & 15);
     const int quarter = el >> 4;
-    float4 a0[OPNET_CH];
+    float4 a0[CH];
 
     if (bx < n2) {
         // ---------------- LSTM2 (video_LSTM, learned_models.py:32,46), step t = s-2 -------------
