@@ -41,16 +41,6 @@ struct StackArgs {
     float4 *ystage;        // [RB*32][T]
 };
 
-// every layer descriptor sits at a fixed kernarg offset: fetch by select, so the scalar loads of a launch go out in one
-// batch instead of a second, role-dependent round trip (a.layer[l] with a runtime l is an indexed s_load)
-__device__ __forceinline__ StackLayer stack_layer(const StackArgs &a, int l)
-{
-    StackLayer r = a.layer[0];
-    if (l == 1) r = a.layer[1];
-    if (l == 2) r = a.layer[2];
-    return r;
-}
-
 // grid.x = L * H/4 recurrent tiles + (L-1) * H/4 x-projection tiles + 1 ; grid.y <= RB.
 // Launch s: layer l's recurrent role runs step t = s - 2l, its x-projection role (l >= 1) step t = s - (2l - 1) -
 // one launch after layer l-1 produced h_t, one before the recurrent role consumes it - and the head t = s - (2L - 1).
@@ -64,8 +54,8 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
 
     int bx = blockIdx.x;
     int l = 0;
-    const int nt = a.layer[0].H >> 2;          // all layers of a stack share H
     for (l = a.L - 1; l >= 0; --l) {
+        const int nt = a.layer[l].H >> 2;
         if (bx < nt) break;
         bx -= nt;
     }
@@ -73,11 +63,12 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         // ---- x-projection role of an upper layer: xg_l[t] = W_ih_l h_{l-1,t} ----
         int lx = 0;
         for (lx = a.L - 1; lx >= 1; --lx) {
+            const int nt = a.layer[lx].H >> 2;
             if (bx < nt) break;
             bx -= nt;
         }
         if (lx >= 1) {
-            const StackLayer ly = stack_layer(a, lx), lower = stack_layer(a, lx - 1);
+            const StackLayer &ly = a.layer[lx];
             const int t = s - (2 * lx - 1);
             if (t < 0 || t >= a.T) return;
             const int H = ly.H, nhh = H >> 4, nhx = ly.a_skip;
@@ -88,7 +79,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
             const int unit = tile * 4 + quarter;
             for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
                 const long so = a.train ? t + 1 : (t & 1);
-                const float4 *xseg = lower.hbuf + (so * a.RB + rb) * ((long)lower.H * 8);
+                const float4 *xseg = a.layer[lx - 1].hbuf + (so * a.RB + rb) * ((long)a.layer[lx - 1].H * 8);
                 gemm16_rb(a0, A, xseg, nhx, xseg, ks, part, s, a.B - rb * 32 > 16);
                 __syncthreads();
                 if (tid < 128)
@@ -101,7 +92,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         }
     }
     if (l >= 0) {
-        const StackLayer ly = stack_layer(a, l);
+        const StackLayer &ly = a.layer[l];
         const int t = s - 2 * l;
         if (t < 0 || t >= a.T) return;
         const int H = ly.H, nhh = H >> 4, nhx = ly.nhx;
@@ -139,7 +130,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         // head: predictions_layer (learned_models.py:101,113 / 137,148 / 172,195)
         const int t = s - (2 * a.L - 1);
         if (t < 0 || t >= a.T) return;
-        const StackLayer ly = stack_layer(a, a.L - 1);
+        const StackLayer &ly = a.layer[a.L - 1];
         const int nh = ly.H >> 4;
         const KSlice ks = wave_slice(nh);
         load_a_chunk(a0, a.headA, ks.q0, ks.q1);
