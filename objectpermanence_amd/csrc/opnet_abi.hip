@@ -835,6 +835,13 @@ static int check_stack(int B, int T, int L, int KX, int H)
 // ("hoisting") and the steps walk only W_hh.
 static bool stack_hoists_input(int KX, int H) { return (KX & 15) == 0 && KX >= 2 * H; }
 
+typedef void (*stack_step_fn)(const StackArgs, const int);
+static stack_step_fn stack_step_kernel(int RB)
+{
+    const char *force = getenv("OPNET_STEP_CH");          // "4" / "8": measurement override
+    return (force ? atoi(force) == 4 : RB >= 2) ? lstm_stack_step<4> : lstm_stack_step<8>;
+}
+
 struct StackPackedLayout { size_t layer[SEQ_MAX_LAYERS], head, wih0g, total; int nhx[SEQ_MAX_LAYERS]; };
 
 static StackPackedLayout stack_packed_layout(int L, int KX, int H)
@@ -1013,7 +1020,8 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
     }
     const dim3 grid(ntiles, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
     if (!graph) {
-        for (int s = 0; s < nlaunch; ++s) lstm_stack_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+        const stack_step_fn stepk = stack_step_kernel(RB);
+        for (int s = 0; s < nlaunch; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     } else {
         StackGraphKey key;
         memset(&key, 0, sizeof(key));
@@ -1034,7 +1042,7 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
                 void *args[] = {(void *)&av, (void *)&step};
                 hipKernelNodeParams kp;
                 memset(&kp, 0, sizeof(kp));
-                kp.func = (void *)lstm_stack_step;
+                kp.func = (void *)stack_step_kernel(RB);
                 kp.gridDim = grid;
                 kp.blockDim = dim3(OPNET_THREADS, 1, 1);
                 kp.kernelParams = args;
@@ -1229,7 +1237,8 @@ extern "C" int opseq_lstm_stack_train_forward_f32(const float *x, const float *p
         a.layer[0].nhx = 0;
     }
     const dim3 grid((2 * L - 1) * (H / 4) + 1, a.RB < OPNET_MAX_GY ? a.RB : OPNET_MAX_GY, 1);
-    for (int s = 0; s < T + 2 * L - 1; ++s) lstm_stack_step<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    const stack_step_fn stepk = stack_step_kernel(a.RB);
+    for (int s = 0; s < T + 2 * L - 1; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     const long ny = (long)B * T;
     copy_y_out<<<(unsigned)((ny + 255) / 256 > 1024 ? 1024 : (ny + 255) / 256), 256, 0, st>>>(a.ystage, (float4 *)y, ny);
     HIP_TRY(hipGetLastError());

@@ -44,13 +44,14 @@ struct StackArgs {
 // grid.x = L * H/4 recurrent tiles + (L-1) * H/4 x-projection tiles + 1 ; grid.y <= RB.
 // Launch s: layer l's recurrent role runs step t = s - 2l, its x-projection role (l >= 1) step t = s - (2l - 1) -
 // one launch after layer l-1 produced h_t, one before the recurrent role consumes it - and the head t = s - (2L - 1).
+template <int CH>      // register chunk, see load_a_chunk: 8 for one row block, 4 (3 waves per SIMD) above
 __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs a, const int s)
 {
     __shared__ __attribute__((aligned(16))) float part[OPNET_NW * 8 * 64];
     const int tid = threadIdx.x;
     const int el = tid & 63, half = tid >> 6;
     const int clip = half * 16 + (el & 15), quarter = el >> 4;
-    float4 a0[OPNET_CH];
+    float4 a0[CH];
 
     int bx = blockIdx.x;
     int l = 0;

@@ -16,7 +16,7 @@ def bench(name, cfg, pf, B, feat, n=5):
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print(f"{name} B={B}: {dt*1e3:.3f} ms/forward  {B/dt:.0f} clips/s", flush=True)
 tcfg = {"boxes_features_dim": 256, "num_attention_heads": 2, "num_attention_layers": 2, "num_lstm_layers": 2, "lstm_hidden_dim": 512}
-for B in (1, 4, 16, 32): bench("transformer_lstm", tcfg, synth.transformer_lstm_synth_params, B, 5)
+for B in (1, 4, 16, 32, 64): bench("transformer_lstm", tcfg, synth.transformer_lstm_synth_params, B, 5)
 t4 = dict(tcfg); t4["num_attention_heads"] = 4
 bench("transformer_lstm", t4, synth.transformer_lstm_synth_params, 1, 5)
 bench("baseline_lstm", {"videos_hidden_dim": 512}, synth.baseline_lstm_synth_params, 32, 5)
