@@ -36,26 +36,30 @@ MAX_OBJECTS = 15
 FRAME_SHAPES = np.array([320, 240, 320, 240], dtype=np.float64)
 
 
-def slot_order(labels: List[np.ndarray]) -> List[int]:
-    ids = set()
-    for frame in labels:
-        ids.update(int(v) for v in np.asarray(frame).reshape(-1))
-    rest = sorted(i for i in ids if i != SNITCH_INDEX)
-    return ([SNITCH_INDEX] if SNITCH_INDEX in ids else []) + rest
+def _flat_ids(labels: List[np.ndarray]) -> np.ndarray:
+    """all detection ids of a clip in frame order (one concatenate; frames may be arrays, lists or empty)"""
+    parts = [np.asarray(l, dtype=np.int64).reshape(-1) for l in labels]
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+
+
+def slot_order(labels: List[np.ndarray], all_ids: np.ndarray = None) -> List[int]:
+    ids = np.unique(_flat_ids(labels) if all_ids is None else all_ids).tolist()
+    rest = [i for i in ids if i != SNITCH_INDEX]                      # np.unique sorts
+    return ([SNITCH_INDEX] if len(rest) != len(ids) else []) + rest
 
 
 def encode_boxes(bb: List[np.ndarray], labels: List[np.ndarray], n_tracks: int = 6) -> np.ndarray:
     """-> float64 [T, 15, n_tracks] normalised boxes (cast to float32 by the caller, like the reference)."""
     T = len(labels)
-    order = slot_order(labels)[:MAX_OBJECTS]
+    all_ids = _flat_ids(labels)
+    order = slot_order(labels, all_ids)[:MAX_OBJECTS]
     out = np.zeros((T, MAX_OBJECTS, n_tracks), dtype=np.float64)
     if n_tracks == 6:
         for s, oid in enumerate(order):
             out[:, s, 5] = 1.0 if oid in CONE_IDS else 0.0        # a cone slot carries its cone bit even when empty
-    counts = np.array([len(l) for l in labels], dtype=np.int64)
-    if counts.sum() > 0:
-        all_ids = np.concatenate([np.asarray(l, dtype=np.int64).reshape(-1) for l in labels])
-        all_bb = np.concatenate([np.asarray(b, dtype=np.float64).reshape(-1, 4) for b, n in zip(bb, counts) if n > 0])
+    counts = np.fromiter((len(l) for l in labels), dtype=np.int64, count=T)
+    if len(all_ids) > 0:
+        all_bb = np.concatenate([b for b, n in zip(bb, counts) if n > 0], axis=None).astype(np.float64).reshape(-1, 4)
         frame = np.repeat(np.arange(T, dtype=np.int64), counts)
         lut = np.full(max(int(all_ids.max()) + 1, SNITCH_INDEX + 1), -1, dtype=np.int64)
         for s, oid in enumerate(order):
@@ -79,13 +83,11 @@ def encode_boxes(bb: List[np.ndarray], labels: List[np.ndarray], n_tracks: int =
     return out
 
 
-def _center(box: np.ndarray) -> np.ndarray:
-    return np.array([(box[0] + box[2]) / 2, (box[1] + box[3]) / 2])
-
-
-def _closest(frame_boxes: np.ndarray, last_location: np.ndarray) -> int:
-    centers = np.stack([(frame_boxes[:, 0] + frame_boxes[:, 2]) / 2, (frame_boxes[:, 1] + frame_boxes[:, 3]) / 2], axis=1)
-    return int(np.argmin(np.linalg.norm(centers - _center(last_location), axis=1)))
+def _closest(frame_centers: np.ndarray, last_location: np.ndarray) -> int:
+    """slot whose box centre is nearest to the centre of `last_location` (argmin of the Euclidean norm, as
+    datasets.py:186-196; the centres of every frame are computed once per clip)"""
+    d = frame_centers - np.array([(last_location[0] + last_location[2]) / 2, (last_location[1] + last_location[3]) / 2])
+    return int(np.argmin(np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])))
 
 
 def index_to_track(boxes: np.ndarray) -> List[int]:
@@ -96,17 +98,20 @@ def index_to_track(boxes: np.ndarray) -> List[int]:
     stack: List[int] = []
     last = np.zeros(boxes.shape[2])
     cur = 0
-    for fb in boxes:
-        if fb[0, 4]:
+    centers = np.stack([(boxes[:, :, 0] + boxes[:, :, 2]) / 2, (boxes[:, :, 1] + boxes[:, :, 3]) / 2], axis=2)
+    vis = boxes[:, :, 4] != 0
+    cone = boxes[:, :, 5] != 0 if six else None
+    for t, fb in enumerate(boxes):
+        if vis[t, 0]:
             out.append(0); last = fb[0]; cur = 0; stack = []
         elif cur == 0:
-            c = _closest(fb, last)
+            c = _closest(centers[t], last)
             if six and not fb[c, 5]:
                 out.append(0)                                      # occlusion by a non-cone: keep the snitch
             else:
                 out.append(c); last = fb[c]; cur = c; stack.append(0)
         elif not fb[cur, 4]:
-            c = _closest(fb, last)
+            c = _closest(centers[t], last)
             if six and not fb[c, 5]:
                 out.append(cur)
             else:
