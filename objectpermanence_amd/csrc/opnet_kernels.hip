@@ -197,17 +197,32 @@ __device__ __forceinline__ KSlice wave_slice(int nhex)
 // CH = hexadecets of a register chunk, deduced from the caller's fragment array.  8 covers a wave's whole K slice of the
 // OPNet roles in one fetch round trip (best at B <= 32); 4 keeps the step kernel at 140 instead of 204 VGPRs, i.e. 3
 // resident waves per SIMD - which wins once several row blocks make the launch compute-bound (B >= 64).
+// Fragment loads go through buffer descriptors: the wave-uniform part of every address (tile base, hexadecet) rides in
+// SGPRs (descriptor + soffset) and ONE VGPR holds the lane's byte offset, instead of a 64-bit VGPR address pair per
+// load that the compiler precomputes - and keeps live - for each of the up to 24 loads of a chunk.
+typedef unsigned opnet_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frag_rsrc(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffffu, 0x00020000);
+}
+__device__ __forceinline__ float4 frag_load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const opnet_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 template <int CH>
 __device__ __forceinline__ void load_a_chunk(float4 (&a)[CH], const float4 *__restrict__ A, int qb, int q1)
 {
     const int lane = threadIdx.x & 63;
+    const __amdgpu_buffer_rsrc_t ra = frag_rsrc(A);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
         if (qb + j < q1) {
 #if (defined(OPNET_TRACE) && OPNET_VARIANT == 2) || defined(OPNET_ABLATE_A)   /* probe: no weight loads */
             a[j] = make_float4(1.f, 2.f, 3.f, (float)(qb + j));
 #else
-            a[j] = A[(qb + j) * 64 + lane];
+            a[j] = frag_load(ra, lane * 16, (qb + j) * 1024);
 #endif
         }
     }
@@ -221,19 +236,21 @@ __device__ __forceinline__ void mma_chunk(const float4 (&a)[CH], const float4 *_
                                           f32x4 &acc0, f32x4 &acc1, const int s, const bool two_halves)
 {
     const int lane = threadIdx.x & 63;
-    const int boff = (lane >> 4) * 32 + (lane & 15);
+    const int boff = ((lane >> 4) * 32 + (lane & 15)) * 16;
+    const __amdgpu_buffer_rsrc_t r0 = frag_rsrc(seg0), r1 = frag_rsrc(seg1);
     float4 b0[CH], b1[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
         const int q = qb + j;
         if (q < q1) {  // wave-uniform
-            const float4 *src = (q < nh0) ? (seg0 + q * 128) : (seg1 + (q - nh0) * 128);
+            const bool first = q < nh0;
+            const int soff = (first ? q : q - nh0) * 2048;
 #if (defined(OPNET_TRACE) && OPNET_VARIANT == 1) || defined(OPNET_ABLATE_B)   /* probe: no activation loads */
             b0[j] = make_float4(1.f, 2.f, 3.f, (float)q);
             b1[j] = make_float4(1.f, 2.f, 3.f, (float)lane);
 #else
-            b0[j] = src[boff];
-            if (two_halves) b1[j] = src[boff + 16];
+            b0[j] = first ? frag_load(r0, boff, soff) : frag_load(r1, boff, soff);
+            if (two_halves) b1[j] = first ? frag_load(r0, boff + 256, soff) : frag_load(r1, boff + 256, soff);
 #endif
         }
     }
@@ -275,21 +292,28 @@ __device__ __forceinline__ void mma_chunk(const float4 (&a)[CH], const float4 *_
     }
 }
 
-// One row block.  `a0` holds the wave's first A chunk already (loaded by the caller, possibly for
-// an earlier row block); further chunks - only when the K slice exceeds CH - are reloaded here.
+// One row block.  `a0` holds the A chunk that starts at hexadecet `a_qb` (the caller loads the wave's first chunk
+// before its row-block loop).  When the K slice fits one chunk the weights simply stay in `a0` across row blocks; when
+// it does not, the further chunks are streamed through the SAME registers (and the first one is fetched again for the
+// next row block) - a second chunk array next to a persistent first one made this rarely-taken path, not the
+// one-chunk path that real OPNet sizes use, set the kernel's register allocation (191 VGPRs).
 template <int CH>
-__device__ __forceinline__ void gemm16_rb(const float4 (&a0)[CH], const float4 *__restrict__ A,
+__device__ __forceinline__ void gemm16_rb(float4 (&a0)[CH], int &a_qb, const float4 *__restrict__ A,
                                           const float4 *__restrict__ seg0, int nh0,
                                           const float4 *__restrict__ seg1, const KSlice ks,
                                           float *__restrict__ part, const int s, const bool two_halves = true)
 {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (a_qb != ks.q0) {  // wave-uniform
+        load_a_chunk(a0, A, ks.q0, ks.q1);
+        a_qb = ks.q0;
+    }
     mma_chunk(a0, seg0, nh0, seg1, ks.q0, ks.q1, acc0, acc1, s, two_halves);
     for (int qb = ks.q0 + CH; qb < ks.q1; qb += CH) {
-        float4 an[CH];
-        load_a_chunk(an, A, qb, ks.q1);
-        mma_chunk(an, seg0, nh0, seg1, qb, ks.q1, acc0, acc1, s, two_halves);
+        load_a_chunk(a0, A, qb, ks.q1);
+        a_qb = qb;
+        mma_chunk(a0, seg0, nh0, seg1, qb, ks.q1, acc0, acc1, s, two_halves);
     }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -391,13 +415,12 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
         const KSlice ks = wave_slice(nh);
         const float4 *A = a.w2p + (long)tile * nh * 64;
         if (!a.mlp) load_a_chunk(a0, A, ks.q0, ks.q1);
+        int a_qb = ks.q0;
         const int unit = tile * 4 + quarter;
-        float4 wv[8];
-        if (tid < 128) {
-            const float4 *wi = a.wih2p + (long)unit * 8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) wv[j] = wi[j];
-        }
+        // the tile's 4 units x 4 gates x 8 input weights (512 B) wait in LDS for the epilogue instead of in 32
+        // registers of every lane across the MFMA phase
+        float4 *wl = (float4 *)lg;
+        if (tid < 32) wl[tid] = a.wih2p[(long)tile * 32 + tid];
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
             const float4 *hprev = a.h2buf + (slot_prev(a, t) * a.RB + rb) * (H2 * 8);
             // epilogue operands are fetched before the MFMA phase so their latency hides under it
@@ -413,18 +436,19 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
                 // hidden = relu(hidden_layer(frames_boxes)) (learned_models.py:83): no recurrence, the
                 // weight rows sit in the "gate 0" slot of the packed x-part
                 if (tid < 128) {
-                    float xs = wv[0].x * xa.x;
-                    xs = fmaf(wv[0].y, xa.y, xs);
-                    xs = fmaf(wv[0].z, xa.z, xs);
-                    xs = fmaf(wv[0].w, xa.w, xs);
-                    xs = fmaf(wv[1].x, xb.x, xs);
-                    xs = fmaf(wv[1].y, xb.y, xs);
+                    const float4 w0 = a.wih2p[(long)unit * 8], w1 = a.wih2p[(long)unit * 8 + 1];
+                    float xs = w0.x * xa.x;
+                    xs = fmaf(w0.y, xa.y, xs);
+                    xs = fmaf(w0.z, xa.z, xs);
+                    xs = fmaf(w0.w, xa.w, xs);
+                    xs = fmaf(w1.x, xb.x, xs);
+                    xs = fmaf(w1.y, xb.y, xs);
                     float *hout = (float *)(a.h2buf + (slot_out(a, t) * a.RB + rb) * (H2 * 8));
                     hout[((long)tile * 32 + clip) * 4 + quarter] = fmaxf(xs, 0.f);
                 }
                 continue;
             }
-            gemm16_rb(a0, A, hprev, nh, hprev, ks, part, s, a.B - rb * 32 > 16);
+            gemm16_rb(a0, a_qb, A, hprev, nh, hprev, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             TRACE_STAMP(4);
             if (tid < 128) {
@@ -432,12 +456,13 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // x part: W_ih2[gate r, unit][0..5] . frames_boxes[clip][0..5]
-                    float xs = wv[2 * r].x * xa.x;
-                    xs = fmaf(wv[2 * r].y, xa.y, xs);
-                    xs = fmaf(wv[2 * r].z, xa.z, xs);
-                    xs = fmaf(wv[2 * r].w, xa.w, xs);
-                    xs = fmaf(wv[2 * r + 1].x, xb.x, xs);
-                    xs = fmaf(wv[2 * r + 1].y, xb.y, xs);
+                    const float4 w0 = wl[quarter * 8 + 2 * r], w1 = wl[quarter * 8 + 2 * r + 1];
+                    float xs = w0.x * xa.x;
+                    xs = fmaf(w0.y, xa.y, xs);
+                    xs = fmaf(w0.z, xa.z, xs);
+                    xs = fmaf(w0.w, xa.w, xs);
+                    xs = fmaf(w1.x, xb.x, xs);
+                    xs = fmaf(w1.y, xb.y, xs);
                     g[r] = part_sum(part, half * 4 + r, el) + xs;
                 }
                 float c = c_old;
@@ -459,13 +484,14 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
         const KSlice ks = wave_slice(OPNET_KXQ / 4 + nhh);
         const float4 *A = a.w1p + (long)tile * (OPNET_KXQ / 4 + nhh) * 64;
         load_a_chunk(a0, A, ks.q0, ks.q1);
+        int a_qb = ks.q0;
         const int unit = tile * 4 + quarter;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
             const float4 *xsrc = a.xp + ((long)t * a.RB + rb) * (OPNET_KXQ * 32);
             const float4 *hprev = a.h1buf + (slot_prev(a, t) * a.RB + rb) * (H1 * 8);
             float c_old = 0.f;
             if (tid < 128) c_old = a.c1[((cslot_prev(a, t) * a.RB + rb) * H1 + unit) * 32 + clip];
-            gemm16_rb(a0, A, xsrc, OPNET_KXQ / 4, hprev, ks, part, s, a.B - rb * 32 > 16);
+            gemm16_rb(a0, a_qb, A, xsrc, OPNET_KXQ / 4, hprev, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             TRACE_STAMP(4);
             if (tid < 128) {
@@ -487,6 +513,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
         const int nh = H1 >> 4;
         const KSlice ks = wave_slice(nh);
         load_a_chunk(a0, a.wselp, ks.q0, ks.q1);
+        int a_qb = ks.q0;
         const int mc = tid >> 3, mf = tid & 7;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
             const float4 *hcur = a.h1buf + (slot_out(a, t) * a.RB + rb) * (H1 * 8);
@@ -501,7 +528,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
                     bxv[o] = xs[((k >> 2) * 32 + mc) * 4 + (k & 3)];
                 }
             }
-            gemm16_rb(a0, a.wselp, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
+            gemm16_rb(a0, a_qb, a.wselp, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             TRACE_STAMP(4);
             if (tid < 128) {
@@ -554,9 +581,10 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
         const int nh = H2 >> 4;
         const KSlice ks = wave_slice(nh);
         load_a_chunk(a0, a.woutp, ks.q0, ks.q1);
+        int a_qb = ks.q0;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
             const float4 *hcur = a.h2buf + (slot_out(a, t) * a.RB + rb) * (H2 * 8);
-            gemm16_rb(a0, a.woutp, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
+            gemm16_rb(a0, a_qb, a.woutp, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             TRACE_STAMP(4);
             if (tid < 128 && quarter == 0) {

@@ -142,10 +142,11 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_bwd_gemm(const BwdArgs a,
     const int nh = H >> 4;  // hexadecets in this K quarter ( (4H/16) / 4 )
     const KSlice ksl = wave_slice(nh);
     load_a_chunk(a0, A, ksl.q0, ksl.q1);
+    int a_qb = ksl.q0;
     for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
         // da_t as a kq-major activation segment: kq = unit, this quarter starts at unit ks*H/4
         const float4 *seg = da + (((long)t * a.RB + rb) * H + (long)ks * (H >> 2)) * 32;
-        gemm16_rb(a0, A, seg, nh, seg, ksl, part, s);
+        gemm16_rb(a0, a_qb, A, seg, nh, seg, ksl, part, s);
         __syncthreads();
         if (tid < 128) {
 #pragma unroll

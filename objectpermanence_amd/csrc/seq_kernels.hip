@@ -77,11 +77,12 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
             const KSlice ks = wave_slice(nhx);
             const float4 *A = ly.A + (long)tile * (nhx + nhh) * 64;           // the x part leads every tile
             load_a_chunk(a0, A, ks.q0, ks.q1);
+            int a_qb = ks.q0;
             const int unit = tile * 4 + quarter;
             for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
                 const long so = a.train ? t + 1 : (t & 1);
                 const float4 *xseg = a.layer[lx - 1].hbuf + (so * a.RB + rb) * ((long)a.layer[lx - 1].H * 8);
-                gemm16_rb(a0, A, xseg, nhx, xseg, ks, part, s, a.B - rb * 32 > 16);
+                gemm16_rb(a0, a_qb, A, xseg, nhx, xseg, ks, part, s, a.B - rb * 32 > 16);
                 __syncthreads();
                 if (tid < 128)
                     ly.xg[(((long)t * a.RB + rb) * H + unit) * 32 + clip] =
@@ -101,6 +102,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         const KSlice ks = wave_slice(nhx + nhh);
         const float4 *A = ly.A + ((long)tile * (ly.a_skip + nhx + nhh) + ly.a_skip) * 64;
         load_a_chunk(a0, A, ks.q0, ks.q1);
+        int a_qb = ks.q0;
         const int unit = tile * 4 + quarter;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
             const long so = a.train ? t + 1 : (t & 1), sp = a.train ? t : ((t + 1) & 1);   // history slots
@@ -113,7 +115,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
                 c_old = ly.c[((cp * a.RB + rb) * H + unit) * 32 + clip];
                 if (ly.xg) xg = ly.xg[(((long)t * a.RB + rb) * H + unit) * 32 + clip];
             }
-            gemm16_rb(a0, A, xseg, nhx, hprev, ks, part, s, a.B - rb * 32 > 16);
+            gemm16_rb(a0, a_qb, A, xseg, nhx, hprev, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             if (tid < 128) {
                 float c = c_old;
@@ -135,9 +137,10 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         const int nh = ly.H >> 4;
         const KSlice ks = wave_slice(nh);
         load_a_chunk(a0, a.headA, ks.q0, ks.q1);
+        int a_qb = ks.q0;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
             const float4 *hcur = ly.hbuf + ((a.train ? t + 1 : (long)(t & 1)) * a.RB + rb) * ((long)ly.H * 8);
-            gemm16_rb(a0, a.headA, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
+            gemm16_rb(a0, a_qb, a.headA, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
             __syncthreads();
             if (tid < 128 && quarter == 0) {
                 const long b = rb * 32 + clip;
@@ -268,9 +271,10 @@ __global__ void __launch_bounds__(OPNET_THREADS) stack_bwd_gemm(const StackBwdAr
     const int nh = H >> 4;
     const KSlice ksl = wave_slice(nh);
     load_a_chunk(a0, A, ksl.q0, ksl.q1);
+    int a_qb = ksl.q0;
     for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
         const float4 *seg = ly.g + (((long)t * a.RB + rb) * H + (long)ks * (H >> 2)) * 32;
-        gemm16_rb(a0, A, seg, nh, seg, ksl, part, s, a.B - rb * 32 > 16);
+        gemm16_rb(a0, a_qb, A, seg, nh, seg, ksl, part, s, a.B - rb * 32 > 16);
         __syncthreads();
         if (tid < 128) {
 #pragma unroll
