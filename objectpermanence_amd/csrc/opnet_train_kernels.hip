@@ -303,15 +303,16 @@ __device__ __forceinline__ float fused_product(const float4 *__restrict__ A, con
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q0 = (w * nq) / FUSED_NW, q1 = ((w + 1) * nq) / FUSED_NW;
-    const int boff = (lane >> 4) * 32 + (lane & 15) + 16 * hf;
+    const int boff = ((lane >> 4) * 32 + (lane & 15) + 16 * hf) * 16;
+    const __amdgpu_buffer_rsrc_t ra = frag_rsrc(A), rs = frag_rsrc(seg);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     for (int qb = q0; qb < q1; qb += FUSED_CH) {
         float4 fa[FUSED_CH], fb[FUSED_CH];
 #pragma unroll
         for (int j = 0; j < FUSED_CH; ++j)
             if (qb + j < q1) {
-                fa[j] = A[(qb + j) * 64 + lane];
-                fb[j] = seg[(qb + j) * 128 + boff];
+                fa[j] = frag_load(ra, lane * 16, (qb + j) * 1024);
+                fb[j] = frag_load(rs, boff, (qb + j) * 2048);
             }
 #pragma unroll
         for (int j = 0; j < FUSED_CH; j += 2) {
@@ -347,6 +348,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) opnet_bwd_fused(const BwdArgs a
 {
     __shared__ __attribute__((aligned(16))) float part[FUSED_NW * 4 * 64];
     __shared__ float dxs[OPNET_FEATS_][16];
+    __shared__ float dps[16][16], pss[16][16], dots[16];
     const int T = a.T, H1 = a.H1, H2 = a.H2;
     const int n2 = 2 * (H2 >> 4), n1 = 2 * (H1 >> 4);
     const int bx = blockIdx.x, tid = threadIdx.x;
@@ -359,25 +361,32 @@ __global__ void __launch_bounds__(FUSED_THREADS) opnet_bwd_fused(const BwdArgs a
         const int tile = bx >> 1, hf = bx & 1;
         const int u = tile * 16 + row, clip = hf * 16 + cl;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            // the cell backward's operands are fetched before the product so their latency hides under it
+            const long e = ((long)rb * H2 + u) * 32 + clip;
+            const long ge = (((long)t * a.RB + rb) * H2 + u) * 32 + clip;
+            float4 dy, gs;
+            float wo0, wo1, wo2, wo3, dcc = 0.f, c_t, c_p;
+            if (owner) {
+                dy = a.dyp[((long)t * a.RB + rb) * 32 + clip];
+                wo0 = a.wout[u]; wo1 = a.wout[H2 + u]; wo2 = a.wout[2 * H2 + u]; wo3 = a.wout[3 * H2 + u];
+                if (t < T - 1) dcc = a.dc2[e];
+                gs = a.g2[ge];
+                c_t = a.c2all[(((long)(t + 1)) * a.RB + rb) * H2 * 32 + (long)u * 32 + clip];
+                c_p = a.c2all[((long)t * a.RB + rb) * H2 * 32 + (long)u * 32 + clip];
+            }
             float rec = 0.f;
             if (t < T - 1)
                 rec = fused_product(a.w2bt + (long)tile * (H2 >> 2) * 64, a.g2 + (((long)(t + 1)) * a.RB + rb) * H2 * 32,
                                     H2 >> 2, hf, part);
             if (owner) {
                 // upstream: prediction_layer (learned_models.py:47): dh += W_out^T dy_t
-                const float4 dy = a.dyp[((long)t * a.RB + rb) * 32 + clip];
-                float dh = a.wout[u] * dy.x;
-                dh = fmaf(a.wout[H2 + u], dy.y, dh);
-                dh = fmaf(a.wout[2 * H2 + u], dy.z, dh);
-                dh = fmaf(a.wout[3 * H2 + u], dy.w, dh);
+                float dh = wo0 * dy.x;
+                dh = fmaf(wo1, dy.y, dh);
+                dh = fmaf(wo2, dy.z, dh);
+                dh = fmaf(wo3, dy.w, dh);
                 dh += rec;
-                const long e = ((long)rb * H2 + u) * 32 + clip;
-                const float dcc = t < T - 1 ? a.dc2[e] : 0.f;
-                const long ge = (((long)t * a.RB + rb) * H2 + u) * 32 + clip;
-                const float c_t = a.c2all[(((long)(t + 1)) * a.RB + rb) * H2 * 32 + (long)u * 32 + clip];
-                const float c_p = a.c2all[((long)t * a.RB + rb) * H2 * 32 + (long)u * 32 + clip];
                 float dco;
-                a.g2[ge] = cell_backward(dh, dcc, a.g2[ge], c_t, c_p, &dco);
+                a.g2[ge] = cell_backward(dh, dcc, gs, c_t, c_p, &dco);
                 a.dc2[e] = dco;
             }
             if (rb + (int)gridDim.y < a.RB) __syncthreads();
@@ -386,44 +395,45 @@ __global__ void __launch_bounds__(FUSED_THREADS) opnet_bwd_fused(const BwdArgs a
         // ---------------- d frames_boxes = W_ih2^T da2_t, then einsum / softmax backward, t = T-n ----------------
         const int t = T - n;
         if (t < 0 || t >= T) return;
-        const int hf = bx - n2, clip = hf * 16 + cl;
+        const int hf = bx - n2;
+        // thread (slot o = tid >> 4, clip c = tid & 15) of the first 256 owns one logit gradient; its operands are
+        // fetched before the product (the serial 16-thread version of this epilogue was the tail of the launch)
+        const int o = (tid >> 4) & 15, c = hf * 16 + cl;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            float xv[OPNET_FEATS_], pv = 0.f;
+            if (owner && o < OPNET_SLOTS_) {
+                const float *xs = (const float *)(a.xp + ((long)t * a.RB + rb) * (OPNET_KXQ * 32));
+                pv = ((const float *)(a.psave + ((long)t * a.RB + rb) * 128))[((o >> 2) * 32 + c) * 4 + (o & 3)];
+#pragma unroll
+                for (int f = 0; f < OPNET_FEATS_; ++f) {
+                    const int k = o * OPNET_FEATS_ + f;
+                    xv[f] = xs[((k >> 2) * 32 + c) * 4 + (k & 3)];
+                }
+            }
             const float dx = fused_product(a.wih2t, a.g2 + ((long)t * a.RB + rb) * H2 * 32, H2 >> 2, hf, part);
             if (owner && row < OPNET_FEATS_) dxs[row][cl] = dx;
             __syncthreads();
-            if (tid < 16) {
-                // einsum backward: dp[o] = sum_f boxes[o][f] dx[f]; softmax backward: dl = p * (dp - <p, dp>)
-                const int c = hf * 16 + tid;
-                const float *xs = (const float *)(a.xp + ((long)t * a.RB + rb) * (OPNET_KXQ * 32));
-                const float4 *pp = a.psave + ((long)t * a.RB + rb) * 128 + c;
-                float p[16], dp[16];
+            // einsum backward: dp[o] = sum_f boxes[o][f] dx[f]; softmax backward: dl = p * (dp - <p, dp>)
+            float dp = 0.f;
+            if (owner && o < OPNET_SLOTS_) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = pp[q * 32];
-                    p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
-                }
+                for (int f = 0; f < OPNET_FEATS_; ++f) dp = fmaf(xv[f], dxs[f][cl], dp);
+            }
+            if (owner) { dps[o][cl] = dp; pss[o][cl] = pv; }
+            __syncthreads();
+            if (tid < 16) {
                 float dot = 0.f;
 #pragma unroll
-                for (int o = 0; o < OPNET_SLOTS_; ++o) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int f = 0; f < OPNET_FEATS_; ++f) {
-                        const int k = o * OPNET_FEATS_ + f;
-                        acc = fmaf(xs[((k >> 2) * 32 + c) * 4 + (k & 3)], dxs[f][tid], acc);
-                    }
-                    dp[o] = acc;
-                    dot = fmaf(p[o], acc, dot);
-                }
-                float dl[16];
-#pragma unroll
-                for (int o = 0; o < 16; ++o) dl[o] = o < OPNET_SLOTS_ ? p[o] * (dp[o] - dot) : 0.f;
-                float4 *dst = a.dlall + ((long)t * a.RB + rb) * 128 + c;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dst[q * 32] = make_float4(dl[4 * q], dl[4 * q + 1], dl[4 * q + 2], dl[4 * q + 3]);
+                for (int q = 0; q < OPNET_SLOTS_; ++q) dot = fmaf(pss[q][tid], dps[q][tid], dot);
+                dots[tid] = dot;
+            }
+            __syncthreads();
+            if (owner) {
+                float *dst = (float *)(a.dlall + ((long)t * a.RB + rb) * 128);
+                dst[((o >> 2) * 32 + c) * 4 + (o & 3)] = o < OPNET_SLOTS_ ? pv * (dp - dots[cl]) : 0.f;
             }
             if (rb + (int)gridDim.y < a.RB) __syncthreads();
         }
-        (void)clip;
     } else {
         // ---------------- LSTM1 at t = T+1-n ----------------
         const int t = T + 1 - n;
@@ -432,30 +442,39 @@ __global__ void __launch_bounds__(FUSED_THREADS) opnet_bwd_fused(const BwdArgs a
         const int tile = b1 >> 1, hf = b1 & 1;
         const int u = tile * 16 + row, clip = hf * 16 + cl;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            const long e = ((long)rb * H1 + u) * 32 + clip;
+            const long ge = (((long)t * a.RB + rb) * H1 + u) * 32 + clip;
+            float4 dlv[4], gs;
+            float ws[16], dcc = 0.f, c_t, c_p;
+            if (owner) {
+                const float4 *dlp = a.dlall + ((long)t * a.RB + rb) * 128 + clip;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dlv[q] = dlp[q * 32];
+#pragma unroll
+                for (int o = 0; o < OPNET_SLOTS_; ++o) ws[o] = a.wsel[o * H1 + u];
+                if (t < T - 1) dcc = a.dc1[e];
+                gs = a.g1[ge];
+                c_t = a.c1all[(((long)(t + 1)) * a.RB + rb) * H1 * 32 + (long)u * 32 + clip];
+                c_p = a.c1all[((long)t * a.RB + rb) * H1 * 32 + (long)u * 32 + clip];
+            }
             float rec = 0.f;
             if (t < T - 1)
                 rec = fused_product(a.w1bt + (long)tile * (H1 >> 2) * 64, a.g1 + (((long)(t + 1)) * a.RB + rb) * H1 * 32,
                                     H1 >> 2, hf, part);
             if (owner) {
                 // upstream: object_to_track_prediction (learned_models.py:40): dh += W_sel^T dl_t
-                const float4 *dlp = a.dlall + ((long)t * a.RB + rb) * 128 + clip;
                 float dh = 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 v = dlp[q * 32];
-                    dh = fmaf(a.wsel[(4 * q) * H1 + u], v.x, dh);
-                    dh = fmaf(a.wsel[(4 * q + 1) * H1 + u], v.y, dh);
-                    dh = fmaf(a.wsel[(4 * q + 2) * H1 + u], v.z, dh);
-                    if (4 * q + 3 < OPNET_SLOTS_) dh = fmaf(a.wsel[(4 * q + 3) * H1 + u], v.w, dh);
+                    const float4 v = dlv[q];
+                    dh = fmaf(ws[4 * q], v.x, dh);
+                    dh = fmaf(ws[4 * q + 1], v.y, dh);
+                    dh = fmaf(ws[4 * q + 2], v.z, dh);
+                    if (4 * q + 3 < OPNET_SLOTS_) dh = fmaf(ws[4 * q + 3], v.w, dh);
                 }
                 dh += rec;
-                const long e = ((long)rb * H1 + u) * 32 + clip;
-                const float dcc = t < T - 1 ? a.dc1[e] : 0.f;
-                const long ge = (((long)t * a.RB + rb) * H1 + u) * 32 + clip;
-                const float c_t = a.c1all[(((long)(t + 1)) * a.RB + rb) * H1 * 32 + (long)u * 32 + clip];
-                const float c_p = a.c1all[((long)t * a.RB + rb) * H1 * 32 + (long)u * 32 + clip];
                 float dco;
-                a.g1[ge] = cell_backward(dh, dcc, a.g1[ge], c_t, c_p, &dco);
+                a.g1[ge] = cell_backward(dh, dcc, gs, c_t, c_p, &dco);
                 a.dc1[e] = dco;
             }
             if (rb + (int)gridDim.y < a.RB) __syncthreads();
