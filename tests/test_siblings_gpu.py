@@ -68,12 +68,16 @@ def test_transformer_batch_coupling_and_ragged_vs_oracle():
     assert np.abs(y_single[0] - y[0]).max() > 1e-3      # clip 0 alone != clip 0 in the batch (reference quirk)
 
 
-@pytest.mark.parametrize("name,B,T", [("baseline_lstm", 33, 9), ("non_linear_lstm", 5, 4), ("opnet_lstm_mlp", 40, 7)])
+@pytest.mark.parametrize("name,B,T", [("baseline_lstm", 33, 9), ("non_linear_lstm", 5, 4), ("opnet_lstm_mlp", 40, 7),
+                                      ("baseline_lstm_wide", 6, 5), ("baseline_lstm_wide", 37, 4)])
 def test_ragged_batches_vs_oracle(name, B, T):
     cfgs = {"baseline_lstm": {"videos_hidden_dim": 512},
+            # a wave's K slice (16 hexadecets) exceeds the register chunk: weight fragments are streamed
+            "baseline_lstm_wide": {"videos_hidden_dim": 1024},
             "non_linear_lstm": {"boxes_features_dim": 32, "videos_hidden_dim": 64},
             "opnet_lstm_mlp": {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}}
     cfg = cfgs[name]
+    name = name.replace("_wide", "")
     boxes, _ = synth.make_batch(300, B, T)
     p = PARAMS[name](cfg)
     if name == "opnet_lstm_mlp":
