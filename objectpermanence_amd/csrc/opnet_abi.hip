@@ -128,12 +128,20 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 extern "C" int opnet_hip_abi_version(void) { return 1; }
 extern "C" const char *opnet_last_error(void) { return g_err; }
 
-// the step kernel comes in two register-chunk sizes (opnet_kernels.hip, load_a_chunk): 8 for one row block, 4 beyond
+// the step kernel comes in two register-chunk sizes (opnet_kernels.hip, load_a_chunk): 8 for one row block, 4 beyond;
+// from OPNET_WIDE_MIN row blocks on, the two-tiles-per-workgroup form (opnet_step_wide) takes over
 typedef void (*opnet_step_fn)(const StepArgs, const int);
-static opnet_step_fn step_kernel(int RB)
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static bool step_is_wide(const StepArgs &a) { return !a.mlp && a.RB >= env_int("OPNET_WIDE_MIN", 4); }
+static opnet_step_fn step_kernel(const StepArgs &a)
 {
     const char *force = getenv("OPNET_STEP_CH");          // "4" / "8": measurement override
-    const bool small_chunks = force ? atoi(force) == 4 : RB >= 2;
+    const bool small_chunks = force ? atoi(force) == 4 : a.RB >= 2;
+    if (step_is_wide(a)) return small_chunks ? opnet_step_wide<4> : opnet_step_wide<8>;
     return small_chunks ? opnet_step<4> : opnet_step<8>;
 }
 
@@ -278,9 +286,13 @@ static int make_args(StepArgs *a, OpnetIO *io, const float *boxes, const float *
 // grid.y: up to OPNET_MAX_GY row blocks side by side (about 3 workgroups a CU at H1=256/H2=512);
 // beyond that a workgroup walks its row blocks with the weights held in registers
 #define OPNET_MAX_GY 4
-static dim3 step_grid(int RB, int H1, int H2)
+static dim3 step_grid(const StepArgs &a)
 {
-    return dim3(H2 / 4 + H1 / 4 + 2, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
+    // the wide form has half the workgroups per row block, so it spreads twice as many row blocks side by side
+    const bool wide = step_is_wide(a);
+    const int gy = env_int("OPNET_MAX_GY", wide ? 2 * OPNET_MAX_GY : OPNET_MAX_GY);
+    const int tiles = wide ? a.H2 / 8 + a.H1 / 8 : a.H2 / 4 + a.H1 / 4;
+    return dim3(tiles + 2, a.RB < gy ? a.RB : gy, 1);
 }
 static dim3 copy_grid(int B, int T)
 {
@@ -301,8 +313,8 @@ extern "C" int opnet_forward_f32(const float *boxes, const float *packed, float 
     OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
-    const dim3 grid = step_grid(a.RB, H1, H2);
-    const opnet_step_fn stepk = step_kernel(a.RB);
+    const dim3 grid = step_grid(a);
+    const opnet_step_fn stepk = step_kernel(a);
     for (int s = 0; s < T + 3; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
@@ -353,8 +365,8 @@ extern "C" int opnet_mlp_forward_f32(const float *boxes, const float *packed, fl
     OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
-    const dim3 grid = step_grid(a.RB, H1, H2);
-    const opnet_step_fn stepk = step_kernel(a.RB);
+    const dim3 grid = step_grid(a);
+    const opnet_step_fn stepk = step_kernel(a);
     for (int s = 0; s < T + 3; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
@@ -427,8 +439,8 @@ static int plan_build(opnet_plan *p, const StepArgs &a, void *ws)
         void *args[] = {(void *)&av, (void *)&step};
         hipKernelNodeParams kp;
         memset(&kp, 0, sizeof(kp));
-        kp.func = (void *)step_kernel(a.RB);
-        kp.gridDim = step_grid(a.RB, p->H1, p->H2);
+        kp.func = (void *)step_kernel(a);
+        kp.gridDim = step_grid(a);
         kp.blockDim = dim3(OPNET_THREADS, 1, 1);
         kp.kernelParams = args;
         HIP_TRY(hipGraphAddKernelNode(&node, p->graph, &prev, 1, &kp));
@@ -626,8 +638,8 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
     OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
-    const dim3 grid = step_grid(a.RB, H1, H2);
-    const opnet_step_fn stepk = step_kernel(a.RB);
+    const dim3 grid = step_grid(a);
+    const opnet_step_fn stepk = step_kernel(a);
     for (int s = 0; s < T + 3; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
@@ -766,8 +778,8 @@ extern "C" int opnet_mlp_train_forward_f32(const float *boxes, const float *pack
     OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
-    const dim3 grid = step_grid(a.RB, H1, H2);
-    const opnet_step_fn stepk = step_kernel(a.RB);
+    const dim3 grid = step_grid(a);
+    const opnet_step_fn stepk = step_kernel(a);
     for (int s = 0; s < T + 3; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());

@@ -378,6 +378,116 @@ __device__ __forceinline__ float lstm_cell_g(float gi, float gf, float gg, float
     return o * fast_tanh(c);
 }
 
+// ---------------- selection head, step t = s-1 (learned_models.py:40-43,50) -------------
+template <int CH>
+__device__ __forceinline__ void role_selection_head(const StepArgs &a, const int s, float *part, float *lg)
+{
+    const int T = a.T, H1 = a.H1;
+    const int tid = threadIdx.x;
+    const int el = tid & 63, half = tid >> 6;
+    const int clip = half * 16 + (el & 15), quarter = el >> 4;
+    float4 a0[CH];
+    const int t = s - 1;
+    if (t < 0 || t >= T) return;
+    const int nh = H1 >> 4;
+    const KSlice ks = wave_slice(nh);
+    load_a_chunk(a0, a.wselp, ks.q0, ks.q1);
+    int a_qb = ks.q0;
+    const int mc = tid >> 3, mf = tid & 7;
+    for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+        const float4 *hcur = a.h1buf + (slot_out(a, t) * a.RB + rb) * (H1 * 8);
+        // this frame's boxes, for the mix below: feature f of slot o of clip c sits at k = 6*o + f
+        // of the packed LSTM1 input.  Issued before the MFMA phase.
+        float bxv[OPNET_SLOTS_];
+        if (tid < 256) {
+            const float *xs = (const float *)(a.xp + ((long)t * a.RB + rb) * (OPNET_KXQ * 32));
+#pragma unroll
+            for (int o = 0; o < OPNET_SLOTS_; ++o) {
+                const int k = o * OPNET_FEATS_ + (mf < OPNET_FEATS_ ? mf : 0);
+                bxv[o] = xs[((k >> 2) * 32 + mc) * 4 + (k & 3)];
+            }
+        }
+        gemm16_rb(a0, a_qb, a.wselp, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
+        __syncthreads();
+        TRACE_STAMP(4);
+        if (tid < 128) {
+            // thread (clip, quarter) holds logits of slots 4*quarter .. +3; the 15-way softmax
+            // (F.softmax(dim=-1), :41) spans the four lanes el, el^16, el^32, el^48
+            const long b = rb * 32 + clip;
+            float v[4];
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int slot = quarter * 4 + r;
+                v[r] = part_sum(part, half * 4 + r, el);
+                // logits [B][15][T] (the permute(0,2,1).contiguous() of :50)
+                if (slot < OPNET_SLOTS_) {
+                    a.lgstage[(b * OPNET_SLOTS_ + slot) * T + t] = v[r];
+                    m = fmaxf(m, v[r]);
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float e[4], sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = (quarter * 4 + r < OPNET_SLOTS_) ? __expf(v[r] - m) : 0.f;
+                sum += e[r];
+            }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            float4 pv = make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv);
+            ((float4 *)lg)[clip * 4 + quarter] = pv;
+            if (a.train) a.psave[(((long)t * a.RB + rb) * 4 + quarter) * 32 + clip] = pv;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            // frames_boxes[clip][f] = sum_o boxes[clip][t][o][f] * p[o]   (einsum "bfot,bfo->bft")
+            float acc = 0.f;
+            const float *p = lg + mc * 16;
+#pragma unroll
+            for (int o = 0; o < OPNET_SLOTS_; ++o) acc = fmaf(bxv[o], p[o], acc);
+            float *x2 = (float *)(a.x2buf + (slot_x2(a, t) * a.RB + rb) * 64);
+            x2[((mf >> 2) * 32 + mc) * 4 + (mf & 3)] = mf < OPNET_FEATS_ ? acc : 0.f;
+        }
+        if (rb + (int)gridDim.y < a.RB) __syncthreads();
+    }
+}
+
+// ---------------- output head, step t = s-3 (prediction_layer, learned_models.py:33,47) --
+template <int CH>
+__device__ __forceinline__ void role_output_head(const StepArgs &a, const int s, float *part)
+{
+    const int T = a.T, H2 = a.H2;
+    const int tid = threadIdx.x;
+    const int el = tid & 63, half = tid >> 6;
+    const int clip = half * 16 + (el & 15), quarter = el >> 4;
+    float4 a0[CH];
+    const int t = s - 3;
+    if (t < 0 || t >= T) return;
+    const int nh = H2 >> 4;
+    const KSlice ks = wave_slice(nh);
+    load_a_chunk(a0, a.woutp, ks.q0, ks.q1);
+    int a_qb = ks.q0;
+    for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+        const float4 *hcur = a.h2buf + (slot_out(a, t) * a.RB + rb) * (H2 * 8);
+        gemm16_rb(a0, a_qb, a.woutp, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
+        __syncthreads();
+        TRACE_STAMP(4);
+        if (tid < 128 && quarter == 0) {
+            const long b = rb * 32 + clip;
+            float4 v;
+            v.x = part_sum(part, half * 4 + 0, el);
+            v.y = part_sum(part, half * 4 + 1, el);
+            v.z = part_sum(part, half * 4 + 2, el);
+            v.w = part_sum(part, half * 4 + 3, el);
+            a.ystage[b * T + t] = v;
+        }
+        if (rb + (int)gridDim.y < a.RB) __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------------
@@ -507,99 +617,193 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
             if (rb + (int)gridDim.y < a.RB) __syncthreads();
         }
     } else if (bx == n2 + n1) {
-        // ---------------- selection head, step t = s-1 (learned_models.py:40-43,50) -------------
-        const int t = s - 1;
-        if (t < 0 || t >= T) return;
-        const int nh = H1 >> 4;
-        const KSlice ks = wave_slice(nh);
-        load_a_chunk(a0, a.wselp, ks.q0, ks.q1);
-        int a_qb = ks.q0;
-        const int mc = tid >> 3, mf = tid & 7;
-        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
-            const float4 *hcur = a.h1buf + (slot_out(a, t) * a.RB + rb) * (H1 * 8);
-            // this frame's boxes, for the mix below: feature f of slot o of clip c sits at k = 6*o + f
-            // of the packed LSTM1 input.  Issued before the MFMA phase.
-            float bxv[OPNET_SLOTS_];
-            if (tid < 256) {
-                const float *xs = (const float *)(a.xp + ((long)t * a.RB + rb) * (OPNET_KXQ * 32));
-#pragma unroll
-                for (int o = 0; o < OPNET_SLOTS_; ++o) {
-                    const int k = o * OPNET_FEATS_ + (mf < OPNET_FEATS_ ? mf : 0);
-                    bxv[o] = xs[((k >> 2) * 32 + mc) * 4 + (k & 3)];
-                }
-            }
-            gemm16_rb(a0, a_qb, a.wselp, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
-            __syncthreads();
-            TRACE_STAMP(4);
-            if (tid < 128) {
-                // thread (clip, quarter) holds logits of slots 4*quarter .. +3; the 15-way softmax
-                // (F.softmax(dim=-1), :41) spans the four lanes el, el^16, el^32, el^48
-                const long b = rb * 32 + clip;
-                float v[4];
-                float m = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int slot = quarter * 4 + r;
-                    v[r] = part_sum(part, half * 4 + r, el);
-                    // logits [B][15][T] (the permute(0,2,1).contiguous() of :50)
-                    if (slot < OPNET_SLOTS_) {
-                        a.lgstage[(b * OPNET_SLOTS_ + slot) * T + t] = v[r];
-                        m = fmaxf(m, v[r]);
-                    }
-                }
-                m = fmaxf(m, __shfl_xor(m, 16));
-                m = fmaxf(m, __shfl_xor(m, 32));
-                float e[4], sum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    e[r] = (quarter * 4 + r < OPNET_SLOTS_) ? __expf(v[r] - m) : 0.f;
-                    sum += e[r];
-                }
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
-                const float inv = 1.0f / sum;
-                float4 pv = make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv);
-                ((float4 *)lg)[clip * 4 + quarter] = pv;
-                if (a.train) a.psave[(((long)t * a.RB + rb) * 4 + quarter) * 32 + clip] = pv;
-            }
-            __syncthreads();
-            if (tid < 256) {
-                // frames_boxes[clip][f] = sum_o boxes[clip][t][o][f] * p[o]   (einsum "bfot,bfo->bft")
-                float acc = 0.f;
-                const float *p = lg + mc * 16;
-#pragma unroll
-                for (int o = 0; o < OPNET_SLOTS_; ++o) acc = fmaf(bxv[o], p[o], acc);
-                float *x2 = (float *)(a.x2buf + (slot_x2(a, t) * a.RB + rb) * 64);
-                x2[((mf >> 2) * 32 + mc) * 4 + (mf & 3)] = mf < OPNET_FEATS_ ? acc : 0.f;
-            }
-            if (rb + (int)gridDim.y < a.RB) __syncthreads();
-        }
+        role_selection_head<CH>(a, s, part, lg);
     } else {
-        // ---------------- output head, step t = s-3 (prediction_layer, learned_models.py:33,47) --
-        const int t = s - 3;
+        role_output_head<CH>(a, s, part);
+    }
+    TRACE_STAMP(5);
+}
+
+// ------------------------------------------------------------------------------------------------
+// the step kernel for several row blocks: two 16-row tiles per workgroup
+// ------------------------------------------------------------------------------------------------
+// With B >= 128 the narrow kernel is bound by every 16-row workgroup re-reading the whole activation block of each row
+// block through its L1 (8 flop per byte filled).  Here a workgroup owns TWO adjacent tiles (32 gate
+// rows = 8 hidden units): each wave's activation fragments feed both tiles' MFMAs, halving the fill traffic per flop, and
+// the second tile's cell update runs on the 128 threads the narrow epilogue leaves idle.  Every accumulator sees exactly
+// the narrow kernel's operation sequence, so the two kernels agree bit for bit.
+// part layout in LDS: [wave][acc reg 0..15][lane]; regs 8*tile + 4*half + r.
+template <int CH>
+__device__ __forceinline__ void mma_chunk2(const float4 (&a0)[CH], const float4 (&a1)[CH], const float4 *__restrict__ seg0,
+                                           int nh0, const float4 *__restrict__ seg1, int qb, int q1, f32x4 (&acc)[4],
+                                           const bool two_halves)
+{
+    const int lane = threadIdx.x & 63;
+    const int boff = ((lane >> 4) * 32 + (lane & 15)) * 16;
+    const __amdgpu_buffer_rsrc_t r0 = frag_rsrc(seg0), r1 = frag_rsrc(seg1);
+    float4 b0[CH], b1[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int q = qb + j;
+        if (q < q1) {  // wave-uniform
+            const bool first = q < nh0;
+            const int soff = (first ? q : q - nh0) * 2048;
+            b0[j] = first ? frag_load(r0, boff, soff) : frag_load(r1, boff, soff);
+            if (two_halves) b1[j] = first ? frag_load(r0, boff + 256, soff) : frag_load(r1, boff + 256, soff);
+        }
+    }
+#define OPNET_MMA2(c)                                                                            \
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].c, b0[j].c, acc[0], 0, 0, 0);           \
+    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].c, b0[j].c, acc[2], 0, 0, 0);           \
+    if (two_halves) {                                                                           \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j].c, b1[j].c, acc[1], 0, 0, 0);       \
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j].c, b1[j].c, acc[3], 0, 0, 0);       \
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        if (qb + j < q1) {
+            OPNET_MMA2(x) OPNET_MMA2(y) OPNET_MMA2(z) OPNET_MMA2(w)
+        }
+    }
+#undef OPNET_MMA2
+}
+
+template <int CH>
+__device__ __forceinline__ void gemm32_rb(float4 (&a0)[CH], float4 (&a1)[CH], int &a_qb, const float4 *__restrict__ A0,
+                                          const float4 *__restrict__ A1, const float4 *__restrict__ seg0, int nh0,
+                                          const float4 *__restrict__ seg1, const KSlice ks, float *__restrict__ part,
+                                          const bool two_halves)
+{
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a_qb != ks.q0) {  // wave-uniform
+        load_a_chunk(a0, A0, ks.q0, ks.q1);
+        load_a_chunk(a1, A1, ks.q0, ks.q1);
+        a_qb = ks.q0;
+    }
+    mma_chunk2(a0, a1, seg0, nh0, seg1, ks.q0, ks.q1, acc, two_halves);
+    for (int qb = ks.q0 + CH; qb < ks.q1; qb += CH) {
+        load_a_chunk(a0, A0, qb, ks.q1);
+        load_a_chunk(a1, A1, qb, ks.q1);
+        a_qb = qb;
+        mma_chunk2(a0, a1, seg0, nh0, seg1, qb, ks.q1, acc, two_halves);
+    }
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *p = part + (w * 16) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[(4 * i + 0) * 64] = acc[i][0]; p[(4 * i + 1) * 64] = acc[i][1];
+        p[(4 * i + 2) * 64] = acc[i][2]; p[(4 * i + 3) * 64] = acc[i][3];
+    }
+}
+
+__device__ __forceinline__ float part_sum2(const float *__restrict__ part, int reg, int lane)
+{
+    float s = part[(0 * 16 + reg) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < OPNET_NW; ++w) s += part[(w * 16 + reg) * 64 + lane];
+    return s;
+}
+
+// grid.x = n2/2 (LSTM2 tile pairs) + n1/2 (LSTM1 tile pairs) + 2 heads ; requires H1 % 8 == 0, H2 % 8 == 0, !mlp
+template <int CH>
+__global__ void __launch_bounds__(OPNET_THREADS) opnet_step_wide(const StepArgs a, const int s)
+{
+    __shared__ __attribute__((aligned(16))) float lds[OPNET_NW * 16 * 64 + 32 * 16];
+    float *part = lds;
+    float *lg = lds + OPNET_NW * 16 * 64;
+
+    const int bx = blockIdx.x;
+    const int T = a.T;
+    const int H1 = a.H1, H2 = a.H2;
+    const int p1 = H1 >> 3, p2 = H2 >> 3;
+    const int tid = threadIdx.x;
+    // epilogue coordinates: threads 0..127 own tile 0, threads 128..255 tile 1
+    const int el = tid & 63;
+    const int half = (tid >> 6) & 1, tsel = tid >> 7;
+    const int clip = half * 16 + (el & 15);
+    const int quarter = el >> 4;
+    const int ereg = tsel * 8 + half * 4;
+
+    if (bx < p2) {
+        // ---------------- LSTM2 (video_LSTM, learned_models.py:32,46), step t = s-2 -------------
+        const int t = s - 2;
         if (t < 0 || t >= T) return;
         const int nh = H2 >> 4;
         const KSlice ks = wave_slice(nh);
-        load_a_chunk(a0, a.woutp, ks.q0, ks.q1);
+        const float4 *A0 = a.w2p + (long)(2 * bx) * nh * 64, *A1 = A0 + (long)nh * 64;
+        float4 a0[CH], a1[CH];
+        load_a_chunk(a0, A0, ks.q0, ks.q1);
+        load_a_chunk(a1, A1, ks.q0, ks.q1);
         int a_qb = ks.q0;
+        const int unit = (2 * bx + tsel) * 4 + quarter;
+        float4 *wl = (float4 *)lg;          // both tiles' input weights: 2 x 4 units x 8 float4
+        if (tid < 64) wl[tid] = a.wih2p[(long)(2 * bx) * 32 + tid];
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
-            const float4 *hcur = a.h2buf + (slot_out(a, t) * a.RB + rb) * (H2 * 8);
-            gemm16_rb(a0, a_qb, a.woutp, hcur, nh, hcur, ks, part, s, a.B - rb * 32 > 16);
+            const float4 *hprev = a.h2buf + (slot_prev(a, t) * a.RB + rb) * (H2 * 8);
+            const float4 *x2 = a.x2buf + (slot_x2(a, t) * a.RB + rb) * 64 + clip;
+            const float4 xa = x2[0], xb = x2[32];
+            const float c_old = a.c2[((cslot_prev(a, t) * a.RB + rb) * H2 + unit) * 32 + clip];
+            gemm32_rb(a0, a1, a_qb, A0, A1, hprev, nh, hprev, ks, part, a.B - rb * 32 > 16);
             __syncthreads();
-            TRACE_STAMP(4);
-            if (tid < 128 && quarter == 0) {
-                const long b = rb * 32 + clip;
-                float4 v;
-                v.x = part_sum(part, half * 4 + 0, el);
-                v.y = part_sum(part, half * 4 + 1, el);
-                v.z = part_sum(part, half * 4 + 2, el);
-                v.w = part_sum(part, half * 4 + 3, el);
-                a.ystage[b * T + t] = v;
+            float g[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 w0 = wl[(tsel * 4 + quarter) * 8 + 2 * r], w1 = wl[(tsel * 4 + quarter) * 8 + 2 * r + 1];
+                float xs = w0.x * xa.x;
+                xs = fmaf(w0.y, xa.y, xs);
+                xs = fmaf(w0.z, xa.z, xs);
+                xs = fmaf(w0.w, xa.w, xs);
+                xs = fmaf(w1.x, xb.x, xs);
+                xs = fmaf(w1.y, xb.y, xs);
+                g[r] = part_sum2(part, ereg + r, el) + xs;
             }
+            float c = c_old;
+            float4 gs;
+            const float h = lstm_cell_g(g[0], g[1], g[2], g[3], &c, &gs);
+            a.c2[((cslot_out(a, t) * a.RB + rb) * H2 + unit) * 32 + clip] = c;
+            if (a.train) a.g2save[(((long)t * a.RB + rb) * H2 + unit) * 32 + clip] = gs;
+            float *hout = (float *)(a.h2buf + (slot_out(a, t) * a.RB + rb) * (H2 * 8));
+            hout[((long)(2 * bx + tsel) * 32 + clip) * 4 + quarter] = h;
+            if (rb + (int)gridDim.y < a.RB) __syncthreads();  // partials are rewritten next round
+        }
+    } else if (bx < p2 + p1) {
+        // ---------------- LSTM1 (object_to_track_LSTM, learned_models.py:29,39), step t = s -----
+        const int t = s;
+        if (t >= T) return;
+        const int pr = bx - p2;
+        const int nhh = H1 >> 4;
+        const int nhex = OPNET_KXQ / 4 + nhh;
+        const KSlice ks = wave_slice(nhex);
+        const float4 *A0 = a.w1p + (long)(2 * pr) * nhex * 64, *A1 = A0 + (long)nhex * 64;
+        float4 a0[CH], a1[CH];
+        load_a_chunk(a0, A0, ks.q0, ks.q1);
+        load_a_chunk(a1, A1, ks.q0, ks.q1);
+        int a_qb = ks.q0;
+        const int unit = (2 * pr + tsel) * 4 + quarter;
+        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+            const float4 *xsrc = a.xp + ((long)t * a.RB + rb) * (OPNET_KXQ * 32);
+            const float4 *hprev = a.h1buf + (slot_prev(a, t) * a.RB + rb) * (H1 * 8);
+            const float c_old = a.c1[((cslot_prev(a, t) * a.RB + rb) * H1 + unit) * 32 + clip];
+            gemm32_rb(a0, a1, a_qb, A0, A1, xsrc, OPNET_KXQ / 4, hprev, ks, part, a.B - rb * 32 > 16);
+            __syncthreads();
+            float c = c_old;
+            float4 gs;
+            const float h = lstm_cell_g(part_sum2(part, ereg + 0, el), part_sum2(part, ereg + 1, el),
+                                        part_sum2(part, ereg + 2, el), part_sum2(part, ereg + 3, el), &c, &gs);
+            a.c1[((cslot_out(a, t) * a.RB + rb) * H1 + unit) * 32 + clip] = c;
+            if (a.train) a.g1save[(((long)t * a.RB + rb) * H1 + unit) * 32 + clip] = gs;
+            float *hout = (float *)(a.h1buf + (slot_out(a, t) * a.RB + rb) * (H1 * 8));
+            hout[((long)(2 * pr + tsel) * 32 + clip) * 4 + quarter] = h;
             if (rb + (int)gridDim.y < a.RB) __syncthreads();
         }
+    } else if (bx == p2 + p1) {
+        role_selection_head<CH>(a, s, part, lg);
+    } else {
+        role_output_head<CH>(a, s, part);
     }
-    TRACE_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
