@@ -83,7 +83,7 @@ def test_real_gradients_match_reference(golden_dir):
         assert np.mean(np.abs(w - g["w_after_val/" + k]) < 2e-5) > 0.98, k
 
 
-@pytest.mark.parametrize("B,T", [(1, 1), (2, 5), (33, 6), (70, 3)])
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 5), (33, 6), (70, 3), (131, 4)])   # 131: wide step kernel + split backward
 def test_gradients_match_torch_port_ragged(B, T):
     boxes, labels = synth.make_batch(200, B, T)
     m = _model(REAL_CFG)
