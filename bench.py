@@ -16,9 +16,9 @@ Rank 0 prints ONE JSON line: BASELINE.json's metric (clips/s, whole job), plus
   cpu_baseline - oracle/opnet_oracle.c (a C/OpenMP port of the reference algorithm) timed on this
                  host's cores on a bounded sample of the same workload (N=1 only).
 
-`oracle/` is used here for exactly three things, none inside a timed region: the seeded synthetic clips / weights
-(`oracle/synth.py` - data, shared with the tests so the in-bench parity assert sees the same inputs), that parity
-assert, and the cpu_baseline leg.  The measured path is libopnet_hip.so only.
+Inputs and weights are seeded synthetic data from `synthdata/` (data only, shared with the tests).  `oracle/` is used
+for exactly two things, both outside the timed region: the cpu_baseline leg and a parity assert of the HIP outputs
+against it.  The measured path is libopnet_hip.so only.
 """
 from __future__ import annotations
 
@@ -59,7 +59,7 @@ def accuracy_block(dev):
     values the reference's own model + ResultsAnalyzer produce for the same weights and clips
     (tests/golden/opnet_trained_*.npz; oracle/gen_golden.py).  Outside the timed region."""
     from objectpermanence_amd import ModelsFactory, metrics
-    from oracle import synth
+    from synthdata import opnet as synth
     wpath = os.path.join(REPO, "tests", "golden", "opnet_trained_fp16.npz")
     epath = os.path.join(REPO, "tests", "golden", "opnet_trained_eval.npz")
     if not (os.path.exists(wpath) and os.path.exists(epath)):
@@ -247,8 +247,8 @@ def bench_detect(args, world, rank, dev, dist):
     """Detector throughput (config 4's front-end, not the BASELINE headline): one step = CaterObjectDetector.detect_batch
     on `--batch` 240x320 frames per GPU (frames are independent: weak scaling, no collective)."""
     from objectpermanence_amd.detector import CaterObjectDetector
-    from oracle import detector_oracle as do
-    params = {**do.synth_backbone_params(), **do.synth_head_params()}
+    from synthdata import detector as sd
+    params = {**sd.synth_backbone_params(), **sd.synth_head_params()}
     det = CaterObjectDetector(None)
     det.load_state_dict(params, dev)
     nf = args.batch
@@ -289,6 +289,7 @@ def bench_detect(args, world, rank, dev, dist):
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
+            from oracle import detector_oracle as do          # cpu_baseline leg only
             t1 = time.perf_counter()
             do.detector_forward(frames[0], params, dtype=torch.float32)
             cpu = {"value": round(1.0 / (time.perf_counter() - t1), 3), "unit": "frames/s", "cores": torch.get_num_threads(),
@@ -335,7 +336,7 @@ def main():
         return bench_detect(args, world, rank, dev, dist)
 
     from objectpermanence_amd import ModelsFactory, metrics
-    from oracle import synth
+    from synthdata import opnet as synth
 
     args.batch = args.batch or 32
     B = args.batch
@@ -486,7 +487,7 @@ def main():
                                    f"independent steps spread over {S} HIP streams",
                        "global_batch": world * B, "frames": T_FRAMES, "parallelism": f"dp{world}",
                        "streams": S,
-                       "weights": "synthetic (oracle/synth.py counter RNG), fp32"},
+                       "weights": "synthetic (synthdata/opnet.py counter RNG), fp32"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(B),
                          "kernel": "opnet_step", "launch_us": round(launch_us, 3), "launches_in_flight": S,
