@@ -137,11 +137,19 @@ static int env_int(const char *name, int dflt)
     return v ? atoi(v) : dflt;
 }
 static bool step_is_wide(const StepArgs &a) { return !a.mlp && a.RB >= env_int("OPNET_WIDE_MIN", 4); }
+// one row block: K split over 8 waves instead of 4 - a wave's whole slice is then one 4-hexadecet chunk (one fetch round
+// trip, 32 instead of 64 chained MFMAs) at 119 VGPRs; the launch is a latency chain there
+static bool step_is_nw8(const StepArgs &a)
+{
+    return !step_is_wide(a) && !getenv("OPNET_STEP_CH") && a.RB <= env_int("OPNET_NW8_MAX_RB", 1);
+}
+static int step_threads(const StepArgs &a) { return step_is_nw8(a) ? 8 * 64 : OPNET_THREADS; }
 static opnet_step_fn step_kernel(const StepArgs &a)
 {
-    const char *force = getenv("OPNET_STEP_CH");          // "4" / "8": measurement override
+    const char *force = getenv("OPNET_STEP_CH");          // "4" / "8": measurement override (4-wave kernels)
     const bool small_chunks = force ? atoi(force) == 4 : a.RB >= 2;
     if (step_is_wide(a)) return small_chunks ? opnet_step_wide<4> : opnet_step_wide<8>;
+    if (step_is_nw8(a)) return opnet_step<4, 8>;
     return small_chunks ? opnet_step<4> : opnet_step<8>;
 }
 
@@ -315,7 +323,7 @@ extern "C" int opnet_forward_f32(const float *boxes, const float *packed, float 
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     const dim3 grid = step_grid(a);
     const opnet_step_fn stepk = step_kernel(a);
-    for (int s = 0; s < T + 3; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    for (int s = 0; s < T + 3; ++s) stepk<<<grid, step_threads(a), 0, st>>>(a, s);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
@@ -367,7 +375,7 @@ extern "C" int opnet_mlp_forward_f32(const float *boxes, const float *packed, fl
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     const dim3 grid = step_grid(a);
     const opnet_step_fn stepk = step_kernel(a);
-    for (int s = 0; s < T + 3; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    for (int s = 0; s < T + 3; ++s) stepk<<<grid, step_threads(a), 0, st>>>(a, s);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
@@ -441,7 +449,7 @@ static int plan_build(opnet_plan *p, const StepArgs &a, void *ws)
         memset(&kp, 0, sizeof(kp));
         kp.func = (void *)step_kernel(a);
         kp.gridDim = step_grid(a);
-        kp.blockDim = dim3(OPNET_THREADS, 1, 1);
+        kp.blockDim = dim3(step_threads(a), 1, 1);
         kp.kernelParams = args;
         HIP_TRY(hipGraphAddKernelNode(&node, p->graph, &prev, 1, &kp));
         prev = node;
@@ -640,7 +648,7 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     const dim3 grid = step_grid(a);
     const opnet_step_fn stepk = step_kernel(a);
-    for (int s = 0; s < T + 3; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    for (int s = 0; s < T + 3; ++s) stepk<<<grid, step_threads(a), 0, st>>>(a, s);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
@@ -780,7 +788,7 @@ extern "C" int opnet_mlp_train_forward_f32(const float *boxes, const float *pack
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     const dim3 grid = step_grid(a);
     const opnet_step_fn stepk = step_kernel(a);
-    for (int s = 0; s < T + 3; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    for (int s = 0; s < T + 3; ++s) stepk<<<grid, step_threads(a), 0, st>>>(a, s);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;

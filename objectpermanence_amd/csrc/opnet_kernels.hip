@@ -185,12 +185,13 @@ struct KSlice {
     int q0, q1;  // this wave's hexadecet range (wave-uniform)
 };
 
+template <int NW = OPNET_NW>
 __device__ __forceinline__ KSlice wave_slice(int nhex)
 {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     KSlice k;
-    k.q0 = (w * nhex) / OPNET_NW;
-    k.q1 = ((w + 1) * nhex) / OPNET_NW;
+    k.q0 = (w * nhex) / NW;
+    k.q1 = ((w + 1) * nhex) / NW;
     return k;
 }
 
@@ -324,11 +325,12 @@ __device__ __forceinline__ void gemm16_rb(float4 (&a0)[CH], int &a_qb, const flo
 }
 
 // fixed-order cross-wave reduction of D element (reg, lane)
+template <int NW = OPNET_NW>
 __device__ __forceinline__ float part_sum(const float *__restrict__ part, int reg, int lane)
 {
     float s = part[(0 * 8 + reg) * 64 + lane];
 #pragma unroll
-    for (int w = 1; w < OPNET_NW; ++w) s += part[(w * 8 + reg) * 64 + lane];
+    for (int w = 1; w < NW; ++w) s += part[(w * 8 + reg) * 64 + lane];
     return s;
 }
 
@@ -379,7 +381,7 @@ __device__ __forceinline__ float lstm_cell_g(float gi, float gf, float gg, float
 }
 
 // ---------------- selection head, step t = s-1 (learned_models.py:40-43,50) -------------
-template <int CH>
+template <int CH, int NW = OPNET_NW>
 __device__ __forceinline__ void role_selection_head(const StepArgs &a, const int s, float *part, float *lg)
 {
     const int T = a.T, H1 = a.H1;
@@ -390,7 +392,7 @@ __device__ __forceinline__ void role_selection_head(const StepArgs &a, const int
     const int t = s - 1;
     if (t < 0 || t >= T) return;
     const int nh = H1 >> 4;
-    const KSlice ks = wave_slice(nh);
+    const KSlice ks = wave_slice<NW>(nh);
     load_a_chunk(a0, a.wselp, ks.q0, ks.q1);
     int a_qb = ks.q0;
     const int mc = tid >> 3, mf = tid & 7;
@@ -419,7 +421,7 @@ __device__ __forceinline__ void role_selection_head(const StepArgs &a, const int
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int slot = quarter * 4 + r;
-                v[r] = part_sum(part, half * 4 + r, el);
+                v[r] = part_sum<NW>(part, half * 4 + r, el);
                 // logits [B][15][T] (the permute(0,2,1).contiguous() of :50)
                 if (slot < OPNET_SLOTS_) {
                     a.lgstage[(b * OPNET_SLOTS_ + slot) * T + t] = v[r];
@@ -456,7 +458,7 @@ __device__ __forceinline__ void role_selection_head(const StepArgs &a, const int
 }
 
 // ---------------- output head, step t = s-3 (prediction_layer, learned_models.py:33,47) --
-template <int CH>
+template <int CH, int NW = OPNET_NW>
 __device__ __forceinline__ void role_output_head(const StepArgs &a, const int s, float *part)
 {
     const int T = a.T, H2 = a.H2;
@@ -467,7 +469,7 @@ __device__ __forceinline__ void role_output_head(const StepArgs &a, const int s,
     const int t = s - 3;
     if (t < 0 || t >= T) return;
     const int nh = H2 >> 4;
-    const KSlice ks = wave_slice(nh);
+    const KSlice ks = wave_slice<NW>(nh);
     load_a_chunk(a0, a.woutp, ks.q0, ks.q1);
     int a_qb = ks.q0;
     for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
@@ -478,10 +480,10 @@ __device__ __forceinline__ void role_output_head(const StepArgs &a, const int s,
         if (tid < 128 && quarter == 0) {
             const long b = rb * 32 + clip;
             float4 v;
-            v.x = part_sum(part, half * 4 + 0, el);
-            v.y = part_sum(part, half * 4 + 1, el);
-            v.z = part_sum(part, half * 4 + 2, el);
-            v.w = part_sum(part, half * 4 + 3, el);
+            v.x = part_sum<NW>(part, half * 4 + 0, el);
+            v.y = part_sum<NW>(part, half * 4 + 1, el);
+            v.z = part_sum<NW>(part, half * 4 + 2, el);
+            v.w = part_sum<NW>(part, half * 4 + 3, el);
             a.ystage[b * T + t] = v;
         }
         if (rb + (int)gridDim.y < a.RB) __syncthreads();
@@ -494,12 +496,12 @@ __device__ __forceinline__ void role_output_head(const StepArgs &a, const int s,
 // grid.x = n2 (LSTM2 tiles, longest K first) + n1 (LSTM1 tiles) + 2 heads ; grid.y <= row blocks
 // (a workgroup walks row blocks rb = blockIdx.y, blockIdx.y + gridDim.y, ... with its weights held
 // in registers).
-template <int CH>
-__global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, const int s)
+template <int CH, int NW = OPNET_NW>
+__global__ void __launch_bounds__(NW * 64) opnet_step(const StepArgs a, const int s)
 {
-    __shared__ __attribute__((aligned(16))) float lds[OPNET_NW * 8 * 64 + 32 * 16];
+    __shared__ __attribute__((aligned(16))) float lds[NW * 8 * 64 + 32 * 16];
     float *part = lds;
-    float *lg = lds + OPNET_NW * 8 * 64;  // [clip][16] slot probabilities (selection head)
+    float *lg = lds + NW * 8 * 64;  // [clip][16] slot probabilities (selection head)
 
     const int bx = blockIdx.x;
     const int T = a.T;
@@ -522,7 +524,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
         if (t < 0 || t >= T) return;
         const int tile = bx;
         const int nh = H2 >> 4;
-        const KSlice ks = wave_slice(nh);
+        const KSlice ks = wave_slice<NW>(nh);
         const float4 *A = a.w2p + (long)tile * nh * 64;
         if (!a.mlp) load_a_chunk(a0, A, ks.q0, ks.q1);
         int a_qb = ks.q0;
@@ -573,7 +575,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
                     xs = fmaf(w0.w, xa.w, xs);
                     xs = fmaf(w1.x, xb.x, xs);
                     xs = fmaf(w1.y, xb.y, xs);
-                    g[r] = part_sum(part, half * 4 + r, el) + xs;
+                    g[r] = part_sum<NW>(part, half * 4 + r, el) + xs;
                 }
                 float c = c_old;
                 float4 gs;
@@ -591,7 +593,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
         if (t >= T) return;
         const int tile = bx - n2;
         const int nhh = H1 >> 4;
-        const KSlice ks = wave_slice(OPNET_KXQ / 4 + nhh);
+        const KSlice ks = wave_slice<NW>(OPNET_KXQ / 4 + nhh);
         const float4 *A = a.w1p + (long)tile * (OPNET_KXQ / 4 + nhh) * 64;
         load_a_chunk(a0, A, ks.q0, ks.q1);
         int a_qb = ks.q0;
@@ -607,8 +609,8 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
             if (tid < 128) {
                 float c = c_old;
                 float4 gs;
-                const float h = lstm_cell_g(part_sum(part, half * 4 + 0, el), part_sum(part, half * 4 + 1, el),
-                                            part_sum(part, half * 4 + 2, el), part_sum(part, half * 4 + 3, el), &c, &gs);
+                const float h = lstm_cell_g(part_sum<NW>(part, half * 4 + 0, el), part_sum<NW>(part, half * 4 + 1, el),
+                                            part_sum<NW>(part, half * 4 + 2, el), part_sum<NW>(part, half * 4 + 3, el), &c, &gs);
                 a.c1[((cslot_out(a, t) * a.RB + rb) * H1 + unit) * 32 + clip] = c;
                 if (a.train) a.g1save[(((long)t * a.RB + rb) * H1 + unit) * 32 + clip] = gs;
                 float *hout = (float *)(a.h1buf + (slot_out(a, t) * a.RB + rb) * (H1 * 8));
@@ -617,9 +619,9 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step(const StepArgs a, co
             if (rb + (int)gridDim.y < a.RB) __syncthreads();
         }
     } else if (bx == n2 + n1) {
-        role_selection_head<CH>(a, s, part, lg);
+        role_selection_head<CH, NW>(a, s, part, lg);
     } else {
-        role_output_head<CH>(a, s, part);
+        role_output_head<CH, NW>(a, s, part);
     }
     TRACE_STAMP(5);
 }
