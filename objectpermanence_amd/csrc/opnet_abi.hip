@@ -856,9 +856,12 @@ static int check_stack(int B, int T, int L, int KX, int H)
 static bool stack_hoists_input(int KX, int H) { return (KX & 15) == 0 && KX >= 2 * H; }
 
 typedef void (*stack_step_fn)(const StackArgs, const int);
+static bool stack_is_nw8(int RB) { return !getenv("OPNET_STEP_CH") && RB <= env_int("OPNET_NW8_MAX_RB", 1); }
+static int stack_step_threads(int RB) { return stack_is_nw8(RB) ? 8 * 64 : OPNET_THREADS; }
 static stack_step_fn stack_step_kernel(int RB)
 {
-    const char *force = getenv("OPNET_STEP_CH");          // "4" / "8": measurement override
+    const char *force = getenv("OPNET_STEP_CH");          // "4" / "8": measurement override (4-wave kernels)
+    if (stack_is_nw8(RB)) return lstm_stack_step<4, 8>;
     return (force ? atoi(force) == 4 : RB >= 2) ? lstm_stack_step<4> : lstm_stack_step<8>;
 }
 
@@ -1041,7 +1044,7 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
     const dim3 grid(ntiles, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
     if (!graph) {
         const stack_step_fn stepk = stack_step_kernel(RB);
-        for (int s = 0; s < nlaunch; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+        for (int s = 0; s < nlaunch; ++s) stepk<<<grid, stack_step_threads(RB), 0, st>>>(a, s);
     } else {
         StackGraphKey key;
         memset(&key, 0, sizeof(key));
@@ -1064,7 +1067,7 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
                 memset(&kp, 0, sizeof(kp));
                 kp.func = (void *)stack_step_kernel(RB);
                 kp.gridDim = grid;
-                kp.blockDim = dim3(OPNET_THREADS, 1, 1);
+                kp.blockDim = dim3(stack_step_threads(RB), 1, 1);
                 kp.kernelParams = args;
                 hipError_t e = hipGraphAddKernelNode(&node, g, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
                 if (e != hipSuccess) { (void)hipGraphDestroy(g); return fail(OPNET_EHIP, "hipGraphAddKernelNode: %s", hipGetErrorString(e)); }
@@ -1258,7 +1261,7 @@ extern "C" int opseq_lstm_stack_train_forward_f32(const float *x, const float *p
     }
     const dim3 grid((2 * L - 1) * (H / 4) + 1, a.RB < OPNET_MAX_GY ? a.RB : OPNET_MAX_GY, 1);
     const stack_step_fn stepk = stack_step_kernel(a.RB);
-    for (int s = 0; s < T + 2 * L - 1; ++s) stepk<<<grid, OPNET_THREADS, 0, st>>>(a, s);
+    for (int s = 0; s < T + 2 * L - 1; ++s) stepk<<<grid, stack_step_threads(a.RB), 0, st>>>(a, s);
     const long ny = (long)B * T;
     copy_y_out<<<(unsigned)((ny + 255) / 256 > 1024 ? 1024 : (ny + 255) / 256), 256, 0, st>>>(a.ystage, (float4 *)y, ny);
     HIP_TRY(hipGetLastError());

@@ -44,10 +44,12 @@ struct StackArgs {
 // grid.x = L * H/4 recurrent tiles + (L-1) * H/4 x-projection tiles + 1 ; grid.y <= RB.
 // Launch s: layer l's recurrent role runs step t = s - 2l, its x-projection role (l >= 1) step t = s - (2l - 1) -
 // one launch after layer l-1 produced h_t, one before the recurrent role consumes it - and the head t = s - (2L - 1).
-template <int CH>      // register chunk, see load_a_chunk: 8 for one row block, 4 (3 waves per SIMD) above
-__global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs a, const int s)
+// CH = register chunk (see load_a_chunk), NW = waves per workgroup: <4, 8> for one row block (a latency chain: 8 waves
+// halve the MFMA chain and need one fetch round trip), <4, 4> above.
+template <int CH, int NW = OPNET_NW>
+__global__ void __launch_bounds__(NW * 64) lstm_stack_step(const StackArgs a, const int s)
 {
-    __shared__ __attribute__((aligned(16))) float part[OPNET_NW * 8 * 64];
+    __shared__ __attribute__((aligned(16))) float part[NW * 8 * 64];
     const int tid = threadIdx.x;
     const int el = tid & 63, half = tid >> 6;
     const int clip = half * 16 + (el & 15), quarter = el >> 4;
@@ -74,7 +76,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
             if (t < 0 || t >= a.T) return;
             const int H = ly.H, nhh = H >> 4, nhx = ly.a_skip;
             const int tile = bx;
-            const KSlice ks = wave_slice(nhx);
+            const KSlice ks = wave_slice<NW>(nhx);
             const float4 *A = ly.A + (long)tile * (nhx + nhh) * 64;           // the x part leads every tile
             load_a_chunk(a0, A, ks.q0, ks.q1);
             int a_qb = ks.q0;
@@ -86,8 +88,8 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
                 __syncthreads();
                 if (tid < 128)
                     ly.xg[(((long)t * a.RB + rb) * H + unit) * 32 + clip] =
-                        make_float4(part_sum(part, half * 4 + 0, el), part_sum(part, half * 4 + 1, el),
-                                    part_sum(part, half * 4 + 2, el), part_sum(part, half * 4 + 3, el));
+                        make_float4(part_sum<NW>(part, half * 4 + 0, el), part_sum<NW>(part, half * 4 + 1, el),
+                                    part_sum<NW>(part, half * 4 + 2, el), part_sum<NW>(part, half * 4 + 3, el));
                 if (rb + (int)gridDim.y < a.RB) __syncthreads();
             }
             return;
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         if (t < 0 || t >= a.T) return;
         const int H = ly.H, nhh = H >> 4, nhx = ly.nhx;
         const int tile = bx;
-        const KSlice ks = wave_slice(nhx + nhh);
+        const KSlice ks = wave_slice<NW>(nhx + nhh);
         const float4 *A = ly.A + ((long)tile * (ly.a_skip + nhx + nhh) + ly.a_skip) * 64;
         load_a_chunk(a0, A, ks.q0, ks.q1);
         int a_qb = ks.q0;
@@ -120,8 +122,8 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
             if (tid < 128) {
                 float c = c_old;
                 float4 gs;
-                const float h = lstm_cell_g(part_sum(part, half * 4 + 0, el) + xg.x, part_sum(part, half * 4 + 1, el) + xg.y,
-                                            part_sum(part, half * 4 + 2, el) + xg.z, part_sum(part, half * 4 + 3, el) + xg.w, &c, &gs);
+                const float h = lstm_cell_g(part_sum<NW>(part, half * 4 + 0, el) + xg.x, part_sum<NW>(part, half * 4 + 1, el) + xg.y,
+                                            part_sum<NW>(part, half * 4 + 2, el) + xg.z, part_sum<NW>(part, half * 4 + 3, el) + xg.w, &c, &gs);
                 ly.c[((co * a.RB + rb) * H + unit) * 32 + clip] = c;
                 if (a.train) ly.gsave[(((long)t * a.RB + rb) * H + unit) * 32 + clip] = gs;
                 float *hout = (float *)(ly.hbuf + (so * a.RB + rb) * ((long)H * 8));
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
         if (t < 0 || t >= a.T) return;
         const StackLayer &ly = a.layer[a.L - 1];
         const int nh = ly.H >> 4;
-        const KSlice ks = wave_slice(nh);
+        const KSlice ks = wave_slice<NW>(nh);
         load_a_chunk(a0, a.headA, ks.q0, ks.q1);
         int a_qb = ks.q0;
         for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
@@ -145,10 +147,10 @@ __global__ void __launch_bounds__(OPNET_THREADS) lstm_stack_step(const StackArgs
             if (tid < 128 && quarter == 0) {
                 const long b = rb * 32 + clip;
                 float4 v;
-                v.x = part_sum(part, half * 4 + 0, el);
-                v.y = part_sum(part, half * 4 + 1, el);
-                v.z = part_sum(part, half * 4 + 2, el);
-                v.w = part_sum(part, half * 4 + 3, el);
+                v.x = part_sum<NW>(part, half * 4 + 0, el);
+                v.y = part_sum<NW>(part, half * 4 + 1, el);
+                v.z = part_sum<NW>(part, half * 4 + 2, el);
+                v.w = part_sum<NW>(part, half * 4 + 3, el);
                 a.ystage[b * a.T + t] = v;
             }
             if (rb + (int)gridDim.y < a.RB) __syncthreads();
