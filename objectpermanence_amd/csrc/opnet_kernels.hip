@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) opnet_copy_out(const OpnetIO *__restrict_
 // before the first MFMA so the memory round trips overlap instead of serialising per hexadecet.
 // A workgroup that serves several row blocks keeps its A fragments (the weights) in registers
 // across them when its K slice fits one chunk (true for H1=256/H2=512: 4..8 hexadecets a wave).
-// part layout in LDS: [wave][acc reg 0..7][lane]; acc regs 0..3 = clips 0..15, 4..7 = clips 16..31.
+// part layout in LDS: [wave][clip half][lane][acc reg 0..3]; half 0 = clips 0..15, half 1 = clips 16..31.
 #ifndef OPNET_CH
 #define OPNET_CH 8
 #endif
@@ -318,9 +318,10 @@ __device__ __forceinline__ void gemm16_rb(float4 (&a0)[CH], int &a_qb, const flo
     }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *p = part + (w * 8) * 64 + lane;
-    p[0 * 64] = acc0[0]; p[1 * 64] = acc0[1]; p[2 * 64] = acc0[2]; p[3 * 64] = acc0[3];
-    p[4 * 64] = acc1[0]; p[5 * 64] = acc1[1]; p[6 * 64] = acc1[2]; p[7 * 64] = acc1[3];
+    // [wave][clip half][lane][4 acc regs]: one 16-byte LDS access per accumulator on both sides, conflict-free
+    float4 *p = (float4 *)part + (w * 2) * 64 + lane;
+    p[0] = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+    p[64] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
     TRACE_STAMP(3);
 }
 
@@ -328,9 +329,10 @@ __device__ __forceinline__ void gemm16_rb(float4 (&a0)[CH], int &a_qb, const flo
 template <int NW = OPNET_NW>
 __device__ __forceinline__ float part_sum(const float *__restrict__ part, int reg, int lane)
 {
-    float s = part[(0 * 8 + reg) * 64 + lane];
+    const int o = (((reg >> 2) * 64) + lane) * 4 + (reg & 3);
+    float s = part[o];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) s += part[(w * 8 + reg) * 64 + lane];
+    for (int w = 1; w < NW; ++w) s += part[w * 512 + o];
     return s;
 }
 
