@@ -31,8 +31,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in user SGPRs at dispatch instead of through
+    # a scalar load (used by opnet_step_pl; harmless for the struct-argument kernels, which have nothing to preload)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-pass-failed", "-o", LIB] + SOURCES
+           "-Wno-pass-failed", "-mllvm", "-amdgpu-kernarg-preload-count=10", "-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, cwd=CSRC, check=True)

@@ -123,7 +123,6 @@ static void launch_attention(const float *qkv, float *att, int S, int E, int nhe
 }
 
 static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" int opnet_hip_abi_version(void) { return 1; }
 extern "C" const char *opnet_last_error(void) { return g_err; }
@@ -142,6 +141,11 @@ static bool step_is_wide(const StepArgs &a) { return !a.mlp && a.RB >= env_int("
 static bool step_is_nw8(const StepArgs &a)
 {
     return !step_is_wide(a) && !getenv("OPNET_STEP_CH") && a.RB <= env_int("OPNET_NW8_MAX_RB", 1);
+}
+// inference at one row block: the scalar-argument (kernarg-preload) form of the same kernel
+static bool step_is_preload(const StepArgs &a)
+{
+    return step_is_nw8(a) && !a.mlp && !a.train && env_int("OPNET_PRELOAD", 1) != 0;
 }
 static int step_threads(const StepArgs &a) { return step_is_nw8(a) ? 8 * 64 : OPNET_THREADS; }
 static opnet_step_fn step_kernel(const StepArgs &a)
@@ -162,47 +166,6 @@ static int check_dims(int B, int T, int H1, int H2)
     if (H1 <= 0 || H2 <= 0 || (H1 & 15) || (H2 & 15))
         return fail(OPNET_ESHAPE, "hidden sizes must be positive multiples of 16 (H1=%d H2=%d)", H1, H2);
     return OPNET_OK;
-}
-
-struct PackedLayout {  // offsets in floats
-    size_t w1p, w2p, wih2p, wselp, woutp, total;
-};
-
-static PackedLayout packed_layout(int H1, int H2)
-{
-    PackedLayout L;
-    size_t o = 0;
-    L.w1p = o;   o += (size_t)(H1 / 4) * ((OPNET_KXQ * 4 + H1) / 16) * 256;
-    L.w2p = o;   o += (size_t)(H2 / 4) * (H2 / 16) * 256;
-    L.wih2p = o; o += (size_t)H2 * 32;
-    L.wselp = o; o += (size_t)(H1 / 16) * 256;
-    L.woutp = o; o += (size_t)(H2 / 16) * 256;
-    L.total = o;
-    return L;
-}
-
-struct WorkspaceLayout {  // offsets in bytes
-    size_t io, xp, state, h1buf, c1, h2buf, c2, x2buf, state_end, ystage, lgstage, total;
-};
-
-static WorkspaceLayout workspace_layout(int B, int T, int H1, int H2)
-{
-    const size_t RB = (B + 31) / 32;
-    WorkspaceLayout L;
-    size_t o = 0;
-    L.io = o;    o += align_up(sizeof(OpnetIO), 256);
-    L.xp = o;    o += (size_t)T * RB * OPNET_KXQ * 32 * 16;
-    L.state = o;
-    L.h1buf = o; o += 2 * RB * (size_t)H1 * 32 * 4;
-    L.c1 = o;    o += RB * (size_t)H1 * 32 * 4;
-    L.h2buf = o; o += 2 * RB * (size_t)H2 * 32 * 4;
-    L.c2 = o;    o += RB * (size_t)H2 * 32 * 4;
-    L.x2buf = o; o += 2 * RB * 32 * 8 * 4;
-    L.state_end = o;
-    L.ystage = o;  o += RB * 32 * (size_t)T * 16;
-    L.lgstage = o; o += RB * 32 * (size_t)T * OPNET_SLOTS * 4;
-    L.total = align_up(o, 256);
-    return L;
 }
 
 extern "C" size_t opnet_packed_weights_bytes(int H1, int H2)
@@ -261,25 +224,8 @@ static int make_args(StepArgs *a, OpnetIO *io, const float *boxes, const float *
         return fail(OPNET_EINVAL, "packed/y/workspace must be 16-byte and boxes 8-byte aligned");
     const WorkspaceLayout W = workspace_layout(B, T, H1, H2);
     if (ws_bytes < W.total) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", ws_bytes, W.total);
-    const PackedLayout P = packed_layout(H1, H2);
     char *w = (char *)ws;
-    memset(a, 0, sizeof(*a));
-    a->B = B; a->T = T; a->RB = (B + 31) / 32; a->H1 = H1; a->H2 = H2;
-    a->train = 0;
-    a->g1save = nullptr; a->g2save = nullptr; a->psave = nullptr;
-    a->xp = (const float4 *)(w + W.xp);
-    a->w1p = (const float4 *)(packed + P.w1p);
-    a->w2p = (const float4 *)(packed + P.w2p);
-    a->wih2p = (const float4 *)(packed + P.wih2p);
-    a->wselp = (const float4 *)(packed + P.wselp);
-    a->woutp = (const float4 *)(packed + P.woutp);
-    a->h1buf = (float4 *)(w + W.h1buf);
-    a->c1 = (float *)(w + W.c1);
-    a->h2buf = (float4 *)(w + W.h2buf);
-    a->c2 = (float *)(w + W.c2);
-    a->x2buf = (float4 *)(w + W.x2buf);
-    a->ystage = (float4 *)(w + W.ystage);
-    a->lgstage = (float *)(w + W.lgstage);
+    step_args_inference(a, w, packed, B, T, H1, H2);
     memset(io, 0, sizeof(*io));
     io->B = B; io->T = T; io->RB = a->RB;
     io->boxes = boxes; io->y = y; io->logits = logits;
@@ -322,8 +268,13 @@ extern "C" int opnet_forward_f32(const float *boxes, const float *packed, float 
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     const dim3 grid = step_grid(a);
-    const opnet_step_fn stepk = step_kernel(a);
-    for (int s = 0; s < T + 3; ++s) stepk<<<grid, step_threads(a), 0, st>>>(a, s);
+    if (step_is_preload(a)) {
+        for (int s = 0; s < T + 3; ++s)
+            opnet_step_pl<4, 8><<<grid, 8 * 64, 0, st>>>((char *)workspace, packed, B, T, H1, H2, s);
+    } else {
+        const opnet_step_fn stepk = step_kernel(a);
+        for (int s = 0; s < T + 3; ++s) stepk<<<grid, step_threads(a), 0, st>>>(a, s);
+    }
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
@@ -445,12 +396,17 @@ static int plan_build(opnet_plan *p, const StepArgs &a, void *ws)
         StepArgs av = a;
         int step = s;
         void *args[] = {(void *)&av, (void *)&step};
+        char *wsb = (char *)ws;
+        const float *pk = (const float *)a.w1p - packed_layout(p->H1, p->H2).w1p;
+        int sB = p->B, sT = p->T, sH1 = p->H1, sH2 = p->H2;
+        void *args_pl[] = {(void *)&wsb, (void *)&pk, (void *)&sB, (void *)&sT, (void *)&sH1, (void *)&sH2, (void *)&step};
         hipKernelNodeParams kp;
         memset(&kp, 0, sizeof(kp));
-        kp.func = (void *)step_kernel(a);
+        const bool pl = step_is_preload(a);
+        kp.func = pl ? (void *)opnet_step_pl<4, 8> : (void *)step_kernel(a);
         kp.gridDim = step_grid(a);
         kp.blockDim = dim3(step_threads(a), 1, 1);
-        kp.kernelParams = args;
+        kp.kernelParams = pl ? args_pl : args;
         HIP_TRY(hipGraphAddKernelNode(&node, p->graph, &prev, 1, &kp));
         prev = node;
     }

@@ -49,3 +49,73 @@ struct OpnetIO {
     float4 *state;         // recurrent state (h1buf .. x2buf), zeroed by pack_input at the start of a forward
     long state_f4;         // its size in float4 units
 };
+
+// ------------------------------------------------------------------------------------------------
+// buffer carving (host and device: the step kernel with preloaded scalar arguments rebuilds its StepArgs from the two
+// base pointers and the shape, see opnet_step_pl)
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct PackedLayout {  // offsets in floats
+    size_t w1p, w2p, wih2p, wselp, woutp, total;
+};
+
+__host__ __device__ inline PackedLayout packed_layout(int H1, int H2)
+{
+    PackedLayout L;
+    size_t o = 0;
+    L.w1p = o;   o += (size_t)(H1 / 4) * ((OPNET_KXQ * 4 + H1) / 16) * 256;
+    L.w2p = o;   o += (size_t)(H2 / 4) * (H2 / 16) * 256;
+    L.wih2p = o; o += (size_t)H2 * 32;
+    L.wselp = o; o += (size_t)(H1 / 16) * 256;
+    L.woutp = o; o += (size_t)(H2 / 16) * 256;
+    L.total = o;
+    return L;
+}
+
+struct WorkspaceLayout {  // offsets in bytes
+    size_t io, xp, state, h1buf, c1, h2buf, c2, x2buf, state_end, ystage, lgstage, total;
+};
+
+__host__ __device__ inline WorkspaceLayout workspace_layout(int B, int T, int H1, int H2)
+{
+    const size_t RB = (B + 31) / 32;
+    WorkspaceLayout L;
+    size_t o = 0;
+    L.io = o;    o += align_up(sizeof(OpnetIO), 256);
+    L.xp = o;    o += (size_t)T * RB * OPNET_KXQ * 32 * 16;
+    L.state = o;
+    L.h1buf = o; o += 2 * RB * (size_t)H1 * 32 * 4;
+    L.c1 = o;    o += RB * (size_t)H1 * 32 * 4;
+    L.h2buf = o; o += 2 * RB * (size_t)H2 * 32 * 4;
+    L.c2 = o;    o += RB * (size_t)H2 * 32 * 4;
+    L.x2buf = o; o += 2 * RB * 32 * 8 * 4;
+    L.state_end = o;
+    L.ystage = o;  o += RB * 32 * (size_t)T * 16;
+    L.lgstage = o; o += RB * 32 * (size_t)T * OPNET_SLOTS_ * 4;
+    L.total = align_up(o, 256);
+    return L;
+}
+
+
+// StepArgs of an inference forward from its workspace and packed-weights bases
+__host__ __device__ inline void step_args_inference(StepArgs *a, char *w, const float *packed, int B, int T, int H1, int H2)
+{
+    const WorkspaceLayout W = workspace_layout(B, T, H1, H2);
+    const PackedLayout P = packed_layout(H1, H2);
+    *a = StepArgs{};
+    a->B = B; a->T = T; a->RB = (B + 31) / 32; a->H1 = H1; a->H2 = H2;
+    a->xp = (const float4 *)(w + W.xp);
+    a->w1p = (const float4 *)(packed + P.w1p);
+    a->w2p = (const float4 *)(packed + P.w2p);
+    a->wih2p = (const float4 *)(packed + P.wih2p);
+    a->wselp = (const float4 *)(packed + P.wselp);
+    a->woutp = (const float4 *)(packed + P.woutp);
+    a->h1buf = (float4 *)(w + W.h1buf);
+    a->c1 = (float *)(w + W.c1);
+    a->h2buf = (float4 *)(w + W.h2buf);
+    a->c2 = (float *)(w + W.c2);
+    a->x2buf = (float4 *)(w + W.x2buf);
+    a->ystage = (float4 *)(w + W.ystage);
+    a->lgstage = (float *)(w + W.lgstage);
+}

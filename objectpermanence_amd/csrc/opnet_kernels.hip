@@ -498,8 +498,8 @@ __device__ __forceinline__ void role_output_head(const StepArgs &a, const int s,
 // grid.x = n2 (LSTM2 tiles, longest K first) + n1 (LSTM1 tiles) + 2 heads ; grid.y <= row blocks
 // (a workgroup walks row blocks rb = blockIdx.y, blockIdx.y + gridDim.y, ... with its weights held
 // in registers).
-template <int CH, int NW = OPNET_NW>
-__global__ void __launch_bounds__(NW * 64) opnet_step(const StepArgs a, const int s)
+template <int CH, int NW>
+__device__ __forceinline__ void opnet_step_body(const StepArgs &a, const int s)
 {
     __shared__ __attribute__((aligned(16))) float lds[NW * 8 * 64 + 32 * 16];
     float *part = lds;
@@ -626,6 +626,24 @@ __global__ void __launch_bounds__(NW * 64) opnet_step(const StepArgs a, const in
         role_output_head<CH, NW>(a, s, part);
     }
     TRACE_STAMP(5);
+}
+
+template <int CH, int NW = OPNET_NW>
+__global__ void __launch_bounds__(NW * 64) opnet_step(const StepArgs a, const int s)
+{
+    opnet_step_body<CH, NW>(a, s);
+}
+
+// The same step with SCALAR arguments only (two base pointers + the shape), so that the compiler's kernarg preloading
+// (-mllvm -amdgpu-kernarg-preload-count) has the CP drop them into user SGPRs at dispatch: the by-value StepArgs costs a
+// scalar-load round trip to memory (the L2s were just invalidated) before the first fragment load can even be issued.
+// The buffer carving is recomputed on the scalar unit (opnet_ctx.h).  Inference forward only.
+template <int CH, int NW>
+__global__ void __launch_bounds__(NW * 64) opnet_step_pl(char *ws, const float *packed, int B, int T, int H1, int H2, int s)
+{
+    StepArgs a;
+    step_args_inference(&a, ws, packed, B, T, H1, H2);
+    opnet_step_body<CH, NW>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------
