@@ -1,4 +1,5 @@
-// probe: does kernarg preloading (user SGPRs filled by the CP at dispatch) shorten a dependent launch whose first memory
+// probe (INCONCLUSIVE as a stand-alone program: a bare-HIP graph chain runs at 12-23 us per node on this stack, bimodal,
+// so the effect was measured on the product kernel instead - opnet_step_pl): does kernarg preloading (user SGPRs filled by the CP at dispatch) shorten a dependent launch whose first memory
 // access needs a pointer argument?  Build twice: plain, and with -mllvm -amdgpu-kernarg-preload-count=12.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
