@@ -551,27 +551,40 @@ __global__ void __launch_bounds__(256) opnet_wgrad(const WgradBatch batch)
 #pragma unroll
         for (int y = 0; y < 4; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int t0 = (w * g.T) / 4, t1 = ((w + 1) * g.T) / 4;
-    for (int t = t0; t < t1; ++t) {
-        for (int rb = 0; rb < g.RB; ++rb) {
-            const float4 *Pp = g.P + ((long)t * g.RB + rb) * g.p_stride + (long)(mq0 + i) * 32 + kc;
-            const float4 *Qp = g.Q + ((long)t * g.RB + rb) * g.q_stride + (long)(nq0 + i) * 32 + kc;
-            float4 av[8], bv[8];
+    // the (t, row block) steps of this wave, software-pipelined: the fragments of step it+1 are in flight while the 128
+    // MFMAs of step it run (one wave per SIMD has nobody else to hide the fetch behind)
+    const long nit = (long)(t1 - t0) * g.RB;
+    const float4 *Pb = g.P + (long)t0 * g.RB * g.p_stride + (long)(mq0 + i) * 32 + kc;
+    const float4 *Qb = g.Q + (long)t0 * g.RB * g.q_stride + (long)(nq0 + i) * 32 + kc;
+    float4 av[8], bv[8], an[8], bn[8];
+    if (nit > 0) {
+#pragma unroll
+        for (int cg = 0; cg < 8; ++cg) {
+            av[cg] = pa ? Pb[cg * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            bv[cg] = pb ? Qb[cg * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    for (long it = 0; it < nit; ++it) {
+        if (it + 1 < nit) {
+            const float4 *Pp = Pb + (it + 1) * g.p_stride, *Qp = Qb + (it + 1) * g.q_stride;
 #pragma unroll
             for (int cg = 0; cg < 8; ++cg) {
-                av[cg] = pa ? Pp[cg * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
-                bv[cg] = pb ? Qp[cg * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int cg = 0; cg < 8; ++cg) {
-                const float ae[4] = {av[cg].x, av[cg].y, av[cg].z, av[cg].w};
-                const float be[4] = {bv[cg].x, bv[cg].y, bv[cg].z, bv[cg].w};
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int y = 0; y < 4; ++y)
-                        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[x], be[y], acc[x][y], 0, 0, 0);
+                an[cg] = pa ? Pp[cg * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                bn[cg] = pb ? Qp[cg * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+#pragma unroll
+        for (int cg = 0; cg < 8; ++cg) {
+            const float ae[4] = {av[cg].x, av[cg].y, av[cg].z, av[cg].w};
+            const float be[4] = {bv[cg].x, bv[cg].y, bv[cg].z, bv[cg].w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[x], be[y], acc[x][y], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cg = 0; cg < 8; ++cg) { av[cg] = an[cg]; bv[cg] = bn[cg]; }
     }
 #pragma unroll
     for (int x = 0; x < 4; ++x)
