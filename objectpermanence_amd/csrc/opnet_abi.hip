@@ -246,7 +246,11 @@ static dim3 step_grid(const StepArgs &a)
     const bool wide = step_is_wide(a);
     const int gy = env_int("OPNET_MAX_GY", wide ? 2 * OPNET_MAX_GY : OPNET_MAX_GY);
     const int tiles = wide ? a.H2 / 8 + a.H1 / 8 : a.H2 / 4 + a.H1 / 4;
-    return dim3(tiles + 2, a.RB < gy ? a.RB : gy, 1);
+    // grid.x is rounded up to a multiple of 8: workgroups are dealt round-robin over the 8 XCDs in linear order, so with
+    // a multiple of 8 per grid row the workgroups (bx, 0), (bx, 1), ... of one tile land on the SAME XCD and the second to
+    // fourth row block's fetch of the tile's weights hits that XCD's L2 instead of crossing the fabric again
+    const int gx = env_int("OPNET_XCD_ALIGN", 1) ? (tiles + 2 + 7) / 8 * 8 : tiles + 2;
+    return dim3(gx, a.RB < gy ? a.RB : gy, 1);
 }
 static dim3 copy_grid(int B, int T)
 {

@@ -622,9 +622,9 @@ __device__ __forceinline__ void opnet_step_body(const StepArgs &a, const int s)
         }
     } else if (bx == n2 + n1) {
         role_selection_head<CH, NW>(a, s, part, lg);
-    } else {
+    } else if (bx == n2 + n1 + 1) {
         role_output_head<CH, NW>(a, s, part);
-    }
+    }   // beyond: padding workgroups (the host rounds grid.x up to a multiple of the 8 XCDs)
     TRACE_STAMP(5);
 }
 
@@ -823,9 +823,9 @@ __global__ void __launch_bounds__(OPNET_THREADS) opnet_step_wide(const StepArgs 
         }
     } else if (bx == p2 + p1) {
         role_selection_head<CH>(a, s, part, lg);
-    } else {
+    } else if (bx == p2 + p1 + 1) {
         role_output_head<CH>(a, s, part);
-    }
+    }   // beyond: padding workgroups
 }
 
 // ------------------------------------------------------------------------------------------------
