@@ -1001,7 +1001,7 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
         rows_to_packed<<<2048, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, RB, KX, P.nhx[0] * 16,
                                               (float4 *)(w + W.state), (long)((W.state_end - W.state) / 16));
     }
-    const dim3 grid(ntiles, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
+    const dim3 grid((ntiles + 7) / 8 * 8, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);   // XCD-aligned, see step_grid
     if (!graph) {
         const stack_step_fn stepk = stack_step_kernel(RB);
         for (int s = 0; s < nlaunch; ++s) stepk<<<grid, stack_step_threads(RB), 0, st>>>(a, s);
@@ -1219,7 +1219,7 @@ extern "C" int opseq_lstm_stack_train_forward_f32(const float *x, const float *p
         a.layer[0].a_skip = P.nhx[0];
         a.layer[0].nhx = 0;
     }
-    const dim3 grid((2 * L - 1) * (H / 4) + 1, a.RB < OPNET_MAX_GY ? a.RB : OPNET_MAX_GY, 1);
+    const dim3 grid(((2 * L - 1) * (H / 4) + 1 + 7) / 8 * 8, a.RB < OPNET_MAX_GY ? a.RB : OPNET_MAX_GY, 1);
     const stack_step_fn stepk = stack_step_kernel(a.RB);
     for (int s = 0; s < T + 2 * L - 1; ++s) stepk<<<grid, stack_step_threads(a.RB), 0, st>>>(a, s);
     const long ny = (long)B * T;

@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_stack_step(const StackArgs a, co
         }
     } else {
         // head: predictions_layer (learned_models.py:101,113 / 137,148 / 172,195)
+        if (bx != 0) return;   // padding workgroups (grid.x is rounded up to a multiple of the 8 XCDs)
         const int t = s - (2 * a.L - 1);
         if (t < 0 || t >= a.T) return;
         const StackLayer &ly = a.layer[a.L - 1];
