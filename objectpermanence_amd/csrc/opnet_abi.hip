@@ -128,14 +128,14 @@ extern "C" int opnet_hip_abi_version(void) { return 1; }
 extern "C" const char *opnet_last_error(void) { return g_err; }
 
 // the step kernel comes in two register-chunk sizes (opnet_kernels.hip, load_a_chunk): 8 for one row block, 4 beyond;
-// from OPNET_WIDE_MIN row blocks on, the two-tiles-per-workgroup form (opnet_step_wide) takes over
+// from OPNET_WIDE_MIN (3) row blocks on, the two-tiles-per-workgroup form (opnet_step_wide) takes over
 typedef void (*opnet_step_fn)(const StepArgs, const int);
 static int env_int(const char *name, int dflt)
 {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-static bool step_is_wide(const StepArgs &a) { return !a.mlp && a.RB >= env_int("OPNET_WIDE_MIN", 4); }
+static bool step_is_wide(const StepArgs &a) { return !a.mlp && a.RB >= env_int("OPNET_WIDE_MIN", 3); }
 // one row block: K split over 8 waves instead of 4 - a wave's whole slice is then one 4-hexadecet chunk (one fetch round
 // trip, 32 instead of 64 chained MFMAs) at 119 VGPRs; the launch is a latency chain there
 static bool step_is_nw8(const StepArgs &a)
