@@ -294,6 +294,44 @@ __global__ void __launch_bounds__(256) opnet_bwd_cell(const BwdArgs a, const int
 #define FUSED_CH 16         // hexadecets a wave fetches up front (H2 = 512: its whole slice, one round trip)
 #define FUSED_THREADS (64 * FUSED_NW)
 
+// NCH chunks of 4 hexadecets, two register stages: chunk c+1 is in flight while chunk c is multiplied.  Everything is
+// unconditional and fully unrolled, so the compiler's waits are counted (vmcnt(8) before a chunk's first MFMA).
+// Hexadecet q0 + j feeds accumulator chain j & 1, in order - the same sums as the generic path.
+template <int NCH>
+__device__ __forceinline__ void fused_pipelined(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rs, int lane, int boff,
+                                                int q0, f32x4 &acc0, f32x4 &acc1)
+{
+    float4 fa[2][4], fb[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        fa[0][j] = frag_load(ra, lane * 16, (q0 + j) * 1024);
+        fb[0][j] = frag_load(rs, boff, (q0 + j) * 2048);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                fa[(c + 1) & 1][j] = frag_load(ra, lane * 16, (q0 + 4 * (c + 1) + j) * 1024);
+                fb[(c + 1) & 1][j] = frag_load(rs, boff, (q0 + 4 * (c + 1) + j) * 2048);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the whole next chunk in flight: the scheduler otherwise sinks loads to their uses
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            const float4 a0 = fa[c & 1][j], b0 = fb[c & 1][j], a1 = fa[c & 1][j + 1], b1 = fb[c & 1][j + 1];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
+        }
+    }
+}
+
 // D[16 rows x 16 clips] = A[16 x 16 nq] . da^T over hexadecets [0, nq) split over the FUSED_NW waves - every wave
 // issues ALL its fragment loads before its first MFMA and keeps two accumulator chains - summed in fixed wave order
 // through `part` ([FUSED_NW][4][64] floats); returns this thread's element (tid < 256): row tid >> 4, clip tid & 15
@@ -306,6 +344,14 @@ __device__ __forceinline__ float fused_product(const float4 *__restrict__ A, con
     const int boff = ((lane >> 4) * 32 + (lane & 15) + 16 * hf) * 16;
     const __amdgpu_buffer_rsrc_t ra = frag_rsrc(A), rs = frag_rsrc(seg);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // Common sizes (a wave's slice = 16 or 8 hexadecets: H = 512 / 256): a two-stage pipeline of 4-hexadecet chunks, fully
+    // unrolled with unconditional loads so that the compiler waits for exactly the chunk it is about to multiply while the
+    // next one streams in.  This workgroup's 256 KB of fragments take as long to cross its CU's L1 (64 B/clk) as its 512
+    // MFMAs take to issue; fetching everything first and multiplying afterwards (the generic path below) serialises the two.
+    const int nslice = q1 - q0;
+    if (nslice == 16) fused_pipelined<4>(ra, rs, lane, boff, q0, acc0, acc1);
+    else if (nslice == 8) fused_pipelined<2>(ra, rs, lane, boff, q0, acc0, acc1);
+    else
     for (int qb = q0; qb < q1; qb += FUSED_CH) {
         float4 fa[FUSED_CH], fb[FUSED_CH];
 #pragma unroll
