@@ -297,29 +297,37 @@ __global__ void __launch_bounds__(256) opnet_bwd_cell(const BwdArgs a, const int
 // NCH chunks of 4 hexadecets, two register stages: chunk c+1 is in flight while chunk c is multiplied.  Everything is
 // unconditional and fully unrolled, so the compiler's waits are counted (vmcnt(8) before a chunk's first MFMA).
 // Hexadecet q0 + j feeds accumulator chain j & 1, in order - the same sums as the generic path.
-template <int NCH>
+#ifndef FUSED_PC
+#define FUSED_PC 2      // hexadecets per pipeline chunk
+#endif
+#ifndef FUSED_ST
+#define FUSED_ST 2      // register stages (chunks in flight + the one being multiplied)
+#endif
+template <int NCH, int PC, int ST>
 __device__ __forceinline__ void fused_pipelined(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rs, int lane, int boff,
                                                 int q0, f32x4 &acc0, f32x4 &acc1)
 {
-    float4 fa[2][4], fb[2][4];
+    float4 fa[ST][PC], fb[ST][PC];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        fa[0][j] = frag_load(ra, lane * 16, (q0 + j) * 1024);
-        fb[0][j] = frag_load(rs, boff, (q0 + j) * 2048);
-    }
+    for (int c = 0; c < ST - 1 && c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < PC; ++j) {
+            fa[c][j] = frag_load(ra, lane * 16, (q0 + PC * c + j) * 1024);
+            fb[c][j] = frag_load(rs, boff, (q0 + PC * c + j) * 2048);
+        }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        if (c + 1 < NCH) {
+        if (c + ST - 1 < NCH) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                fa[(c + 1) & 1][j] = frag_load(ra, lane * 16, (q0 + 4 * (c + 1) + j) * 1024);
-                fb[(c + 1) & 1][j] = frag_load(rs, boff, (q0 + 4 * (c + 1) + j) * 2048);
+            for (int j = 0; j < PC; ++j) {
+                fa[(c + ST - 1) % ST][j] = frag_load(ra, lane * 16, (q0 + PC * (c + ST - 1) + j) * 1024);
+                fb[(c + ST - 1) % ST][j] = frag_load(rs, boff, (q0 + PC * (c + ST - 1) + j) * 2048);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the whole next chunk in flight: the scheduler otherwise sinks loads to their uses
+        __builtin_amdgcn_sched_barrier(0);   // keep the later chunks in flight: the scheduler otherwise sinks loads to their uses
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) {
-            const float4 a0 = fa[c & 1][j], b0 = fb[c & 1][j], a1 = fa[c & 1][j + 1], b1 = fb[c & 1][j + 1];
+        for (int j = 0; j < PC; j += 2) {
+            const float4 a0 = fa[c % ST][j], b0 = fb[c % ST][j], a1 = fa[c % ST][j + 1], b1 = fb[c % ST][j + 1];
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
@@ -349,8 +357,8 @@ __device__ __forceinline__ float fused_product(const float4 *__restrict__ A, con
     // next one streams in.  This workgroup's 256 KB of fragments take as long to cross its CU's L1 (64 B/clk) as its 512
     // MFMAs take to issue; fetching everything first and multiplying afterwards (the generic path below) serialises the two.
     const int nslice = q1 - q0;
-    if (nslice == 16) fused_pipelined<4>(ra, rs, lane, boff, q0, acc0, acc1);
-    else if (nslice == 8) fused_pipelined<2>(ra, rs, lane, boff, q0, acc0, acc1);
+    if (nslice == 16) fused_pipelined<16 / FUSED_PC, FUSED_PC, FUSED_ST>(ra, rs, lane, boff, q0, acc0, acc1);
+    else if (nslice == 8) fused_pipelined<8 / FUSED_PC, FUSED_PC, FUSED_ST>(ra, rs, lane, boff, q0, acc0, acc1);
     else
     for (int qb = q0; qb < q1; qb += FUSED_CH) {
         float4 fa[FUSED_CH], fb[FUSED_CH];
