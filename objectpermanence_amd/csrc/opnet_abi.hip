@@ -655,12 +655,12 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
                                         (long)((W.dcz_end - W.dcz) / 4), B, T, RB);
     bw.mlp = mlp;
     if (mlp) opnet_mlp_dhid<<<4096, 256, 0, st>>>(bw);
-    // Reverse recurrence.  Small batches (one or two row blocks): ONE fused launch per step - a workgroup owns complete
-    // dh rows, so the cell backward rides the product's epilogue.  Larger batches: the split-K pair (4x the
-    // workgroups per product, partials met by the next launch's cell kernel) - with many row blocks per tile the
-    // fused form's 98 workgroups leave most of the chip idle (measured B=256: 16.9 vs 14.5 ms per step).
+    // Reverse recurrence.  Up to four row blocks: ONE fused launch per step - a workgroup owns complete dh rows, so the
+    // cell backward rides the product's epilogue.  Larger batches: the split-K pair (4x the workgroups per product,
+    // partials met by the next launch's cell kernel) - with many row blocks per tile the fused form's 98 workgroups
+    // leave most of the chip idle (measured per step, fused / split: B=96 6.72 / 7.17 ms, B=128 7.79 / 7.92, B=256 12.97 / 12.38).
     const char *mode = getenv("OPNET_BWD_MODE");          // "fused" / "split": measurement override
-    const bool fused = mode ? strcmp(mode, "fused") == 0 : RB <= 2;
+    const bool fused = mode ? strcmp(mode, "fused") == 0 : RB <= 4;
     if (fused) {
         const dim3 gfused(2 * (H2 / 16 + H1 / 16 + 1), RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
         for (int n = 0; n <= T + 1; ++n) opnet_bwd_fused<<<gfused, FUSED_THREADS, 0, st>>>(bw, n);
