@@ -52,19 +52,28 @@ def encode_boxes(bb: List[np.ndarray], labels: List[np.ndarray], n_tracks: int =
     """-> float64 [T, 15, n_tracks] normalised boxes (cast to float32 by the caller, like the reference)."""
     T = len(labels)
     all_ids = _flat_ids(labels)
-    order = slot_order(labels, all_ids)[:MAX_OBJECTS]
+    full_order = slot_order(labels, all_ids)
+    order = full_order[:MAX_OBJECTS]
     out = np.zeros((T, MAX_OBJECTS, n_tracks), dtype=np.float64)
-    if n_tracks == 6:
-        for s, oid in enumerate(order):
-            out[:, s, 5] = 1.0 if oid in CONE_IDS else 0.0        # a cone slot carries its cone bit even when empty
     counts = np.fromiter((len(l) for l in labels), dtype=np.int64, count=T)
     if len(all_ids) > 0:
         all_bb = np.concatenate([b for b, n in zip(bb, counts) if n > 0], axis=None).astype(np.float64).reshape(-1, 4)
         frame = np.repeat(np.arange(T, dtype=np.int64), counts)
         lut = np.full(max(int(all_ids.max()) + 1, SNITCH_INDEX + 1), -1, dtype=np.int64)
-        for s, oid in enumerate(order):
+        for s, oid in enumerate(full_order):
             lut[oid] = s
-        slot = lut[all_ids]
+        rank = lut[all_ids]                                       # position in the video's order, truncated ids too
+        if n_tracks == 6:
+            # An empty cone slot keeps its cone bit ONLY while the reference's walk still has detections to place
+            # (datasets.py:288-318: the while loop ends with the frame's last sorted detection, everything behind it -
+            # a whole empty frame included - is plain zero padding, :320-324): slot s of frame t gets [0,0,0,0,0,1]
+            # iff s is a cone and s < the largest rank present in t.  An id truncated beyond slot 15 has rank >= 15:
+            # the walk then pads every remaining slot before it breaks (:291-292).
+            last_rank = np.full(T, -1, dtype=np.int64)
+            np.maximum.at(last_rank, frame, rank)
+            cone = np.array([1.0 if oid in CONE_IDS else 0.0 for oid in order], dtype=np.float64)
+            out[:, :len(order), 5] = cone[None, :] * (np.arange(len(order))[None, :] < last_rank[:, None])
+        slot = np.where(rank < MAX_OBJECTS, rank, -1)
         keep = slot >= 0
         key = frame[keep] * MAX_OBJECTS + slot[keep]
         _, first = np.unique(key, return_index=True)              # first occurrence of every (frame, slot)
@@ -79,6 +88,8 @@ def encode_boxes(bb: List[np.ndarray], labels: List[np.ndarray], n_tracks: int =
             rows = np.concatenate([rows[slot[rows] != lut[SNITCH_INDEX]], rev[last]])
         out[frame[rows], slot[rows], :4] = all_bb[rows]
         out[frame[rows], slot[rows], 4] = 1.0
+        if n_tracks == 6:
+            out[frame[rows], slot[rows], 5] = cone[slot[rows]]    # a detected object carries is_cone_object(id) (:302)
     out[..., :4] /= FRAME_SHAPES
     return out
 

@@ -154,7 +154,7 @@ def gen_datasets():
     with tempfile.TemporaryDirectory() as tmp:
         samples, labels_dir = os.path.join(tmp, "s"), os.path.join(tmp, "l")
         os.makedirs(samples); os.makedirs(labels_dir)
-        variants = ["plain", "dups", "crowded", "nosnitch0"]
+        variants = ["plain", "dups", "crowded", "nosnitch0", "sparse"]
         lines = []
         for i, v in enumerate(variants):
             name = f"vid_{i:02d}_{v}"
@@ -381,25 +381,51 @@ def gen_metric(tu, y, labels):
     print("metric: mean IoU jit =", res["video_mean_iou_jit"].mean(), " mAP50 jit =", res["video_map50_jit"].mean())
 
 
+def gen_cone_ids():
+    """tests/golden/cone_ids.json: the cone class ids, class count and snitch id of the reference's 193-name table
+    (object_indices.py:1-202), obtained by calling its own is_cone_object on every id."""
+    sys.path.insert(0, REF)
+    import object_indices as roi
+    from baselines import datasets as rd
+    n = len(roi.OBJECTS_NAME_TO_IDX)
+    cones = [i for i in range(n) if roi.is_cone_object(i)]
+    with open(os.path.join(OUT, "cone_ids.json"), "w") as f:
+        json.dump({"cone_ids": cones, "num_classes": n, "snitch": int(rd.SNITCH_INDEX)}, f)
+    print("cone_ids:", len(cones), "cones of", n)
+
+
 def main():
+    """`python oracle/gen_golden.py` rewrites every fixture; `python oracle/gen_golden.py datasets cone_ids ...`
+    only the named sections."""
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])
+    want = lambda k: not only or k in only
     lm, tu = _import_reference()
     tiny = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 16, "videos_hidden_dim": 32}
-    gen_opnet(lm, tiny, n_clips=2, t_frames=12, tag="tiny", keep_intermediates=True)
     with open(os.path.join(REF, "configs", "opnet_model_config.json")) as f:
         real = json.load(f)
-    y, labels = gen_opnet(lm, real, n_clips=4, t_frames=300, tag="real", keep_intermediates=False)
-    gen_metric(tu, y, labels)
-    gen_detector_filter()
-    gen_analysis()
-    gen_trained(lm, tu, real)
-    gen_siblings(lm)
-    gen_sibling_train(lm)
-    gen_datasets()
-    gen_train(lm, tiny, n_clips=3, t_frames=12, tag="tiny", full=True, adam_steps=3)
-    gen_train(lm, real, n_clips=4, t_frames=300, tag="real", full=False, adam_steps=2)
+    if want("opnet"):
+        gen_opnet(lm, tiny, n_clips=2, t_frames=12, tag="tiny", keep_intermediates=True)
+        y, labels = gen_opnet(lm, real, n_clips=4, t_frames=300, tag="real", keep_intermediates=False)
+        gen_metric(tu, y, labels)
+    if want("detector_filter"):
+        gen_detector_filter()
+    if want("analysis"):
+        gen_analysis()
+    if want("trained"):
+        gen_trained(lm, tu, real)
+    if want("siblings"):
+        gen_siblings(lm)
+        gen_sibling_train(lm)
+    if want("datasets"):
+        gen_datasets()
+    if want("cone_ids"):
+        gen_cone_ids()
+    if want("train"):
+        gen_train(lm, tiny, n_clips=3, t_frames=12, tag="tiny", full=True, adam_steps=3)
+        gen_train(lm, real, n_clips=4, t_frames=300, tag="real", full=False, adam_steps=2)
 
 
 if __name__ == "__main__":

@@ -240,11 +240,15 @@ def make_raw_video(c: int, variant: str = "plain", t_frames: int = T_FRAMES):
     """Raw perception sample as the detector / "perfect perception" tools write it:
     returns (bb list[T] of int64 [n_f,4] xyxy pixels, labels list[T] of int64 [n_f], gt dict name -> list[T] [x,y,w,h]).
     variants: "plain" (10 objects, random drop-outs), "dups" (duplicate ids + shuffled order inside frames),
-    "crowded" (17 distinct objects -> the encoder truncates to 15 slots), "nosnitch0" (snitch absent at frame 0)."""
+    "crowded" (17 distinct objects -> the encoder truncates to 15 slots), "nosnitch0" (snitch absent at frame 0),
+    "sparse" (the two HIGHEST ids of the video are cones - 185, 189 -, every object is visible only half of the time and
+    every 7th frame is empty: slots behind a frame's last detection must get plain zero padding, datasets.py:288-323)."""
     rng = np.random.default_rng(5000 + c)
     ids = [SNITCH_ID] + list(CONE_IDS) + list(OTHER_IDS)
     if variant == "crowded":
         ids = ids + [8, 12, 16, 66, 67, 99, 134]         # three more cones (8, 12, 16) and four non-cones
+    if variant == "sparse":
+        ids = ids[:-2] + [185, 189]                      # cones in the last two slots of the video's order
     n = len(ids)
     w = rng.integers(8, 65, size=n); h = rng.integers(8, 65, size=n)
     px = rng.uniform(0, 236, size=n); py = rng.uniform(0, 156, size=n)
@@ -261,8 +265,10 @@ def make_raw_video(c: int, variant: str = "plain", t_frames: int = T_FRAMES):
         px = np.clip(px + vx, 0, 235); py = np.clip(py + vy, 0, 155)
         x1 = px.astype(np.int64); y1 = py.astype(np.int64)
         box = np.stack([x1, y1, x1 + w, y1 + h], axis=1)
-        vis = rng.random(n) < 0.9
+        vis = rng.random(n) < (0.5 if variant == "sparse" else 0.9)
         vis[0] = not hidden[t]
+        if variant == "sparse" and t % 7 == 3:
+            vis[:] = False                                  # a frame without a single detection
         idx = np.flatnonzero(vis)
         if variant == "dups" and len(idx) > 2:
             extra = rng.choice(idx, size=2)                 # the perception model repeats two ids ...
