@@ -70,6 +70,23 @@ int opnet_plan_forward(opnet_plan *plan, const float *boxes, const float *packed
                        float *logits, void *workspace, size_t workspace_bytes, void *stream);
 void opnet_plan_destroy(opnet_plan *plan);
 
+/* Per-XCD persistent form (H1 = 256, H2 = 512 only - configs/opnet_model_config.json): ONE launch in which each of the
+ * chip's 8 XCDs runs the whole T-step forward of its own share of the clips (groups of 16) with every weight resident in
+ * registers; the only exchange is h1 / h2 among the 32 CUs of one XCD.  Same inputs / outputs as opnet_forward_f32 and
+ * the same `packed` image; results agree with the step-launch form to fp32 rounding (different K-split summation
+ * order).  B <= opnet_xcd_max_batch() clips per call; throughput needs >= 2 groups per XCD (B >= 256), a small batch is
+ * faster through opnet_plan_forward.  The workspace keeps the h1 / h2 history (~1 MB per clip at T = 300); its first 12
+ * bytes are status words {abort code, block, phase}: a launch that could not complete (a workgroup not resident for
+ * ~1.5 s) sets the code and fills y with NaN instead of hanging.  Launches of this form are chained per device through
+ * an event (two persistent grids must not be co-resident), whatever streams the callers use. */
+int opnet_xcd_max_batch(void);
+size_t opnet_xcd_workspace_bytes(int B, int T, int H1, int H2);
+int opnet_xcd_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
+                          void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
+                          void *stream);
+/* tools: device buffer of >= (T+1) * ceil(B/128) * 4 uint64 receiving s_memtime stamps of block 0 (NULL = off) */
+void opnet_xcd_set_trace(void *device_buffer);
+
 /* ---- training (replaces torch autograd through OPNet.forward, nn.L1Loss and torch.optim.Adam as used
  *      at training_main.py:150-152,183-217) ---------------------------------------------------------
  * opnet_train_forward_f32 is opnet_forward_f32 that additionally keeps every step's h, c, gates,

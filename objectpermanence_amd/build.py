@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libopnet_hip.so")
 SOURCES = ["opnet_abi.hip", "opdet_abi.hip"]
-DEPS = ["opnet_abi.hip", "opdet_abi.hip", "det_head_kernels.hip", "attn_kernels.hip", "enc_train_kernels.hip", "opnet_kernels.hip", "opnet_train_kernels.hip", "seq_kernels.hip", "conv_kernels.hip", "opnet_ctx.h", os.path.join("..", "..", "include", "opnet_hip.h")]
+DEPS = ["opnet_abi.hip", "opdet_abi.hip", "det_head_kernels.hip", "attn_kernels.hip", "enc_train_kernels.hip", "opnet_kernels.hip", "opnet_xcd_kernels.hip", "opnet_train_kernels.hip", "seq_kernels.hip", "conv_kernels.hip", "opnet_ctx.h", os.path.join("..", "..", "include", "opnet_hip.h")]
 
 
 def _hipcc() -> str:

@@ -1,6 +1,7 @@
 // opnet_abi.hip - host side of libopnet_hip.so: the C ABI declared in include/opnet_hip.h.
 // Plain pointers and sizes in, HIP launches on the caller's stream out; no torch types.
 #include "opnet_kernels.hip"
+#include "opnet_xcd_kernels.hip"
 #include "opnet_train_kernels.hip"
 #include "seq_kernels.hip"
 #include "conv_kernels.hip"
@@ -280,6 +281,108 @@ extern "C" int opnet_forward_f32(const float *boxes, const float *packed, float 
         for (int s = 0; s < T + 3; ++s) stepk<<<grid, step_threads(a), 0, st>>>(a, s);
     }
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, per-XCD persistent form (opnet_xcd_kernels.hip): ONE launch, weights resident in registers
+// ------------------------------------------------------------------------------------------------
+struct XcdWorkspaceLayout {  // offsets in bytes
+    size_t status, flags, xp, h1h, h2h, total;
+    int NGT;
+};
+
+static XcdWorkspaceLayout xcd_workspace_layout(int B, int T)
+{
+    XcdWorkspaceLayout L;
+    const size_t NGT = (size_t)(B + 15) / 16;
+    size_t o = 0;
+    L.NGT = (int)NGT;
+    L.status = o; o += 2048;                                   // 8 control words + 256 XCC ids
+    L.flags = o;  o += align_up(NGT * XCD_CUS * 4, 256);
+    L.xp = o;     o += NGT * (size_t)(T + 2) * OPNET_KXQ * 256;
+    L.h1h = o;    o += NGT * (size_t)(T + 1) * (XCD_H1 / 4) * 256;
+    L.h2h = o;    o += NGT * (size_t)(T + 1) * (XCD_H2 / 4) * 256;
+    L.total = align_up(o, 256);
+    return L;
+}
+
+// largest batch one launch carries: XCD_NGMAX groups of 16 clips on each of the 8 XCDs
+#define XCD_MAX_B (XCD_COUNT * XCD_NGMAX * 16)
+
+static int check_xcd(int B, int T, int H1, int H2)
+{
+    if (B <= 0 || T <= 0) return fail(OPNET_ESHAPE, "B=%d T=%d must be positive", B, T);
+    if (H1 != XCD_H1 || H2 != XCD_H2)
+        return fail(OPNET_ESHAPE, "the per-XCD persistent forward is built for H1=%d, H2=%d (got %d, %d); use opnet_forward_f32",
+                    XCD_H1, XCD_H2, H1, H2);
+    if (B > XCD_MAX_B) return fail(OPNET_ESHAPE, "B=%d > %d clips per launch: split the batch", B, XCD_MAX_B);
+    const XcdWorkspaceLayout L = xcd_workspace_layout(B, T);
+    if (L.h2h + (L.total - L.h2h) >= ((size_t)1 << 31) || (L.total - L.h2h) >= ((size_t)1 << 31))
+        return fail(OPNET_ESHAPE, "B=%d x T=%d: a history buffer exceeds the 2 GiB a buffer descriptor addresses", B, T);
+    return OPNET_OK;
+}
+
+extern "C" int opnet_xcd_max_batch(void) { return XCD_MAX_B; }
+
+extern "C" size_t opnet_xcd_workspace_bytes(int B, int T, int H1, int H2)
+{
+    if (check_xcd(B, T, H1, H2)) return 0;
+    return xcd_workspace_layout(B, T).total;
+}
+
+// tools: in-kernel timeline of block 0 (device buffer of >= (T+1) * groups-per-XCD * 4 u64), null = off
+static unsigned long long *g_xcd_trace = nullptr;
+extern "C" void opnet_xcd_set_trace(void *device_buffer) { g_xcd_trace = (unsigned long long *)device_buffer; }
+
+// Two persistent launches must never be co-resident (each needs every CU of its XCDs: two half-resident grids would
+// wait for each other until the spin limit), so launches are chained per device through an event whatever streams
+// the callers use.
+static std::mutex g_xcd_mu;
+static hipEvent_t g_xcd_done[64] = {};
+static int g_xcd_cus[64] = {};
+
+extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
+                                     void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
+                                     void *stream)
+{
+    if (int rc = check_xcd(B, T, H1, H2)) return rc;
+    if (!boxes || !packed || !y || !logits || !workspace) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(packed) || !aligned16(y) || !aligned16(workspace) || (((uintptr_t)boxes) & 7u))
+        return fail(OPNET_EINVAL, "packed/y/workspace must be 16-byte and boxes 8-byte aligned");
+    const XcdWorkspaceLayout L = xcd_workspace_layout(B, T);
+    if (workspace_bytes < L.total) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", workspace_bytes, L.total);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(OPNET_EINVAL, "device index %d out of range", dev);
+    hipStream_t st = (hipStream_t)stream;
+    char *w = (char *)workspace;
+    XcdArgs a;
+    a.B = B; a.T = T; a.NGT = L.NGT;
+    a.packed = packed;
+    a.xp = (const float4 *)(w + L.xp);
+    a.h1h = (float4 *)(w + L.h1h);
+    a.h2h = (float4 *)(w + L.h2h);
+    a.flags = (unsigned *)(w + L.flags);
+    a.status = (unsigned *)(w + L.status);
+    a.logits = logits;
+    a.trace = g_xcd_trace;
+    std::lock_guard<std::mutex> lock(g_xcd_mu);
+    if (!g_xcd_cus[dev]) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        g_xcd_cus[dev] = prop.multiProcessorCount;
+    }
+    if (g_xcd_cus[dev] < XCD_COUNT * XCD_CUS)
+        return fail(OPNET_ESHAPE, "device %d exposes %d CUs; the persistent forward needs %d resident workgroups", dev,
+                    g_xcd_cus[dev], XCD_COUNT * XCD_CUS);
+    if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
+    else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
+    opnet_xcd_pack_input<<<dim3(T + 2, L.NGT), 384, 0, st>>>(boxes, a);
+    opnet_xcd_forward<XCD_PF><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
+    HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
+    opnet_xcd_out_head<<<dim3(T, L.NGT), 256, 0, st>>>(a, y);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

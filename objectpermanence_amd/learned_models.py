@@ -215,6 +215,10 @@ class OPNet(AbstractCaterModel):
         self._tws_key = None
         self._train_gen = 0
         self.use_graph = os.environ.get("OPNET_HIP_EAGER", "0") != "1"
+        # per-XCD persistent forward (include/opnet_hip.h): "auto" = batches of at least XCD_MIN_BATCH clips at the
+        # reference sizes; "1" / "0" force it on / off
+        self.use_xcd = os.environ.get("OPNET_XCD", "auto")
+        self._xws: Dict[Tuple[int, int, int], torch.Tensor] = {}
 
     # -- weights ------------------------------------------------------------------------------
     def _weights(self):
@@ -242,6 +246,41 @@ class OPNet(AbstractCaterModel):
             self._packed_key = key
         return self._packed
 
+    XCD_MIN_BATCH = 128
+
+    def _wants_xcd(self, B: int) -> bool:
+        if self.use_xcd in ("0", 0, False) or (self._h1, self._h2) != (256, 512):
+            return False
+        return self.use_xcd in ("1", 1, True) or B >= self.XCD_MIN_BATCH
+
+    def _forward_xcd(self, boxes: torch.Tensor, packed: torch.Tensor, stream: int):
+        """one persistent launch per chunk of opnet_xcd_max_batch() clips (csrc/opnet_xcd_kernels.hip)"""
+        lib = _lib.load()
+        B, T, dev = int(boxes.shape[0]), int(boxes.shape[1]), boxes.device
+        y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, 15, T), dtype=torch.float32, device=dev)
+        step = int(lib.opnet_xcd_max_batch())
+        for lo in range(0, B, step):
+            n = min(step, B - lo)
+            key = (n, T, dev.index if dev.index is not None else torch.cuda.current_device())
+            if key not in self._xws:
+                nbytes = lib.opnet_xcd_workspace_bytes(n, T, self._h1, self._h2)
+                if nbytes == 0:
+                    _lib.check(-2, "opnet_xcd_workspace_bytes")
+                if len(self._xws) >= 4:
+                    self._xws.pop(next(iter(self._xws)))
+                self._xws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ws = self._xws[key]
+            rc = lib.opnet_xcd_forward_f32(boxes[lo:lo + n].data_ptr(), packed.data_ptr(), y[lo:lo + n].data_ptr(),
+                                           logits[lo:lo + n].data_ptr(), ws.data_ptr(), ws.numel(), n, T,
+                                           self._h1, self._h2, stream)
+            _lib.check(rc, "opnet_xcd_forward_f32")
+        return y, logits
+
+    def xcd_status(self):
+        """{abort code, block, phase} of the last persistent launches (synchronises); code 0 = completed"""
+        return {k: ws[:12].view(torch.int32).tolist() for k, ws in self._xws.items()}
+
     # -- forward ------------------------------------------------------------------------------
     def forward(self, boxes: torch.Tensor):
         if not boxes.is_cuda:
@@ -262,6 +301,8 @@ class OPNet(AbstractCaterModel):
         with torch.cuda.device(dev):
             packed = self._packed_weights(dev)
             stream = _stream_ptr(dev)
+            if self._wants_xcd(B):
+                return self._forward_xcd(boxes, packed, stream)
             # one workspace + graph per (shape, device, stream): forwards enqueued on different HIP
             # streams run concurrently (the step kernel leaves most of a CU idle at small batches)
             key = (B, T, dev.index if dev.index is not None else torch.cuda.current_device(), stream)

@@ -1,0 +1,132 @@
+"""GPU parity tests of the per-XCD persistent OPNet forward (csrc/opnet_xcd_kernels.hip, opnet_xcd_forward_f32)
+against the reference's goldens, the fp64 oracle and the step-launch form.  `pytest -m gpu` on the MI355X box."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import opnet_oracle as oo
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+REAL_CFG = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
+TOL_Y = 2e-5          # fp32 through 300 recurrent steps, as tests/test_opnet_gpu.py
+TOL_LOGITS = 1e-4
+
+
+def _model(xcd, device="cuda:0"):
+    from objectpermanence_amd import ModelsFactory
+    m = ModelsFactory.get_model("opnet", REAL_CFG)
+    params = synth.opnet_synth_params(REAL_CFG)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    m.eval()
+    m.use_xcd = "1" if xcd else "0"
+    return m.to(device), params
+
+
+def _run(m, boxes):
+    with torch.no_grad():
+        y, lg = m(torch.from_numpy(boxes).to("cuda:0"))
+    torch.cuda.synchronize()
+    if m.use_xcd == "1":
+        for key, st in m.xcd_status().items():
+            assert st[0] == 0, f"persistent launch {key} aborted: block {st[1]} phase {st[2]}"
+    return y.cpu().numpy(), lg.cpu().numpy()
+
+
+def test_persistent_forward_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "opnet_real.npz"))
+    assert json.loads(str(g["cfg"])) == REAL_CFG
+    n, t = int(g["n_clips"]), int(g["t_frames"])
+    boxes, _ = synth.make_batch(0, n, t)
+    m, _ = _model(True)
+    y, lg = _run(m, boxes)
+    assert y.shape == g["y"].shape and lg.shape == g["logits"].shape
+    assert np.abs(y - g["y"]).max() < TOL_Y
+    assert np.abs(y[:, -5:] - g["y"][:, -5:]).max() < TOL_Y
+    assert np.abs(lg - g["logits"]).max() < TOL_LOGITS
+    px, px_ref = oo.postprocess_to_pixels(y), oo.postprocess_to_pixels(g["y"])
+    assert (px != px_ref).sum() <= 6 and np.abs(px - px_ref).max() <= 1
+
+
+# one group on one XCD (exposed exchange), ragged last group, one group on every XCD, uneven groups per XCD,
+# two and three groups per XCD (the overlapped ring), single frame
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (16, 5), (17, 9), (128, 6), (150, 11), (256, 8), (300, 5), (384, 4)])
+def test_persistent_forward_matches_oracle_ragged(B, T):
+    boxes, _ = synth.make_batch(100, B, T)
+    m, params = _model(True)
+    y, lg = _run(m, boxes)
+    y_ref, lg_ref = oo.opnet_forward(boxes, params, dtype=np.float64)
+    assert np.isfinite(y).all()
+    assert np.abs(y - y_ref).max() < TOL_Y
+    assert np.abs(lg - lg_ref).max() < TOL_LOGITS
+
+
+def test_persistent_forward_full_size_matches_step_launch_form_and_is_deterministic():
+    """BASELINE shape on every XCD: 8 x 32 clips x 300 frames.  The persistent form sums K in a different order than
+    the step launches -> rounding-level agreement; and it must reproduce ITSELF bit for bit from run to run (a stale
+    hand-off would not)."""
+    boxes, _ = synth.make_batch(0, 256, 300)
+    m, _ = _model(True)
+    y, lg = _run(m, boxes)
+    m0, _ = _model(False)
+    y0, lg0 = _run(m0, boxes)
+    assert np.abs(y - y0).max() < 1e-5
+    assert np.abs(lg - lg0).max() < 5e-5
+    for _ in range(3):
+        y2, lg2 = _run(m, boxes)
+        assert np.array_equal(y2, y) and np.array_equal(lg2, lg)
+
+
+def test_persistent_forward_chunks_large_batches():
+    """more clips than one launch carries (opnet_xcd_max_batch) are run as several chained launches"""
+    from objectpermanence_amd import _lib
+    step = int(_lib.load().opnet_xcd_max_batch())
+    B = step + 40
+    boxes, _ = synth.make_batch(3, B, 3)
+    m, params = _model(True)
+    y, lg = _run(m, boxes)
+    y_ref, lg_ref = oo.opnet_forward(boxes, params, dtype=np.float64)
+    assert np.abs(y - y_ref).max() < TOL_Y and np.abs(lg - lg_ref).max() < TOL_LOGITS
+
+
+def test_persistent_forward_under_concurrent_load_on_other_streams():
+    """Uneven load: a second stream keeps streaming kernels running while the persistent launch is resident, and two
+    persistent forwards are issued from different streams (the library chains them through an event)."""
+    boxes, _ = synth.make_batch(9, 256, 40)
+    m, _ = _model(True)
+    y_ref, lg_ref = _run(m, boxes)
+    xb = torch.from_numpy(boxes).to("cuda:0")
+    big = torch.empty(64 << 20, dtype=torch.float32, device="cuda:0")
+    s1, s2, s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    with torch.no_grad():
+        for it in range(3):
+            with torch.cuda.stream(s3):
+                for _ in range(20):
+                    big.mul_(1.0001)
+            with torch.cuda.stream(s1):
+                outs.append(m(xb))
+            with torch.cuda.stream(s2):
+                outs.append(m(xb))
+    torch.cuda.synchronize()
+    for key, st in m.xcd_status().items():
+        assert st[0] == 0
+    for y, lg in outs[-2:]:
+        assert np.array_equal(y.cpu().numpy(), y_ref) and np.array_equal(lg.cpu().numpy(), lg_ref)
+
+
+def test_workgroups_of_a_group_share_an_xcd():
+    """placement is for speed only (block b -> XCD b % 8 is observed, not promised): report it"""
+    boxes, _ = synth.make_batch(1, 256, 2)
+    m, _ = _model(True)
+    _run(m, boxes)
+    ws = next(iter(m._xws.values()))
+    xcc = ws[32:32 + 4 * 256].view(torch.int32).cpu().numpy()
+    same = all(len(set(xcc[x::8].tolist())) == 1 for x in range(8))
+    print("XCC ids of blocks 0..15:", xcc[:16].tolist(), "groups XCD-local:", same)
+    assert set(xcc.tolist()) <= set(range(8))

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Timing of the per-XCD persistent OPNet forward (opnet_xcd_forward_f32) against the step-launch form.
+    python tools/xcd_probe.py [--batches 32,64,128,256,512] [--frames 300] [--trace]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from objectpermanence_amd import ModelsFactory, _lib  # noqa: E402
+from synthdata import opnet as synth  # noqa: E402
+
+CFG = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
+
+
+def timed(fn, reps):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", default="32,64,128,256,512,1024")
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--trace", action="store_true")
+    ap.add_argument("--no-chain", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    m = ModelsFactory.get_model("opnet", CFG)
+    params = synth.opnet_synth_params(CFG)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    m = m.eval().to(dev)
+    T = args.frames
+    for B in [int(b) for b in args.batches.split(",")]:
+        boxes, _ = synth.make_batch(0, min(B, 64), T)
+        boxes = np.tile(boxes, ((B + boxes.shape[0] - 1) // boxes.shape[0], 1, 1, 1))[:B]
+        x = torch.from_numpy(boxes).to(dev)
+        res = {}
+        with torch.no_grad():
+            m.use_xcd = "1"
+            y1, l1 = m(x)
+            ms_x = timed(lambda: m(x), args.reps)
+            st = m.xcd_status()
+            res["xcd"] = ms_x
+            if not args.no_chain:
+                m.use_xcd = "0"
+                y0, l0 = m(x)
+                res["chain"] = timed(lambda: m(x), args.reps)
+                res["max|dy|"] = float((y1 - y0).abs().max())
+                res["max|dlogits|"] = float((l1 - l0).abs().max())
+        flops = B * 852.7e6
+        print(f"B={B:5d} T={T}: xcd {ms_x:8.3f} ms = {B / ms_x * 1e3:9.0f} clips/s ({flops / ms_x * 1e-9 / 157.3:.3f} of fp32 MFMA peak)"
+              + (f" | chain {res['chain']:8.3f} ms = {B / res['chain'] * 1e3:9.0f} clips/s | max|dy| {res['max|dy|']:.2e} max|dlg| {res['max|dlogits|']:.2e}"
+                 if "chain" in res else "") + f" | status {list(st.values())[-1]}", flush=True)
+    if args.trace:
+        B = 256
+        ng = 2
+        lib = _lib.load()
+        tr = torch.zeros((T + 1) * ng * 4, dtype=torch.int64, device=dev)
+        lib.opnet_xcd_set_trace(tr.data_ptr())
+        boxes, _ = synth.make_batch(0, 64, T)
+        x = torch.from_numpy(np.tile(boxes, (4, 1, 1, 1))).to(dev)
+        m.use_xcd = "1"
+        with torch.no_grad():
+            m(x)
+        torch.cuda.synchronize()
+        lib.opnet_xcd_set_trace(None)
+        t = tr.cpu().numpy().reshape(-1, 4)
+        ph = t[100:500]
+        print("cycles per phase (median): total %.0f | products %.0f | finish %.0f | publish+barrier %.0f" % (
+            np.median(np.diff(ph[:, 0])), np.median(ph[:, 1] - ph[:, 0]), np.median(ph[:, 2] - ph[:, 1]),
+            np.median(ph[:, 3] - ph[:, 2])))
+
+
+if __name__ == "__main__":
+    main()
