@@ -84,7 +84,7 @@ size_t opnet_xcd_workspace_bytes(int B, int T, int H1, int H2);
 int opnet_xcd_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
                           void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
                           void *stream);
-/* tools: device buffer of >= (T+1) * ceil(B/128) * 4 uint64 receiving s_memtime stamps of block 0 (NULL = off) */
+/* tools: device buffer of >= (T+1) * ceil(B/128) * 8 uint64 receiving s_memtime stamps of block 0 (NULL = off) */
 void opnet_xcd_set_trace(void *device_buffer);
 
 /* ---- training (replaces torch autograd through OPNet.forward, nn.L1Loss and torch.optim.Adam as used

@@ -319,8 +319,8 @@ static int check_xcd(int B, int T, int H1, int H2)
                     XCD_H1, XCD_H2, H1, H2);
     if (B > XCD_MAX_B) return fail(OPNET_ESHAPE, "B=%d > %d clips per launch: split the batch", B, XCD_MAX_B);
     const XcdWorkspaceLayout L = xcd_workspace_layout(B, T);
-    if (L.h2h + (L.total - L.h2h) >= ((size_t)1 << 31) || (L.total - L.h2h) >= ((size_t)1 << 31))
-        return fail(OPNET_ESHAPE, "B=%d x T=%d: a history buffer exceeds the 2 GiB a buffer descriptor addresses", B, T);
+    if (L.total >= ((size_t)1 << 31))
+        return fail(OPNET_ESHAPE, "B=%d x T=%d: the workspace exceeds the 2 GiB one buffer descriptor addresses; split the batch", B, T);
     return OPNET_OK;
 }
 
@@ -367,7 +367,11 @@ extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, fl
     a.flags = (unsigned *)(w + L.flags);
     a.status = (unsigned *)(w + L.status);
     a.logits = logits;
+    a.ws = w;
+    a.xp_off = (unsigned)L.xp; a.h1_off = (unsigned)L.h1h; a.h2_off = (unsigned)L.h2h; a.flags_off = (unsigned)L.flags;
     a.trace = g_xcd_trace;
+    a.force_safe = env_int("OPNET_XCD_SAFE", 0);
+    a.debug = env_int("OPNET_XCD_DEBUG", 0);
     std::lock_guard<std::mutex> lock(g_xcd_mu);
     if (!g_xcd_cus[dev]) {
         hipDeviceProp_t prop;
@@ -377,10 +381,10 @@ extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, fl
     if (g_xcd_cus[dev] < XCD_COUNT * XCD_CUS)
         return fail(OPNET_ESHAPE, "device %d exposes %d CUs; the persistent forward needs %d resident workgroups", dev,
                     g_xcd_cus[dev], XCD_COUNT * XCD_CUS);
+    opnet_xcd_pack_input<<<dim3(T + 2, L.NGT), 384, 0, st>>>(boxes, a);
     if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
     else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
-    opnet_xcd_pack_input<<<dim3(T + 2, L.NGT), 384, 0, st>>>(boxes, a);
-    opnet_xcd_forward<XCD_PF><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
+    opnet_xcd_forward<<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
     HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
     opnet_xcd_out_head<<<dim3(T, L.NGT), 256, 0, st>>>(a, y);
     HIP_TRY(hipGetLastError());

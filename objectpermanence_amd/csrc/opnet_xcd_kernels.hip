@@ -29,7 +29,7 @@
 //     nothing depends on which XCD a workgroup landed on - placement is for speed only: block b runs on XCD b % 8).
 // y = W_out h2 is not on the recurrence: it is computed from the h2 history by opnet_xcd_out_head afterwards.
 //
-// Every spin is bounded (XCD_SPIN_LIMIT cycles): a workgroup that cannot see its producers raises the abort word, every
+// Every spin is bounded (XCD_SPIN_LIMIT = 1.5 s): a workgroup that cannot see its producers raises the abort word, every
 // other poller sees it and leaves, and opnet_xcd_out_head poisons y with NaN - nothing can hang the device.
 //
 // Summation order (differs from the launch chain's K-split, agrees to rounding; tests hold both to the oracle):
@@ -38,6 +38,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "opnet_ctx.h"
 
 #define XCD_COUNT 8
@@ -45,18 +47,14 @@
 #define XCD_NGMAX 8            // 16-clip groups one XCD carries in one launch (8 x 16 x 8 XCDs = 1024 clips)
 #define XCD_H1 256
 #define XCD_H2 512
-#define XCD_SPIN_LIMIT (3ll << 30)   // shader cycles (~1.5 s) before a poller gives up
-#ifndef XCD_PF
-#define XCD_PF 5               // LSTM2 hexadecet pair after which the next phase's gather is issued
-#endif
+#define XCD_SPIN_LIMIT 150000000ll    // wall_clock64 ticks (100 MHz: 1.5 s) before a poller gives up
 
-// LDS gather buffer of one phase, in float4 units: X0 = x[s] | X1 = x[s-1] | H1 = h1[s-1] | H2 = h2[s-2]
+// LDS gather buffer of one phase, in float4 units: X0 = x[s] | H1 = h1[s-1] | H2 = h2[s-2]
 #define XB_X0 0
-#define XB_X1 (6 * 64)
-#define XB_H1 (12 * 64)
-#define XB_H2 (28 * 64)
-#define XB_F4 (60 * 64)        // 60 KB
-#define XB_CHUNKS 60
+#define XB_H1 (6 * 64)
+#define XB_H2 (22 * 64)
+#define XB_F4 (54 * 64)        // 54 KB
+#define XB_CHUNKS 54
 
 struct XcdArgs {
     int B, T, NGT;             // clips, frames, 16-clip groups = ceil(B / 16)
@@ -65,9 +63,14 @@ struct XcdArgs {
     float4 *h1h;               // [NGT][T+1][64][16]   slot t+1 = h1[t]; slot 0 zero
     float4 *h2h;               // [NGT][T+1][128][16]  slot t+1 = h2[t]; slot 0 zero
     unsigned *flags;           // [NGT][32]            steps published by CU c of the group's XCD
-    unsigned *status;          // [0] abort code (0 = ok), [1] first failing block, [2] phase, [8 + b] XCC_ID of block b
+    unsigned *status;          // [0] abort code (0 = ok), [1] first failing block, [2] phase, [3] groups not XCD-local,
+                               // [8 + b] XCC_ID of block b
     float *logits;             // caller's [B][15][T]
-    unsigned long long *trace; // optional [phases][4] s_memtime stamps of block 0 wave 0 (tools), or null
+    char *ws;                  // workspace base and the byte offsets of xp / h1h / h2h / flags in it (one buffer descriptor)
+    unsigned xp_off, h1_off, h2_off, flags_off;
+    int force_safe;            // 1: always use the placement-independent write-through protocol (tests)
+    int debug;                 // tools only (wrong results): bit 0 no poll/gather, 1 no head, 2 no cells, 3 no publish, 4 no x fetch
+    unsigned long long *trace; // optional [phases][8] s_memtime stamps of block 0 (product wave 0: 0-1, finish wave 4: 2-7), or null
 };
 
 __host__ __device__ inline void xcd_groups(int NGT, int x, int *g0, int *ng)
@@ -81,28 +84,29 @@ typedef unsigned xcd_u32x4 __attribute__((ext_vector_type(4)));
 
 // one 1-KiB LDS-DMA piece: lane l -> 16 B from (rsrc base + soff + 16 l) to LDS byte address lds_dst + 16 l.
 // sc1: served by the L2 / fabric, never by this CU's L1 (which other CUs' stores do not refresh).
-__device__ __forceinline__ void xcd_glds16(xcd_u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst)
+__device__ __forceinline__ void xcd_glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_dst)
 {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
 }
 
-__device__ __forceinline__ xcd_u32x4 xcd_rsrc(const void *base)
+// 16-byte store to (wave-uniform descriptor, wave-uniform byte offset soff) + lane offset voff, counted by the compiler's
+// vmcnt bookkeeping.  local = false: write-through (aux 16 = sc1; the line leaves the L2, every reader - any XCD - then
+// fetches it across the fabric: placement-independent, Guideline 16 R1).  local = true: plain store, the line stays in
+// THIS XCD's L2, where the group's other CUs read it with sc1 (L1-bypassing) loads - valid only when every workgroup of
+// the group sits on the same XCD, which the kernel verifies at start (xcd_group_is_local).
+__device__ __forceinline__ void xcd_store16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v, bool local)
 {
-    const unsigned long long b = (unsigned long long)base;
-    xcd_u32x4 r;
-    r.x = (unsigned)b; r.y = (unsigned)(b >> 32); r.z = 0x7fffffffu; r.w = 0x00020000u;
-    return r;
-}
-
-// 16-byte write-through store (aux 16 = sc1), counted by the compiler's vmcnt bookkeeping
-__device__ __forceinline__ void xcd_store16_sc1(float4 *p, float4 v)
-{
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, 16, 0x00020000);
     xcd_u32x4 u;
     u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, 0, 0, 16);
+    if (local) __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 16);
+}
+__device__ __forceinline__ void xcd_store_flag(unsigned *p, unsigned v, bool local)
+{
+    if (local) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // plain store: stays in the L2
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // boxes [B][T][90] -> xp; zero slot 0 / T+1 of xp, slot 0 of the histories, the flags and the status words.
@@ -131,24 +135,29 @@ __global__ void __launch_bounds__(384) opnet_xcd_pack_input(const float *__restr
         for (int i = tid; i < XCD_H2 * 4; i += 384) h2[i] = z;
         if (tid < XCD_CUS) a.flags[gg * XCD_CUS + tid] = 0u;
         if (gg == 0 && tid < 8) a.status[tid] = 0u;
+        if (gg == 0 && tid < XCD_COUNT * XCD_CUS) a.status[8 + tid] = 0xffffffffu;
     }
 }
 
-// bounded wait until all 32 CUs of the group have published `need` steps; false = abort (wave-uniform)
+// have all 32 CUs of the group's XCD published `need` steps?  (one sc1 load per lane: L2-served, never this CU's L1)
+__device__ __forceinline__ bool xcd_flags_ready(const unsigned *flags, unsigned need)
+{
+    const unsigned v = __hip_atomic_load(flags + (threadIdx.x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __all(v >= need);
+}
+
+// bounded wait for the same; false = abort (wave-uniform)
 __device__ __forceinline__ bool xcd_wait_flags(const unsigned *flags, unsigned need, unsigned *status, int phase)
 {
+    if (xcd_flags_ready(flags, need)) return true;
     const int lane = threadIdx.x & 63;
-    const unsigned *f = flags + (lane & 31);
-    unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__all(v >= need)) return true;
-    const long long t0 = clock64();
+    const long long t0 = wall_clock64();
     for (unsigned spins = 1;; ++spins) {
-        __builtin_amdgcn_s_sleep(2);
-        v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all(v >= need)) return true;
+        __builtin_amdgcn_s_sleep(4);
+        if (xcd_flags_ready(flags, need)) return true;
         if ((spins & 63u) == 0) {
             if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if (clock64() - t0 > XCD_SPIN_LIMIT) {
+            if ((long long)wall_clock64() - t0 > XCD_SPIN_LIMIT) {
                 if (lane == 0) {
                     __hip_atomic_store(status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(status + 2, (unsigned)phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -160,202 +169,370 @@ __device__ __forceinline__ bool xcd_wait_flags(const unsigned *flags, unsigned n
     }
 }
 
+// Do the 32 workgroups of group x (blocks x, x + 8, ...) sit on one XCD?  Every block publishes its XCC_ID (write-through)
+// and reads the 32 ids of its group (sc1 loads), so all of them reach the same verdict.  -1 = gave up (abort raised).
+__device__ __forceinline__ int xcd_group_is_local(unsigned *status, int x)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned mine = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf;   // HW_REG_XCC_ID[3:0]
+    if (lane == 0) __hip_atomic_store(status + 8 + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned *p = status + 8 + x + XCD_COUNT * (lane & 31);
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 1;; ++spins) {
+        const unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v != 0xffffffffu)) return __all(v == mine) ? 1 : 0;
+        __builtin_amdgcn_s_sleep(4);
+        if ((spins & 63u) == 0) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return -1;
+            if ((long long)wall_clock64() - t0 > XCD_SPIN_LIMIT) {
+                if (lane == 0) {
+                    __hip_atomic_store(status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(status + 2, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return -1;
+            }
+        }
+    }
+}
+
 // wave-private LDS scratch written by some lanes and read by others of the SAME wave: the LDS queue is in order per
 // wave, so only the compiler has to be kept from moving the read above the write
 #define XCD_WAVE_LDS_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
-#define XCD_MFMA(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0)
+// XCD_GAP: idle issue states the product wave spends after every MFMA.  A wave whose next instruction is an MFMA that the
+// (busy) matrix pipe cannot accept yet holds its SIMD's VALU issue port, and with four independent accumulator chains the
+// product wave ALWAYS has one pending: the finish wave on the same SIMD then does not get a single VALU instruction
+// issued until the product phase is over (measured: frozen for exactly the 6 100 cycles of the products, whatever the
+// s_setprio / wave age).  An s_nop shorter than the MFMA's 32-cycle occupancy costs the MFMA stream nothing and leaves
+// the port to the other wave in the meantime.
+#ifndef XCD_GAP
+#define XCD_GAP 0
+#endif
+// The MFMA and its idle states are ONE asm statement (volatile asm statements keep their order; a builtin MFMA next to an
+// asm s_nop gets re-paired by the scheduler).  What hipcc then no longer does for these MFMAs (cdna_hip_programming.md
+// section 5.7): the first MFMA of a chain takes the constant 0 as C (no VALU-written accumulator is read), chains
+// accumulate in place (D = C: no wait states needed), the B operands come from counted ds_reads, the A operands were
+// written long ago, and XCD_MFMA_DRAIN pads the last MFMAs' results before the compiler's code reads them.
+#define XCD_STR2(x) #x
+#define XCD_STR(x) XCD_STR2(x)
+#define XCD_MFMA0(acc, av, bv) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0\n\ts_nop " XCD_STR(XCD_GAP) : "=&v"(acc) : "v"(av), "v"(bv))
+#define XCD_MFMA(acc, av, bv) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\ts_nop " XCD_STR(XCD_GAP) : "+v"(acc) : "v"(av), "v"(bv))
+// XCD_YIELD: what the product wave does after every row of MFMAs when finish waves run beside it (two or more groups
+// per XCD).  fp32 MFMA executes on the SIMD's fp32 lanes - it runs at exactly the VALU rate - so while the product wave
+// keeps the matrix queue full the finish wave on the same SIMD gets no VALU cycle at all (measured: frozen for the whole
+// product phase, whatever s_setprio or the wave age).  The product wave therefore idles a little
+// after each row; the VALU cycles it gives up are what the finish wave computes in, and the finish wave's LATENCIES
+// (LDS, shuffles, memory, the hand-off) then overlap the MFMA stream instead of following it.
+// YM = how much: 0 none (one group per XCD: the finish runs while this wave waits for the exchange anyway), 1 = s_sleep 1
+// (~64 cycles, ~32 of them with the VALU idle) after every row (two groups: the exchange is on the critical path, the
+// finish must be quick: 101 k clips/s against 94 k with YM = 2), 2 = after three rows of four (three or more groups: the
+// finish has a whole window of slack; 107-111 k against 104-105 k with YM = 1).  s_nop N after a row idles the VALU
+// for 4 (N + 1) - 32 cycles: N = 15 behaves like s_sleep 1, N <= 7 gives the finish wave nothing.
+template <int YM>
+__device__ __forceinline__ void xcd_yield(int row)
+{
+    if (YM == 1 || (YM == 2 && (row & 3) != 3)) asm volatile("s_sleep 1");
+}
+#define XCD_YIELD(row) xcd_yield<YM>(row)
+#define XCD_MFMA_DRAIN(a0, a1, a2, a3) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
 
-// PF = the LSTM2 hexadecet pair after which the next phase's gather is issued (tuning knob)
-template <int PF>
-__global__ void __launch_bounds__(256, 1) opnet_xcd_forward(const XcdArgs a)
+// ------------------------------------------------------------------------------------------------------------------
+// the persistent kernel: 8 waves per CU, two roles
+//   waves 0..3 ("product" waves, one per SIMD): hold the weights, run the 188 MFMAs of a phase out of the LDS gather
+//                buffer, hand their accumulators to LDS (sHAND), barrier, next phase - nothing else;
+//   waves 4..7 ("finish" waves, the second wave of each SIMD): in the window of the NEXT phase's products they finish the
+//                phase - head sum, softmax, einsum, the LSTM cells, write-through stores of h, drain, one flag per wave -
+//                and poll + issue the LDS-DMA gather of the phase after next.  Their LDS / transcendental / memory
+//                latencies run under the other wave's MFMA stream instead of in series with it.
+// One s_barrier per phase (every wave): it says "accumulators of phase p are in sHAND, the gather of phase p+1 has
+// landed".  Timeline of group A with three groups per XCD:  products A(s) | finish A(s) + publish | gather A(s+1) |
+// products A(s+1): the product waves never wait.  With two groups the gather of A(s+1) can only be issued once every CU
+// has finished A(s), ~0.15 phase too late (measured stall); with one group the exchange is fully exposed (second
+// barrier per phase).
+// ------------------------------------------------------------------------------------------------------------------
+// first finish wave: 0 = the finish waves are the OLDER wave of each SIMD (waves 0..3), 4 = the younger one
+#ifndef XCD_FW0
+#define XCD_FW0 0
+#endif
+#define XH_F4 (3 * 64)         // sHAND per product wave: LSTM2 gates | LSTM1 partial | head partial
+
+__global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
 {
     __shared__ __attribute__((aligned(1024))) float4 sbuf[2][XB_F4];
-    __shared__ __attribute__((aligned(16))) float4 sPH[4][64];       // head partials (K quarters)
-    __shared__ __attribute__((aligned(16))) float4 sP1[2][64];       // LSTM1 partial of the lower-K wave of each pair
-    __shared__ __attribute__((aligned(16))) float sSP[4][16][16];    // slot probabilities, wave-private
-    __shared__ __attribute__((aligned(16))) float sFB[4][16][8];     // frames_boxes (6 -> 8), wave-private
+    __shared__ __attribute__((aligned(16))) float4 sHAND[2][4][XH_F4];
     __shared__ __attribute__((aligned(16))) float sTR[4][2][64];     // (clip, unit) -> float4-per-clip transposes
     __shared__ float sC2[XCD_NGMAX][4][64];
     __shared__ float sC1[XCD_NGMAX][2][64];
+    __shared__ volatile int sAbort, sLocal;
+    __shared__ unsigned sArrive[2];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv & 3;
     const int x = blockIdx.x & (XCD_COUNT - 1), c = blockIdx.x >> 3;
     const int T = a.T;
     int g0, ng;
     xcd_groups(a.NGT, x, &g0, &ng);
-    if (tid == 0) a.status[8 + blockIdx.x] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf;  // HW_REG_XCC_ID[3:0]
-    if (ng == 0) return;
     if (ng > XCD_NGMAX) ng = XCD_NGMAX;   // the host never asks for more
 
     const int n = lane & 15, u = lane >> 4;
-    const int t2 = 4 * c + w;                 // LSTM2 tile
+    const int t2 = 4 * c + w;                 // LSTM2 tile of this SIMD
     const int t1 = 2 * c + (w >> 1), kh = w & 1;
-
-    // ---- resident weights ------------------------------------------------------------------------------------------
+    const int nph = (T + 1) * ng;
     const PackedLayout P = packed_layout(XCD_H1, XCD_H2);
-    float4 a2[32], a1[11], as_[4], wx[8];
+    if (wv == XCD_FW0) {
+        // placement check by the first finish wave (groups with no work still publish their id and leave)
+        const int loc = ng > 0 ? xcd_group_is_local(a.status, x) : 0;
+        if (ng == 0) {
+            if (lane == 0) __hip_atomic_store(a.status + 8 + blockIdx.x, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane == 0) {
+            sLocal = loc > 0 && a.force_safe == 0;
+            sAbort = loc < 0;
+            sArrive[0] = 0u; sArrive[1] = 0u;
+            if (loc == 0 && c == 0) atomicAdd(a.status + 3, 1u);
+        }
+    }
+    if (ng == 0) return;
+    for (int i = tid; i < XCD_NGMAX * 4 * 64; i += 512) (&sC2[0][0][0])[i] = 0.f;
+    for (int i = tid; i < XCD_NGMAX * 2 * 64; i += 512) (&sC1[0][0][0])[i] = 0.f;
+
+    if ((wv >= 4) == (XCD_FW0 == 0)) {
+        // =========================================== product waves ===================================================
+        float4 a2[32], a1[11], as_[4];
+        {
+            const float4 *p2 = (const float4 *)(a.packed + P.w2p) + (long)t2 * 32 * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) a2[q] = p2[q * 64];
+            const float4 *p1 = (const float4 *)(a.packed + P.w1p) + ((long)t1 * 22 + 11 * kh) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 11; ++q) a1[q] = p1[q * 64];
+            const float4 *ps = (const float4 *)(a.packed + P.wselp) + (4 * w) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) as_[q] = ps[q * 64];
+        }
+        const bool mtracer = a.trace && blockIdx.x == 0 && tid == (4 - XCD_FW0) * 64;
+        __syncthreads();                        // phase 0's gather has landed
+        if (sAbort) return;
+        for (int p = 0; p < nph; ++p) {
+            const float4 *F = &sbuf[p & 1][0] + lane;
+            // B fragment of LSTM1 hexadecet 11 kh + j of [x 0..5 | h1 6..21]: the buffer is X0 | H1 | H2, so the lower-K
+            // wave reads fragment j of the buffer, the upper-K wave fragment 11 + j
+            const float4 *FL = F + (kh ? 11 * 64 : 0);
+            const float4 *FH = F + XB_H1 + 4 * w * 64;     // head: K quarter w of h1
+            if (mtracer) a.trace[(long)p * 8 + 0] = clock64();
+            // 188 MFMAs on four accumulator chains (LSTM2 even / odd hexadecets, LSTM1, head).  The issue order is pinned
+            // with sched_barrier after every row of independent MFMAs: left alone, the scheduler clusters the four MFMAs
+            // of one hexadecet on the same accumulator (40-cycle dependent latency against a 32-cycle issue) and keeps
+            // only one or two B fragments in flight.  Fragments are fetched one j-step (12 MFMAs ~ 400 cycles) ahead.
+            f32x4 accH, acc1, acc2a, acc2b;
+            auto products = [&](auto ym) {
+                constexpr int YM = decltype(ym)::value;
+                float4 fa[2], fb[2], fl[2];
+                fa[0] = F[XB_H2]; fb[0] = F[XB_H2 + 64]; fl[0] = FL[0];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int cur = j & 1, nxt = cur ^ 1;
+                    const bool l1 = j < 11, hd = j >= 11 && j < 15;
+                    if (j == 0) {
+                        XCD_MFMA0(acc2a, a2[0].x, fa[cur].x); XCD_MFMA0(acc2b, a2[1].x, fb[cur].x);
+                        XCD_MFMA0(acc1, a1[0].x, fl[cur].x);
+                    } else {
+                        XCD_MFMA(acc2a, a2[2 * j].x, fa[cur].x); XCD_MFMA(acc2b, a2[2 * j + 1].x, fb[cur].x);
+                        if (l1) XCD_MFMA(acc1, a1[j].x, fl[cur].x);
+                        if (j == 11) XCD_MFMA0(accH, as_[0].x, fl[cur].x);
+                        else if (hd) XCD_MFMA(accH, as_[j - 11].x, fl[cur].x);
+                    }
+                    if (j + 1 < 16) fa[nxt] = F[XB_H2 + (2 * j + 2) * 64];
+                    XCD_YIELD(4 * j + 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    XCD_MFMA(acc2a, a2[2 * j].y, fa[cur].y); XCD_MFMA(acc2b, a2[2 * j + 1].y, fb[cur].y);
+                    if (l1) XCD_MFMA(acc1, a1[j].y, fl[cur].y);
+                    if (hd) XCD_MFMA(accH, as_[j - 11].y, fl[cur].y);
+                    if (j + 1 < 16) fb[nxt] = F[XB_H2 + (2 * j + 3) * 64];
+                    XCD_YIELD(4 * j + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    XCD_MFMA(acc2a, a2[2 * j].z, fa[cur].z); XCD_MFMA(acc2b, a2[2 * j + 1].z, fb[cur].z);
+                    if (l1) XCD_MFMA(acc1, a1[j].z, fl[cur].z);
+                    if (hd) XCD_MFMA(accH, as_[j - 11].z, fl[cur].z);
+                    if (j + 1 < 11) fl[nxt] = FL[(j + 1) * 64];
+                    else if (j + 1 < 15) fl[nxt] = FH[(j + 1 - 11) * 64];
+                    XCD_YIELD(4 * j + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    XCD_MFMA(acc2a, a2[2 * j].w, fa[cur].w); XCD_MFMA(acc2b, a2[2 * j + 1].w, fb[cur].w);
+                    if (l1) XCD_MFMA(acc1, a1[j].w, fl[cur].w);
+                    if (hd) XCD_MFMA(accH, as_[j - 11].w, fl[cur].w);
+                    XCD_YIELD(4 * j + 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (ng == 1) products(std::integral_constant<int, 0>{});
+            else if (ng == 2) products(std::integral_constant<int, 1>{});
+            else products(std::integral_constant<int, 2>{});
+            XCD_MFMA_DRAIN(acc2a, acc2b, acc1, accH);
+            if (mtracer) a.trace[(long)p * 8 + 1] = clock64();
+            float4 *hd_ = &sHAND[p & 1][w][0] + lane;
+            hd_[0] = make_float4(acc2a[0] + acc2b[0], acc2a[1] + acc2b[1], acc2a[2] + acc2b[2], acc2a[3] + acc2b[3]);
+            hd_[64] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+            hd_[128] = make_float4(accH[0], accH[1], accH[2], accH[3]);
+            __syncthreads();                    // barrier p
+            if (sAbort) return;
+            if (ng == 1) {                      // exposed exchange: wait for this phase's finish + the next gather
+                __syncthreads();
+                if (sAbort) return;
+            }
+        }
+        return;
+    }
+
+    // ============================================== finish waves ======================================================
+    // fp32 MFMA runs at the VALU rate, so every VALU instruction of this wave takes its cycles from the product wave of the
+    // same SIMD (measured: DESIGN.md section 7) - what this role hides is LATENCY (LDS, memory, hand-off), and its
+    // instruction count is kept down: ONE buffer descriptor over the whole workspace with 32-bit offsets (wave-uniform part
+    // on the scalar unit, one constant VGPR of lane offset) instead of 64-bit per-lane address arithmetic, nothing spilled.
+    float4 wx[8];
     {
-        const float4 *p2 = (const float4 *)(a.packed + P.w2p) + (long)t2 * 32 * 64 + lane;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) a2[q] = p2[q * 64];
-        const float4 *p1 = (const float4 *)(a.packed + P.w1p) + ((long)t1 * 22 + 11 * kh) * 64 + lane;
-#pragma unroll
-        for (int q = 0; q < 11; ++q) a1[q] = p1[q * 64];
-        const float4 *ps = (const float4 *)(a.packed + P.wselp) + (4 * w) * 64 + lane;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) as_[q] = ps[q * 64];
         const float4 *px = (const float4 *)(a.packed + P.wih2p) + (long)(4 * t2 + u) * 8;
 #pragma unroll
         for (int q = 0; q < 8; ++q) wx[q] = px[q];
     }
-    for (int i = tid; i < XCD_NGMAX * 4 * 64; i += 256) (&sC2[0][0][0])[i] = 0.f;
-    for (int i = tid; i < XCD_NGMAX * 2 * 64; i += 256) (&sC1[0][0][0])[i] = 0.f;
-
     const unsigned lds0 = (unsigned)(unsigned long long)(const void *)&sbuf[0][0];
-    const xcd_u32x4 rx = xcd_rsrc(a.xp), rh1 = xcd_rsrc(a.h1h), rh2 = xcd_rsrc(a.h2h);
+    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void *)a.ws, 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = lane * 16;
+    const unsigned xq_voff = ((6 * u) * 16 + n) * 16;            // this lane's first k-quad of the packed input
+    const unsigned flag_voff = (lane & 31) * 4;
+    // logits [B][15][T]: byte offset of (clip n of the group, slot 4u + r, frame 0), 0xffffffff = not stored
+    unsigned lg_voff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lg_voff[r] = (4 * u + r < OPNET_SLOTS_) ? (unsigned)(((n * OPNET_SLOTS_ + 4 * u + r) * T) * 4) : 0xffffffffu;
+    bool alive = true;
 
     // this wave's share (chunks w, w+4, ...) of the gather of phase (group gi, step s) into LDS buffer `buf`
     auto gather = [&](int gi, int s, int buf) {
-        const long gg = g0 + gi;
-        const unsigned dst = lds0 + (unsigned)buf * (XB_F4 * 16);
-        const unsigned ox0 = (unsigned)(((gg * (T + 2) + s + 1) * OPNET_KXQ) * 256);
-        const unsigned ox1 = (unsigned)(((gg * (T + 2) + s) * OPNET_KXQ) * 256);
-        const unsigned oh1 = (unsigned)(((gg * (T + 1) + s) * (XCD_H1 / 4)) * 256);
-        const unsigned oh2 = (unsigned)(((gg * (T + 1) + (s > 0 ? s - 1 : 0)) * (XCD_H2 / 4)) * 256);
+        const unsigned gg = g0 + gi;
+        const unsigned dst = lds0 + (unsigned)buf * (XB_F4 * 16) + w * 1024;
+        const unsigned ox0 = a.xp_off + ((gg * (T + 2) + s + 1) * OPNET_KXQ) * 256 + w * 1024;
+        const unsigned oh1 = a.h1_off + ((gg * (T + 1) + s) * (XCD_H1 / 4)) * 256 + (w - 6) * 1024;
+        const unsigned oh2 = a.h2_off + ((gg * (T + 1) + (s > 0 ? s - 1 : 0)) * (XCD_H2 / 4)) * 256 + (w - 22) * 1024;
 #pragma unroll
-        for (int j = 0; j < XB_CHUNKS / 4; ++j) {
-            const int ch = 4 * j + w;          // wave-uniform; the section a chunk falls in depends on j only up to w
-            if (4 * j + 3 < 6) xcd_glds16(rx, lane * 16, ox0 + ch * 1024, dst + ch * 1024);
-            else if (4 * j >= 6 && 4 * j + 3 < 12) xcd_glds16(rx, lane * 16, ox1 + (ch - 6) * 1024, dst + ch * 1024);
-            else if (4 * j >= 12 && 4 * j + 3 < 28) xcd_glds16(rh1, lane * 16, oh1 + (ch - 12) * 1024, dst + ch * 1024);
-            else if (4 * j >= 28) xcd_glds16(rh2, lane * 16, oh2 + (ch - 28) * 1024, dst + ch * 1024);
-            else {                              // a j whose four chunks straddle two sections
-                if (ch < 6) xcd_glds16(rx, lane * 16, ox0 + ch * 1024, dst + ch * 1024);
-                else if (ch < 12) xcd_glds16(rx, lane * 16, ox1 + (ch - 6) * 1024, dst + ch * 1024);
-                else xcd_glds16(rh1, lane * 16, oh1 + (ch - 12) * 1024, dst + ch * 1024);
-            }
+        for (int j = 0; j < (XB_CHUNKS + 3) / 4; ++j) {
+            // chunk 4j + w (wave-uniform): X0 = chunks 0..5, H1 = 6..21, H2 = 22..53
+            if (4 * j + 3 < 6) xcd_glds16(rws, lane16, ox0 + j * 4096, dst + j * 4096);
+            else if (4 * j >= 6 && 4 * j + 3 < 22) xcd_glds16(rws, lane16, oh1 + j * 4096, dst + j * 4096);
+            else if (4 * j >= 22 && 4 * j + 3 < XB_CHUNKS) xcd_glds16(rws, lane16, oh2 + j * 4096, dst + j * 4096);
+            else if (4 * j + w < 6) xcd_glds16(rws, lane16, ox0 + j * 4096, dst + j * 4096);
+            else if (4 * j + w < 22) xcd_glds16(rws, lane16, oh1 + j * 4096, dst + j * 4096);
+            else if (4 * j + w < XB_CHUNKS) xcd_glds16(rws, lane16, oh2 + j * 4096, dst + j * 4096);
         }
     };
+    auto flags_ready = [&](int gn, unsigned need) -> bool {
+        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rws, flag_voff, a.flags_off + (g0 + gn) * (XCD_CUS * 4), 16);   // sc1
+        return __all(v >= need);
+    };
+    // wait until every CU of the group's XCD has published step sn - 1, then gather phase (gn, sn)
+    auto poll_gather = [&](int gn, int sn, int buf, int phase) {
+        if (!alive || (a.debug & 1)) return;
+        if (sn > 0 && !flags_ready(gn, (unsigned)sn))
+            alive = xcd_wait_flags(a.flags + (g0 + gn) * XCD_CUS, (unsigned)sn, a.status, phase);
+        if (alive) gather(gn, sn, buf);
+        else sAbort = 1;
+    };
 
-    const int nph = (T + 1) * ng;
-    bool alive = true;
-    gather(0, 0, 0);                        // phase 0 reads only zero slots and x[0]: nothing to wait for
+    gather(0, 0, 0);                            // phase 0 reads only zero slots and x[0]: nothing to wait for
+    if (ng >= 2 && nph > 1) gather(1, 0, 1);    // phase 1 = group 1, step 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (sAbort) return;
+    const bool local = __builtin_amdgcn_readfirstlane(sLocal) != 0;
+    const bool tracer = a.trace && blockIdx.x == 0 && tid == XCD_FW0 * 64;
 
-    int gi = 0, s = 0;                      // phase p = s * ng + gi
-    for (int p = 0; p < nph; ++p) {
-        const int buf = p & 1;
-        int gn = gi + 1, sn = s;            // the next phase
-        if (gn == ng) { gn = 0; sn = s + 1; }
-        const float4 *F = &sbuf[buf][0] + lane;
-        // B fragment of LSTM1 hexadecet 11 kh + j of [x 0..5 | h1 6..21]: X0 and H1 are 6 KB apart in the buffer (X1 sits
-        // between them), so the lower-K wave reads F[j] for j < 6 and F[6 + j] from there on, the upper-K wave F[17 + j]
-        const float4 *FLa = F + (kh ? 17 * 64 : 0), *FLb = F + (kh ? 17 * 64 : 6 * 64);
-        const float4 *FH = F + XB_H1 + 4 * w * 64;     // head: K quarter w of h1
-        if (a.trace && blockIdx.x == 0 && tid == 0) a.trace[(long)p * 4 + 0] = clock64();
-
-        // ---- products ------------------------------------------------------------------------------------------
-        // 188 MFMAs on four accumulator chains (LSTM2 even / odd hexadecets, LSTM1, head).  The issue order is pinned with
-        // sched_barrier after every row of independent MFMAs: left alone, the scheduler clusters the four MFMAs of one
-        // hexadecet on the same accumulator (40-cycle dependent latency against a 32-cycle issue) and keeps only one or
-        // two B fragments in flight.  Fragments are fetched one j-step (12 MFMAs ~ 400 cycles) ahead of their use.
-        f32x4 accH = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 acc2a = {0.f, 0.f, 0.f, 0.f}, acc2b = {0.f, 0.f, 0.f, 0.f};
-        float4 fa[2], fb[2], fl[2];
-        fa[0] = F[XB_H2]; fb[0] = F[XB_H2 + 64]; fl[0] = FLa[0];
-        __builtin_amdgcn_sched_barrier(0);
+    int gi = 0, s = 0;                          // phase fp = s * ng + gi
+    for (int fp = 0; fp < nph; ++fp) {
+        const unsigned gg = g0 + gi;
+        // the phase after next (two or more groups) / the next phase (one group)
+        const int ahead = ng >= 2 ? 2 : 1;
+        int gn = gi + ahead, sn = s;
+        while (gn >= ng) { gn -= ng; ++sn; }
+        // boxes[s-1] of this lane's clip n and slots 4u .. 4u+3 (24 consecutive k = 6 float4 of the packed input, each a
+        // coalesced 256-B run per 16 clips), straight from global memory (read-only here, L2-resident); issued before the
+        // barrier - which must therefore not drain vmcnt - so that the round trip is over when the phase's sums arrive
+        xcd_u32x4 xq[6];
+        {
+            const unsigned xs = a.xp_off + ((gg * (T + 2) + s) * OPNET_KXQ) * 256;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int cur = j & 1, nxt = cur ^ 1;
-            const bool l1 = j < 11, hd = j >= 11 && j < 15;
-            XCD_MFMA(acc2a, a2[2 * j].x, fa[cur].x); XCD_MFMA(acc2b, a2[2 * j + 1].x, fb[cur].x);
-            if (l1) XCD_MFMA(acc1, a1[j].x, fl[cur].x);
-            if (hd) XCD_MFMA(accH, as_[j - 11].x, fl[cur].x);
-            if (j + 1 < 16) fa[nxt] = F[XB_H2 + (2 * j + 2) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-            XCD_MFMA(acc2a, a2[2 * j].y, fa[cur].y); XCD_MFMA(acc2b, a2[2 * j + 1].y, fb[cur].y);
-            if (l1) XCD_MFMA(acc1, a1[j].y, fl[cur].y);
-            if (hd) XCD_MFMA(accH, as_[j - 11].y, fl[cur].y);
-            if (j + 1 < 16) fb[nxt] = F[XB_H2 + (2 * j + 3) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-            XCD_MFMA(acc2a, a2[2 * j].z, fa[cur].z); XCD_MFMA(acc2b, a2[2 * j + 1].z, fb[cur].z);
-            if (l1) XCD_MFMA(acc1, a1[j].z, fl[cur].z);
-            if (hd) XCD_MFMA(accH, as_[j - 11].z, fl[cur].z);
-            if (j + 1 < 11) fl[nxt] = j + 1 < 6 ? FLa[(j + 1) * 64] : FLb[(j + 1) * 64];
-            else if (j + 1 < 15) fl[nxt] = FH[(j + 1 - 11) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-            XCD_MFMA(acc2a, a2[2 * j].w, fa[cur].w); XCD_MFMA(acc2b, a2[2 * j + 1].w, fb[cur].w);
-            if (l1) XCD_MFMA(acc1, a1[j].w, fl[cur].w);
-            if (hd) XCD_MFMA(accH, as_[j - 11].w, fl[cur].w);
-            __builtin_amdgcn_sched_barrier(0);
-            if (j == PF && ng > 1 && p + 1 < nph && alive) {
-                // the next phase's group published its previous step one phase ago: poll, then gather under the
-                // remaining MFMAs (the buffer it fills was last read in the previous phase)
-                if (sn > 0) alive = xcd_wait_flags(a.flags + (g0 + gn) * XCD_CUS, (unsigned)sn, a.status, p);
-                if (alive) gather(gn, sn, buf ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int j = 0; j < 6; ++j) xq[j] = __builtin_amdgcn_raw_buffer_load_b128(rws, xq_voff + j * 256, xs, 0);
         }
-        if (a.trace && blockIdx.x == 0 && tid == 0) a.trace[(long)p * 4 + 1] = clock64();
-        sPH[w][lane] = make_float4(accH[0], accH[1], accH[2], accH[3]);
-        if (!kh) sP1[w >> 1][lane] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
-        __syncthreads();
-        if (!alive) return;                 // wave-uniform; the others leave at their own poll
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();           // barrier fp: the phase's accumulators are in sHAND[fp & 1]
+        asm volatile("" ::: "memory");
+        if (tracer) a.trace[(long)fp * 8 + 2] = clock64();
+        if (sAbort) return;
+        // If the phase after next already has its inputs published (four or more groups per XCD: its group finished its
+        // previous step more than a window ago) the gather goes first and lands under the finish; otherwise the finish
+        // goes first and the gather follows it (three groups: published by then; two: it is THIS finish - the product
+        // waves wait for the exchange)
+        bool early = false;
+        if (ng >= 4 && fp + 2 < nph && alive && !(a.debug & 1) && (sn == 0 || flags_ready(gn, (unsigned)sn))) {
+            gather(gn, sn, fp & 1);
+            early = true;
+        }
+        if (tracer) a.trace[(long)fp * 8 + 3] = clock64();
 
-        const long gg = g0 + gi;
-        // ---- selection head of step s-1, finished by every wave (learned_models.py:40-43,50) -------------------
+        const float4 *H = &sHAND[fp & 1][0][0] + lane;
+        // ---- selection head of step s-1 (learned_models.py:40-43,50), finished by every finish wave -------------
         float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
-        if (s > 0) {
-            const float4 h0 = sPH[0][lane], h1 = sPH[1][lane], h2 = sPH[2][lane], h3 = sPH[3][lane];
+        if (s > 0 && alive && !(a.debug & 2)) {
+            const float4 h0 = H[0 * XH_F4 + 128], h1 = H[1 * XH_F4 + 128], h2 = H[2 * XH_F4 + 128], h3 = H[3 * XH_F4 + 128];
             float v[4] = {((h0.x + h1.x) + h2.x) + h3.x, ((h0.y + h1.y) + h2.y) + h3.y,
                           ((h0.z + h1.z) + h2.z) + h3.z, ((h0.w + h1.w) + h2.w) + h3.w};
-            const long b = gg * 16 + n;
-            const bool writer = (c == ((s - 1) & (XCD_CUS - 1))) && w == 0 && b < a.B;
-            float m = -INFINITY;
+            if (c == ((s - 1) & (XCD_CUS - 1)) && w == 0) {       // wave-uniform: this wave writes the step's logits
+                float *lg = a.logits + ((long)gg * 16 * OPNET_SLOTS_) * T + (s - 1);
+                const bool clip_ok = (int)(gg * 16 + n) < a.B;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int slot = 4 * u + r;
-                if (slot < OPNET_SLOTS_) {
-                    if (writer) a.logits[(b * OPNET_SLOTS_ + slot) * T + (s - 1)] = v[r];
-                    m = fmaxf(m, v[r]);
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (clip_ok && lg_voff[r] != 0xffffffffu) *(float *)((char *)lg + lg_voff[r]) = v[r];
             }
+            float m = fmaxf(fmaxf(v[0], v[1]), v[2]);
+            if (u < 3) m = fmaxf(m, v[3]);                        // slot 15 does not exist
             m = fmaxf(m, __shfl_xor(m, 16));
             m = fmaxf(m, __shfl_xor(m, 32));
-            float e[4], sum = 0.f;
+            float e[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                e[r] = (4 * u + r < OPNET_SLOTS_) ? __expf(v[r] - m) : 0.f;
-                sum += e[r];
-            }
+            for (int r = 0; r < 4; ++r) e[r] = __expf(v[r] - m);
+            if (u == 3) e[3] = 0.f;
+            float sum = (e[0] + e[1]) + (e[2] + e[3]);
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
-            *(float4 *)&sSP[w][n][4 * u] = make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv);
-            XCD_WAVE_LDS_SYNC();
-            // frames_boxes[n][f] = sum_o boxes[n][s-1][o][f] * p[o], one ascending-o fmaf chain per (clip, feature)
-            // (einsum "bfot,bfo->bft"); lane (n, u) carries features u and u + 4
-            const float *xs = (const float *)&sbuf[buf][XB_X1];
-            const float *pp = &sSP[w][n][0];
-            float f0 = 0.f, f1 = 0.f;
-            const int fb1 = u + 4 < OPNET_FEATS_ ? u + 4 : 0;
+            const float inv = __builtin_amdgcn_rcpf(sum);
+            const float pr[4] = {e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
+            // frames_boxes[n][f] = sum_o boxes[n][s-1][o][f] * p[o] (einsum "bfot,bfo->bft"): this lane's four slots as one
+            // ascending fmaf chain per feature, then the four lane groups of the clip are added (0+1) + (2+3)
+            const float xf[24] = {__uint_as_float(xq[0].x), __uint_as_float(xq[0].y), __uint_as_float(xq[0].z), __uint_as_float(xq[0].w),
+                                  __uint_as_float(xq[1].x), __uint_as_float(xq[1].y), __uint_as_float(xq[1].z), __uint_as_float(xq[1].w),
+                                  __uint_as_float(xq[2].x), __uint_as_float(xq[2].y), __uint_as_float(xq[2].z), __uint_as_float(xq[2].w),
+                                  __uint_as_float(xq[3].x), __uint_as_float(xq[3].y), __uint_as_float(xq[3].z), __uint_as_float(xq[3].w),
+                                  __uint_as_float(xq[4].x), __uint_as_float(xq[4].y), __uint_as_float(xq[4].z), __uint_as_float(xq[4].w),
+                                  __uint_as_float(xq[5].x), __uint_as_float(xq[5].y), __uint_as_float(xq[5].z), __uint_as_float(xq[5].w)};
+            float fbv[OPNET_FEATS_];
 #pragma unroll
-            for (int o = 0; o < OPNET_SLOTS_; ++o) {
-                const int k0 = o * OPNET_FEATS_ + u, k1 = o * OPNET_FEATS_ + fb1;
-                const float pv = pp[o];
-                f0 = fmaf(xs[((k0 >> 2) * 16 + n) * 4 + (k0 & 3)], pv, f0);
-                f1 = fmaf(xs[((k1 >> 2) * 16 + n) * 4 + (k1 & 3)], pv, f1);
+            for (int f = 0; f < OPNET_FEATS_; ++f) {
+                float t = pr[0] * xf[f];
+                t = fmaf(pr[1], xf[6 + f], t);
+                t = fmaf(pr[2], xf[12 + f], t);
+                t = fmaf(pr[3], xf[18 + f], t);
+                t += __shfl_xor(t, 16);
+                t += __shfl_xor(t, 32);
+                fbv[f] = t;
             }
-            sFB[w][n][u] = f0;
-            sFB[w][n][u + 4] = u + 4 < OPNET_FEATS_ ? f1 : 0.f;
-            XCD_WAVE_LDS_SYNC();
-            xa = *(const float4 *)&sFB[w][n][0];
-            xb = *(const float4 *)&sFB[w][n][4];
+            xa = make_float4(fbv[0], fbv[1], fbv[2], fbv[3]);
+            xb = make_float4(fbv[4], fbv[5], 0.f, 0.f);
         }
+        if (tracer) a.trace[(long)fp * 8 + 4] = clock64();
         // ---- LSTM2 cell of step s-1 (learned_models.py:46): lane (clip n, unit 4 t2 + u) -----------------------
-        if (s > 0) {
+        if (s > 0 && alive && !(a.debug & 4)) {
+            const float4 acc2 = H[w * XH_F4];
+            const float a2v[4] = {acc2.x, acc2.y, acc2.z, acc2.w};
             float g[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -366,7 +543,7 @@ __global__ void __launch_bounds__(256, 1) opnet_xcd_forward(const XcdArgs a)
                 xsum = fmaf(w0.w, xa.w, xsum);
                 xsum = fmaf(w1.x, xb.x, xsum);
                 xsum = fmaf(w1.y, xb.y, xsum);
-                g[r] = (acc2a[r] + acc2b[r]) + xsum;
+                g[r] = a2v[r] + xsum;
             }
             float cc = sC2[gi][w][lane];
             const float h = lstm_cell(g[0], g[1], g[2], g[3], &cc);
@@ -375,37 +552,43 @@ __global__ void __launch_bounds__(256, 1) opnet_xcd_forward(const XcdArgs a)
             XCD_WAVE_LDS_SYNC();
             if (lane < 16) {
                 const float4 hv = *(const float4 *)&sTR[w][0][lane * 4];
-                xcd_store16_sc1(a.h2h + ((gg * (T + 1) + s) * (XCD_H2 / 4) + t2) * 16 + lane, hv);
+                xcd_store16(rws, lane16, a.h2_off + (((gg * (T + 1) + s) * (XCD_H2 / 4) + t2) * 16) * 16, hv, local);
             }
         }
         // ---- LSTM1 cell of step s (learned_models.py:39), by the upper-K wave of each pair ---------------------
-        if (kh && s < T) {
-            const float4 lo = sP1[w >> 1][lane];
+        if (kh && s < T && alive && !(a.debug & 4)) {
+            const float4 lo = H[(w - 1) * XH_F4 + 64], hi = H[w * XH_F4 + 64];
             float cc = sC1[gi][w >> 1][lane];
-            const float h = lstm_cell(lo.x + acc1[0], lo.y + acc1[1], lo.z + acc1[2], lo.w + acc1[3], &cc);
+            const float h = lstm_cell(lo.x + hi.x, lo.y + hi.y, lo.z + hi.z, lo.w + hi.w, &cc);
             sC1[gi][w >> 1][lane] = cc;
             sTR[w][1][n * 4 + u] = h;
             XCD_WAVE_LDS_SYNC();
             if (lane < 16) {
                 const float4 hv = *(const float4 *)&sTR[w][1][lane * 4];
-                xcd_store16_sc1(a.h1h + ((gg * (T + 1) + s + 1) * (XCD_H1 / 4) + t1) * 16 + lane, hv);
+                xcd_store16(rws, lane16, a.h1_off + (((gg * (T + 1) + s + 1) * (XCD_H1 / 4) + t1) * 16) * 16, hv, local);
             }
         }
-        if (a.trace && blockIdx.x == 0 && tid == 0) a.trace[(long)p * 4 + 2] = clock64();
-        // ---- publish: every wave drains its stores (and its share of the gather), barrier, ONE flag per CU ------
+        if (tracer) a.trace[(long)fp * 8 + 5] = clock64();
+        // ---- publish: every finish wave drains its stores (and DMA) and arrives at an LDS counter; the last one stores
+        //      the CU's flag -------------------------------------------------------------------------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.flags + gg * XCD_CUS + c, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ng == 1 && p + 1 < nph) {
-            // one group per XCD: its own next step needs what was just published - the exchange is exposed
-            alive = xcd_wait_flags(a.flags + (g0 + gn) * XCD_CUS, (unsigned)sn, a.status, p);
-            if (!alive) return;
-            gather(gn, sn, buf ^ 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+        if (lane == 0 && alive && !(a.debug & 8)) {
+            if (__hip_atomic_fetch_add(&sArrive[fp & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3u) {
+                __hip_atomic_store(&sArrive[fp & 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                xcd_store_flag(a.flags + gg * XCD_CUS + c, (unsigned)(s + 1), local);
+            }
         }
-        if (a.trace && blockIdx.x == 0 && tid == 0) a.trace[(long)p * 4 + 3] = clock64();
-        gi = gn; s = sn;
+        if (tracer) a.trace[(long)fp * 8 + 6] = clock64();
+        if (!early && fp + ahead < nph) {
+            poll_gather(gn, sn, (fp + ahead) & 1, fp);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (tracer) a.trace[(long)fp * 8 + 7] = clock64();
+        if (ng == 1) {
+            __syncthreads();
+            if (sAbort) return;
+        }
+        if (++gi == ng) { gi = 0; ++s; }
     }
 }
 

@@ -218,7 +218,7 @@ class OPNet(AbstractCaterModel):
         # per-XCD persistent forward (include/opnet_hip.h): "auto" = batches of at least XCD_MIN_BATCH clips at the
         # reference sizes; "1" / "0" force it on / off
         self.use_xcd = os.environ.get("OPNET_XCD", "auto")
-        self._xws: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self._xws: Dict[Tuple[int, int, int, int], torch.Tensor] = {}
 
     # -- weights ------------------------------------------------------------------------------
     def _weights(self):
@@ -262,12 +262,14 @@ class OPNet(AbstractCaterModel):
         step = int(lib.opnet_xcd_max_batch())
         for lo in range(0, B, step):
             n = min(step, B - lo)
-            key = (n, T, dev.index if dev.index is not None else torch.cuda.current_device())
+            # one workspace per (shape, device, stream), like the launch plans: forwards enqueued on different streams
+            # must not share a history buffer
+            key = (n, T, dev.index if dev.index is not None else torch.cuda.current_device(), stream)
             if key not in self._xws:
                 nbytes = lib.opnet_xcd_workspace_bytes(n, T, self._h1, self._h2)
                 if nbytes == 0:
                     _lib.check(-2, "opnet_xcd_workspace_bytes")
-                if len(self._xws) >= 4:
+                if len(self._xws) >= 8:
                     self._xws.pop(next(iter(self._xws)))
                 self._xws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             ws = self._xws[key]

@@ -120,6 +120,17 @@ def test_persistent_forward_under_concurrent_load_on_other_streams():
         assert np.array_equal(y.cpu().numpy(), y_ref) and np.array_equal(lg.cpu().numpy(), lg_ref)
 
 
+def test_write_through_protocol_gives_the_same_bits(monkeypatch):
+    """OPNET_XCD_SAFE=1 forces the placement-independent hand-off (write-through stores, every read across the fabric)
+    that the kernel falls back to when a group's workgroups are not on one XCD; same arithmetic, same bits."""
+    boxes, _ = synth.make_batch(21, 256, 30)
+    m, _ = _model(True)
+    y, lg = _run(m, boxes)
+    monkeypatch.setenv("OPNET_XCD_SAFE", "1")
+    y2, lg2 = _run(m, boxes)
+    assert np.array_equal(y2, y) and np.array_equal(lg2, lg)
+
+
 def test_workgroups_of_a_group_share_an_xcd():
     """placement is for speed only (block b -> XCD b % 8 is observed, not promised): report it"""
     boxes, _ = synth.make_batch(1, 256, 2)
@@ -128,5 +139,7 @@ def test_workgroups_of_a_group_share_an_xcd():
     ws = next(iter(m._xws.values()))
     xcc = ws[32:32 + 4 * 256].view(torch.int32).cpu().numpy()
     same = all(len(set(xcc[x::8].tolist())) == 1 for x in range(8))
-    print("XCC ids of blocks 0..15:", xcc[:16].tolist(), "groups XCD-local:", same)
+    not_local = int(ws[12:16].view(torch.int32).item())
+    print("XCC ids of blocks 0..15:", xcc[:16].tolist(), "groups XCD-local:", same, "| groups on the write-through path:", not_local)
+    assert (not_local == 0) == same
     assert set(xcc.tolist()) <= set(range(8))

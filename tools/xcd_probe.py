@@ -62,23 +62,27 @@ def main():
               + (f" | chain {res['chain']:8.3f} ms = {B / res['chain'] * 1e3:9.0f} clips/s | max|dy| {res['max|dy|']:.2e} max|dlg| {res['max|dlogits|']:.2e}"
                  if "chain" in res else "") + f" | status {list(st.values())[-1]}", flush=True)
     if args.trace:
-        B = 256
-        ng = 2
         lib = _lib.load()
-        tr = torch.zeros((T + 1) * ng * 4, dtype=torch.int64, device=dev)
-        lib.opnet_xcd_set_trace(tr.data_ptr())
-        boxes, _ = synth.make_batch(0, 64, T)
-        x = torch.from_numpy(np.tile(boxes, (4, 1, 1, 1))).to(dev)
-        m.use_xcd = "1"
-        with torch.no_grad():
-            m(x)
-        torch.cuda.synchronize()
-        lib.opnet_xcd_set_trace(None)
-        t = tr.cpu().numpy().reshape(-1, 4)
-        ph = t[100:500]
-        print("cycles per phase (median): total %.0f | products %.0f | finish %.0f | publish+barrier %.0f" % (
-            np.median(np.diff(ph[:, 0])), np.median(ph[:, 1] - ph[:, 0]), np.median(ph[:, 2] - ph[:, 1]),
-            np.median(ph[:, 3] - ph[:, 2])))
+        for B in (128, 256, 384, 512):
+            ng = (B + 127) // 128
+            tr = torch.zeros((T + 1) * ng * 8, dtype=torch.int64, device=dev)
+            lib.opnet_xcd_set_trace(tr.data_ptr())
+            boxes, _ = synth.make_batch(0, 64, T)
+            x = torch.from_numpy(np.tile(boxes, ((B + 63) // 64, 1, 1, 1))[:B]).to(dev)
+            m.use_xcd = "1"
+            with torch.no_grad():
+                m(x)
+            torch.cuda.synchronize()
+            lib.opnet_xcd_set_trace(None)
+            t = tr.cpu().numpy().reshape(-1, 8)
+            ph = t[len(t) // 3: 2 * len(t) // 3]
+            med = lambda v: float(np.median(v))
+            print("B=%d (%d groups per XCD), cycles (median): period %.0f | product wave: products %.0f, hand-off + barrier wait %.0f | "
+                  "finish wave after the barrier: early-gather %.0f, head %.0f, cells %.0f, drain+flag %.0f, late poll+gather+land %.0f, "
+                  "to next barrier %.0f" % (
+                      B, ng, med(np.diff(ph[:, 0])), med(ph[:, 1] - ph[:, 0]), med(ph[1:, 0] - ph[:-1, 1]),
+                      med(ph[:, 3] - ph[:, 2]), med(ph[:, 4] - ph[:, 3]), med(ph[:, 5] - ph[:, 4]), med(ph[:, 6] - ph[:, 5]),
+                      med(ph[:, 7] - ph[:, 6]), med(ph[1:, 2] - ph[:-1, 7])))
 
 
 if __name__ == "__main__":
