@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
 """bench.py - OPNet inference throughput on MI355X (the BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--batch 32]
+    python bench.py --gpus N --steps K --warmup W [--batch 32] [--engine xcd|chain]
 
-One "step" = one pass of the hot path (OPNet.forward through libopnet_hip.so) over one batch of
-`--batch` synthetic CATER clips (300 frames x 15 slots x 6 features, fp32) that is already resident in
-HBM, followed by the device-side post-processing to int32 pixel boxes.  Independent steps are spread over
-S HIP streams (several forwards in flight).  With N > 1 every rank runs its own batch (clips are independent:
-weak scaling, no data-path collective inside the forward) and the per-clip predictions are all-gathered
-over RCCL; only the issuing step's stream waits for the collective, the other forwards keep running.
+One "step" = one pass of the hot path (OPNet.forward through libopnet_hip.so) over one batch of `--batch` synthetic CATER
+clips (300 frames x 15 slots x 6 features, fp32) that is already resident in HBM, followed by the device-side
+post-processing to int32 pixel boxes.  Steps are independent requests; how many are in flight is the engine's business:
+
+  --engine xcd (default)  the steps are submitted to objectpermanence_amd.serving.ReasonerServer, which concatenates up to
+                          `--inflight` pending batches into ONE per-XCD persistent forward (csrc/opnet_xcd_kernels.hip:
+                          every XCD runs the 300-step recurrence of its own clips with all weights in registers);
+  --engine chain          round 1's form: one hipGraph of T+3 step launches per batch, spread over S HIP streams.
+
+With N > 1 every rank runs its own batches (clips are independent: weak scaling, no data-path collective inside the
+forward) and the int32 predictions of every launch are all-gathered over RCCL.  `--gpus N` without a launcher re-executes
+itself under torch.distributed.run (one rank per GPU) and fails loudly if the node has fewer GPUs.
 
 Rank 0 prints ONE JSON line: BASELINE.json's metric (clips/s, whole job), plus
-  roofline     - the dominant kernel (opnet_step) against the HBM roofline under SURVEY.md 8-d4's
-                 per-time-step weight-streaming model, timed live with HIP events on the launch stream;
-  cpu_baseline - oracle/opnet_oracle.c (a C/OpenMP port of the reference algorithm) timed on this
-                 host's cores on a bounded sample of the same workload (N=1 only).
+  roofline     - the dominant kernel against the roofline that bounds it: opnet_xcd_forward against the fp32 MFMA peak
+                 (algorithmic FLOPs of the clips of a launch / the kernel's own duration, HIP events around every launch of
+                 it on its stream); for --engine chain, opnet_step against the HBM streaming model of SURVEY.md 8-d4 with
+                 the duration of ONE launch (single-stream pass), the multi-stream figure under `roofline_amortised`;
+  roofline_hbm_model / whole_job_mfma_frac - the same run expressed in north_star's streaming-model bytes and as
+                 clips/s x FLOPs/clip over the fp32 MFMA peak (wall clock, all overheads in);
+  cpu_baseline - oracle/opnet_oracle.c (a C/OpenMP port of the reference algorithm) timed on this host's cores on a
+                 bounded sample of the same workload, batch 8 / 16 / 32, N = 1 only.
 
 Inputs and weights are seeded synthetic data from `synthdata/` (data only, shared with the tests).  `oracle/` is used
 for exactly two things, both outside the timed region: the cpu_baseline leg and a parity assert of the HIP outputs
@@ -23,8 +33,10 @@ against it.  The measured path is libopnet_hip.so only.
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,21 +49,10 @@ sys.path.insert(0, REPO)
 CFG = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
 T_FRAMES = 300
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate
+FLOP_PER_CLIP = 2 * 300 * 1_421_146   # 852.7 MFLOP per 300-frame clip (forward)
 W_BYTES = 5_684_224            # all six fp32 weight tensors
 STATE_BYTES_PER_CLIP = 12_672  # per clip per time step: x_t + h,c read + h,c write of both LSTMs (8-d4)
-
-
-def pmc_traffic(batch):
-    """HBM bytes per opnet_step launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE; profiles/r*_pmc_b<batch>.json says how they were collected). PMC cannot be
-    sampled from inside this process, so this is the last committed measurement of the same command,
-    or None when there is none for this batch size."""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_pmc_b{batch}.json"))):
-        with open(path) as f:
-            best = json.load(f)
-    return None if best is None else int(best["traffic_bytes_per_launch"])
 
 
 def accuracy_block(dev):
@@ -87,6 +88,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=None,
                     help="clips per GPU per step (default 32, the BASELINE configs); frames per pass for --mode detect (default 16)")
+    ap.add_argument("--engine", choices=["xcd", "chain"], default="xcd",
+                    help="xcd = request batching into the per-XCD persistent forward (default); chain = one hipGraph of "
+                         "step launches per batch on S streams (round 1)")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="--engine xcd: batches concatenated into one persistent launch (0 = all steps up to 1024 clips, "
+                         "split evenly when there are more)")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="only exercise the rank launcher / rendezvous (gloo, no GPU work) and print the world size")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the independent steps are spread over (step i runs on stream i %% S); "
                          "0 = calibrate S in {1,2,3,4} on untimed steps before the warm-up and keep the fastest")
@@ -103,25 +112,31 @@ def parse():
 
 
 def cpu_baseline(boxes_np, params, seconds):
-    """Time the C/OpenMP port on this host. Returns the dict for the JSON line + its output."""
+    """Time the C/OpenMP port on this host at the batch sizes of SURVEY.md 8-d5 (8 / 16 / 32 clips, best of >= 5 after a
+    warm-up).  Returns the dict for the JSON line (value = the bench's own batch) + the port's output for that batch."""
     from oracle import c_oracle
     threads = c_oracle.usable_cores()  # affinity mask capped by the cgroup CPU quota
-    y, _ = c_oracle.opnet_forward(boxes_np, params, threads)  # warm-up (also page-in / build)
-    reps, t_total = 0, 0.0
-    t_end = time.perf_counter() + seconds
-    while True:
-        t0 = time.perf_counter()
-        y, _ = c_oracle.opnet_forward(boxes_np, params, threads)
-        t_total += time.perf_counter() - t0
-        reps += 1
-        if time.perf_counter() >= t_end:
-            break
-    clips = reps * boxes_np.shape[0]
+    B = boxes_np.shape[0]
+    sweep, y_full, t_used = {}, None, 0.0
+    sizes = sorted({b for b in (8, 16, 32) if b <= B} | {B})
+    for b in sizes:
+        x = np.ascontiguousarray(boxes_np[:b])
+        y, _ = c_oracle.opnet_forward(x, params, threads)           # warm-up (also page-in / build)
+        best, reps, t_end = float("inf"), 0, time.perf_counter() + seconds / len(sizes)
+        while reps < 5 or time.perf_counter() < t_end:
+            t0 = time.perf_counter()
+            y, _ = c_oracle.opnet_forward(x, params, threads)
+            dt = time.perf_counter() - t0
+            best, reps, t_used = min(best, dt), reps + 1, t_used + dt
+        sweep[str(b)] = round(b / best, 2)
+        if b == B:
+            y_full = y
     return {
-        "value": round(clips / t_total, 2), "unit": "clips/s", "cores": threads, "kind": "port",
-        "sample": f"{reps} x forward of {boxes_np.shape[0]} clips x {boxes_np.shape[1]} frames "
-                  f"(oracle/opnet_oracle.c, gcc -O3 -march=native -fopenmp, {threads} threads, {t_total:.1f} s)",
-    }, y
+        "value": sweep[str(B)], "unit": "clips/s", "cores": threads, "kind": "port",
+        "sample": f"best-of-n forward of {B} clips x {boxes_np.shape[1]} frames (oracle/opnet_oracle.c, gcc -O3 -march=native "
+                  f"-fopenmp, {threads} threads, {t_used:.1f} s of CPU work in total)",
+        "clips_per_s_by_batch": sweep,
+    }, y_full
 
 
 def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
@@ -197,8 +212,8 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
                        "parallelism": f"dp{world}", "loss": args.loss},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "opnet_step + opnet_bwd_gemm + opnet_bwd_cell (the 3 launches of a time step); "
-                                   "algorithmic bytes of the whole step / GPU time",
+                         "kernel": "opnet_step + opnet_bwd_fused (the 2 launches of a time step; opnet_bwd_gemm + opnet_bwd_cell "
+                                   "above 128 clips) + opnet_wgrad; algorithmic bytes of the whole step / GPU time",
                          "alg_bytes_per_step": alg},
             "cpu_baseline": cpu,
             "final_loss": float(loss.item())}), flush=True)
@@ -310,13 +325,45 @@ def bench_detect(args, world, rank, dev, dist):
         dist.destroy_process_group()
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1) and return its exit code."""
+    if not args.launcher_selftest:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s); refusing to print a line for "
+                             f"fewer ranks than asked")
+    port = os.environ.get("MASTER_PORT") or str(29500 + (os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def launcher_selftest(world, rank):
+    """rendezvous + one collective on gloo: what `--gpus N` has to get right before any GPU work (CPU test)"""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    assert int(t.item()) == dist.get_world_size() == world
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": int(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.launcher_selftest:
+        return launcher_selftest(world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     dev = torch.device("cuda", local_rank)
@@ -327,7 +374,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    exchange = dist is not None
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
 
     if args.mode == "detect":
         args.batch = args.batch or 16     # frames per pass
@@ -335,7 +383,7 @@ def main():
             args.steps, args.warmup = 10, 2
         return bench_detect(args, world, rank, dev, dist)
 
-    from objectpermanence_amd import ModelsFactory, metrics
+    from objectpermanence_amd import ModelsFactory
     from synthdata import opnet as synth
 
     args.batch = args.batch or 32
@@ -355,6 +403,170 @@ def main():
     boxes = torch.from_numpy(boxes_np).to(dev)
     labels = torch.from_numpy(labels_np).to(dev)
 
+    if args.mode == "train":
+        return bench_train(args, model, boxes, labels, world, rank, dev, dist, params)
+    if args.engine == "chain":
+        out, y = bench_infer_chain(args, model, boxes, world, rank, dev, dist)
+    else:
+        out, y = bench_infer_xcd(args, model, boxes, world, rank, dev, dist)
+    if rank == 0:
+        out.update(accuracy_block(dev))
+        out.update(other_batches(model, boxes, dev))
+        if world == 1 and not args.no_cpu_baseline:
+            cb, y_cpu = cpu_baseline(boxes_np, params, args.cpu_seconds)
+            out["cpu_baseline"] = cb
+            err = float(np.abs(y.cpu().numpy() - y_cpu).max())
+            out["parity_max_abs_dy_vs_cpu_port"] = err
+            if not err < 1e-4 and not os.environ.get("OPNET_HIP_LIB"):
+                raise SystemExit(f"bench: HIP output of the last timed step differs from the CPU port by {err}")
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _line(args, world, B, clips_per_s, elapsed, workload, extra_cfg):
+    return {
+        "metric": "CATER clips/sec (300f x 10obj) OPNet inference",
+        "value": round(clips_per_s, 1), "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "global_batch": world * B, "frames": T_FRAMES, "parallelism": f"dp{world}",
+                   "weights": "synthetic (synthdata/opnet.py counter RNG), fp32", **extra_cfg},
+        # the whole job against the machine: every overhead (input concatenation, pack, output head, post-process,
+        # launch gaps) is inside this one
+        "whole_job_mfma_frac": round(clips_per_s / world * FLOP_PER_CLIP / (MFMA_F32_PEAK_TF * 1e12), 4),
+    }
+
+
+def other_batches(model, boxes, dev):
+    """The reference's own shipped batch sizes next to the bench's: configs/inference_config.json batch_size 16 and
+    configs/training_config.json inference_batch_size 400 (one forward in flight, whatever engine OPNet.forward picks).
+    Outside the timed region."""
+    res = {}
+    forced, model.use_xcd = model.use_xcd, "auto"
+    for b in (16, 400):
+        reps = (b + boxes.shape[0] - 1) // boxes.shape[0]
+        x = boxes.repeat(reps, 1, 1, 1)[:b].contiguous()
+        with torch.no_grad():
+            model(x)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                model(x)
+            e1.record()
+            torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / 5
+        res[str(b)] = {"ms_per_forward": round(ms, 3), "clips_per_s": round(b / ms * 1e3, 1),
+                       "engine": "xcd" if model._wants_xcd(b) else "chain"}
+    model.use_xcd = forced
+    return {"reference_batch_sizes": res}
+
+
+def bench_infer_xcd(args, model, boxes, world, rank, dev, dist):
+    """Request batching into the per-XCD persistent forward: every step submits its batch to a ReasonerServer, which runs
+    `per_launch` pending batches as one launch; the post-process (and, N > 1, the all-gather of the int32 predictions) runs
+    once per launch on the launch's whole output."""
+    from objectpermanence_amd import _lib, metrics
+    from objectpermanence_amd.serving import ReasonerServer
+    lib = _lib.load()
+    B = int(boxes.shape[0])
+    cap = max(1, int(lib.opnet_xcd_max_batch()) // B)
+    if args.inflight > 0:
+        per_launch = min(args.inflight, cap)
+    else:                                       # all steps in one launch when they fit, else even shares
+        n_launch = (args.steps + cap - 1) // cap
+        per_launch = (args.steps + n_launch - 1) // n_launch
+    model.use_xcd = "1"
+    server = ReasonerServer(model, "opnet", max_clips=per_launch * B)
+    exchange = dist is not None
+    state = {"y": None, "pred": None, "seen": 0}
+
+    def after_flush():
+        # one post-process (+ one collective) per launch, on the stream the forward was enqueued on
+        if server.forwards == state["seen"]:
+            return
+        state["seen"] = server.forwards
+        y = server.last_output[0]
+        pred_px, _, _ = metrics.postprocess_and_iou(y)
+        if exchange:
+            gathered = torch.empty((world * pred_px.shape[0],) + tuple(pred_px.shape[1:]), dtype=pred_px.dtype, device=dev)
+            dist.all_gather_into_tensor(gathered, pred_px)
+        state["y"], state["pred"] = y, pred_px
+
+    def run(n):
+        for _ in range(n):
+            server.submit(boxes)
+            after_flush()
+        server.flush()
+        after_flush()
+
+    # untimed: one launch of every shape the timed region will issue (the full launch and the remainder), so that its
+    # history workspaces exist - a steady-state server has them - then the W warm-up steps
+    for shape_steps in sorted({per_launch, args.steps % per_launch} - {0}):
+        run(shape_steps)
+    run(max(args.warmup, 1))
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    lib.opnet_xcd_profile(1)
+    f0 = server.forwards
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kms, nl = ctypes.c_double(0.0), ctypes.c_int(0)
+    _lib.check(lib.opnet_xcd_profile_read(ctypes.byref(kms), ctypes.byref(nl)), "opnet_xcd_profile_read")
+    lib.opnet_xcd_profile(0)
+    for key, st in model.xcd_status().items():
+        if st[0] != 0:
+            raise SystemExit(f"bench: persistent launch {key} aborted (block {st[1]}, phase {st[2]})")
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return None, None
+    clips = B * args.steps
+    clips_per_s = world * clips / elapsed
+    launches = server.forwards - f0
+    assert launches == nl.value, (launches, nl.value)
+    kernel_s = kms.value * 1e-3
+    tf = clips * FLOP_PER_CLIP / kernel_s / 1e12
+    # north_star's streaming model (SURVEY.md 8-d4: every time step streams all weights once per B-clip batch and moves
+    # each clip's state): what the launch-per-step design had to move for these clips, over this kernel's time.  It is a
+    # MODEL figure here - the persistent kernel reads the weights once per launch and keeps them in registers.
+    model_bytes = clips * T_FRAMES * (W_BYTES / B + STATE_BYTES_PER_CLIP)
+    out = _line(args, world, B, clips_per_s, elapsed,
+                f"opnet (configs/opnet_model_config.json: H1=256, H2=512) inference, batch={B} clips/GPU/step x 300 frames x "
+                "15 slots (10 objects) x 6 features, precomputed bbox input resident in HBM, int32 pixel-box post-process on "
+                f"device; steps are requests to a ReasonerServer that runs up to {per_launch} pending batches "
+                f"({per_launch * B} clips) as one per-XCD persistent forward",
+                {"engine": "xcd", "batches_per_launch": per_launch, "launches": launches})
+    out["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                       "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                       "kernel": "opnet_xcd_forward", "launch_ms": round(kms.value / max(launches, 1), 4),
+                       "launches": launches, "alg_flop_per_launch": int(clips * FLOP_PER_CLIP / max(launches, 1)),
+                       "timing": "HIP events around every launch of the kernel on its stream (opnet_xcd_profile)"}
+    out["roofline_hbm_model"] = {"bound": "hbm", "achieved": round(model_bytes / kernel_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": round(model_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
+                                 "note": "SURVEY.md 8-d4 streaming-model bytes of the same clips (weights once per time step per "
+                                         f"{B}-clip batch) over the kernel time; not bytes this kernel moves"}
+    return out, state["y"][-B:]
+
+
+def bench_infer_chain(args, model, boxes, world, rank, dev, dist):
+    """round 1's engine: one hipGraph of T+3 opnet_step launches per batch, independent batches spread over S streams"""
+    from objectpermanence_amd import metrics
+    B = int(boxes.shape[0])
+    model.use_xcd = "0"
+    exchange = dist is not None
     S = args.streams if args.streams > 0 else 4
     # HIP multiplexes streams onto 4 hardware queues by default and streams sharing a queue serialise
     # (measured: raising GPU_MAX_HW_QUEUES to 8 collapses the overlap), so the timed region uses exactly
@@ -365,9 +577,6 @@ def main():
     pool = [torch.cuda.Stream(device=dev) for _ in range(8)]
     streams = pool[:S]
     main_stream = streams[0]
-    # inference exchange (N > 1): every stream collects the int32 predictions of G of its steps and all-gathers them in
-    # ONE collective (G x 154 KB per rank instead of G latency-bound 154 KB messages); xGMI is point-to-point, so the
-    # per-call latency of a small all-gather is what would otherwise cap the scaling
     G = max(1, args.gather_every)
     local_acc = [torch.empty((G, B, T_FRAMES, 4), dtype=torch.int32, device=dev) for _ in range(4)] if exchange else None
     gathered = [torch.empty((world * G * B, T_FRAMES, 4), dtype=torch.int32, device=dev) for _ in range(4)] if exchange else None
@@ -380,20 +589,14 @@ def main():
                 dist.all_gather_into_tensor(gathered[k][:world * n * B], local_acc[k][:n].view(n * B, T_FRAMES, 4))
             filled[k] = 0
 
-    if args.mode == "train":
-        return bench_train(args, model, boxes, labels, world, rank, dev, dist, params)
-
     def step(i):
         # independent batches: step i is enqueued on stream i % S, so up to S forwards are in flight
-        nonlocal S, streams
         k = i % S
         with torch.cuda.stream(streams[k]):
             with torch.no_grad():
                 y, _logits = model(boxes)
             pred_px, _, _ = metrics.postprocess_and_iou(y)
             if exchange:
-                # the collective runs on the process group's own stream and only THIS stream waits for it, so it
-                # overlaps with the forwards in flight on the other streams
                 local_acc[k][filled[k]].copy_(pred_px)
                 filled[k] += 1
         if exchange and filled[k] == G:
@@ -408,7 +611,7 @@ def main():
             if st is not main_stream:
                 main_stream.wait_stream(st)
 
-    if args.streams <= 0 and args.mode == "infer":
+    if args.streams <= 0:
         # untimed calibration: how many of the 4 streams to use (stream -> hardware-queue mapping varies)
         best = (0.0, 1, 0)
         for off in (0, 4):
@@ -457,53 +660,45 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)  # HIP events bracketing all launch streams: the kernels only
+    # ONE launch's own duration: a single-stream pass (nothing overlaps it), HIP events on that stream
+    single = streams[:1]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(single[0]), torch.no_grad():
+        model(boxes)
+        e0.record(single[0])
+        for _ in range(10):
+            model(boxes)
+        e1.record(single[0])
+    torch.cuda.synchronize(dev)
+    single_launch_us = e0.elapsed_time(e1) * 1e3 / (10 * (T_FRAMES + 3))
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
-    if rank == 0:
-        clips_per_s = world * B * args.steps / elapsed
-        # dominant kernel: opnet_step, T+3 launches per forward.  Algorithmic bytes under the
-        # per-time-step streaming model: every step reads all weights once and moves each clip's state.
-        n_launch = args.steps * (T_FRAMES + 3)
-        alg_bytes_per_launch = (W_BYTES + B * STATE_BYTES_PER_CLIP) * T_FRAMES / (T_FRAMES + 3)
-        # device-level achieved bandwidth = all algorithmic bytes of the timed region / its GPU time.
-        # With S > 1 streams up to S launches overlap, so `launch_us` is the AMORTISED time per launch
-        # (GPU time / launches); a single launch's own duration in a rocprof trace is about S x longer
-        # (profiles/README.md shows how the two reconcile: sum of durations / wall = overlap factor).
-        launch_us = gpu_ms * 1e3 / n_launch
-        achieved = alg_bytes_per_launch / (launch_us * 1e-6) / 1e9
-        out = {
-            "metric": "CATER clips/sec (300f x 10obj) OPNet inference",
-            "value": round(clips_per_s, 1), "unit": "clips/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"opnet (configs/opnet_model_config.json: H1=256, H2=512) inference, "
-                                   f"batch={B} clips/GPU/step x 300 frames x 15 slots (10 objects) x 6 features, "
-                                   "precomputed bbox input resident in HBM, int32 pixel-box post-process on device; "
-                                   f"independent steps spread over {S} HIP streams",
-                       "global_batch": world * B, "frames": T_FRAMES, "parallelism": f"dp{world}",
-                       "streams": S,
-                       "weights": "synthetic (synthdata/opnet.py counter RNG), fp32"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(B),
-                         "kernel": "opnet_step", "launch_us": round(launch_us, 3), "launches_in_flight": S,
-                         "alg_bytes_per_launch": int(alg_bytes_per_launch)},
-        }
-        out.update(accuracy_block(dev))
-        if world == 1 and not args.no_cpu_baseline:
-            cb, y_cpu = cpu_baseline(boxes_np, params, args.cpu_seconds)
-            out["cpu_baseline"] = cb
-            err = float(np.abs(y.cpu().numpy() - y_cpu).max())
-            out["parity_max_abs_dy_vs_cpu_port"] = err
-            if not err < 1e-4 and not os.environ.get("OPNET_HIP_LIB"):
-                raise SystemExit(f"bench: HIP output of the last timed step differs from the CPU port by {err}")
-        print(json.dumps(out), flush=True)
-    if exchange:
-        dist.destroy_process_group()
+    if rank != 0:
+        return None, None
+    clips_per_s = world * B * args.steps / elapsed
+    # dominant kernel: opnet_step, T+3 launches per forward.  Algorithmic bytes under the per-time-step streaming model:
+    # every step reads all weights once and moves each clip's state.
+    n_launch = args.steps * (T_FRAMES + 3)
+    alg_bytes_per_launch = (W_BYTES + B * STATE_BYTES_PER_CLIP) * T_FRAMES / (T_FRAMES + 3)
+    achieved = alg_bytes_per_launch / (single_launch_us * 1e-6) / 1e9
+    amort_us = gpu_ms * 1e3 / n_launch
+    amort = alg_bytes_per_launch / (amort_us * 1e-6) / 1e9
+    out = _line(args, world, B, clips_per_s, elapsed,
+                f"opnet (configs/opnet_model_config.json: H1=256, H2=512) inference, batch={B} clips/GPU/step x 300 frames x "
+                "15 slots (10 objects) x 6 features, precomputed bbox input resident in HBM, int32 pixel-box post-process on "
+                f"device; independent steps spread over {S} HIP streams",
+                {"engine": "chain", "streams": S})
+    out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "opnet_step",
+                       "launch_us": round(single_launch_us, 3), "alg_bytes_per_launch": int(alg_bytes_per_launch),
+                       "timing": "HIP events around 10 forwards (T+3 launches each) alone on one stream"}
+    out["roofline_amortised"] = {"achieved": round(amort, 1), "frac": round(amort / HBM_PEAK_GBS, 4), "unit": "GB/s",
+                                 "launches_in_flight": S, "amortised_launch_us": round(amort_us, 3),
+                                 "note": "all algorithmic bytes of the timed region / GPU time with S forwards in flight: counts "
+                                         "the weight stream once per concurrent forward; not a per-kernel figure"}
+    return out, y
 
 
 if __name__ == "__main__":

@@ -84,6 +84,11 @@ size_t opnet_xcd_workspace_bytes(int B, int T, int H1, int H2);
 int opnet_xcd_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
                           void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
                           void *stream);
+/* measurement: with profiling enabled every launch of the persistent kernel (not the input pack / output head around
+ * it) is bracketed by HIP events on the caller's stream; opnet_xcd_profile_read waits for them (host sync) and returns
+ * the summed kernel time and the number of launches since the last read. */
+int opnet_xcd_profile(int enable);
+int opnet_xcd_profile_read(double *kernel_ms_total, int *launches);
 /* tools: device buffer of >= (T+1) * ceil(B/128) * 8 uint64 receiving s_memtime stamps of block 0 (NULL = off) */
 void opnet_xcd_set_trace(void *device_buffer);
 

@@ -343,6 +343,39 @@ static std::mutex g_xcd_mu;
 static hipEvent_t g_xcd_done[64] = {};
 static int g_xcd_cus[64] = {};
 
+// Measurement (bench.py): with profiling on, every launch of the persistent kernel is bracketed by a pair of HIP events
+// on the caller's stream; opnet_xcd_profile_read waits for them and returns the summed kernel time.
+static bool g_xcd_prof = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_xcd_prof_ev;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_xcd_prof_pool;
+
+extern "C" int opnet_xcd_profile(int enable)
+{
+    std::lock_guard<std::mutex> lock(g_xcd_mu);
+    g_xcd_prof = enable != 0;
+    for (auto &e : g_xcd_prof_ev) g_xcd_prof_pool.push_back(e);
+    g_xcd_prof_ev.clear();
+    return OPNET_OK;
+}
+
+extern "C" int opnet_xcd_profile_read(double *kernel_ms_total, int *launches)
+{
+    if (!kernel_ms_total || !launches) return fail(OPNET_EINVAL, "null pointer");
+    std::lock_guard<std::mutex> lock(g_xcd_mu);
+    double total = 0.0;
+    for (auto &e : g_xcd_prof_ev) {
+        HIP_TRY(hipEventSynchronize(e.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+        total += ms;
+    }
+    *kernel_ms_total = total;
+    *launches = (int)g_xcd_prof_ev.size();
+    for (auto &e : g_xcd_prof_ev) g_xcd_prof_pool.push_back(e);
+    g_xcd_prof_ev.clear();
+    return OPNET_OK;
+}
+
 extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
                                      void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
                                      void *stream)
@@ -384,7 +417,17 @@ extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, fl
     opnet_xcd_pack_input<<<dim3(T + 2, L.NGT), 384, 0, st>>>(boxes, a);
     if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
     else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
+    std::pair<hipEvent_t, hipEvent_t> pe{};
+    if (g_xcd_prof) {
+        if (!g_xcd_prof_pool.empty()) { pe = g_xcd_prof_pool.back(); g_xcd_prof_pool.pop_back(); }
+        else { HIP_TRY(hipEventCreate(&pe.first)); HIP_TRY(hipEventCreate(&pe.second)); }
+        HIP_TRY(hipEventRecord(pe.first, st));
+    }
     opnet_xcd_forward<<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
+    if (g_xcd_prof) {
+        HIP_TRY(hipEventRecord(pe.second, st));
+        g_xcd_prof_ev.push_back(pe);
+    }
     HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
     opnet_xcd_out_head<<<dim3(T, L.NGT), 256, 0, st>>>(a, y);
     HIP_TRY(hipGetLastError());

@@ -209,7 +209,9 @@ class OPNet(AbstractCaterModel):
         self._h1, self._h2 = h1, h2
         self._packed = None
         self._packed_key = None
+        self._packed_event, self._packed_stream = None, None
         self._plans: Dict[Tuple[int, int, int, int], Tuple[int, torch.Tensor]] = {}
+        self._retired = []
         self._tpacked = None     # training: inference tiles + transposed tiles
         self._tws = None         # training workspace (one forward's history)
         self._tws_key = None
@@ -244,9 +246,17 @@ class OPNet(AbstractCaterModel):
                                             nbytes, self._h1, self._h2, _stream_ptr(device))
             _lib.check(rc, "opnet_pack_weights_f32")
             self._packed_key = key
+            # forwards of this module may be in flight on several streams: the others must not read the packed image
+            # before (or while) this stream's pack kernels have written it
+            self._packed_event = torch.cuda.Event()
+            self._packed_event.record(torch.cuda.current_stream(device))
+            self._packed_stream = _stream_ptr(device)
+        elif self._packed_event is not None and self._packed_stream != _stream_ptr(device):
+            torch.cuda.current_stream(device).wait_event(self._packed_event)
         return self._packed
 
-    XCD_MIN_BATCH = 128
+    XCD_MIN_BATCH = 64       # measured: 38.3 k clips/s against 37.4 k through the launch chain at 64 clips, 74 k against 49 k at 128
+    MAX_PLANS = 16           # (shape, device, stream) launch plans kept alive
 
     def _wants_xcd(self, B: int) -> bool:
         if self.use_xcd in ("0", 0, False) or (self._h1, self._h2) != (256, 512):
@@ -316,7 +326,20 @@ class OPNet(AbstractCaterModel):
                 plan = _lib.c_void_p()
                 _lib.check(lib.opnet_plan_create(_lib.ctypes.byref(plan), B, T, self._h1, self._h2),
                            "opnet_plan_create")
+                # least-recently-used bound: a server that sees many (shape, stream) pairs must not keep a hipGraph and
+                # a workspace for each of them forever.  The evicted plan may still have work in flight on its stream:
+                # park it until the next eviction instead of destroying it under the GPU.
+                while len(self._plans) >= self.MAX_PLANS:
+                    old_key = next(iter(self._plans))
+                    self._retired.append(self._plans.pop(old_key))
+                    if len(self._retired) > self.MAX_PLANS:
+                        torch.cuda.synchronize(dev)
+                        for old_plan, _ in self._retired:
+                            lib.opnet_plan_destroy(old_plan)
+                        self._retired.clear()
                 self._plans[key] = (plan, ws)
+            else:
+                self._plans[key] = self._plans.pop(key)      # move to the most-recently-used end
             plan, ws = self._plans[key]
             y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
             logits = torch.empty((B, 15, T), dtype=torch.float32, device=dev)
@@ -334,7 +357,7 @@ class OPNet(AbstractCaterModel):
     def __del__(self):
         try:
             lib = _lib.load()
-            for plan, _ in self._plans.values():
+            for plan, _ in list(self._plans.values()) + list(self._retired):
                 lib.opnet_plan_destroy(plan)
         except Exception:
             pass
@@ -424,8 +447,9 @@ class _SlotEmbedFunction(torch.autograd.Function):
         lib = _lib.load()
         ntok, F = int(x.shape[0] * x.shape[1]), int(weight.shape[0])
         out = torch.empty((x.shape[0], x.shape[1], nslots_out * F), dtype=torch.float32, device=x.device)
-        _lib.check(lib.opseq_slot_embed_relu_f32(x.data_ptr(), weight.data_ptr(), out.data_ptr(), ntok, nslots_out, F,
-                                                 _stream_ptr(x.device)), "opseq_slot_embed_relu_f32")
+        with torch.cuda.device(x.device):
+            _lib.check(lib.opseq_slot_embed_relu_f32(x.data_ptr(), weight.data_ptr(), out.data_ptr(), ntok, nslots_out, F,
+                                                     _stream_ptr(x.device)), "opseq_slot_embed_relu_f32")
         ctx.save_for_backward(x, out)
         ctx.dims = (ntok, nslots_out, F)
         return out
@@ -441,17 +465,6 @@ class _SlotEmbedFunction(torch.autograd.Function):
             _lib.check(lib.opseq_slot_embed_relu_bwd_f32(x.data_ptr(), out.data_ptr(), dout.data_ptr(), dW.data_ptr(), ntok,
                                                          nslots_out, F, _stream_ptr(x.device)), "opseq_slot_embed_relu_bwd_f32")
         return None, dW, None
-
-
-def _require_inference(module: nn.Module, x: torch.Tensor, feat: int):
-    if not x.is_cuda:
-        raise RuntimeError(f"objectpermanence_amd.{type(module).__name__} runs on MI355X only: move the input "
-                           "(and the model) to a ROCm device; there is no CPU fallback")
-    if x.dim() != 4 or x.shape[2] != 15 or x.shape[3] != feat:
-        raise ValueError(f"input must be [B, T, 15, {feat}], got {tuple(x.shape)}")
-    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise RuntimeError(f"{type(module).__name__}: training through the HIP path is not implemented for this model; "
-                           "wrap inference in torch.no_grad()")
 
 
 def _weights_key(ws, dev):
@@ -691,7 +704,8 @@ class TransformerLstm(AbstractCaterModel):
         _check_input(self, x, 5)
         x = x.contiguous().float()
         if _wants_grad(self):
-            return self._forward_train(x)
+            with torch.cuda.device(x.device):
+                return self._forward_train(x)
         if self.training and self.dropout > 0:
             raise RuntimeError("TransformerLstm: train mode without gradients would still apply dropout; call eval() "
                                "for inference")

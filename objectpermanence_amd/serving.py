@@ -1,0 +1,88 @@
+"""Request batching in front of the reasoners.
+
+The reference calls its model one DataLoader minibatch at a time (baselines/inference_main.py:191-217, batch_size 16 in
+configs/inference_config.json).  On the MI355X the unit that fills the chip is much larger: the per-XCD persistent OPNet
+forward (csrc/opnet_xcd_kernels.hip) wants at least two 16-clip groups on each of the 8 XCDs, i.e. >= 256 clips per launch,
+and gives 99 k clips/s there against 26 k for one 32-clip batch alone.  Clips are independent
+(SURVEY.md 8-e1), so concurrent requests can simply be concatenated: `ReasonerServer` collects submitted minibatches,
+runs them as ONE forward when `max_clips` are pending (or on `flush()`), and hands every request its own slice of the
+outputs.  Results are bit-identical to running the concatenation through `model(...)` directly.
+
+TransformerLstm is deliberately refused: its attention spans all clips of a minibatch, so merging
+requests would change its results.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from .supported_models import DOUBLE_OUTPUT_MODELS
+
+
+class PendingResult:
+    """Handle returned by ReasonerServer.submit(); `.result()` flushes the server if the request is still queued."""
+
+    def __init__(self, server: "ReasonerServer", n_clips: int):
+        self._server, self.n_clips = server, n_clips
+        self._value = None
+
+    def done(self) -> bool:
+        return self._value is not None
+
+    def result(self):
+        if self._value is None:
+            self._server.flush()
+        return self._value
+
+
+class ReasonerServer:
+    def __init__(self, model: torch.nn.Module, model_name: str = "opnet", max_clips: int = 1024):
+        if type(model).__name__ == "TransformerLstm":
+            raise ValueError("TransformerLstm couples the clips of a minibatch (sequence-first attention): requests "
+                             "cannot be merged without changing its outputs")
+        self.model, self.model_name, self.max_clips = model, model_name, int(max_clips)
+        self._queue: List[Tuple[torch.Tensor, PendingResult]] = []
+        self._pending = 0
+        self.last_output = None      # the whole output of the last forward (callers that post-process per launch)
+        self.forwards = 0            # statistics: forwards issued / clips served
+        self.clips = 0
+
+    def submit(self, boxes: torch.Tensor) -> PendingResult:
+        """boxes [b, T, 15, F] on the model's device.  Returns a handle; the forward runs when `max_clips` clips are
+        pending or on flush() / handle.result()."""
+        if self._queue and tuple(boxes.shape[1:]) != tuple(self._queue[0][0].shape[1:]):
+            self.flush()             # a different clip length cannot share a launch
+        h = PendingResult(self, int(boxes.shape[0]))
+        self._queue.append((boxes, h))
+        self._pending += h.n_clips
+        if self._pending >= self.max_clips:
+            self.flush()
+        return h
+
+    @torch.no_grad()
+    def flush(self) -> None:
+        if not self._queue:
+            return
+        queue, self._queue, self._pending = self._queue, [], 0
+        x = queue[0][0] if len(queue) == 1 else torch.cat([q[0] for q in queue], dim=0)
+        out = self.model(x)
+        double = isinstance(out, tuple)
+        self.last_output = out if double else (out,)
+        self.forwards += 1
+        self.clips += int(x.shape[0])
+        lo = 0
+        for boxes, h in queue:
+            hi = lo + h.n_clips
+            h._value = (out[0][lo:hi], out[1][lo:hi]) if double else out[lo:hi]
+            lo = hi
+
+    def infer(self, boxes: torch.Tensor):
+        """submit + wait: what a caller without concurrency gets (one forward per call)"""
+        h = self.submit(boxes)
+        return h.result()
+
+
+def output_boxes(model_name: str, out):
+    """the y_boxes part of a model output (DOUBLE_OUTPUT_MODELS return (y_boxes, logits), inference_main.py:203-207)"""
+    return out[0] if model_name in DOUBLE_OUTPUT_MODELS else out

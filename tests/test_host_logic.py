@@ -222,3 +222,62 @@ def test_cli_mirrors_reference_subcommands(tmp_path):
                  "--output_file", str(out)]) == 0
     rows = open(out).read().strip().splitlines()
     assert len(rows) >= 3 and "overall" in rows[0]
+
+
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks itself (torch.distributed.run, rendezvous on
+    127.0.0.1); --launcher-selftest stops after the rendezvous + one gloo collective, so this runs without a GPU."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    import subprocess
+    import sys
+    import torch
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(have + 1 if have else 2)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_reasoner_server_batches_requests_and_slices_outputs():
+    """request batching (serving.ReasonerServer) with a stand-in model on CPU: several submitted minibatches run as ONE
+    forward and every request gets exactly its own rows back"""
+    import torch
+    from objectpermanence_amd.serving import ReasonerServer
+
+    calls = []
+
+    class Fake(torch.nn.Module):
+        def forward(self, x):
+            calls.append(int(x.shape[0]))
+            return x[:, :, 0, :4] * 2.0, x[:, :, :, 0].permute(0, 2, 1)
+
+    srv = ReasonerServer(Fake(), "opnet", max_clips=96)
+    xs = [torch.randn(n, 5, 15, 6) for n in (32, 16, 48, 8)]
+    hs = [srv.submit(x) for x in xs[:3]]            # 32 + 16 + 48 = 96 -> flushes itself
+    assert calls == [96] and all(h.done() for h in hs)
+    h4 = srv.submit(xs[3])
+    assert not h4.done()
+    y4, lg4 = h4.result()                           # flushes the remainder
+    assert calls == [96, 8] and srv.forwards == 2 and srv.clips == 104
+    for x, h in zip(xs, hs + [h4]):
+        y, lg = h.result()
+        assert torch.equal(y, x[:, :, 0, :4] * 2.0) and torch.equal(lg, x[:, :, :, 0].permute(0, 2, 1))
+    # a request with another clip length cannot share the launch
+    a, b = srv.submit(torch.randn(4, 5, 15, 6)), srv.submit(torch.randn(4, 7, 15, 6))
+    assert a.done() and not b.done()
+    srv.flush()
+    assert b.done() and calls[-2:] == [4, 4]
