@@ -5,8 +5,12 @@ Same config keys (configs/inference_config.json): batch_size, num_workers, devic
 labels_dir (videos_dir is only used by the reference for its debug AVI, which is not produced here - cv2 /
 video IO is outside the hot path).  Differences, all deliberate:
   * the model, the int32 pixel post-process and the IoU metric run in the HIP library;
-  * with torch.distributed initialised the videos are sharded in contiguous blocks over the ranks and the
-    int32 predictions are all-gathered (parallel.py); every rank returns the full result, rank 0 writes;
+  * with torch.distributed initialised the videos are sharded over the ranks (parallel.plan_inference_batches: contiguous
+    blocks for the clip-independent reasoners; WHOLE reference minibatches for transformer_lstm*, whose attention couples
+    the clips of a minibatch - a split batch would change its outputs) and the int32 predictions are all-gathered by
+    dataset index; every rank returns the full result, rank 0 writes;
+  * the clip-independent reasoners do not run one forward per DataLoader minibatch: the minibatches are submitted to a
+    serving.ReasonerServer, which runs up to 1024 pending clips as one forward (same outputs, clips are independent);
   * predictions are written for every dataset video (the reference writes only those it also finds as .avi).
 """
 from __future__ import annotations
@@ -23,7 +27,7 @@ from torch.utils import data
 from . import metrics, parallel
 from .datasets import DatasetsFactory
 from .models_factory import ModelsFactory
-from .supported_models import DOUBLE_OUTPUT_MODELS
+from .serving import ReasonerServer, output_boxes
 
 
 def write_bb_predictions_to_file(video_name: str, results_dir: str, predictions) -> str:
@@ -49,32 +53,39 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
     n_total = len(dataset)
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
-    lo, hi = parallel.shard_range(n_total, world, rank)
-    subset = data.Subset(dataset, range(lo, hi))
-    loader = data.DataLoader(subset, batch_size=batch_size, num_workers=num_workers)
+    batches = parallel.plan_inference_batches(model_name, n_total, batch_size, world, rank)
+    loader = data.DataLoader(dataset, batch_sampler=batches, num_workers=num_workers)
 
     model = ModelsFactory.get_model(model_name, model_config, config.get("model_path"))
     model.eval()
     model.to(device)
+    server = None if parallel.couples_clips(model_name) else ReasonerServer(model, model_name)
 
     names: List[str] = []
-    preds, gts, ious = [], [], []
+    pending, preds, gts, ious = [], [], [], []
+
+    def finish(handle, labels_dev):
+        output = output_boxes(model_name, handle.result() if server is not None else handle)
+        pred_px, gt_px, iou = metrics.postprocess_and_iou(output, labels_dev)
+        preds.append(pred_px); gts.append(gt_px); ious.append(iou)
+
     with torch.no_grad():
         for (boxes, _index_to_track), (labels, _), video_names in loader:
-            out = model(boxes.to(device))
-            output = out[0] if model_name in DOUBLE_OUTPUT_MODELS else out
-            pred_px, gt_px, iou = metrics.postprocess_and_iou(output, labels.to(device))
-            preds.append(pred_px); gts.append(gt_px); ious.append(iou)
             names.extend(video_names)
+            if server is None:
+                finish(model(boxes.to(device)), labels.to(device))
+            else:
+                pending.append((server.submit(boxes.to(device)), labels.to(device)))
+        for handle, labels_dev in pending:
+            finish(handle, labels_dev)
     t_frames = preds[0].shape[1] if preds else 300
     local_pred = torch.cat(preds) if preds else torch.zeros((0, t_frames, 4), dtype=torch.int32, device=device)
     local_iou = torch.cat(ious) if ious else torch.zeros((0, t_frames), dtype=torch.float64, device=device)
     if world > 1:
-        all_pred, _ = parallel.all_gather_predictions(local_pred, n_total)
-        all_iou, _ = parallel.all_gather_predictions(local_iou, n_total)
-        gathered_names: List[List[str]] = [None] * world
-        dist.all_gather_object(gathered_names, names)
-        names = [n for part in gathered_names for n in part]
+        index = torch.tensor([i for b in batches for i in b], dtype=torch.int64, device=device)
+        all_pred = parallel.all_gather_by_index(local_pred, index, n_total)
+        all_iou = parallel.all_gather_by_index(local_iou, index, n_total)
+        names = list(dataset.videos_names)          # dataset order = global index order (datasets.py:70-74)
     else:
         all_pred, all_iou = local_pred, local_iou
     mean_iou, map50 = metrics.mean_iou_and_map(all_iou, 0.5) if n_total else (float("nan"), float("nan"))

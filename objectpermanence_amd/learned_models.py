@@ -115,7 +115,14 @@ class _OPNetTrainFunction(torch.autograd.Function):
         B, T = ctx.shape
         dev = grad_y.device
         grad_y = grad_y.contiguous().float()
-        grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.wshapes]
+        # with a gradient bucket on the module (data-parallel training, parallel.GradBucket) the six weight gradients are
+        # written straight into its flat buffer: the all-reduce then needs no gather copy
+        bucket = getattr(module, "_grad_bucket", None)
+        if bucket is not None and len(bucket.params) == len(ctx.wshapes) and bucket.flat.device == dev and \
+                all(tuple(p.shape) == s for p, s in zip(bucket.params, ctx.wshapes)):
+            grads = [bucket.view(i) for i in range(len(ctx.wshapes))]
+        else:
+            grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.wshapes]
         with torch.cuda.device(dev):
             rc = lib.opnet_train_backward_f32(grad_y.data_ptr(), module._tpacked.data_ptr(), module._tws.data_ptr(),
                                               module._tws.numel(), *(g.data_ptr() for g in grads), B, T,

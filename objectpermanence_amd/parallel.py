@@ -34,6 +34,53 @@ def shard_batches(n_items: int, batch_size: int, world: int, rank: int):
     return [(b * batch_size, min(n_items, (b + 1) * batch_size)) for b in range(rank, n_batches, world)]
 
 
+def balanced_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """np.array_split-style block of `rank`: sizes differ by at most one and no rank is empty while n_items >= world
+    (the per-batch split of a TRAINING minibatch: with ceil(N/W) blocks a last batch of 5 clips on 4 ranks would leave
+    rank 3 without work)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def couples_clips(model_name: str) -> bool:
+    """TransformerLstm attends over all clips of a minibatch (S = B*T, reference learned_models.py:183-185; SURVEY.md
+    section 0): its outputs depend on batch composition, so it may only be sharded in whole reference batches."""
+    return model_name.startswith("transformer_lstm")
+
+
+def plan_inference_batches(model_name: str, n_items: int, batch_size: int, world: int, rank: int):
+    """The minibatches (lists of dataset indices) `rank` evaluates.  Clip-independent reasoners: the contiguous block
+    shard_range() cut into batches (any cut gives the same outputs).  TransformerLstm: exactly the batches the reference's
+    DataLoader would form over the WHOLE dataset, dealt round-robin (shard_batches) - never a split batch."""
+    if couples_clips(model_name):
+        return [list(range(lo, hi)) for lo, hi in shard_batches(n_items, batch_size, world, rank)]
+    lo, hi = shard_range(n_items, world, rank)
+    return [list(range(b, min(hi, b + batch_size))) for b in range(lo, hi, batch_size)]
+
+
+def all_gather_by_index(local: torch.Tensor, index: torch.Tensor, n_total: int,
+                        group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """local [n_local, ...] with the global dataset index of every row -> [n_total, ...] in dataset order on every rank
+    (ranks may own any subset; n_local may be zero).  Two collectives: the padded rows and their indices."""
+    world = dist.get_world_size(group)
+    counts = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device), group=group)
+    per = max(int(max(c.item() for c in counts)), 1)
+    pad = local.new_zeros((per,) + tuple(local.shape[1:]))
+    pad[: local.shape[0]] = local
+    ipad = torch.full((per,), -1, dtype=torch.int64, device=local.device)
+    ipad[: local.shape[0]] = index.to(local.device)
+    rows = local.new_empty((world * per,) + tuple(local.shape[1:]))
+    idx = torch.empty(world * per, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(rows, pad, group=group)
+    dist.all_gather_into_tensor(idx, ipad, group=group)
+    keep = idx >= 0
+    out = local.new_zeros((n_total,) + tuple(local.shape[1:]))
+    out[idx[keep]] = rows[keep]
+    return out
+
+
 def all_gather_predictions(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessGroup] = None,
                            async_op: bool = False):
     """local [n_local, ...] (this rank's shard, n_local may be short or zero on the last ranks) ->
@@ -46,6 +93,46 @@ def all_gather_predictions(local: torch.Tensor, n_total: int, group: Optional[di
     out = local.new_empty((world * per,) + tuple(local.shape[1:]))
     work = dist.all_gather_into_tensor(out, pad, group=group, async_op=async_op)
     return out[:n_total], work
+
+
+class GradBucket:
+    """ONE flat fp32 buffer behind the gradients of a FIXED parameter list (1 421 056 floats = 5.68 MB for OPNet): the
+    backward pass writes every weight gradient straight into its slice (learned_models._OPNetTrainFunction when the module
+    carries the bucket), the data-parallel exchange is one all-reduce over `flat`, and the optimiser reads the reduced
+    slices - no torch.cat before and no copy back after the collective.  The list is fixed at construction, so every rank
+    reduces the same number of elements whatever gradients it happened to produce (a rank with an empty shard contributes
+    zeros and still joins)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(n, dtype=torch.float32, device=ref.device)
+        self.offsets, o = [], 0
+        for p in self.params:
+            self.offsets.append(o)
+            o += p.numel()
+
+    def view(self, i: int) -> torch.Tensor:
+        p, o = self.params[i], self.offsets[i]
+        return self.flat[o:o + p.numel()].view_as(p)       # a fresh tensor object on the bucket's storage
+
+    def collect(self) -> None:
+        """make `flat` hold the current gradients: slices the backward already wrote in place are left alone, anything
+        else (a sibling model's autograd-made gradient, a missing gradient) is copied / zeroed; then p.grad aliases it"""
+        for i, p in enumerate(self.params):
+            v = self.view(i)
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            p.grad = v
+
+    def all_reduce(self, n_local: int, n_global: int, group: Optional[dist.ProcessGroup] = None, async_op: bool = False):
+        """weighted n_local / n_global so that an uneven split still reproduces the single-process mean-loss gradient
+        (SURVEY.md 8-e1); call on the stream the collective should run on"""
+        self.flat.mul_(float(n_local) / float(n_global))
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
 def all_reduce_gradients(params, n_local: int, n_global: int, group: Optional[dist.ProcessGroup] = None,

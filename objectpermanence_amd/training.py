@@ -34,25 +34,50 @@ def compute_loss(model_name: str, output: torch.Tensor, labels: torch.Tensor, ma
     return pred, pred, consistency.detach()
 
 
-def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.Optimizer, boxes: torch.Tensor,
-               labels: torch.Tensor, mask: Optional[torch.Tensor] = None, group: Optional[dist.ProcessGroup] = None,
+def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.Optimizer, boxes: Optional[torch.Tensor],
+               labels: Optional[torch.Tensor], mask: Optional[torch.Tensor] = None, group: Optional[dist.ProcessGroup] = None,
                n_global: Optional[int] = None, comm_stream: Optional[torch.cuda.Stream] = None,
-               loss_kind: str = "l1") -> torch.Tensor:
+               loss_kind: str = "l1", overlap=None) -> torch.Tensor:
+    """zero_grad -> forward -> loss -> backward -> [gradient all-reduce] -> Adam (training_main.py:183-217).
+
+    Data parallel: EVERY rank calls this for every global batch - a rank whose slice of the batch is empty passes
+    boxes=None, contributes zero gradients with weight 0 / n_global and still joins the collective and the optimiser step
+    (otherwise the other ranks would wait in the all-reduce forever and this rank's weights would drift).  The gradients
+    live in one flat bucket (parallel.GradBucket) that the HIP backward writes in place; the all-reduce is enqueued on
+    `comm_stream` as soon as the backward (its last kernel is the merged weight-gradient GEMM) is enqueued, `overlap()` -
+    the caller's work that does not depend on the new weights: the next batch's host-to-device copies, its input packing -
+    runs on the current stream meanwhile, and only then does the current stream wait for the collective and run Adam."""
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    bucket = getattr(model, "_grad_bucket", None)
+    if bucket is None:
+        bucket = model._grad_bucket = parallel.GradBucket(model.parameters())
     optimizer.zero_grad(set_to_none=True)
-    out = model(boxes)
-    output = out[0] if model_name in DOUBLE_OUTPUT_MODELS else out
-    loss, _, _ = compute_loss(model_name, output, labels, mask, loss_kind)
-    loss.backward()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        params = [p for p in model.parameters() if p.grad is not None]
-        n_local = int(boxes.shape[0])
+    n_local = 0 if boxes is None else int(boxes.shape[0])
+    if n_local > 0:
+        out = model(boxes)
+        output = out[0] if model_name in DOUBLE_OUTPUT_MODELS else out
+        loss, _, _ = compute_loss(model_name, output, labels, mask, loss_kind)
+        loss.backward()
+        loss = loss.detach()
+    else:
+        loss = bucket.flat.new_zeros(())
+    bucket.collect()
+    if distributed:
         n_glob = n_global if n_global is not None else n_local * dist.get_world_size(group)
-        cur = torch.cuda.current_stream(boxes.device)
+        cur = torch.cuda.current_stream(bucket.flat.device) if bucket.flat.is_cuda else None
         st = comm_stream or cur
-        st.wait_stream(cur)
-        with torch.cuda.stream(st):
-            flat, _ = parallel.all_reduce_gradients(params, n_local, n_glob, group)
-            parallel.unflatten_gradients(params, flat)
-        cur.wait_stream(st)
+        if cur is not None:
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                bucket.all_reduce(n_local, max(n_glob, 1), group)
+            if overlap is not None:
+                overlap()
+            cur.wait_stream(st)
+        else:                                   # CPU tensors (gloo tests)
+            bucket.all_reduce(n_local, max(n_glob, 1), group)
+            if overlap is not None:
+                overlap()
+    elif overlap is not None:
+        overlap()
     optimizer.step()
-    return loss.detach()
+    return loss

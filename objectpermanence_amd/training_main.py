@@ -1,10 +1,19 @@
-"""Training driver - mirror of reference baselines/training_main.py:120-252 for the reasoners whose training
-path is built (OPNet / opnet_no_labels).  Same config keys (configs/training_config.json), same loop
-semantics: unshuffled loaders (:155-159), Adam lr (:150), ReduceLROnPlateau(min, factor, patience) stepped
-on the TRAIN loss (:151,247), per-epoch evaluation of train and dev sets with mean IoU and containment-masked
-mean IoU (:32-117, :240-241), best-dev-IoU checkpoint `<checkpoints_path>/<model>/<dd-mm-yy>_<iou>.pth` holding
-the plain state_dict (:19-29, :250-252).  Forward/backward/Adam/post-process/IoU run in the HIP library; with
-torch.distributed initialised the training batches are split over the ranks (training.train_step)."""
+"""Training driver - mirror of reference baselines/training_main.py:120-252 for every reasoner of
+supported_models.TRAINING_SUPPORTED_MODELS (OPNet, OPNetLstmMlp, BaselineLstm, NonLinearLstm, TransformerLstm and their
+*_no_labels variants).  Same config keys (configs/training_config.json), same loop semantics: unshuffled loaders (:155-159),
+Adam lr (:150), ReduceLROnPlateau(min, factor, patience) stepped on the TRAIN loss (:151,247), per-epoch evaluation of
+train and dev sets with mean IoU and containment-masked mean IoU (:32-117, :240-241), best-dev-IoU checkpoint
+`<checkpoints_path>/<model>/<dd-mm-yy>_<iou>.pth` holding the plain state_dict (:19-29, :250-252).  Forward / backward /
+Adam / post-process / IoU run in the HIP library.
+
+With torch.distributed initialised (not in the reference):
+  * every reference minibatch is split over the ranks in balanced contiguous slices and each rank LOADS ONLY ITS SLICE
+    (parallel.RankSliceSampler) - the input pipeline is not replicated; the gradients are exchanged by one all-reduce over
+    the flat bucket (training.train_step), every rank joining every step even when its slice is empty;
+  * transformer_lstm* couples the clips of a minibatch (sequence-first attention), so there a rank takes WHOLE reference
+    batches (k*W + r) and one optimiser step spans W of them;
+  * the per-epoch evaluation is sharded too and its per-frame IoUs are gathered, so every rank sees the same metrics.
+"""
 from __future__ import annotations
 
 import time
@@ -36,11 +45,28 @@ def save_checkpoint(model: torch.nn.Module, model_name: str, dev_iou: float, che
     return str(f)
 
 
-def inference_and_iou_comp(model_name: str, model: torch.nn.Module, device: torch.device, loader: data.DataLoader):
-    """training_main.py:32-117: average loss, dataset mean IoU, containment-masked mean IoU (a video whose mask is
-    empty contributes NaN to the containment mean, exactly like np.mean over the reference's DataFrame column)."""
+def masked_mean_iou(iou: torch.Tensor, cm: torch.Tensor) -> float:
+    """Mean over videos of the mean IoU over the video's containment frames.  The reference takes np.mean of a pandas
+    Series (training_main.py:105-112) = Series.mean(skipna=True): a video without containment frames is NaN there and
+    is SKIPPED, not propagated; NaN only if no video has any."""
+    cnt = cm.sum(dim=1)
+    masked = torch.where(cm, iou, torch.zeros_like(iou)).sum(dim=1) / cnt.clamp(min=1)
+    keep = cnt > 0
+    return float(masked[keep].mean()) if bool(keep.any()) else float("nan")
+
+
+def inference_and_iou_comp(model_name: str, model: torch.nn.Module, device: torch.device, dataset, batch_size: int,
+                           num_workers: int):
+    """training_main.py:32-117: average loss, dataset mean IoU, containment-masked mean IoU.  Under data parallelism every
+    rank evaluates its share of the minibatches (parallel.plan_inference_batches) and the per-frame IoUs / masks / loss
+    sums are gathered, so all ranks return the same numbers."""
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    n_total = len(dataset)
+    batches = parallel.plan_inference_batches(model_name, n_total, batch_size, world, rank)
+    loader = data.DataLoader(dataset, batch_sampler=batches, num_workers=num_workers)
     model.eval()
-    total_loss, n_seen = 0.0, 0
+    loss_sum = torch.zeros((), dtype=torch.float64, device=device)
     ious, contain = [], []
     with torch.no_grad():
         for (boxes, _), (labels, mask), _names in loader:
@@ -51,15 +77,36 @@ def inference_and_iou_comp(model_name: str, model: torch.nn.Module, device: torc
             _, _, iou = metrics.postprocess_and_iou(output, labels)
             ious.append(iou)
             contain.append(torch.sum(mask, dim=-1).type(torch.bool))
-            total_loss += float(loss) * boxes.shape[0]
-            n_seen += boxes.shape[0]
-    iou = torch.cat(ious)
-    cm = torch.cat(contain)
-    video_mean = iou.mean(dim=1)
-    cnt = cm.sum(dim=1)
-    masked = torch.where(cm, iou, torch.zeros_like(iou)).sum(dim=1) / cnt.clamp(min=1)
-    masked = torch.where(cnt > 0, masked, torch.full_like(masked, float("nan")))
-    return total_loss / max(n_seen, 1), float(video_mean.mean()), float(masked.mean())
+            loss_sum += loss.double() * boxes.shape[0]
+    t_frames = ious[0].shape[1] if ious else 300
+    iou = torch.cat(ious) if ious else torch.zeros((0, t_frames), dtype=torch.float64, device=device)
+    cm = torch.cat(contain) if contain else torch.zeros((0, t_frames), dtype=torch.bool, device=device)
+    if world > 1:
+        index = torch.tensor([i for b in batches for i in b], dtype=torch.int64, device=device)
+        iou = parallel.all_gather_by_index(iou, index, n_total)
+        cm = parallel.all_gather_by_index(cm.to(torch.uint8), index, n_total).bool()
+        dist.all_reduce(loss_sum)
+    return float(loss_sum) / max(n_total, 1), float(iou.mean(dim=1).mean()) if n_total else float("nan"), masked_mean_iou(iou, cm)
+
+
+def training_batches(model_name: str, n_items: int, batch_size: int, world: int, rank: int):
+    """-> (per optimiser step: the dataset indices THIS rank trains on (possibly none), the clips of the whole step).
+    Clip-independent reasoners: step k = reference batch k, split in balanced slices.  transformer_lstm*: step k = the W
+    reference batches k*W .. k*W + W-1, rank r taking batch k*W + r whole."""
+    n_batches = (n_items + batch_size - 1) // batch_size
+    span = lambda b: (b * batch_size, min(n_items, (b + 1) * batch_size))
+    steps = []
+    if parallel.couples_clips(model_name):
+        for k in range(0, n_batches, world):
+            mine = span(k + rank) if k + rank < n_batches else (0, 0)
+            total = sum(span(b)[1] - span(b)[0] for b in range(k, min(k + world, n_batches)))
+            steps.append((list(range(*mine)), total))
+    else:
+        for b in range(n_batches):
+            lo, hi = span(b)
+            a, z = parallel.balanced_range(hi - lo, world, rank)
+            steps.append((list(range(lo + a, lo + z)), hi - lo))
+    return steps
 
 
 def training_main(model_name: str, train_config: Dict[str, Any], model_config: Dict[str, int]) -> Dict[str, Any]:
@@ -69,35 +116,46 @@ def training_main(model_name: str, train_config: Dict[str, Any], model_config: D
     dev_ds = DatasetsFactory.get_training_dataset(model_name, train_config["dev_sample_dir"], train_config["dev_labels_dir"],
                                                   train_config["dev_containment_file"])
     bs, nw = train_config["batch_size"], train_config["num_workers"]
+    ibs = train_config["inference_batch_size"]
     model = ModelsFactory.get_model(model_name, model_config).to(device)
     optimizer = FusedAdam(model.parameters(), lr=train_config["learning_rate"])
     scheduler = ReduceLROnPlateau(optimizer, mode="min", factor=train_config["lr_scheduler_factor"],
                                   patience=train_config["lr_scheduler_patience"])
-    training_loader = data.DataLoader(train_ds, batch_size=bs, num_workers=nw)
-    infer_cfg = {"batch_size": train_config["inference_batch_size"], "num_workers": nw}
-    train_inference_loader = data.DataLoader(train_ds, **infer_cfg)
-    dev_loader = data.DataLoader(dev_ds, **infer_cfg)
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
+    steps = training_batches(model_name, len(train_ds), bs, world, rank)
+    # this rank's loader yields only its own non-empty slices, in step order
+    training_loader = data.DataLoader(train_ds, batch_sampler=[idx for idx, _ in steps if idx], num_workers=nw)
+    comm = torch.cuda.Stream(device=device) if world > 1 else None
 
     highest_dev_iou, best_path, history = 0.0, None, []
     start = time.time()
     for epoch in range(train_config["num_epochs"]):
         model.train(mode=True)
         running = 0.0
-        for batch_idx, ((boxes, _), (labels, mask), _) in enumerate(training_loader, 1):
-            n_global = int(boxes.shape[0])
-            lo, hi = parallel.shard_range(n_global, world, rank)          # DP: contiguous slice of every batch
-            if hi > lo:
-                loss = train_step(model_name, model, optimizer, boxes[lo:hi].to(device), labels[lo:hi].to(device),
-                                  mask[lo:hi].to(device), n_global=n_global)
-                running += float(loss)
-            if batch_idx % train_config["print_step"] == 0:
+        it = iter(training_loader)
+
+        def fetch(step_idx):
+            """host-to-device copies of step `step_idx` (None past the end / for an empty slice)"""
+            if step_idx >= len(steps) or not steps[step_idx][0]:
+                return None
+            (boxes, _), (labels, mask), _ = next(it)
+            return boxes.to(device, non_blocking=True), labels.to(device, non_blocking=True), mask.to(device, non_blocking=True)
+
+        nxt = fetch(0)
+        for k, (_, n_global) in enumerate(steps):
+            cur, box = nxt, {}
+            # the next step's batch is fetched while the gradient all-reduce of this one is in flight
+            loss = train_step(model_name, model, optimizer, *(cur if cur is not None else (None, None, None)), n_global=n_global,
+                              comm_stream=comm, overlap=lambda: box.setdefault("n", fetch(k + 1)))
+            nxt = box.get("n")
+            running += float(loss)
+            if (k + 1) % train_config["print_step"] == 0:
                 print("Train Epoch: {} [{}/{}]\t Average Loss: {:.4f} Training began {} seconds ago".format(
-                    epoch + 1, batch_idx * bs, len(train_ds), running / train_config["print_step"], int(time.time() - start)))
+                    epoch + 1, (k + 1) * bs, len(train_ds), running / train_config["print_step"], int(time.time() - start)))
                 running = 0.0
-        train_loss, train_miou, train_cmiou = inference_and_iou_comp(model_name, model, device, train_inference_loader)
-        dev_loss, dev_miou, dev_cmiou = inference_and_iou_comp(model_name, model, device, dev_loader)
+        train_loss, train_miou, train_cmiou = inference_and_iou_comp(model_name, model, device, train_ds, ibs, nw)
+        dev_loss, dev_miou, dev_cmiou = inference_and_iou_comp(model_name, model, device, dev_ds, ibs, nw)
         print("Epoch {} Training Set: Loss {:.4f}, Mean IoU {:.6f}, Mask Mean Iou {:.6f}".format(epoch + 1, train_loss, train_miou, train_cmiou))
         print("Epoch {} Dev Set: Loss {:.4f}, Mean IoU {:.6f}, Mask Mean Iou {:.6f}".format(epoch + 1, dev_loss, dev_miou, dev_cmiou))
         scheduler.step(train_loss)

@@ -281,3 +281,132 @@ def test_reasoner_server_batches_requests_and_slices_outputs():
     assert a.done() and not b.done()
     srv.flush()
     assert b.done() and calls[-2:] == [4, 4]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# data-parallel drivers (round 2): every rank always joins, balanced slices, whole batches for transformer_lstm
+# ---------------------------------------------------------------------------------------------------------------------
+def test_balanced_range_leaves_no_rank_empty():
+    from objectpermanence_amd import parallel
+    for n in (0, 1, 4, 5, 7, 16, 33):
+        for w in (1, 2, 4, 8):
+            spans = [parallel.balanced_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+            if n >= w:
+                assert min(sizes) >= 1          # shard_range(5, 4, 3) == (5, 5): the case that used to hang training
+
+
+def test_training_batches_plan():
+    from objectpermanence_amd.training_main import training_batches
+    # clip-independent model: every step is one reference batch, split; the last batch of 5 on 4 ranks leaves nobody empty
+    plans = [training_batches("opnet", 21, 16, 4, r) for r in range(4)]
+    assert all(len(p) == 2 for p in plans) and [p[1][1] for p in plans] == [5] * 4
+    for k in range(2):
+        got = sorted(i for p in plans for i in p[k][0])
+        assert got == list(range(16 * k, min(21, 16 * k + 16)))
+    assert all(len(p[1][0]) >= 1 for p in plans)
+    # fewer clips than ranks: some ranks get nothing for that step but still have the step (and join its collective)
+    plans = [training_batches("opnet", 2, 16, 4, r) for r in range(4)]
+    assert [len(p) for p in plans] == [1] * 4 and sorted(len(p[0][0]) for p in plans) == [0, 0, 1, 1]
+    # transformer_lstm: whole reference batches, one optimiser step spans `world` of them
+    plans = [training_batches("transformer_lstm", 40, 16, 2, r) for r in range(2)]
+    assert [p[0][0] for p in plans] == [list(range(0, 16)), list(range(16, 32))] and plans[0][0][1] == 32
+    assert plans[0][1] == (list(range(32, 40)), 8) and plans[1][1] == ([], 8)
+
+
+def _dp_train_worker(rank, world, port, n_total, tmp):
+    """training.train_step on CPU tensors over gloo with a stand-in model (the OPNet graph on torch ops): rank 1's slice of
+    the batch is EMPTY when n_total == 1 - it must still join the all-reduce and take the same Adam step"""
+    import torch.distributed as dist
+    from objectpermanence_amd import parallel, training
+    from oracle import synth, torch_port
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 16, "videos_hidden_dim": 32}
+    model = torch_port.OPNetTorch(synth.opnet_synth_params(cfg))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    lo, hi = parallel.balanced_range(n_total, world, rank)
+    boxes, labels = synth.make_batch(0, n_total, 8)
+    old = training.compute_loss
+    training.compute_loss = lambda name, out, lab, mask=None, kind="l1": (torch.mean(torch.abs(out - lab)),) * 3
+    try:
+        xb = torch.from_numpy(boxes[lo:hi]) if hi > lo else None
+        lb = torch.from_numpy(labels[lo:hi]) if hi > lo else None
+        training.train_step("baseline_lstm", model, opt, xb, lb, n_global=n_total)   # single-output stand-in
+    finally:
+        training.compute_loss = old
+    np.savez(os.path.join(tmp, f"w{rank}.npz"), **{k: v.detach().numpy() for k, v in model.state_dict().items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [3, 1])
+def test_dp_train_step_joins_with_empty_shard_and_matches_single_process(tmp_path, n_total):
+    import torch.multiprocessing as mp
+    from oracle import synth, torch_port
+    port = 31500 + (os.getpid() + n_total) % 1000
+    mp.spawn(_dp_train_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)   # would hang before the fix
+    cfg = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 16, "videos_hidden_dim": 32}
+    model = torch_port.OPNetTorch(synth.opnet_synth_params(cfg))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    boxes, labels = synth.make_batch(0, n_total, 8)
+    opt.zero_grad()
+    torch.mean(torch.abs(model(torch.from_numpy(boxes)) - torch.from_numpy(labels))).backward()
+    opt.step()
+    ref = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    for r in range(2):
+        got = np.load(os.path.join(str(tmp_path), f"w{r}.npz"))
+        for k in ref:
+            assert np.abs(got[k] - ref[k]).max() <= 2e-6, (r, k)      # both ranks hold the single-process weights
+
+
+def _dp_transformer_worker(rank, world, port, n_total, bs, tmp):
+    import torch.distributed as dist
+    from objectpermanence_amd import parallel
+    from oracle import synth, torch_port
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg = {"boxes_features_dim": 16, "num_attention_heads": 2, "num_attention_layers": 1, "num_lstm_layers": 1, "lstm_hidden_dim": 16}
+    params = {k: torch.from_numpy(v) for k, v in synth.transformer_lstm_synth_params(cfg, ffn=64).items()}
+    x_all, _ = synth.make_batch(0, n_total, 6)
+    x_all = torch.from_numpy(synth.boxes5(x_all))
+    for tag, plan in (("whole", parallel.plan_inference_batches("transformer_lstm", n_total, bs, world, rank)),
+                      ("split", parallel.plan_inference_batches("opnet", n_total, bs, world, rank))):
+        rows, index = [], []
+        for b in plan:
+            with torch.no_grad():
+                rows.append(torch_port.transformer_lstm_forward(x_all[b], params, cfg["num_attention_heads"]))
+            index.extend(b)
+        local = torch.cat(rows) if rows else torch.zeros((0, 6, 4))
+        full = parallel.all_gather_by_index(local, torch.tensor(index, dtype=torch.int64), n_total)
+        np.save(os.path.join(tmp, f"{tag}{rank}.npy"), full.numpy())
+    dist.destroy_process_group()
+
+
+def test_dp_transformer_lstm_needs_whole_reference_batches(tmp_path):
+    """TransformerLstm attends across the clips of a minibatch (reference learned_models.py:183-185): two ranks that take
+    WHOLE reference batches reproduce the single-process outputs; the contiguous clip split that is fine for OPNet cuts a
+    batch in two (5 clips, batch 4, 2 ranks: rank 0 gets clips 0-2) and changes them."""
+    import torch.multiprocessing as mp
+    from oracle import synth, torch_port
+    n_total, bs = 5, 4
+    port = 32500 + os.getpid() % 1000
+    mp.spawn(_dp_transformer_worker, args=(2, port, n_total, bs, str(tmp_path)), nprocs=2, join=True)
+    cfg = {"boxes_features_dim": 16, "num_attention_heads": 2, "num_attention_layers": 1, "num_lstm_layers": 1, "lstm_hidden_dim": 16}
+    params = {k: torch.from_numpy(v) for k, v in synth.transformer_lstm_synth_params(cfg, ffn=64).items()}
+    x_all, _ = synth.make_batch(0, n_total, 6)
+    x_all = torch.from_numpy(synth.boxes5(x_all))
+    with torch.no_grad():
+        ref = torch.cat([torch_port.transformer_lstm_forward(x_all[b:b + bs], params, 2) for b in range(0, n_total, bs)]).numpy()
+    for r in range(2):
+        assert np.abs(np.load(os.path.join(str(tmp_path), f"whole{r}.npy")) - ref).max() < 1e-6
+        assert np.abs(np.load(os.path.join(str(tmp_path), f"split{r}.npy")) - ref).max() > 1e-4
+
+
+def test_masked_mean_iou_skips_videos_without_containment_frames():
+    """np.mean over the reference's DataFrame column is Series.mean(skipna=True) (training_main.py:105-112)"""
+    import torch
+    from objectpermanence_amd.training_main import masked_mean_iou
+    iou = torch.tensor([[0.5, 1.0, 0.0], [0.2, 0.4, 0.6], [0.9, 0.9, 0.9]], dtype=torch.float64)
+    cm = torch.tensor([[True, True, False], [False, False, False], [False, False, True]])
+    assert abs(masked_mean_iou(iou, cm) - (0.75 + 0.9) / 2) < 1e-12
+    assert np.isnan(masked_mean_iou(iou, torch.zeros_like(cm)))
