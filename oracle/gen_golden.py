@@ -381,6 +381,81 @@ def gen_metric(tu, y, labels):
     print("metric: mean IoU jit =", res["video_mean_iou_jit"].mean(), " mAP50 jit =", res["video_map50_jit"].mean())
 
 
+def gen_no_labels(lm):
+    """The *_no_labels training loss (training_main.py:192-210: masked L1 + 0.5 * consistency) and its gradients under the
+    reference's OPNet class and torch autograd; the loss lines are executed as the reference writes them."""
+    cfg = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 16, "videos_hidden_dim": 32}
+    params = synth.opnet_synth_params(cfg)
+    model = lm.OPNet(cfg)
+    _load_params(model, params)
+    model.train(True)
+    n_clips, t_frames = 3, 12
+    boxes, labels = synth.make_batch(0, n_clips, t_frames)
+    rng = np.random.default_rng(77)
+    mask = np.repeat(rng.random((n_clips, t_frames, 1)) < 0.6, 4, axis=2)          # datasets.py:545-547: whole frames
+    output, _ = model(torch.from_numpy(boxes))
+    loss_function = torch.nn.L1Loss(reduction="none")
+    pred_loss = loss_function(output, torch.from_numpy(labels))
+    next_output_frames = output[:, 1:, :]
+    current_output_frames = output[:, :-1, :]
+    consistency_loss = torch.mean(torch.norm(next_output_frames - current_output_frames, p=2, dim=-1))
+    pred_loss = pred_loss * torch.from_numpy(mask)
+    pred_loss = torch.mean(pred_loss)
+    loss = pred_loss + 0.5 * consistency_loss
+    loss.backward()
+    out = {"cfg": np.array(json.dumps(cfg)), "n_clips": n_clips, "t_frames": t_frames, "mask": mask,
+           "loss": np.float64(loss.item()), "pred_loss": np.float64(pred_loss.item()),
+           "consistency_loss": np.float64(consistency_loss.item())}
+    for k, v in model.named_parameters():
+        out["grad/" + k] = v.grad.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "opnet_no_labels_train.npz"), **out)
+    print("no_labels: loss", float(loss), "pred", float(pred_loss), "consistency", float(consistency_loss))
+
+
+def gen_grid_classes():
+    """The reference's 6x6-grid classification (baselines/proj_utils.py:37-75) run as written, with cv2's two functions
+    supplied by oracle/homography.py (4-point DLT; projective map).  Stores H and the classes of a lattice of image
+    points plus projected floor points."""
+    import importlib
+    from oracle import homography
+    cv2 = sys.modules.get("cv2") or types.ModuleType("cv2")
+    cv2.findHomography = homography.find_homography_dlt
+    cv2.perspectiveTransform = homography.perspective_transform
+    sys.modules["cv2"] = cv2
+    sys.path.insert(0, REF)
+    sys.modules.pop("baselines.proj_utils", None)
+    pu = importlib.import_module("baselines.proj_utils")
+    g = np.linspace(-1.0, 1.0, 41)
+    cx, cy = [a.reshape(-1) for a in np.meshgrid(g, g)]
+    rng = np.random.default_rng(5)
+    floor = np.concatenate([rng.uniform(-3, 3, size=(400, 2)), np.full((400, 1), pu.Z)], axis=1)
+    pim = pu.project_3d_point(floor)
+    cx, cy = np.concatenate([cx, pim[:, 0]]), np.concatenate([cy, pim[:, 1]])
+    cls = np.array([pu.get_class_prediction(float(a), float(b)) for a, b in zip(cx, cy)], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "grid_classes.npz"), H=np.asarray(pu.H), cx=cx, cy=cy, cls=cls)
+    print("grid_classes:", len(cls), "points,", len(np.unique(cls)), "distinct classes")
+
+
+def gen_detector_preprocess():
+    """CaterObjectDetector.__call__'s frame preparation (detector.py:74-80: BGR -> RGB, / 256 - not 255 -, float32, HWC ->
+    CHW, batch axis) run as written: cv2.cvtColor is supplied as the channel reversal it is for COLOR_BGR2RGB and the
+    torchvision model is replaced by an identity that hands back the tensor it was given."""
+    cv2 = sys.modules.get("cv2") or types.ModuleType("cv2")
+    cv2.COLOR_BGR2RGB = 4
+    cv2.cvtColor = lambda frame, code: np.ascontiguousarray(frame[..., ::-1]) if code == 4 else (_ for _ in ()).throw(ValueError(code))
+    sys.modules["cv2"] = cv2
+    sys.path.insert(0, REF)
+    import importlib
+    sys.modules.pop("baselines.detector", None)
+    det_mod = importlib.import_module("baselines.detector")
+    det = det_mod.CaterObjectDetector.__new__(det_mod.CaterObjectDetector)
+    det.detector = lambda t: t
+    frame = np.random.default_rng(11).integers(0, 256, size=(24, 32, 3), dtype=np.uint8)
+    x = det(frame, torch.device("cpu"))
+    np.savez_compressed(os.path.join(OUT, "detector_preprocess.npz"), frame=frame, tensor=x.numpy())
+    print("detector_preprocess:", tuple(x.shape), x.dtype, float(x.max()))
+
+
 def gen_cone_ids():
     """tests/golden/cone_ids.json: the cone class ids, class count and snitch id of the reference's 193-name table
     (object_indices.py:1-202), obtained by calling its own is_cone_object on every id."""
@@ -423,6 +498,12 @@ def main():
         gen_datasets()
     if want("cone_ids"):
         gen_cone_ids()
+    if want("no_labels"):
+        gen_no_labels(lm)
+    if want("grid_classes"):
+        gen_grid_classes()
+    if want("detector_preprocess"):
+        gen_detector_preprocess()
     if want("train"):
         gen_train(lm, tiny, n_clips=3, t_frames=12, tag="tiny", full=True, adam_steps=3)
         gen_train(lm, real, n_clips=4, t_frames=300, tag="real", full=False, adam_steps=2)

@@ -410,3 +410,26 @@ def test_masked_mean_iou_skips_videos_without_containment_frames():
     cm = torch.tensor([[True, True, False], [False, False, False], [False, False, True]])
     assert abs(masked_mean_iou(iou, cm) - (0.75 + 0.9) / 2) < 1e-12
     assert np.isnan(masked_mean_iou(iou, torch.zeros_like(cm)))
+
+
+def test_grid_classes_match_reference_proj_utils(golden_dir):
+    """6x6-grid snitch localisation (reference baselines/proj_utils.py:37-75, run as written under a numpy-DLT stand-in for
+    cv2.findHomography - oracle/homography.py, oracle/gen_golden.py): the closed-form homography of
+    objectpermanence_amd/proj_utils.py gives the same H and the same class for every lattice / projected floor point that
+    is not within rounding of a cell border."""
+    from objectpermanence_amd import proj_utils as pu
+    from oracle import homography
+    g = np.load(os.path.join(golden_dir, "grid_classes.npz"))
+    assert np.abs(pu.H - g["H"]).max() < 1e-9
+    cls = pu.get_class_predictions(g["cx"], g["cy"])
+    q = g["H"] @ np.stack([g["cx"], g["cy"], np.ones_like(g["cx"])])
+    xy = q[:2] / q[2]
+    # floor() is discontinuous at the cell borders: skip points within rounding of one (points beyond the grid are clipped
+    # to exactly -3 / 3 - 1e-5 by both and are safe)
+    away = np.all((np.abs(xy - np.round(xy)) > 1e-6) | (xy < -3.001) | (xy > 3.001), axis=0)
+    assert away.sum() > 2000 and np.array_equal(cls[away], g["cls"][away])
+    # the stand-in itself: four exact correspondences are reproduced
+    pts3 = np.array([[-3, -3, pu.Z], [0, 3, pu.Z], [-3, 0, pu.Z], [0, 0, pu.Z]])
+    Hd, _ = homography.find_homography_dlt(pu.project_3d_point(pts3), pts3[:, :2])
+    back = homography.perspective_transform(pu.project_3d_point(pts3).reshape(-1, 1, 2), Hd).reshape(-1, 2)
+    assert np.abs(back - pts3[:, :2]).max() < 1e-9
