@@ -202,7 +202,7 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
             cpu = {"value": round(n_cpu * B / dt, 2), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
                    "sample": f"{n_cpu} x (forward + {args.loss} + backward + Adam) of {B} clips x 300 frames, "
                              f"oracle/torch_port.OPNetTorch (the graph on torch's CPU LSTM op, fp32), {dt:.1f} s"}
-        print(json.dumps({
+        line = ({
             "metric": "CATER clips/sec OPNet training step (fwd + loss + bwd + Adam)",
             "value": round(world * B * args.steps / elapsed, 1), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -216,9 +216,11 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
                                    "above 128 clips) + opnet_wgrad; algorithmic bytes of the whole step / GPU time",
                          "alg_bytes_per_step": alg},
             "cpu_baseline": cpu,
-            "final_loss": float(loss.item())}), flush=True)
+            "final_loss": float(loss.item())})
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        emit(line)
 
 
 def detector_flops_per_frame(h=800, w=1088, rois=1000, classes=193):
@@ -309,7 +311,7 @@ def bench_detect(args, world, rank, dev, dist):
             do.detector_forward(frames[0], params, dtype=torch.float32)
             cpu = {"value": round(1.0 / (time.perf_counter() - t1), 3), "unit": "frames/s", "cores": torch.get_num_threads(),
                    "kind": "port", "sample": "1 frame through oracle/detector_oracle.py (torch fp32 convs + numpy selection stages)"}
-        print(json.dumps({
+        line = ({
             "metric": "detector frames/sec (Faster-RCNN R50-FPN 193 classes, 240x320 frame -> 800x1066, eval)",
             "value": round(world * nf * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -320,9 +322,11 @@ def bench_detect(args, world, rank, dev, dist):
                          "kernel": "all dense launches of a pass (conv2d_nhwc_glds dominates); whole-step time incl. selection stages",
                          "gflop_per_frame": round(fl / 1e9, 1)},
             "cpu_baseline": cpu,
-            "detections_per_frame": [len(o["scores"]) for o in out][:4]}), flush=True)
-    if world > 1:
+            "detections_per_frame": [len(o["scores"]) for o in out][:4]})
+    if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        emit(line)
 
 
 def launch_ranks(args) -> int:
@@ -419,9 +423,21 @@ def main():
             out["parity_max_abs_dy_vs_cpu_port"] = err
             if not err < 1e-4 and not os.environ.get("OPNET_HIP_LIB"):
                 raise SystemExit(f"bench: HIP output of the last timed step differs from the CPU port by {err}")
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        emit(out)
+
+
+def emit(out):
+    """the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which is only flushed at
+    exit - flush it first"""
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 def _line(args, world, B, clips_per_s, elapsed, workload, extra_cfg):

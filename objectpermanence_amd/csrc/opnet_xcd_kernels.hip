@@ -206,7 +206,7 @@ __device__ __forceinline__ int xcd_group_is_local(unsigned *status, int x)
 // s_setprio / wave age).  An s_nop shorter than the MFMA's 32-cycle occupancy costs the MFMA stream nothing and leaves
 // the port to the other wave in the meantime.
 #ifndef XCD_GAP
-#define XCD_GAP 0
+#define XCD_GAP 8
 #endif
 // The MFMA and its idle states are ONE asm statement (volatile asm statements keep their order; a builtin MFMA next to an
 // asm s_nop gets re-paired by the scheduler).  What hipcc then no longer does for these MFMAs (cdna_hip_programming.md
@@ -215,25 +215,40 @@ __device__ __forceinline__ int xcd_group_is_local(unsigned *status, int x)
 // written long ago, and XCD_MFMA_DRAIN pads the last MFMAs' results before the compiler's code reads them.
 #define XCD_STR2(x) #x
 #define XCD_STR(x) XCD_STR2(x)
-#define XCD_MFMA0(acc, av, bv) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0\n\ts_nop " XCD_STR(XCD_GAP) : "=&v"(acc) : "v"(av), "v"(bv))
-#define XCD_MFMA(acc, av, bv) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\ts_nop " XCD_STR(XCD_GAP) : "+v"(acc) : "v"(av), "v"(bv))
-// XCD_YIELD: what the product wave does after every row of MFMAs when finish waves run beside it (two or more groups
-// per XCD).  fp32 MFMA executes on the SIMD's fp32 lanes - it runs at exactly the VALU rate - so while the product wave
+#define XCD_MFMA0_G(acc, av, bv, g) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0\n\ts_nop " XCD_STR(g) : "=&v"(acc) : "v"(av), "v"(bv))
+#define XCD_MFMA_G(acc, av, bv, g) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\ts_nop " XCD_STR(g) : "+v"(acc) : "v"(av), "v"(bv))
+// inside the product loop: rows below YM (a compile-time constant there) issue with the yielding gap, the rest dense
+#define XCD_MFMA0(acc, av, bv) do { if (ROW < YM) XCD_MFMA0_G(acc, av, bv, XCD_GAP); else XCD_MFMA0_G(acc, av, bv, 0); } while (0)
+#define XCD_MFMA(acc, av, bv) do { if (ROW < YM) XCD_MFMA_G(acc, av, bv, XCD_GAP); else XCD_MFMA_G(acc, av, bv, 0); } while (0)
+// the first MFMA of a row: in the dense tail (rows >= YM) it still carries the gap when XCD_TAIL is set, so that the few VALU
+// instructions the finish wave has left (flag compare of the poll, address moves of the gather) are not frozen until the
+// product phase ends
+#ifndef XCD_TAIL
+#define XCD_TAIL 1
+#endif
+#define XCD_MFMA_LEAD(acc, av, bv) do { if (ROW < YM || (XCD_TAIL > 0 && YM >= 0 && (ROW % (XCD_TAIL > 0 ? XCD_TAIL : 1)) == 0)) XCD_MFMA_G(acc, av, bv, XCD_GAP); else XCD_MFMA_G(acc, av, bv, 0); } while (0)
+// Yielding.  fp32 MFMA executes on the SIMD's fp32 lanes - it runs at exactly the VALU rate - so while the product wave
 // keeps the matrix queue full the finish wave on the same SIMD gets no VALU cycle at all (measured: frozen for the whole
-// product phase, whatever s_setprio or the wave age).  The product wave therefore idles a little
-// after each row; the VALU cycles it gives up are what the finish wave computes in, and the finish wave's LATENCIES
-// (LDS, shuffles, memory, the hand-off) then overlap the MFMA stream instead of following it.
-// YM = how much: 0 none (one group per XCD: the finish runs while this wave waits for the exchange anyway), 1 = s_sleep 1
-// (~64 cycles, ~32 of them with the VALU idle) after every row (two groups: the exchange is on the critical path, the
-// finish must be quick: 101 k clips/s against 94 k with YM = 2), 2 = after three rows of four (three or more groups: the
-// finish has a whole window of slack; 107-111 k against 104-105 k with YM = 1).  s_nop N after a row idles the VALU
-// for 4 (N + 1) - 32 cycles: N = 15 behaves like s_sleep 1, N <= 7 gives the finish wave nothing.
-template <int YM>
-__device__ __forceinline__ void xcd_yield(int row)
-{
-    if (YM == 1 || (YM == 2 && (row & 3) != 3)) asm volatile("s_sleep 1");
-}
-#define XCD_YIELD(row) xcd_yield<YM>(row)
+// product phase, whatever s_setprio or the wave age).  The product wave therefore issues the MFMAs of
+// the first YM rows of a phase (of 64) with an idle gap LONGER than the MFMA's own 32 cycles (XCD_GAP = 8: 36 cycles of
+// s_nop, i.e. a bubble of a few cycles after every MFMA in which the finish wave's next VALU instruction issues), and the
+// rest dense.  The finish wave needs its VALU cycles at the START of its window (head, cells; afterwards it only drains,
+// polls and issues DMA) and with a bubble after every MFMA it runs at close to its stand-alone latency; its latencies
+// (LDS, shuffles, memory, the hand-off) overlap the MFMA stream instead of following it.  YM per groups per XCD:
+// -1 (no gap anywhere) for one group: the finish runs while this wave waits for the exchange anyway.
+// Tried before: s_sleep 1 after a row idles the VALU ~32 of ~64 cycles - coarser, 8 300-9 200 cycles
+// per phase; a gap <= 28 cycles gives the finish wave nothing; gaps of 40-52 cycles on every row 9 500-12 300 cycles.
+// Measured (clips/s at 256 / 384 / 512 / 1024 clips, tail gap on): YM 16: 106-107 k at 256; YM 8: 113.8 k at 384; YM 0:
+// 115.8 k / 118.5 k at 512 / 1024 (YM 8 there: 115.4 / 116.8, YM 16: 114.1 / 114.3).
+#ifndef XCD_NY2
+#define XCD_NY2 16             // two groups per XCD: the exchange is on the critical path, the finish must be quick
+#endif
+#ifndef XCD_NY3
+#define XCD_NY3 8              // three groups: the finish has some slack
+#endif
+#ifndef XCD_NY4
+#define XCD_NY4 0              // four or more: a window of slack - the tail gap alone is enough
+#endif
 #define XCD_MFMA_DRAIN(a0, a1, a2, a3) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -335,41 +350,42 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
                 for (int j = 0; j < 16; ++j) {
                     const int cur = j & 1, nxt = cur ^ 1;
                     const bool l1 = j < 11, hd = j >= 11 && j < 15;
+                    int ROW = 4 * j;            // compile-time after unrolling: picks the MFMA form of the row
                     if (j == 0) {
                         XCD_MFMA0(acc2a, a2[0].x, fa[cur].x); XCD_MFMA0(acc2b, a2[1].x, fb[cur].x);
                         XCD_MFMA0(acc1, a1[0].x, fl[cur].x);
                     } else {
-                        XCD_MFMA(acc2a, a2[2 * j].x, fa[cur].x); XCD_MFMA(acc2b, a2[2 * j + 1].x, fb[cur].x);
+                        XCD_MFMA_LEAD(acc2a, a2[2 * j].x, fa[cur].x); XCD_MFMA(acc2b, a2[2 * j + 1].x, fb[cur].x);
                         if (l1) XCD_MFMA(acc1, a1[j].x, fl[cur].x);
                         if (j == 11) XCD_MFMA0(accH, as_[0].x, fl[cur].x);
                         else if (hd) XCD_MFMA(accH, as_[j - 11].x, fl[cur].x);
                     }
                     if (j + 1 < 16) fa[nxt] = F[XB_H2 + (2 * j + 2) * 64];
-                    XCD_YIELD(4 * j + 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    XCD_MFMA(acc2a, a2[2 * j].y, fa[cur].y); XCD_MFMA(acc2b, a2[2 * j + 1].y, fb[cur].y);
+                    ROW = 4 * j + 1;
+                    XCD_MFMA_LEAD(acc2a, a2[2 * j].y, fa[cur].y); XCD_MFMA(acc2b, a2[2 * j + 1].y, fb[cur].y);
                     if (l1) XCD_MFMA(acc1, a1[j].y, fl[cur].y);
                     if (hd) XCD_MFMA(accH, as_[j - 11].y, fl[cur].y);
                     if (j + 1 < 16) fb[nxt] = F[XB_H2 + (2 * j + 3) * 64];
-                    XCD_YIELD(4 * j + 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    XCD_MFMA(acc2a, a2[2 * j].z, fa[cur].z); XCD_MFMA(acc2b, a2[2 * j + 1].z, fb[cur].z);
+                    ROW = 4 * j + 2;
+                    XCD_MFMA_LEAD(acc2a, a2[2 * j].z, fa[cur].z); XCD_MFMA(acc2b, a2[2 * j + 1].z, fb[cur].z);
                     if (l1) XCD_MFMA(acc1, a1[j].z, fl[cur].z);
                     if (hd) XCD_MFMA(accH, as_[j - 11].z, fl[cur].z);
                     if (j + 1 < 11) fl[nxt] = FL[(j + 1) * 64];
                     else if (j + 1 < 15) fl[nxt] = FH[(j + 1 - 11) * 64];
-                    XCD_YIELD(4 * j + 2);
                     __builtin_amdgcn_sched_barrier(0);
-                    XCD_MFMA(acc2a, a2[2 * j].w, fa[cur].w); XCD_MFMA(acc2b, a2[2 * j + 1].w, fb[cur].w);
+                    ROW = 4 * j + 3;
+                    XCD_MFMA_LEAD(acc2a, a2[2 * j].w, fa[cur].w); XCD_MFMA(acc2b, a2[2 * j + 1].w, fb[cur].w);
                     if (l1) XCD_MFMA(acc1, a1[j].w, fl[cur].w);
                     if (hd) XCD_MFMA(accH, as_[j - 11].w, fl[cur].w);
-                    XCD_YIELD(4 * j + 3);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if (ng == 1) products(std::integral_constant<int, 0>{});
-            else if (ng == 2) products(std::integral_constant<int, 1>{});
-            else products(std::integral_constant<int, 2>{});
+            if (ng == 1) products(std::integral_constant<int, -1>{});
+            else if (ng == 2) products(std::integral_constant<int, XCD_NY2>{});
+            else if (ng == 3) products(std::integral_constant<int, XCD_NY3>{});
+            else products(std::integral_constant<int, XCD_NY4>{});
             XCD_MFMA_DRAIN(acc2a, acc2b, acc1, accH);
             if (mtracer) a.trace[(long)p * 8 + 1] = clock64();
             float4 *hd_ = &sHAND[p & 1][w][0] + lane;
