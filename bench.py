@@ -8,7 +8,7 @@ clips (300 frames x 15 slots x 6 features, fp32) that is already resident in HBM
 post-processing to int32 pixel boxes.  Steps are independent requests; how many are in flight is the engine's business:
 
   --engine xcd (default)  the steps are submitted to objectpermanence_amd.serving.ReasonerServer, which concatenates up to
-                          `--inflight` pending batches into ONE per-XCD persistent forward (csrc/opnet_xcd_kernels.hip:
+                          `--inflight` pending batches (default: up to 32 = 1024 clips) into ONE per-XCD persistent forward (csrc/opnet_xcd_kernels.hip:
                           every XCD runs the 300-step recurrence of its own clips with all weights in registers);
   --engine chain          round 1's form: one hipGraph of T+3 step launches per batch, spread over S HIP streams.
 
@@ -492,9 +492,10 @@ def bench_infer_xcd(args, model, boxes, world, rank, dev, dist):
     cap = max(1, int(lib.opnet_xcd_max_batch()) // B)
     if args.inflight > 0:
         per_launch = min(args.inflight, cap)
-    else:                                       # all steps in one launch when they fit, else even shares
-        n_launch = (args.steps + cap - 1) // cap
-        per_launch = (args.steps + n_launch - 1) // n_launch
+    else:
+        # all steps in one launch when they fit; otherwise full launches (1024 clips = 8 groups on every XCD - a launch
+        # takes as long as its fullest XCD, so 29 batches would cost the time of 32) and one smaller launch for the rest
+        per_launch = min(args.steps, cap)
     model.use_xcd = "1"
     server = ReasonerServer(model, "opnet", max_clips=per_launch * B)
     exchange = dist is not None
