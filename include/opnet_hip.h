@@ -80,6 +80,8 @@ void opnet_plan_destroy(opnet_plan *plan);
  * ~1.5 s) sets the code and fills y with NaN instead of hanging.  Launches of this form are chained per device through
  * an event (two persistent grids must not be co-resident), whatever streams the callers use. */
 int opnet_xcd_max_batch(void);
+/* 1 when the persistent form can run on the current device for these sizes (H1 = 256, H2 = 512, all 256 CUs visible) */
+int opnet_xcd_supported(int H1, int H2);
 size_t opnet_xcd_workspace_bytes(int B, int T, int H1, int H2);
 int opnet_xcd_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
                           void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,

@@ -376,6 +376,28 @@ extern "C" int opnet_xcd_profile_read(double *kernel_ms_total, int *launches)
     return OPNET_OK;
 }
 
+static int xcd_device_cus(int dev)
+{
+    if (dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lock(g_xcd_mu);
+    if (!g_xcd_cus[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        g_xcd_cus[dev] = prop.multiProcessorCount;
+    }
+    return g_xcd_cus[dev];
+}
+
+// 1 when the persistent form can run on the CURRENT device for these sizes (reference hidden sizes, all 8 XCDs x 32 CUs
+// visible - not a compute partition), else 0: callers then use opnet_forward_f32 / opnet_plan_forward
+extern "C" int opnet_xcd_supported(int H1, int H2)
+{
+    if (H1 != XCD_H1 || H2 != XCD_H2) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    return xcd_device_cus(dev) >= XCD_COUNT * XCD_CUS ? 1 : 0;
+}
+
 extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
                                      void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
                                      void *stream)
@@ -405,15 +427,11 @@ extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, fl
     a.trace = g_xcd_trace;
     a.force_safe = env_int("OPNET_XCD_SAFE", 0);
     a.debug = env_int("OPNET_XCD_DEBUG", 0);
-    std::lock_guard<std::mutex> lock(g_xcd_mu);
-    if (!g_xcd_cus[dev]) {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        g_xcd_cus[dev] = prop.multiProcessorCount;
-    }
-    if (g_xcd_cus[dev] < XCD_COUNT * XCD_CUS)
+    const int cus = xcd_device_cus(dev);
+    if (cus < XCD_COUNT * XCD_CUS)
         return fail(OPNET_ESHAPE, "device %d exposes %d CUs; the persistent forward needs %d resident workgroups", dev,
-                    g_xcd_cus[dev], XCD_COUNT * XCD_CUS);
+                    cus, XCD_COUNT * XCD_CUS);
+    std::lock_guard<std::mutex> lock(g_xcd_mu);
     opnet_xcd_pack_input<<<dim3(T + 2, L.NGT), 384, 0, st>>>(boxes, a);
     if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
     else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));

@@ -3,30 +3,32 @@
 //
 // What is computed: reference baselines/learned_models.py:35-52 (the same function as opnet_kernels.hip).
 //
-// Why: the launch-per-step chain re-fetches the 5.68 MB weight set 303 times per forward and pays a
-// dependent kernel boundary per step; a chip-wide persistent kernel pays a chip-wide exchange per step instead and lost.
-// Here the chip is cut along its XCDs.  One XCD = 32 CUs = 128 SIMDs, and 128 one-wave-per-SIMD register files hold the
-// whole weight set:
-//     wave (CU c, SIMD w)   LSTM2 tile 4c+w   : 16 gate rows (4 units x i,f,g,o) x K = 512        128 VGPRs
-//                           LSTM1 tile 2c+w/2 : 16 gate rows x half of K = 96 + 256 (w&1 picks)     44 VGPRs
-//                           selection head    : 16 (15) rows x K quarter w of 256                   16 VGPRs
-//                           W_ih2 rows of the lane's own unit (6 -> 8 wide)                         32 VGPRs
-// Each XCD runs ITS OWN clips (groups of 16 = one MFMA column block), so nothing crosses an XCD boundary on the data
-// path and the only exchange is h1 / h2 between the 32 CUs of one XCD, once per (group, step):
+// Why (DESIGN.md sections 3, 3a, 7): the launch-per-step chain re-fetches the 5.68 MB weight set 303 times per forward and
+// pays a dependent kernel boundary per step; a chip-wide persistent kernel pays a chip-wide exchange per step instead and
+// lost.  Here the chip is cut along its XCDs.  One XCD = 32 CUs = 128 SIMDs, and 128 register files hold the whole weight
+// set.  A workgroup = 8 waves on one CU; SIMD w carries a PRODUCT wave and a FINISH wave:
+//     product wave (CU c, SIMD w)  LSTM2 tile 4c+w   : 16 gate rows (4 units x i,f,g,o) x K = 512        128 VGPRs
+//                                  LSTM1 tile 2c+w/2 : 16 gate rows x half of K = 96 + 256 (w&1 picks)     44 VGPRs
+//                                  selection head    : 16 (15) rows x K quarter w of 256                   16 VGPRs
+//     finish wave                  W_ih2 rows of the lane's own unit (6 -> 8 wide)                         32 VGPRs
+// Each XCD runs ITS OWN clips (groups of 16 = one MFMA column block, 1..8 groups per XCD), so nothing crosses an XCD
+// boundary on the data path and the only exchange is h1 / h2 between the 32 CUs of one XCD, once per (group, step):
 //     phase (group g, step s):  LSTM1 step s | selection head + einsum + LSTM2 step s-1        (T+1 steps per forward)
-//   * barrier; the phase's activations x[s], x[s-1], h1[s-1], h2[s-2] (60 KB, "kq-major" [k/4][16 clips][4] so that
-//     1 KB = one MFMA B fragment set of a 16-k step) are in LDS, gathered by LDS-DMA during the PREVIOUS phase;
-//   * 188 MFMAs a wave (v_mfma_f32_16x16x4_f32, exact fp32) on 4 independent accumulator chains, B operands by
-//     ds_read_b128, A operands = the resident registers;
-//   * half way through, the wave polls the 32 per-CU flags of the NEXT phase's group (published one phase ago) and
-//     issues its share of that phase's gather (15 x buffer_load_dwordx4 ... sc1 lds) under the remaining MFMAs:
-//     with >= 2 groups per XCD the exchange latency hides under the other group's compute;
-//   * LDS: K-split partials of LSTM1 (2 waves) and of the head (4 waves), barrier, then every wave finishes the head
-//     redundantly (softmax, einsum - every CU needs frames_boxes), its LSTM2 cell and (odd waves) its LSTM1 cell;
-//   * h is published with write-through (sc1) 16-byte stores into FULL-HISTORY buffers (slot t+1 = step t; every word
-//     is written once per launch and only read after its flag), then vmcnt(0), barrier, ONE flag store per CU
-//     (cdna_hip_programming.md Guideline 16 recipe R1; the consumer side reads with sc1 loads, so no acquire fence and
-//     nothing depends on which XCD a workgroup landed on - placement is for speed only: block b runs on XCD b % 8).
+//   * the phase's activations x[s], h1[s-1], h2[s-2] (54 KB, "kq-major" [k/4][16 clips][4] so that 1 KB = one MFMA B
+//     fragment set of a 16-k step) sit in one of two LDS buffers, gathered by LDS-DMA while the previous phase computes;
+//   * the product wave runs the phase's 188 MFMAs (v_mfma_f32_16x16x4_f32, exact fp32) on 4 independent accumulator
+//     chains, B operands by ds_read_b128 one step ahead, A operands = the resident registers, hands its accumulators to
+//     LDS and meets the one barrier of the phase; it issues some of its MFMAs with an idle gap, because fp32 MFMA runs on
+//     the SIMD's fp32 lanes and the finish wave beside it otherwise gets no VALU cycle at all (see "Yielding" below);
+//   * the finish wave, in the window of the NEXT phase's products: sums the K-split partials (head 4 waves, LSTM1 2),
+//     softmax, einsum (every CU redundantly - every LSTM2 tile needs frames_boxes), its LSTM2 cell and (odd waves) its LSTM1
+//     cell, publishes h, then polls the flags of the phase after next and issues its quarter of that gather;
+//   * h is published with 16-byte stores into FULL-HISTORY buffers (slot t+1 = step t; every word is written once per
+//     launch and only read after its flag), every storing wave drains vmcnt(0), the last of the CU's four finish waves
+//     (LDS arrival counter) stores ONE flag per CU (cdna_hip_programming.md Guideline 16 recipe R1; consumers read with
+//     sc1 loads, so no acquire fence).  Stores are plain - the line stays in this XCD's L2 - when the kernel has verified at
+//     start that the group's 32 workgroups share an XCD (block b runs on XCD b % 8: observed, not promised), write-through
+//     (sc1) otherwise: placement is for speed only.
 // y = W_out h2 is not on the recurrence: it is computed from the h2 history by opnet_xcd_out_head afterwards.
 //
 // Every spin is bounded (XCD_SPIN_LIMIT = 1.5 s): a workgroup that cannot see its producers raises the abort word, every
@@ -34,7 +36,8 @@
 //
 // Summation order (differs from the launch chain's K-split, agrees to rounding; tests hold both to the oracle):
 //   LSTM2 gate = (sum over even 16-k steps) + (sum over odd 16-k steps) + x part; LSTM1 gate = lower K half + upper K
-//   half; logits = ((w0 + w1) + w2) + w3 over K quarters; each partial an ascending-k fmaf chain per MFMA lane group.
+//   half; logits = ((w0 + w1) + w2) + w3 over K quarters; each partial an ascending-k fmaf chain per MFMA lane group;
+//   frames_boxes = per lane group an ascending-slot fmaf chain over its 4 slots, then (g0 + g1) + (g2 + g3).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -228,6 +228,7 @@ class OPNet(AbstractCaterModel):
         # reference sizes; "1" / "0" force it on / off
         self.use_xcd = os.environ.get("OPNET_XCD", "auto")
         self._xws: Dict[Tuple[int, int, int, int], torch.Tensor] = {}
+        self._xcd_ok = None
 
     # -- weights ------------------------------------------------------------------------------
     def _weights(self):
@@ -268,6 +269,10 @@ class OPNet(AbstractCaterModel):
     def _wants_xcd(self, B: int) -> bool:
         if self.use_xcd in ("0", 0, False) or (self._h1, self._h2) != (256, 512):
             return False
+        if self._xcd_ok is None:       # all 8 XCDs x 32 CUs visible on this device? (not in a compute partition)
+            self._xcd_ok = bool(_lib.load().opnet_xcd_supported(self._h1, self._h2))
+        if not self._xcd_ok:
+            return False
         return self.use_xcd in ("1", 1, True) or B >= self.XCD_MIN_BATCH
 
     def _forward_xcd(self, boxes: torch.Tensor, packed: torch.Tensor, stream: int):
@@ -277,6 +282,8 @@ class OPNet(AbstractCaterModel):
         y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
         logits = torch.empty((B, 15, T), dtype=torch.float32, device=dev)
         step = int(lib.opnet_xcd_max_batch())
+        while step > 64 and lib.opnet_xcd_workspace_bytes(min(step, B), T, self._h1, self._h2) == 0:
+            step //= 2                  # very long clips: the history of a full launch would exceed one buffer descriptor
         for lo in range(0, B, step):
             n = min(step, B - lo)
             # one workspace per (shape, device, stream), like the launch plans: forwards enqueued on different streams
