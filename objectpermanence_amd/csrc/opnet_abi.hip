@@ -289,7 +289,7 @@ extern "C" int opnet_forward_f32(const float *boxes, const float *packed, float 
 // forward, per-XCD persistent form (opnet_xcd_kernels.hip): ONE launch, weights resident in registers
 // ------------------------------------------------------------------------------------------------
 struct XcdWorkspaceLayout {  // offsets in bytes
-    size_t status, flags, xp, h1h, h2h, total;
+    size_t status, flags, xp, h1h, h2h, fbh, total;
     int NGT;
 };
 
@@ -304,6 +304,7 @@ static XcdWorkspaceLayout xcd_workspace_layout(int B, int T)
     L.xp = o;     o += NGT * (size_t)(T + 2) * OPNET_KXQ * 256;
     L.h1h = o;    o += NGT * (size_t)(T + 1) * (XCD_H1 / 4) * 256;
     L.h2h = o;    o += NGT * (size_t)(T + 1) * (XCD_H2 / 4) * 256;
+    L.fbh = o;    o += NGT * (size_t)(T + 1) * 1024;
     L.total = align_up(o, 256);
     return L;
 }
@@ -419,11 +420,12 @@ extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, fl
     a.xp = (const float4 *)(w + L.xp);
     a.h1h = (float4 *)(w + L.h1h);
     a.h2h = (float4 *)(w + L.h2h);
+    a.fbh = (float4 *)(w + L.fbh);
     a.flags = (unsigned *)(w + L.flags);
     a.status = (unsigned *)(w + L.status);
     a.logits = logits;
     a.ws = w;
-    a.xp_off = (unsigned)L.xp; a.h1_off = (unsigned)L.h1h; a.h2_off = (unsigned)L.h2h; a.flags_off = (unsigned)L.flags;
+    a.xp_off = (unsigned)L.xp; a.h1_off = (unsigned)L.h1h; a.h2_off = (unsigned)L.h2h; a.fb_off = (unsigned)L.fbh; a.flags_off = (unsigned)L.flags;
     a.trace = g_xcd_trace;
     a.force_safe = env_int("OPNET_XCD_SAFE", 0);
     a.debug = env_int("OPNET_XCD_DEBUG", 0);
@@ -441,7 +443,12 @@ extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, fl
         else { HIP_TRY(hipEventCreate(&pe.first)); HIP_TRY(hipEventCreate(&pe.second)); }
         HIP_TRY(hipEventRecord(pe.first, st));
     }
-    opnet_xcd_forward<<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
+    // three or more groups on every XCD: the "head once" form (the selection head on one wave per XCD and phase, LSTM2 one
+    // more step behind); fewer: every CU computes the head (the exchange is on the critical path there and a lone head
+    // wave would lengthen it).  OPNET_XCD_HO = 0 / 1 overrides.
+    const int ho = env_int("OPNET_XCD_HO", L.NGT / XCD_COUNT >= 3 ? 1 : 0);
+    if (ho) opnet_xcd_forward<true><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
+    else opnet_xcd_forward<false><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
     if (g_xcd_prof) {
         HIP_TRY(hipEventRecord(pe.second, st));
         g_xcd_prof_ev.push_back(pe);

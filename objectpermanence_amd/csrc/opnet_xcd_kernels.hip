@@ -52,12 +52,13 @@
 #define XCD_H2 512
 #define XCD_SPIN_LIMIT 150000000ll    // wall_clock64 ticks (100 MHz: 1.5 s) before a poller gives up
 
-// LDS gather buffer of one phase, in float4 units: X0 = x[s] | H1 = h1[s-1] | H2 = h2[s-2]
+// LDS gather buffer of one phase, in float4 units: X0 = x[s] | H1 = h1[s-1] | H2 = h2[s-3] | FB = frames_boxes[s-2]
 #define XB_X0 0
 #define XB_H1 (6 * 64)
 #define XB_H2 (22 * 64)
-#define XB_F4 (54 * 64)        // 54 KB
-#define XB_CHUNKS 54
+#define XB_FB (54 * 64)        // [2 k-quads][4][16 clips] floats = 512 B of the 1-KB piece
+#define XB_F4 (55 * 64)        // 55 KB
+#define XB_CHUNKS 55
 
 struct XcdArgs {
     int B, T, NGT;             // clips, frames, 16-clip groups = ceil(B / 16)
@@ -65,12 +66,13 @@ struct XcdArgs {
     const float4 *xp;          // [NGT][T+2][24][16]   slot t+1 = x[t]; slots 0 and T+1 zero
     float4 *h1h;               // [NGT][T+1][64][16]   slot t+1 = h1[t]; slot 0 zero
     float4 *h2h;               // [NGT][T+1][128][16]  slot t+1 = h2[t]; slot 0 zero
+    float4 *fbh;               // [NGT][T+1][64]       slot t+1 = frames_boxes[t] as [8 features][16 clips] floats in the first 512 B; slot 0 zero
     unsigned *flags;           // [NGT][32]            steps published by CU c of the group's XCD
     unsigned *status;          // [0] abort code (0 = ok), [1] first failing block, [2] phase, [3] groups not XCD-local,
                                // [8 + b] XCC_ID of block b
     float *logits;             // caller's [B][15][T]
     char *ws;                  // workspace base and the byte offsets of xp / h1h / h2h / flags in it (one buffer descriptor)
-    unsigned xp_off, h1_off, h2_off, flags_off;
+    unsigned xp_off, h1_off, h2_off, fb_off, flags_off;
     int force_safe;            // 1: always use the placement-independent write-through protocol (tests)
     int debug;                 // tools only (wrong results): bit 0 no poll/gather, 1 no head, 2 no cells, 3 no publish, 4 no x fetch
     unsigned long long *trace; // optional [phases][8] s_memtime stamps of block 0 (product wave 0: 0-1, finish wave 4: 2-7), or null
@@ -106,6 +108,11 @@ __device__ __forceinline__ void xcd_store16(__amdgpu_buffer_rsrc_t r, unsigned v
     if (local) __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
     else __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 16);
 }
+__device__ __forceinline__ void xcd_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v, bool local)
+{
+    if (local) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 16);
+}
 __device__ __forceinline__ void xcd_store_flag(unsigned *p, unsigned v, bool local)
 {
     if (local) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // plain store: stays in the L2
@@ -136,6 +143,7 @@ __global__ void __launch_bounds__(384) opnet_xcd_pack_input(const float *__restr
         float4 *h2 = a.h2h + (long)gg * (T + 1) * (XCD_H2 * 4);
         for (int i = tid; i < XCD_H1 * 4; i += 384) h1[i] = z;
         for (int i = tid; i < XCD_H2 * 4; i += 384) h2[i] = z;
+        if (tid < 64) a.fbh[(long)gg * (T + 1) * 64 + tid] = z;
         if (tid < XCD_CUS) a.flags[gg * XCD_CUS + tid] = 0u;
         if (gg == 0 && tid < 8) a.status[tid] = 0u;
         if (gg == 0 && tid < XCD_COUNT * XCD_CUS) a.status[8 + tid] = 0xffffffffu;
@@ -273,8 +281,13 @@ __device__ __forceinline__ int xcd_group_is_local(unsigned *status, int x)
 #ifndef XCD_FW0
 #define XCD_FW0 0
 #endif
+// which CU of the XCD computes the selection head of (step s's phase, group gi): rotates so that the extra work (16 MFMAs a
+// wave + softmax / einsum in one finish wave) lands on every CU once in 32 phases
+__host__ __device__ inline int xcd_head_cu(int s, int gi) { return (s + 11 * gi) & (XCD_CUS - 1); }
+
 #define XH_F4 (3 * 64)         // sHAND per product wave: LSTM2 gates | LSTM1 partial | head partial
 
+template <bool HO>
 __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
 {
     __shared__ __attribute__((aligned(1024))) float4 sbuf[2][XB_F4];
@@ -282,7 +295,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
     __shared__ __attribute__((aligned(16))) float sTR[4][2][64];     // (clip, unit) -> float4-per-clip transposes
     __shared__ float sC2[XCD_NGMAX][4][64];
     __shared__ float sC1[XCD_NGMAX][2][64];
-    __shared__ volatile int sAbort, sLocal;
+    __shared__ volatile int sAbort, sLocal, sH1done;
     __shared__ unsigned sArrive[2];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -297,7 +310,9 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
     const int n = lane & 15, u = lane >> 4;
     const int t2 = 4 * c + w;                 // LSTM2 tile of this SIMD
     const int t1 = 2 * c + (w >> 1), kh = w & 1;
-    const int nph = (T + 1) * ng;
+    // HO ("head once"): steps 0 .. T+1 = LSTM1 step s | head step s-1 on ONE wave of the XCD | LSTM2 step s-2;
+    // otherwise steps 0 .. T = LSTM1 step s | head + LSTM2 step s-1 on every CU
+    const int nph = (HO ? T + 2 : T + 1) * ng;
     const PackedLayout P = packed_layout(XCD_H1, XCD_H2);
     if (wv == XCD_FW0) {
         // placement check by the first finish wave (groups with no work still publish their id and leave)
@@ -309,6 +324,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             sLocal = loc > 0 && a.force_safe == 0;
             sAbort = loc < 0;
             sArrive[0] = 0u; sArrive[1] = 0u;
+            sH1done = 0;
             if (loc == 0 && c == 0) atomicAdd(a.status + 3, 1u);
         }
     }
@@ -318,7 +334,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
 
     if ((wv >= 4) == (XCD_FW0 == 0)) {
         // =========================================== product waves ===================================================
-        float4 a2[32], a1[11], as_[4];
+        float4 a2[32], a1[11], as_[HO ? 1 : 4];
         {
             const float4 *p2 = (const float4 *)(a.packed + P.w2p) + (long)t2 * 32 * 64 + lane;
 #pragma unroll
@@ -326,15 +342,26 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             const float4 *p1 = (const float4 *)(a.packed + P.w1p) + ((long)t1 * 22 + 11 * kh) * 64 + lane;
 #pragma unroll
             for (int q = 0; q < 11; ++q) a1[q] = p1[q * 64];
-            const float4 *ps = (const float4 *)(a.packed + P.wselp) + (4 * w) * 64 + lane;
+            if (!HO) {          // every CU computes the head: K quarter w of W_sel, resident
+                const float4 *ps = (const float4 *)(a.packed + P.wselp) + (4 * w) * 64 + lane;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) as_[q] = ps[q * 64];
+                for (int q = 0; q < (HO ? 1 : 4); ++q) as_[q] = ps[q * 64];
+            }
+        }
+        // HO: W_ih2 of the tile as two more A fragments (K = 6 -> 8): lane (row i, k-quad position kq) holds W_ih2[row(i)][4 j + kq],
+        // row i <-> (unit 4 t2 + (i >> 2), gate i & 3); packed as wih2p[unit][gate][8]
+        float ax[2] = {0.f, 0.f};
+        if (HO) {
+            const float *px = a.packed + P.wih2p + ((long)(4 * t2 + (n >> 2)) * 4 + (n & 3)) * 8 + u;
+            ax[0] = px[0];
+            ax[1] = px[4];
         }
         const bool mtracer = a.trace && blockIdx.x == 0 && tid == (4 - XCD_FW0) * 64;
         __syncthreads();                        // phase 0's gather has landed
         if (sAbort) return;
         for (int p = 0; p < nph; ++p) {
             const float4 *F = &sbuf[p & 1][0] + lane;
+            const float *FBp = (const float *)(&sbuf[p & 1][XB_FB]) + u * 16 + n;   // frames_boxes[s-2][4 j + u][clip n]
             // B fragment of LSTM1 hexadecet 11 kh + j of [x 0..5 | h1 6..21]: the buffer is X0 | H1 | H2, so the lower-K
             // wave reads fragment j of the buffer, the upper-K wave fragment 11 + j
             const float4 *FL = F + (kh ? 11 * 64 : 0);
@@ -344,7 +371,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             // with sched_barrier after every row of independent MFMAs: left alone, the scheduler clusters the four MFMAs
             // of one hexadecet on the same accumulator (40-cycle dependent latency against a 32-cycle issue) and keeps
             // only one or two B fragments in flight.  Fragments are fetched one j-step (12 MFMAs ~ 400 cycles) ahead.
-            f32x4 accH, acc1, acc2a, acc2b;
+            f32x4 accH = {0.f, 0.f, 0.f, 0.f}, acc1, acc2a, acc2b;   // accH: !HO only
             auto products = [&](auto ym) {
                 constexpr int YM = decltype(ym)::value;
                 float4 fa[2], fb[2], fl[2];
@@ -361,28 +388,38 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
                     } else {
                         XCD_MFMA_LEAD(acc2a, a2[2 * j].x, fa[cur].x); XCD_MFMA(acc2b, a2[2 * j + 1].x, fb[cur].x);
                         if (l1) XCD_MFMA(acc1, a1[j].x, fl[cur].x);
-                        if (j == 11) XCD_MFMA0(accH, as_[0].x, fl[cur].x);
-                        else if (hd) XCD_MFMA(accH, as_[j - 11].x, fl[cur].x);
+                        if (!HO) {
+                            if (j == 11) XCD_MFMA0(accH, as_[0].x, fl[cur].x);
+                            else if (hd) XCD_MFMA(accH, as_[HO ? 0 : j - 11].x, fl[cur].x);
+                        }
                     }
                     if (j + 1 < 16) fa[nxt] = F[XB_H2 + (2 * j + 2) * 64];
                     __builtin_amdgcn_sched_barrier(0);
                     ROW = 4 * j + 1;
                     XCD_MFMA_LEAD(acc2a, a2[2 * j].y, fa[cur].y); XCD_MFMA(acc2b, a2[2 * j + 1].y, fb[cur].y);
                     if (l1) XCD_MFMA(acc1, a1[j].y, fl[cur].y);
-                    if (hd) XCD_MFMA(accH, as_[j - 11].y, fl[cur].y);
+                    if (hd && !HO) XCD_MFMA(accH, as_[HO ? 0 : j - 11].y, fl[cur].y);
                     if (j + 1 < 16) fb[nxt] = F[XB_H2 + (2 * j + 3) * 64];
                     __builtin_amdgcn_sched_barrier(0);
                     ROW = 4 * j + 2;
                     XCD_MFMA_LEAD(acc2a, a2[2 * j].z, fa[cur].z); XCD_MFMA(acc2b, a2[2 * j + 1].z, fb[cur].z);
                     if (l1) XCD_MFMA(acc1, a1[j].z, fl[cur].z);
-                    if (hd) XCD_MFMA(accH, as_[j - 11].z, fl[cur].z);
+                    if (hd && !HO) XCD_MFMA(accH, as_[HO ? 0 : j - 11].z, fl[cur].z);
                     if (j + 1 < 11) fl[nxt] = FL[(j + 1) * 64];
-                    else if (j + 1 < 15) fl[nxt] = FH[(j + 1 - 11) * 64];
+                    else if (j + 1 < 15 && !HO) fl[nxt] = FH[(j + 1 - 11) * 64];
                     __builtin_amdgcn_sched_barrier(0);
                     ROW = 4 * j + 3;
                     XCD_MFMA_LEAD(acc2a, a2[2 * j].w, fa[cur].w); XCD_MFMA(acc2b, a2[2 * j + 1].w, fb[cur].w);
                     if (l1) XCD_MFMA(acc1, a1[j].w, fl[cur].w);
-                    if (hd) XCD_MFMA(accH, as_[j - 11].w, fl[cur].w);
+                    if (hd && !HO) XCD_MFMA(accH, as_[HO ? 0 : j - 11].w, fl[cur].w);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // HO: LSTM2's input part W_ih2 . frames_boxes[s-2] (K = 6 -> 8): two more MFMAs on the two LSTM2 chains
+                if (HO) {
+                    const int ROW = 64;
+                    const float b0 = FBp[0], b1 = FBp[64];
+                    XCD_MFMA(acc2a, ax[0], b0);
+                    XCD_MFMA(acc2b, ax[1], b1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
@@ -395,7 +432,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             float4 *hd_ = &sHAND[p & 1][w][0] + lane;
             hd_[0] = make_float4(acc2a[0] + acc2b[0], acc2a[1] + acc2b[1], acc2a[2] + acc2b[2], acc2a[3] + acc2b[3]);
             hd_[64] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
-            hd_[128] = make_float4(accH[0], accH[1], accH[2], accH[3]);
+            if (!HO) hd_[128] = make_float4(accH[0], accH[1], accH[2], accH[3]);
             __syncthreads();                    // barrier p
             if (sAbort) return;
             if (ng == 1) {                      // exposed exchange: wait for this phase's finish + the next gather
@@ -411,11 +448,11 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
     // same SIMD (measured: DESIGN.md section 7) - what this role hides is LATENCY (LDS, memory, hand-off), and its
     // instruction count is kept down: ONE buffer descriptor over the whole workspace with 32-bit offsets (wave-uniform part
     // on the scalar unit, one constant VGPR of lane offset) instead of 64-bit per-lane address arithmetic, nothing spilled.
-    float4 wx[8];
-    {
+    float4 wx[HO ? 1 : 8];                      // !HO: W_ih2 rows of the lane's own unit (the input part is added in the cell)
+    if (!HO) {
         const float4 *px = (const float4 *)(a.packed + P.wih2p) + (long)(4 * t2 + u) * 8;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) wx[q] = px[q];
+        for (int q = 0; q < (HO ? 1 : 8); ++q) wx[q] = px[q];
     }
     const unsigned lds0 = (unsigned)(unsigned long long)(const void *)&sbuf[0][0];
     const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void *)a.ws, 0, 0x7fffffff, 0x00020000);
@@ -432,18 +469,22 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
     auto gather = [&](int gi, int s, int buf) {
         const unsigned gg = g0 + gi;
         const unsigned dst = lds0 + (unsigned)buf * (XB_F4 * 16) + w * 1024;
-        const unsigned ox0 = a.xp_off + ((gg * (T + 2) + s + 1) * OPNET_KXQ) * 256 + w * 1024;
-        const unsigned oh1 = a.h1_off + ((gg * (T + 1) + s) * (XCD_H1 / 4)) * 256 + (w - 6) * 1024;
-        const unsigned oh2 = a.h2_off + ((gg * (T + 1) + (s > 0 ? s - 1 : 0)) * (XCD_H2 / 4)) * 256 + (w - 22) * 1024;
+        // x[s] (slot s+1; past the end: the zero slot T+1), h1[s-1] (slot s), and HO: h2[s-3] (slot s-2), frames_boxes[s-2]
+        // (slot s-1) / !HO: h2[s-2] (slot s-1)
+        const unsigned ox0 = a.xp_off + ((gg * (T + 2) + (s < T ? s + 1 : T + 1)) * OPNET_KXQ) * 256 + w * 1024;
+        const unsigned oh1 = a.h1_off + ((gg * (T + 1) + (s <= T ? s : T)) * (XCD_H1 / 4)) * 256 + (w - 6) * 1024;
+        const unsigned oh2 = a.h2_off + ((gg * (T + 1) + (HO ? (s > 2 ? s - 2 : 0) : (s > 0 ? s - 1 : 0))) * (XCD_H2 / 4)) * 256 + (w - 22) * 1024;
+        const unsigned ofb = a.fb_off + (gg * (T + 1) + (s > 1 ? s - 1 : 0)) * 1024;
 #pragma unroll
         for (int j = 0; j < (XB_CHUNKS + 3) / 4; ++j) {
-            // chunk 4j + w (wave-uniform): X0 = chunks 0..5, H1 = 6..21, H2 = 22..53
+            // chunk 4j + w (wave-uniform): X0 = chunks 0..5, H1 = 6..21, H2 = 22..53, FB = 54
             if (4 * j + 3 < 6) xcd_glds16(rws, lane16, ox0 + j * 4096, dst + j * 4096);
             else if (4 * j >= 6 && 4 * j + 3 < 22) xcd_glds16(rws, lane16, oh1 + j * 4096, dst + j * 4096);
-            else if (4 * j >= 22 && 4 * j + 3 < XB_CHUNKS) xcd_glds16(rws, lane16, oh2 + j * 4096, dst + j * 4096);
+            else if (4 * j >= 22 && 4 * j + 3 < 54) xcd_glds16(rws, lane16, oh2 + j * 4096, dst + j * 4096);
             else if (4 * j + w < 6) xcd_glds16(rws, lane16, ox0 + j * 4096, dst + j * 4096);
             else if (4 * j + w < 22) xcd_glds16(rws, lane16, oh1 + j * 4096, dst + j * 4096);
-            else if (4 * j + w < XB_CHUNKS) xcd_glds16(rws, lane16, oh2 + j * 4096, dst + j * 4096);
+            else if (4 * j + w < 54) xcd_glds16(rws, lane16, oh2 + j * 4096, dst + j * 4096);
+            else if (HO && 4 * j + w == 54) xcd_glds16(rws, lane16, ofb, dst - w * 1024 + 54 * 1024);
         }
     };
     auto flags_ready = [&](int gn, unsigned need) -> bool {
@@ -474,14 +515,25 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         const int ahead = ng >= 2 ? 2 : 1;
         int gn = gi + ahead, sn = s;
         while (gn >= ng) { gn -= ng; ++sn; }
-        // boxes[s-1] of this lane's clip n and slots 4u .. 4u+3 (24 consecutive k = 6 float4 of the packed input, each a
-        // coalesced 256-B run per 16 clips), straight from global memory (read-only here, L2-resident); issued before the
-        // barrier - which must therefore not drain vmcnt - so that the round trip is over when the phase's sums arrive
+        // Who computes the selection head of step s-1: !HO every finish wave (every CU needs frames_boxes at once); HO wave 0
+        // of the step's head CU alone.  It needs boxes[s-1] - this lane's clip n and slots 4u .. 4u+3 (24 consecutive k = 6
+        // float4 of the packed input, each a coalesced 256-B run per 16 clips), straight from global memory (read-only here,
+        // L2-resident) - and, HO, the 16 A fragments of W_sel (not resident anywhere: one wave in 128 needs them per phase);
+        // all issued before the barrier - which must therefore not drain vmcnt - so that the round trips are over when the
+        // phase's sums arrive
+        const bool head_cu = HO && xcd_head_cu(s, gi) == c && s >= 1 && s <= T;
+        const bool head_wave = HO ? (head_cu && w == 0) : (s >= 1);
         xcd_u32x4 xq[6];
-        {
+        float4 wsel[HO ? 16 : 1];
+        if (head_wave) {
             const unsigned xs = a.xp_off + ((gg * (T + 2) + s) * OPNET_KXQ) * 256;
 #pragma unroll
             for (int j = 0; j < 6; ++j) xq[j] = __builtin_amdgcn_raw_buffer_load_b128(rws, xq_voff + j * 256, xs, 0);
+            if (HO) {
+                const float4 *ps = (const float4 *)(a.packed + P.wselp) + lane;
+#pragma unroll
+                for (int q = 0; q < (HO ? 16 : 1); ++q) wsel[q] = ps[q * 64];
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // barrier fp: the phase's accumulators are in sHAND[fp & 1]
@@ -493,20 +545,47 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         // goes first and the gather follows it (three groups: published by then; two: it is THIS finish - the product
         // waves wait for the exchange)
         bool early = false;
-        if (ng >= 4 && fp + 2 < nph && alive && !(a.debug & 1) && (sn == 0 || flags_ready(gn, (unsigned)sn))) {
+        if (ng >= 4 && !head_cu && fp + 2 < nph && alive && !(a.debug & 1) && (sn == 0 || flags_ready(gn, (unsigned)sn))) {
             gather(gn, sn, fp & 1);
             early = true;
         }
         if (tracer) a.trace[(long)fp * 8 + 3] = clock64();
 
         const float4 *H = &sHAND[fp & 1][0][0] + lane;
-        // ---- selection head of step s-1 (learned_models.py:40-43,50), finished by every finish wave -------------
+        // ---- selection head of step s-1 (learned_models.py:40-43,50): logits, softmax, einsum -> frames_boxes[s-1].  !HO: it
+        //      feeds this wave's LSTM2 cell right away; HO: it travels to every CU with this phase's publish and enters LSTM2
+        //      as two MFMAs one step later -----------------------------------------------------------------------------
         float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
-        if (s > 0 && alive && !(a.debug & 2)) {
-            const float4 h0 = H[0 * XH_F4 + 128], h1 = H[1 * XH_F4 + 128], h2 = H[2 * XH_F4 + 128], h3 = H[3 * XH_F4 + 128];
-            float v[4] = {((h0.x + h1.x) + h2.x) + h3.x, ((h0.y + h1.y) + h2.y) + h3.y,
-                          ((h0.z + h1.z) + h2.z) + h3.z, ((h0.w + h1.w) + h2.w) + h3.w};
-            if (c == ((s - 1) & (XCD_CUS - 1)) && w == 0) {       // wave-uniform: this wave writes the step's logits
+        if (head_wave && alive && !(a.debug & 2)) {
+            float v[4];
+            if (HO) {
+                // the whole 16 x 256 x 16-clip product on this one wave: B fragments = h1[s-1] out of the phase's gather buffer
+                // (which the gather of the phase after next will overwrite: sH1done releases it), two accumulator chains
+                const float4 *Fh = &sbuf[fp & 1][XB_H1] + lane;
+                float4 bh[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) bh[q] = Fh[q * 64];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) sH1done = fp + 1;
+                f32x4 ha = {0.f, 0.f, 0.f, 0.f}, hb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    ha = __builtin_amdgcn_mfma_f32_16x16x4f32(wsel[HO ? q : 0].x, bh[q].x, ha, 0, 0, 0);
+                    hb = __builtin_amdgcn_mfma_f32_16x16x4f32(wsel[HO ? q + 1 : 0].x, bh[q + 1].x, hb, 0, 0, 0);
+                    ha = __builtin_amdgcn_mfma_f32_16x16x4f32(wsel[HO ? q : 0].y, bh[q].y, ha, 0, 0, 0);
+                    hb = __builtin_amdgcn_mfma_f32_16x16x4f32(wsel[HO ? q + 1 : 0].y, bh[q + 1].y, hb, 0, 0, 0);
+                    ha = __builtin_amdgcn_mfma_f32_16x16x4f32(wsel[HO ? q : 0].z, bh[q].z, ha, 0, 0, 0);
+                    hb = __builtin_amdgcn_mfma_f32_16x16x4f32(wsel[HO ? q + 1 : 0].z, bh[q + 1].z, hb, 0, 0, 0);
+                    ha = __builtin_amdgcn_mfma_f32_16x16x4f32(wsel[HO ? q : 0].w, bh[q].w, ha, 0, 0, 0);
+                    hb = __builtin_amdgcn_mfma_f32_16x16x4f32(wsel[HO ? q + 1 : 0].w, bh[q + 1].w, hb, 0, 0, 0);
+                }
+                v[0] = ha[0] + hb[0]; v[1] = ha[1] + hb[1]; v[2] = ha[2] + hb[2]; v[3] = ha[3] + hb[3];
+            } else {
+                const float4 h0 = H[0 * XH_F4 + 128], h1 = H[1 * XH_F4 + 128], h2 = H[2 * XH_F4 + 128], h3 = H[3 * XH_F4 + 128];
+                v[0] = ((h0.x + h1.x) + h2.x) + h3.x; v[1] = ((h0.y + h1.y) + h2.y) + h3.y;
+                v[2] = ((h0.z + h1.z) + h2.z) + h3.z; v[3] = ((h0.w + h1.w) + h2.w) + h3.w;
+            }
+            if (HO || (c == ((s - 1) & (XCD_CUS - 1)) && w == 0)) {   // wave-uniform: this wave writes the step's logits
                 float *lg = a.logits + ((long)gg * 16 * OPNET_SLOTS_) * T + (s - 1);
                 const bool clip_ok = (int)(gg * 16 + n) < a.B;
 #pragma unroll
@@ -547,23 +626,34 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             }
             xa = make_float4(fbv[0], fbv[1], fbv[2], fbv[3]);
             xb = make_float4(fbv[4], fbv[5], 0.f, 0.f);
+          if (HO) {
+            // every lane now holds the clip's six values: lane (n, u) stores features u and u + 4 (6, 7 = padding zeros) of
+            // slot s (= frames_boxes[s-1]) as [feature][clip]
+            const float f_lo = u == 0 ? fbv[0] : u == 1 ? fbv[1] : u == 2 ? fbv[2] : fbv[3];
+            const float f_hi = u == 0 ? fbv[4] : u == 1 ? fbv[5] : 0.f;
+            const unsigned fo = a.fb_off + (gg * (T + 1) + s) * 1024;
+            xcd_store4(rws, (u * 16 + n) * 4, fo, f_lo, local);
+            xcd_store4(rws, ((u + 4) * 16 + n) * 4, fo, f_hi, local);
+          }
         }
         if (tracer) a.trace[(long)fp * 8 + 4] = clock64();
-        // ---- LSTM2 cell of step s-1 (learned_models.py:46): lane (clip n, unit 4 t2 + u) -----------------------
-        if (s > 0 && alive && !(a.debug & 4)) {
-            const float4 acc2 = H[w * XH_F4];
-            const float a2v[4] = {acc2.x, acc2.y, acc2.z, acc2.w};
-            float g[4];
+        // ---- LSTM2 cell (learned_models.py:46): lane (clip n, unit 4 t2 + u).  HO: step s-2, the gates arrive complete (the
+        //      input part W_ih2 . frames_boxes[s-2] rode the MFMA stream); !HO: step s-1, the input part is added here -------
+        if ((HO ? s >= 2 : s >= 1) && alive && !(a.debug & 4)) {
+            const float4 g2 = H[w * XH_F4];
+            float g[4] = {g2.x, g2.y, g2.z, g2.w};
+            if (!HO) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float4 w0 = wx[2 * r], w1 = wx[2 * r + 1];
-                float xsum = w0.x * xa.x;
-                xsum = fmaf(w0.y, xa.y, xsum);
-                xsum = fmaf(w0.z, xa.z, xsum);
-                xsum = fmaf(w0.w, xa.w, xsum);
-                xsum = fmaf(w1.x, xb.x, xsum);
-                xsum = fmaf(w1.y, xb.y, xsum);
-                g[r] = a2v[r] + xsum;
+                for (int r = 0; r < 4; ++r) {
+                    const float4 w0 = wx[HO ? 0 : 2 * r], w1 = wx[HO ? 0 : 2 * r + 1];
+                    float xsum = w0.x * xa.x;
+                    xsum = fmaf(w0.y, xa.y, xsum);
+                    xsum = fmaf(w0.z, xa.z, xsum);
+                    xsum = fmaf(w0.w, xa.w, xsum);
+                    xsum = fmaf(w1.x, xb.x, xsum);
+                    xsum = fmaf(w1.y, xb.y, xsum);
+                    g[r] += xsum;
+                }
             }
             float cc = sC2[gi][w][lane];
             const float h = lstm_cell(g[0], g[1], g[2], g[3], &cc);
@@ -572,7 +662,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             XCD_WAVE_LDS_SYNC();
             if (lane < 16) {
                 const float4 hv = *(const float4 *)&sTR[w][0][lane * 4];
-                xcd_store16(rws, lane16, a.h2_off + (((gg * (T + 1) + s) * (XCD_H2 / 4) + t2) * 16) * 16, hv, local);
+                xcd_store16(rws, lane16, a.h2_off + (((gg * (T + 1) + (HO ? s - 1 : s)) * (XCD_H2 / 4) + t2) * 16) * 16, hv, local);
             }
         }
         // ---- LSTM1 cell of step s (learned_models.py:39), by the upper-K wave of each pair ---------------------
@@ -600,6 +690,9 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         }
         if (tracer) a.trace[(long)fp * 8 + 6] = clock64();
         if (!early && fp + ahead < nph) {
+            if (head_cu && ng >= 2) {           // the gather fills the buffer this CU's head wave read h1 from
+                while (sH1done < fp + 1) __builtin_amdgcn_s_sleep(1);
+            }
             poll_gather(gn, sn, (fp + ahead) & 1, fp);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }

@@ -65,11 +65,27 @@ def test_persistent_forward_matches_oracle_ragged(B, T):
     assert np.abs(lg - lg_ref).max() < TOL_LOGITS
 
 
+@pytest.mark.parametrize("ho", ["0", "1"])
+@pytest.mark.parametrize("B,T", [(5, 1), (16, 2), (40, 3), (130, 9), (256, 7), (400, 12), (600, 5)])
+def test_both_head_forms_match_oracle(monkeypatch, ho, B, T):
+    """The library picks the "head once" form (selection head on one wave per XCD and phase, LSTM2 one more step behind,
+    frames_boxes exchanged like h) when every XCD carries >= 3 groups, else the every-CU-computes-the-head form;
+    OPNET_XCD_HO forces either one for every shape - both must match the oracle on all of them, 1-2 frame clips included."""
+    monkeypatch.setenv("OPNET_XCD_HO", ho)
+    boxes, _ = synth.make_batch(200, B, T)
+    m, params = _model(True)
+    y, lg = _run(m, boxes)
+    y_ref, lg_ref = oo.opnet_forward(boxes, params, dtype=np.float64)
+    assert np.isfinite(y).all()
+    assert np.abs(y - y_ref).max() < TOL_Y
+    assert np.abs(lg - lg_ref).max() < TOL_LOGITS
+
+
 def test_persistent_forward_full_size_matches_step_launch_form_and_is_deterministic():
     """BASELINE shape on every XCD: 8 x 32 clips x 300 frames.  The persistent form sums K in a different order than
     the step launches -> rounding-level agreement; and it must reproduce ITSELF bit for bit from run to run (a stale
     hand-off would not)."""
-    boxes, _ = synth.make_batch(0, 256, 300)
+    boxes, _ = synth.make_batch(0, 384, 300)        # 3 groups per XCD: the "head once" form
     m, _ = _model(True)
     y, lg = _run(m, boxes)
     m0, _ = _model(False)
@@ -93,10 +109,12 @@ def test_persistent_forward_chunks_large_batches():
     assert np.abs(y - y_ref).max() < TOL_Y and np.abs(lg - lg_ref).max() < TOL_LOGITS
 
 
-def test_persistent_forward_under_concurrent_load_on_other_streams():
+@pytest.mark.parametrize("B", [256, 512])
+def test_persistent_forward_under_concurrent_load_on_other_streams(B):
     """Uneven load: a second stream keeps streaming kernels running while the persistent launch is resident, and two
-    persistent forwards are issued from different streams (the library chains them through an event)."""
-    boxes, _ = synth.make_batch(9, 256, 40)
+    persistent forwards are issued from different streams (the library chains them through an event).  256 clips = the
+    every-CU-head form, 512 = the head-once form."""
+    boxes, _ = synth.make_batch(9, B, 40)
     m, _ = _model(True)
     y_ref, lg_ref = _run(m, boxes)
     xb = torch.from_numpy(boxes).to("cuda:0")
@@ -120,10 +138,11 @@ def test_persistent_forward_under_concurrent_load_on_other_streams():
         assert np.array_equal(y.cpu().numpy(), y_ref) and np.array_equal(lg.cpu().numpy(), lg_ref)
 
 
-def test_write_through_protocol_gives_the_same_bits(monkeypatch):
+@pytest.mark.parametrize("B", [256, 512])
+def test_write_through_protocol_gives_the_same_bits(monkeypatch, B):
     """OPNET_XCD_SAFE=1 forces the placement-independent hand-off (write-through stores, every read across the fabric)
     that the kernel falls back to when a group's workgroups are not on one XCD; same arithmetic, same bits."""
-    boxes, _ = synth.make_batch(21, 256, 30)
+    boxes, _ = synth.make_batch(21, B, 30)
     m, _ = _model(True)
     y, lg = _run(m, boxes)
     monkeypatch.setenv("OPNET_XCD_SAFE", "1")
