@@ -237,7 +237,11 @@ __device__ __forceinline__ int xcd_group_is_local(unsigned *status, int x)
 #ifndef XCD_TAIL
 #define XCD_TAIL 1
 #endif
-#define XCD_MFMA_LEAD(acc, av, bv) do { if (ROW < YM || (XCD_TAIL > 0 && YM >= 0 && (ROW % (XCD_TAIL > 0 ? XCD_TAIL : 1)) == 0)) XCD_MFMA_G(acc, av, bv, XCD_GAP); else XCD_MFMA_G(acc, av, bv, 0); } while (0)
+#ifndef XCD_TAIL_HO
+#define XCD_TAIL_HO 1          // head-once form: measured 124 / 126 / 129 k clips/s at 384 / 512 / 1024 clips; every 2nd row 117 / 126 / 129, 3rd 105 / 123 / 125
+#endif
+#define XCD_TAILV (HO ? XCD_TAIL_HO : XCD_TAIL)
+#define XCD_MFMA_LEAD(acc, av, bv) do { if (ROW < YM || (XCD_TAILV > 0 && YM >= 0 && (ROW % (XCD_TAILV > 0 ? XCD_TAILV : 1)) == 0)) XCD_MFMA_G(acc, av, bv, XCD_GAP); else XCD_MFMA_G(acc, av, bv, 0); } while (0)
 // Yielding.  fp32 MFMA executes on the SIMD's fp32 lanes - it runs at exactly the VALU rate - so while the product wave
 // keeps the matrix queue full the finish wave on the same SIMD gets no VALU cycle at all (measured: frozen for the whole
 // product phase, whatever s_setprio or the wave age).  The product wave therefore issues the MFMAs of
@@ -425,7 +429,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             };
             if (ng == 1) products(std::integral_constant<int, -1>{});
             else if (ng == 2) products(std::integral_constant<int, XCD_NY2>{});
-            else if (ng == 3) products(std::integral_constant<int, XCD_NY3>{});
+            else if (ng == 3) products(std::integral_constant<int, HO ? 0 : XCD_NY3>{});
             else products(std::integral_constant<int, XCD_NY4>{});
             XCD_MFMA_DRAIN(acc2a, acc2b, acc1, accH);
             if (mtracer) a.trace[(long)p * 8 + 1] = clock64();
