@@ -443,10 +443,11 @@ extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, fl
         else { HIP_TRY(hipEventCreate(&pe.first)); HIP_TRY(hipEventCreate(&pe.second)); }
         HIP_TRY(hipEventRecord(pe.first, st));
     }
-    // three or more groups on every XCD: the "head once" form (the selection head on one wave per XCD and phase, LSTM2 one
-    // more step behind); fewer: every CU computes the head (the exchange is on the critical path there and a lone head
-    // wave would lengthen it).  OPNET_XCD_HO = 0 / 1 overrides.
-    const int ho = env_int("OPNET_XCD_HO", L.NGT / XCD_COUNT >= 3 ? 1 : 0);
+    // three or more groups on the fullest XCD (they set the launch's duration): the "head once" form (the selection head on
+    // one wave per XCD and phase, LSTM2 one more step behind); fewer: every CU computes the head (the exchange is on the
+    // critical path there and a lone head wave lengthens it: 88 k against 106 k clips/s at 256 clips, 68 k against 75 k at
+    // 128; at 320 clips - XCDs with 3 and with 2 groups - 106 k against 93 k the other way).  OPNET_XCD_HO = 0 / 1 overrides.
+    const int ho = env_int("OPNET_XCD_HO", (L.NGT + XCD_COUNT - 1) / XCD_COUNT >= 3 ? 1 : 0);
     if (ho) opnet_xcd_forward<true><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
     else opnet_xcd_forward<false><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
     if (g_xcd_prof) {
