@@ -560,6 +560,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         //      feeds this wave's LSTM2 cell right away; HO: it travels to every CU with this phase's publish and enters LSTM2
         //      as two MFMAs one step later -----------------------------------------------------------------------------
         float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
+        if (HO && head_wave && !(alive && !(a.debug & 2)) && lane == 0) sH1done = fp + 1;   // skipped head: still release the buffer
         if (head_wave && alive && !(a.debug & 2)) {
             float v[4];
             if (HO) {
@@ -695,7 +696,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         if (tracer) a.trace[(long)fp * 8 + 6] = clock64();
         if (!early && fp + ahead < nph) {
             if (head_cu && ng >= 2) {           // the gather fills the buffer this CU's head wave read h1 from
-                while (sH1done < fp + 1) __builtin_amdgcn_s_sleep(1);
+                while (sH1done < fp + 1 && !sAbort) __builtin_amdgcn_s_sleep(1);
             }
             poll_gather(gn, sn, (fp + ahead) & 1, fp);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -162,3 +162,25 @@ def test_workgroups_of_a_group_share_an_xcd():
     print("XCC ids of blocks 0..15:", xcc[:16].tolist(), "groups XCD-local:", same, "| groups on the write-through path:", not_local)
     assert (not_local == 0) == same
     assert set(xcc.tolist()) <= set(range(8))
+
+
+@pytest.mark.parametrize("B", [256, 512])
+def test_launch_that_cannot_complete_aborts_instead_of_hanging(monkeypatch, B):
+    """Every spin in the persistent kernel is bounded: with the flag publication switched off (OPNET_XCD_DEBUG bit 3, a
+    tools-only switch) no consumer ever sees its producers; after 1.5 s the pollers raise the abort word, every wave
+    leaves, and the output head fills y with NaN - the status words say which block gave up."""
+    import time
+    boxes, _ = synth.make_batch(4, B, 6)
+    m, _ = _model(True)
+    monkeypatch.setenv("OPNET_XCD_DEBUG", "8")
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        y, _ = m(torch.from_numpy(boxes).to("cuda:0"))
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 20.0
+    st = next(iter(m.xcd_status().values()))
+    assert st[0] != 0 and 0 <= st[1] < 256
+    assert torch.isnan(y).all()
+    monkeypatch.delenv("OPNET_XCD_DEBUG")
+    y2, _ = _run(m, boxes)                  # and the next launch is healthy again
+    assert np.isfinite(y2).all()
