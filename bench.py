@@ -417,6 +417,11 @@ def main():
         out, y = bench_infer_chain(args, model, boxes, world, rank, dev, dist)
     else:
         out, y = bench_infer_xcd(args, model, boxes, world, rank, dev, dist)
+    # the ranks part here: everything below is rank 0's own (no collective), so that no rank waits in a process-group
+    # shutdown while rank 0 is still measuring the extras
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         out.update(accuracy_block(dev))
         out.update(other_batches(model, boxes, dev))
@@ -427,9 +432,6 @@ def main():
             out["parity_max_abs_dy_vs_cpu_port"] = err
             if not err < 1e-4 and not os.environ.get("OPNET_HIP_LIB"):
                 raise SystemExit(f"bench: HIP output of the last timed step differs from the CPU port by {err}")
-    if dist is not None:
-        dist.destroy_process_group()
-    if rank == 0:
         emit(out)
 
 
