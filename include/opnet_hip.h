@@ -93,6 +93,9 @@ int opnet_xcd_profile(int enable);
 int opnet_xcd_profile_read(double *kernel_ms_total, int *launches);
 /* tools: device buffer of >= (T+1) * ceil(B/128) * 8 uint64 receiving s_memtime stamps of block 0 (NULL = off) */
 void opnet_xcd_set_trace(void *device_buffer);
+/* tools: the same for the 4-clip persistent training kernels (opnet_train_forward_f32 / opnet_train_backward_f32 on
+ * batches of up to 32 clips): >= (T+2) * ceil(B/32) * 8 uint64 */
+void opnet_xcd4_set_trace(void *device_buffer);
 
 /* ---- training (replaces torch autograd through OPNet.forward, nn.L1Loss and torch.optim.Adam as used
  *      at training_main.py:150-152,183-217) ---------------------------------------------------------

@@ -2,6 +2,7 @@
 // Plain pointers and sizes in, HIP launches on the caller's stream out; no torch types.
 #include "opnet_kernels.hip"
 #include "opnet_xcd_kernels.hip"
+#include "opnet_xcd4_kernels.hip"
 #include "opnet_train_kernels.hip"
 #include "seq_kernels.hip"
 #include "conv_kernels.hip"
@@ -621,8 +622,10 @@ extern "C" int opnet_plan_forward(opnet_plan *p, const float *boxes, const float
 // training: forward with saved history, backward, loss, optimiser
 // ------------------------------------------------------------------------------------------------
 struct TrainPackedLayout {  // offsets in floats; the inference layout comes first
-    size_t fwd_total, w2bt, w1bt, wih2t, wsel, wout, total;
+    size_t fwd_total, w2bt, w1bt, wih2t, wsel, wout, x4fwd, total;   // x4fwd: register images of opnet_xcd4_forward (reference sizes only)
 };
+
+static bool x4_dims(int H1, int H2) { return H1 == XCD_H1 && H2 == XCD_H2; }
 
 static TrainPackedLayout train_packed_layout(int H1, int H2)
 {
@@ -635,14 +638,18 @@ static TrainPackedLayout train_packed_layout(int H1, int H2)
     L.wih2t = o; o += (size_t)(H2 / 4) * 256;
     L.wsel = o;  o += align_up((size_t)OPNET_SLOTS * H1, 4);
     L.wout = o;  o += align_up((size_t)4 * H2, 4);
+    L.x4fwd = o; o += x4_dims(H1, H2) ? x4_packed_layout().total : 0;
     L.total = o;
     return L;
 }
 
 struct TrainWorkspaceLayout {  // offsets in bytes
     size_t io, xp, state, h1all, c1all, h2all, c2all, state_end, x2all, g1, g2, psave, ystage, lgstage,
-        dyp, dlall, dhpart2, dhpart1, dx2part, dcz, dc2, dc1, dcz_end, l1part, total;
+        dyp, dlall, dhpart2, dhpart1, dx2part, dcz, dc2, dc1, dcz_end, l1part, x4h1x, x4h2x, x4flags, x4status, total;
 };
+
+// the 4-clip persistent step carries up to X4_NGMAX row blocks; its exchange buffers exist only for such batches
+static bool x4_batch(int B, int H1, int H2) { return x4_dims(H1, H2) && (B + 31) / 32 <= X4_NGMAX; }
 
 static TrainWorkspaceLayout train_workspace_layout(int B, int T, int H1, int H2)
 {
@@ -673,6 +680,12 @@ static TrainWorkspaceLayout train_workspace_layout(int B, int T, int H1, int H2)
     L.dc1 = o;     o += RB * (size_t)H1 * 32 * 4;
     L.dcz_end = o;
     L.l1part = o;  o += 1024 * 4;
+    o = align_up(o, 4096);
+    const size_t NG = x4_batch(B, H1, H2) ? RB * 8 : 0;     // 4-clip groups
+    L.x4h1x = o;   o += NG * (TT + 1) * 4096;
+    L.x4h2x = o;   o += NG * (TT + 1) * 8192;
+    L.x4flags = o; o += align_up(NG * 32 * 4, 256);
+    L.x4status = o; o += NG ? 2048 : 0;
     L.total = align_up(o, 256);
     return L;
 }
@@ -707,6 +720,7 @@ extern "C" int opnet_train_pack_weights_f32(const float *w_ih1, const float *w_h
     opnet_pack_tiles_t<<<blocks((size_t)(H2 / 4) * 256), 256, 0, st>>>(packed + L.wih2t, w_ih2, H2, OPNET_FEATS, 1, 1);
     opnet_copy_f32<<<blocks((size_t)OPNET_SLOTS * H1), 256, 0, st>>>(packed + L.wsel, w_sel, (long)OPNET_SLOTS * H1);
     opnet_copy_f32<<<blocks((size_t)4 * H2), 256, 0, st>>>(packed + L.wout, w_out, (long)4 * H2);
+    if (x4_dims(H1, H2)) opnet_xcd4_pack_fwd<<<1024, 256, 0, st>>>(packed + L.x4fwd, w_ih1, w_hh1, w_sel, w_ih2, w_hh2);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }
@@ -768,6 +782,48 @@ static int make_train_args(StepArgs *a, OpnetIO *io, BwdArgs *bw, const float *b
     return OPNET_OK;
 }
 
+// tools: in-kernel timeline of block 0 of the 4-clip persistent kernels (device buffer of >= (T + 2) * row blocks * 8 u64)
+static unsigned long long *g_x4_trace = nullptr;
+extern "C" void opnet_xcd4_set_trace(void *device_buffer) { g_x4_trace = (unsigned long long *)device_buffer; }
+
+// Does the training step of this batch run on the 4-clip persistent kernels?  Reference hidden sizes, a whole device (8 XCDs
+// x 32 CUs), at most OPNET_XCD4_MAX_B clips (default 32: one group per XCD - larger batches serialise their row blocks and
+// the launch chain's wide step wins again), OPNET_XCD4 = 0 switches it off.
+static bool x4_use(int B, int T, int H1, int H2)
+{
+    if (!x4_batch(B, H1, H2) || env_int("OPNET_XCD4", 1) == 0) return false;
+    if (B > env_int("OPNET_XCD4_MAX_B", 32)) return false;
+    if (train_workspace_layout(B, T, H1, H2).total >= ((size_t)1 << 31)) return false;   // one buffer descriptor
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    return xcd_device_cus(dev) >= XCD_COUNT * XCD_CUS;
+}
+
+static int make_x4_args(Xcd4Args *x, const float *packed, void *ws, int B, int T, int H1, int H2)
+{
+    const TrainWorkspaceLayout W = train_workspace_layout(B, T, H1, H2);
+    const TrainPackedLayout TP = train_packed_layout(H1, H2);
+    const PackedLayout P = packed_layout(H1, H2);
+    memset(x, 0, sizeof(*x));
+    x->B = B; x->T = T; x->RB = (B + 31) / 32;
+    x->pk = packed + TP.x4fwd;
+    x->woutp = packed + P.woutp;
+    x->ws = (char *)ws;
+    x->xp_off = (unsigned)W.xp;
+    x->h1_off = (unsigned)W.h1all; x->h2_off = (unsigned)W.h2all;
+    x->c1_off = (unsigned)W.c1all; x->c2_off = (unsigned)W.c2all;
+    x->g1_off = (unsigned)W.g1; x->g2_off = (unsigned)W.g2;
+    x->ps_off = (unsigned)W.psave; x->x2_off = (unsigned)W.x2all;
+    x->lg_off = (unsigned)W.lgstage; x->ys_off = (unsigned)W.ystage;
+    x->h1x_off = (unsigned)W.x4h1x; x->h2x_off = (unsigned)W.x4h2x;
+    x->flags_off = (unsigned)W.x4flags;
+    x->flags = (unsigned *)((char *)ws + W.x4flags);
+    x->status = (unsigned *)((char *)ws + W.x4status);
+    x->force_safe = env_int("OPNET_XCD_SAFE", 0);
+    x->trace = g_x4_trace;
+    return OPNET_OK;
+}
+
 extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
                                        void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
                                        void *stream)
@@ -782,6 +838,23 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
     OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
+    if (x4_use(B, T, H1, H2)) {
+        // small batch on a whole device: the 4-clip persistent step (opnet_xcd4_kernels.hip) writes the same histories
+        Xcd4Args x;
+        if (int rc = make_x4_args(&x, packed, workspace, B, T, H1, H2)) return rc;
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        opnet_xcd4_init<<<8, 256, 0, st>>>(x);
+        std::lock_guard<std::mutex> lock(g_xcd_mu);
+        if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
+        else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
+        opnet_xcd4_forward<true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(x);
+        HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
+        opnet_xcd4_out_head<<<dim3(T, a.RB), 256, 0, st>>>(x);
+        opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
+        HIP_TRY(hipGetLastError());
+        return OPNET_OK;
+    }
     const dim3 grid = step_grid(a);
     const opnet_step_fn stepk = step_kernel(a);
     for (int s = 0; s < T + 3; ++s) stepk<<<grid, step_threads(a), 0, st>>>(a, s);

@@ -1,0 +1,517 @@
+// opnet_xcd4_kernels.hip - the per-XCD persistent OPNet step for SMALL batches (the training batch of 32 clips): groups of
+// FOUR clips, one group per XCD and row block, every weight resident in registers for all T steps.
+//
+// What is computed: reference baselines/learned_models.py:35-52 (forward) - the same function as opnet_kernels.hip and
+// opnet_xcd_kernels.hip - here in the TRAINING form of opnet_train_forward_f32: every step's activations are kept in the
+// launch chain's own history layouts (opnet_ctx.h StepArgs, "train"), so that the backward pass and the weight-gradient
+// GEMMs (opnet_train_kernels.hip) run on them unchanged.
+//
+// Why a third form.  The 16-clip persistent kernel (opnet_xcd_kernels.hip) needs >= 3 groups per XCD
+// (384 clips) to hide its exchange; a 32-clip batch is 2 groups - 2 XCDs busy, 5.5 us per step - and the launch chain pays
+// a kernel boundary + a 5.68 MB weight fetch per step (4.9 us).  A 32-clip batch cut into EIGHT groups of 4 clips puts every
+// XCD to work with a quarter of the matrix work per step: v_mfma_f32_4x4x1_16b_f32 = 16 independent 4x4 outer products per
+// instruction, used as 64 gate rows x 1 k x 4 clips (measured 9.5 cycles per instruction, tools/probes/mfma4x4_probe.hip),
+// so the 188 MFMAs of a step cost ~1 800 cycles instead of 6 000 and the step is the exchange latency + that.
+//
+// One workgroup = 4 waves on one CU (one per SIMD), 256 workgroups; XCD x = blockIdx.x & 7 runs clips 4x .. 4x+3 of every
+// row block (group gi = row block gi), CU c = blockIdx.x >> 3 owns
+//     LSTM2 units 16c .. 16c+15 (64 gate rows), K = 512 split over the 4 waves              128 VGPRs a wave
+//     LSTM1 units  8c ..  8c+7  (32 gate rows), K = 96 + 256 split over the 4 waves           44 VGPRs
+//     the selection head (every CU, redundantly): 16 (15) rows, K = 256 split over the waves  16 VGPRs
+//     wave 0: W_ih2 of the CU's 64 gate rows (K = 6 -> 8)                                       8 VGPRs
+// MFMA operand layout (probe): lane = 4 b + i holds A[block b][row i], lane 4 b + j holds B[block b][col j], D[b][i][j] sits in
+// lane 4 b + j, register i.  LSTM2: block = unit, row = gate, one k per instruction, B = h2[k][clip j] in every block (a
+// ds_read_b128 of the [k/4][clip] float4 buffer, the same address in all 16 blocks).  LSTM1: block = (unit, k half).  Head:
+// block = (slot quad, k quarter).
+// Phase (row block gi, step s), T + 2 steps:  LSTM1 step s | selection head step s-1 | LSTM2 step s-2.
+//     1. products out of the LDS gather buffer of the phase (x[s], h1[s-1], h2[s-3], x[s-1]) and the CU's own
+//        frames_boxes[s-2] (LDS) -> K-split partials to LDS, barrier;
+//     2. wave 0: LSTM2 cell (lane = unit b, clip j), wave 1: LSTM1 cell, wave 2: head sum, softmax, einsum ->
+//        frames_boxes[s-1] to LDS, wave 3: LDS-DMA of the next phase's x pieces;
+//     3. waves 0, 1 publish h into the exchange buffers ([group][slot][k/4][4 clips] float4: a CU's piece is whole 128-B
+//        lines), drain, arrive; the second one stores the CU's flag (Guideline 16 recipe R1, as in opnet_xcd_kernels.hip:
+//        XCD-local plain stores when the placement check passed, write-through otherwise); THEN the history stores the
+//        backward needs (gates, c, h, p, frames_boxes, logits - off the critical path);
+//     4. every wave polls the 32 flags of the next phase's group, issues its LDS-DMA pieces, waits, barrier.
+// Every spin is bounded (xcd_wait_flags); an aborted launch poisons y with NaN (opnet_xcd4_out_head).
+//
+// Summation order: LSTM2 gate = ((w0 + w1) + w2) + w3 over the K quarters, each quarter (c0 + c1) + (c2 + c3) over four
+// interleaved ascending-k chains (k mod 4), wave 0's chains continued by the W_ih2 part; LSTM1 gate = sum over waves of
+// (low k half + high k half), each half two chains; logits = sum over waves, over k quarters of the wave's slice.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "opnet_ctx.h"
+
+#define X4_NGMAX 4             // row blocks (groups per XCD) one launch carries: B <= 128
+#define X4_NBUF 6              // LDS gather buffers allocated (two are used): 96 KB keep a second workgroup off the CU
+// LDS gather buffer of one phase, float4 units: [k-quad][4 clips]
+#define X4B_X0 0               // x[s]      24 k-quads
+#define X4B_H1 96              // h1[s-1]   64
+#define X4B_H2 352             // h2[s-3]  128
+#define X4B_X1 864             // x[s-1]    24 (the head's einsum)
+#define X4B_F4 1024            // 16 KB
+#ifndef X4_RING
+#define X4_RING 6
+#endif
+#ifndef X4_AHEAD
+#define X4_AHEAD 5
+#endif
+
+struct X4Packed { size_t a2, a1, as, ax, total; };     // offsets in floats
+__host__ __device__ inline X4Packed x4_packed_layout()
+{
+    X4Packed P;
+    size_t o = 0;
+    P.a2 = o; o += (size_t)32 * 4 * 32 * 256;    // [cu][wave][q][lane] float4
+    P.a1 = o; o += (size_t)32 * 4 * 11 * 256;    // [cu][wave][m][lane]
+    P.as = o; o += (size_t)4 * 4 * 256;          // [wave][m][lane]
+    P.ax = o; o += (size_t)32 * 2 * 256;         // [cu][q][lane]
+    P.total = o;
+    return P;
+}
+
+struct Xcd4Args {
+    int B, T, RB;
+    const float *pk;           // x4_packed_layout image
+    const float *woutp;        // output head tiles of the inference layout (opnet_xcd4_out_head)
+    char *ws;                  // training workspace base; everything below is a byte offset into it (one buffer descriptor)
+    unsigned xp_off;           // [T][RB][24][32] float4
+    unsigned h1_off, h2_off;   // [T+1][RB][H/4][32] float4, slot t+1 = step t
+    unsigned c1_off, c2_off;   // [T+1][RB][H][32] float
+    unsigned g1_off, g2_off;   // [T][RB][H][32] float4 post-activation gates
+    unsigned ps_off, x2_off;   // [T][RB][4][32], [T][RB][2][32] float4
+    unsigned lg_off, ys_off;   // logits / y staging
+    unsigned h1x_off, h2x_off; // exchange: [RB*8 groups][T+1][H/4][4] float4
+    unsigned flags_off;        // [RB*8][32] u32
+    unsigned *flags;
+    unsigned *status;          // as XcdArgs.status
+    int force_safe;
+    unsigned long long *trace; // optional [phases][8] s_memtime stamps of block 0, wave 0
+};
+
+typedef float x4_f32x4 __attribute__((ext_vector_type(4)));
+#define X4_MFMA(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc, 0, 0, 0)
+
+// fp32 weights -> the register images of opnet_xcd4_forward (see the layout notes above)
+__global__ void __launch_bounds__(256) opnet_xcd4_pack_fwd(float *__restrict__ out, const float *__restrict__ w_ih1,
+                                                           const float *__restrict__ w_hh1, const float *__restrict__ w_sel,
+                                                           const float *__restrict__ w_ih2, const float *__restrict__ w_hh2)
+{
+    const X4Packed P = x4_packed_layout();
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < P.total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, b = lane >> 2, i = lane & 3;
+        float v = 0.f;
+        if (idx < P.a1) {
+            const size_t r = idx >> 8;
+            const int q = r % 32, w = (r / 32) % 4, cu = r / 128;
+            const int k = 4 * (32 * w + q) + e;
+            v = w_hh2[(size_t)(i * 512 + 16 * cu + b) * 512 + k];
+        } else if (idx < P.as) {
+            const size_t r = (idx - P.a1) >> 8;
+            const int m = r % 11, w = (r / 11) % 4, cu = r / 44;
+            const int k = 4 * (22 * w + 2 * m + (b >> 3)) + e;
+            const size_t row = i * 256 + 8 * cu + (b & 7);
+            v = k < 96 ? (k < OPNET_KX ? w_ih1[row * OPNET_KX + k] : 0.f) : w_hh1[row * 256 + (k - 96)];
+        } else if (idx < P.ax) {
+            const size_t r = (idx - P.as) >> 8;
+            const int m = r % 4, w = r / 4;
+            const int slot = 4 * (b & 3) + i;
+            const int k = 4 * (16 * w + 4 * m + (b >> 2)) + e;
+            v = slot < OPNET_SLOTS_ ? w_sel[(size_t)slot * 256 + k] : 0.f;
+        } else {
+            const size_t r = (idx - P.ax) >> 8;
+            const int q = r % 2, cu = r / 2;
+            const int k = 4 * q + e;
+            v = k < OPNET_FEATS_ ? w_ih2[(size_t)(i * 512 + 16 * cu + b) * OPNET_FEATS_ + k] : 0.f;
+        }
+        out[idx] = v;
+    }
+}
+
+// flags, status words and the XCC sentinels; slot 0 of the exchange buffers (h(-1) = 0)
+__global__ void __launch_bounds__(256) opnet_xcd4_init(Xcd4Args a)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
+    const int NG = a.RB * 8;
+    for (int i = tid; i < NG * 32; i += n) a.flags[i] = 0u;
+    if (tid < 8) a.status[tid] = 0u;
+    for (int i = tid; i < 256; i += n) a.status[8 + i] = 0xffffffffu;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 *h1x = (float4 *)(a.ws + a.h1x_off), *h2x = (float4 *)(a.ws + a.h2x_off);
+    for (int i = tid; i < NG * 256; i += n) h1x[(size_t)(i >> 8) * (a.T + 1) * 256 + (i & 255)] = z;
+    for (int i = tid; i < NG * 512; i += n) h2x[(size_t)(i >> 9) * (a.T + 1) * 512 + (i & 511)] = z;
+}
+
+// lane i of every row of 16 lanes receives lane i + N of its row
+template <int N>
+__device__ __forceinline__ float x4_row_shl(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
+}
+
+template <bool TRAIN>
+__global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
+{
+    __shared__ __attribute__((aligned(1024))) float4 sbuf[X4_NBUF][X4B_F4];
+    __shared__ __attribute__((aligned(16))) float4 sP[4][3][64];       // K-split partials: LSTM2 | LSTM1 | head
+    __shared__ __attribute__((aligned(16))) float sFB[X4_NGMAX][4][8]; // frames_boxes of the group's previous head step
+    __shared__ float sC2[X4_NGMAX][64];
+    __shared__ float sC1[X4_NGMAX][32];
+    __shared__ volatile int sAbort, sLocal;
+    __shared__ unsigned sArrive;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = blockIdx.x & 7, c = blockIdx.x >> 3;
+    const int T = a.T, RB = a.RB, ng = a.RB;
+    const int b = lane >> 2, j = lane & 3;
+    if (w == 0) {
+        const int loc = xcd_group_is_local(a.status, x);
+        if (lane == 0) {
+            sLocal = loc > 0 && a.force_safe == 0;
+            sAbort = loc < 0;
+            sArrive = 0u;
+            if (loc == 0 && c == 0) atomicAdd(a.status + 3, 1u);
+        }
+    }
+    for (int i = tid; i < X4_NGMAX * 64; i += 256) (&sC2[0][0])[i] = 0.f;
+    for (int i = tid; i < X4_NGMAX * 32; i += 256) { (&sC1[0][0])[i] = 0.f; (&sFB[0][0][0])[i] = 0.f; }
+
+    // ---- resident weights ------------------------------------------------------------------------------------------------
+    const X4Packed P = x4_packed_layout();
+    float4 a2[32], a1[11], as_[4], ax[2];
+    {
+        const float4 *p2 = (const float4 *)(a.pk + P.a2) + ((size_t)(c * 4 + w) * 32) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) a2[q] = p2[q * 64];
+        const float4 *p1 = (const float4 *)(a.pk + P.a1) + ((size_t)(c * 4 + w) * 11) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 11; ++q) a1[q] = p1[q * 64];
+        const float4 *ps = (const float4 *)(a.pk + P.as) + (size_t)(w * 4) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) as_[q] = ps[q * 64];
+        const float4 *px = (const float4 *)(a.pk + P.ax) + (size_t)(c * 2) * 64 + lane;
+        ax[0] = px[0];
+        ax[1] = px[64];
+    }
+
+    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void *)a.ws, 0, 0x7fffffff, 0x00020000);
+    const unsigned lds0 = (unsigned)(unsigned long long)(const void *)&sbuf[0][0];
+    const unsigned cb = 4 * x;                                  // first clip of this XCD's groups within a row block
+    const unsigned lane16 = lane * 16;
+    const unsigned xlane = ((lane >> 2) * 32 + cb + (lane & 3)) * 16;   // [k-quad][32 clips] float4: k-quad lane >> 2, clip cb + (lane & 3)
+    bool alive = true;
+
+    // this wave's LDS-DMA pieces (1 KB = 16 k-quads x 4 clips) of the gather of phase (gi, s) into buffer `buf`:
+    // wave 3: the four x pieces (no flag needed) and h pieces 8..11; waves 0, 1: h pieces 0..3, 4..7; wave 2 (the head) none
+    auto gather_x = [&](int gi, int s, int buf) {
+        const unsigned dst = lds0 + (unsigned)buf * (X4B_F4 * 16);
+        const int t0 = s < T ? s : T - 1, t1 = s > 0 ? (s - 1 < T ? s - 1 : T - 1) : 0;
+        const unsigned o0 = a.xp_off + (unsigned)((t0 * RB + gi) * OPNET_KXQ) * 512;
+        const unsigned o1 = a.xp_off + (unsigned)((t1 * RB + gi) * OPNET_KXQ) * 512;
+        xcd_glds16(rws, xlane, o0, dst + X4B_X0 * 16);
+        xcd_glds16(rws, xlane, o1, dst + X4B_X1 * 16);
+        if (lane < 32) {                                        // k-quads 16 .. 23
+            xcd_glds16(rws, xlane, o0 + 16 * 512, dst + X4B_X0 * 16 + 1024);
+            xcd_glds16(rws, xlane, o1 + 16 * 512, dst + X4B_X1 * 16 + 1024);
+        }
+    };
+    auto gather_h = [&](int gi, int s, int buf) {
+        const unsigned dst = lds0 + (unsigned)buf * (X4B_F4 * 16);
+        const unsigned gg = gi * 8 + x;
+        const int s1 = s <= T ? s : T;                          // slot of h1[s-1]
+        const int s2 = s >= 2 ? (s - 2 <= T ? s - 2 : T) : 0;   // slot of h2[s-3]
+        const unsigned o1 = a.h1x_off + (gg * (T + 1) + s1) * 4096;
+        const unsigned o2 = a.h2x_off + (gg * (T + 1) + s2) * 8192;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = 4 * (w == 3 ? 2 : w) + q;         // wave-uniform: 0..3 = h1, 4..11 = h2
+            if (piece < 4) xcd_glds16(rws, lane16, o1 + piece * 1024, dst + X4B_H1 * 16 + piece * 1024);
+            else xcd_glds16(rws, lane16, o2 + (piece - 4) * 1024, dst + X4B_H2 * 16 + (piece - 4) * 1024);
+        }
+    };
+
+    if (w == 3) gather_x(0, 0, 0);
+    if (w != 2) gather_h(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (sAbort) return;
+    const bool local = __builtin_amdgcn_readfirstlane(sLocal) != 0;
+    const bool tracer = a.trace && blockIdx.x == 0 && tid == 0;
+    const int nph = (T + 2) * ng;
+
+    int gi = 0, s = 0;
+    for (int p = 0; p < nph; ++p) {
+        const int buf = p & 1;
+        if (tracer) a.trace[(long)p * 8 + 0] = clock64();
+        // ================================ products =======================================================================
+        {
+            const float4 *S = &sbuf[buf][0];
+            const float4 *F2 = S + X4B_H2 + (32 * w) * 4 + j;
+            const float4 *F1 = S + X4B_X0 + (22 * w + (b >> 3)) * 4 + j;
+            const float4 *FH = S + X4B_H1 + (16 * w + (b >> 2)) * 4 + j;
+            x4_f32x4 c2[4], c1[2], cH[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c2[q] = (x4_f32x4){0.f, 0.f, 0.f, 0.f};
+            c1[0] = c1[1] = cH[0] = cH[1] = (x4_f32x4){0.f, 0.f, 0.f, 0.f};
+            // 47 B fragments (32 LSTM2 | 11 LSTM1 | 4 head) through a ring of X4_RING registers quads, fetched X4_AHEAD
+            // fragments (~40 cycles of MFMA each) ahead: with one ds_read in flight per 4 MFMAs (what the compiler schedules
+            // when left alone) every fragment's LDS latency is exposed (measured 2 750 cycles for the 194 MFMAs instead of
+            // 1 850); a bigger ring pushes weights into AGPRs, and every MFMA operand then costs a v_accvgpr_read (2 470)
+            auto frag = [&](int idx) -> const float4 * {
+                return idx < 32 ? F2 + idx * 4 : idx < 43 ? F1 + (idx - 32) * 8 : FH + (idx - 43) * 16;
+            };
+            float4 bf[X4_RING];
+            float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
+            if (w == 0) { f0 = *(const float4 *)&sFB[gi][j][0]; f1 = *(const float4 *)&sFB[gi][j][4]; }
+#pragma unroll
+            for (int i = 0; i < X4_AHEAD; ++i) bf[i] = *frag(i);
+#pragma unroll
+            for (int idx = 0; idx < 47; ++idx) {
+                if (idx + X4_AHEAD < 47) bf[(idx + X4_AHEAD) % X4_RING] = *frag(idx + X4_AHEAD);
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 bq = bf[idx % X4_RING];
+                if (idx < 32) {
+                    X4_MFMA(c2[0], a2[idx < 32 ? idx : 0].x, bq.x);
+                    X4_MFMA(c2[1], a2[idx < 32 ? idx : 0].y, bq.y);
+                    X4_MFMA(c2[2], a2[idx < 32 ? idx : 0].z, bq.z);
+                    X4_MFMA(c2[3], a2[idx < 32 ? idx : 0].w, bq.w);
+                } else if (idx < 43) {
+                    const int m = idx < 43 ? idx - 32 : 0;
+                    X4_MFMA(c1[0], a1[m].x, bq.x);
+                    X4_MFMA(c1[1], a1[m].y, bq.y);
+                    X4_MFMA(c1[0], a1[m].z, bq.z);
+                    X4_MFMA(c1[1], a1[m].w, bq.w);
+                } else {
+                    const int m = idx - 43;
+                    X4_MFMA(cH[0], as_[m].x, bq.x);
+                    X4_MFMA(cH[1], as_[m].y, bq.y);
+                    X4_MFMA(cH[0], as_[m].z, bq.z);
+                    X4_MFMA(cH[1], as_[m].w, bq.w);
+                }
+                if (idx == 31 && w == 0) {      // LSTM2's input part: W_ih2 . frames_boxes[s-2] (K = 6)
+                    X4_MFMA(c2[0], ax[0].x, f0.x);
+                    X4_MFMA(c2[1], ax[0].y, f0.y);
+                    X4_MFMA(c2[2], ax[0].z, f0.z);
+                    X4_MFMA(c2[3], ax[0].w, f0.w);
+                    X4_MFMA(c2[0], ax[1].x, f1.x);
+                    X4_MFMA(c2[1], ax[1].y, f1.y);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float4 *pp = &sP[w][0][lane];
+            pp[0] = make_float4((c2[0][0] + c2[1][0]) + (c2[2][0] + c2[3][0]), (c2[0][1] + c2[1][1]) + (c2[2][1] + c2[3][1]),
+                                (c2[0][2] + c2[1][2]) + (c2[2][2] + c2[3][2]), (c2[0][3] + c2[1][3]) + (c2[2][3] + c2[3][3]));
+            pp[64] = make_float4(c1[0][0] + c1[1][0], c1[0][1] + c1[1][1], c1[0][2] + c1[1][2], c1[0][3] + c1[1][3]);
+            pp[128] = make_float4(cH[0][0] + cH[1][0], cH[0][1] + cH[1][1], cH[0][2] + cH[1][2], cH[0][3] + cH[1][3]);
+        }
+        if (tracer) a.trace[(long)p * 8 + 1] = clock64();
+        __syncthreads();                        // barrier 1: the phase's partials are in sP
+        if (tracer) a.trace[(long)p * 8 + 2] = clock64();
+        if (sAbort) return;
+        // the next phase
+        int gn = gi + 1, sn = s;
+        if (gn == ng) { gn = 0; ++sn; }
+        const bool more = p + 1 < nph;
+        const unsigned gg = gi * 8 + x;
+        const int rb = gi;
+
+        // ================================ finish, by wave =================================================================
+        float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);
+        float cc = 0.f, hsave = 0.f;
+        bool saved = false;
+        if (w == 0) {
+            // ---- LSTM2 cell of step t = s - 2 (learned_models.py:46): lane = (unit 16 c + b, clip j) ----------------------
+            const int t = s - 2;
+            if (t >= 0 && t < T && alive) {
+                const float4 p0 = sP[0][0][lane], p1 = sP[1][0][lane], p2 = sP[2][0][lane], p3 = sP[3][0][lane];
+                cc = sC2[gi][lane];
+                const float h = lstm_cell_g(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                                            ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w, &cc, &gs);
+                sC2[gi][lane] = cc;
+                hsave = h;
+                saved = true;
+                // exchange: float4 = units 4 q .. 4 q + 3 of clip j, by the lanes with (b & 3) == 0
+                const float4 hv = make_float4(h, x4_row_shl<4>(h), x4_row_shl<8>(h), x4_row_shl<12>(h));
+                if ((b & 3) == 0)
+                    xcd_store16(rws, ((b >> 2) * 4 + j) * 16, a.h2x_off + ((gg * (T + 1) + t + 1) * 128 + 4 * c) * 64, hv, local);
+            }
+        } else if (w == 1) {
+            // ---- LSTM1 cell of step t = s (learned_models.py:39): lanes 0..31 = (unit 8 c + b, clip j) --------------------
+            const int t = s;
+            if (t < T && alive && lane < 32) {
+                float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 lo = sP[q][1][lane], hi = sP[q][1][lane + 32];
+                    g[0] += lo.x + hi.x; g[1] += lo.y + hi.y; g[2] += lo.z + hi.z; g[3] += lo.w + hi.w;
+                }
+                cc = sC1[gi][lane];
+                const float h = lstm_cell_g(g[0], g[1], g[2], g[3], &cc, &gs);
+                sC1[gi][lane] = cc;
+                hsave = h;
+                saved = true;
+                const float4 hv = make_float4(h, x4_row_shl<4>(h), x4_row_shl<8>(h), x4_row_shl<12>(h));
+                if ((b & 3) == 0)
+                    xcd_store16(rws, ((b >> 2) * 4 + j) * 16, a.h1x_off + ((gg * (T + 1) + t + 1) * 64 + 2 * c) * 64, hv, local);
+            }
+        } else if (w == 2) {
+            // ---- selection head of step t = s - 1 (learned_models.py:40-43,50): lanes 0..15 = (slot quad rg, clip j) ------
+            const int t = s - 1;
+            if (t >= 0 && t < T && alive && lane < 16) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const float4 pv = sP[q][2][lane + 16 * kk];
+                        v[0] += pv.x; v[1] += pv.y; v[2] += pv.z; v[3] += pv.w;
+                    }
+                const int rg = lane >> 2;
+                float m = fmaxf(fmaxf(v[0], v[1]), v[2]);
+                if (rg < 3) m = fmaxf(m, v[3]);                 // slot 15 does not exist
+                m = fmaxf(m, __shfl_xor(m, 4));
+                m = fmaxf(m, __shfl_xor(m, 8));
+                float e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e[r] = __expf(v[r] - m);
+                if (rg == 3) e[3] = 0.f;
+                float sum = (e[0] + e[1]) + (e[2] + e[3]);
+                sum += __shfl_xor(sum, 4);
+                sum += __shfl_xor(sum, 8);
+                const float inv = 1.0f / sum;
+                const float pr[4] = {e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
+                // frames_boxes[j][f] = sum_o boxes[j][t][o][f] p[o] (einsum "bfot,bfo->bft"): this lane's slots 4 rg .. 4 rg + 3
+                // = k 24 rg .. 24 rg + 23 of x[t] = k-quads 6 rg .. 6 rg + 5 of the X1 piece
+                const float4 *X = &sbuf[buf][X4B_X1] + (6 * rg) * 4 + j;
+                float xf[24];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const float4 xv = X[q * 4];
+                    xf[4 * q] = xv.x; xf[4 * q + 1] = xv.y; xf[4 * q + 2] = xv.z; xf[4 * q + 3] = xv.w;
+                }
+                float fbv[8];
+#pragma unroll
+                for (int f = 0; f < OPNET_FEATS_; ++f) {
+                    float acc = pr[0] * xf[f];
+                    acc = fmaf(pr[1], xf[6 + f], acc);
+                    acc = fmaf(pr[2], xf[12 + f], acc);
+                    acc = fmaf(pr[3], xf[18 + f], acc);
+                    acc += __shfl_xor(acc, 4);
+                    acc += __shfl_xor(acc, 8);
+                    fbv[f] = acc;
+                }
+                fbv[6] = fbv[7] = 0.f;
+                if (rg == 0) {
+                    *(float4 *)&sFB[gi][j][0] = make_float4(fbv[0], fbv[1], fbv[2], fbv[3]);
+                    *(float4 *)&sFB[gi][j][4] = make_float4(fbv[4], fbv[5], 0.f, 0.f);
+                }
+                if (c == (s & 31)) {            // every CU computes the head; one of them records it
+                    const unsigned clip = rb * 32 + cb + j;
+                    float *lg = (float *)(a.ws + a.lg_off);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * rg + r < OPNET_SLOTS_) lg[((size_t)clip * OPNET_SLOTS_ + 4 * rg + r) * T + t] = v[r];
+                    if (TRAIN) {
+                        float4 *ps = (float4 *)(a.ws + a.ps_off);
+                        ps[((size_t)(t * RB + rb) * 4 + rg) * 32 + cb + j] = make_float4(pr[0], pr[1], pr[2], pr[3]);
+                    }
+                    if (rg < 2) {
+                        float4 *x2 = (float4 *)(a.ws + a.x2_off);
+                        x2[((size_t)(t * RB + rb) * 2 + rg) * 32 + cb + j] =
+                            rg == 0 ? make_float4(fbv[0], fbv[1], fbv[2], fbv[3]) : make_float4(fbv[4], fbv[5], 0.f, 0.f);
+                    }
+                }
+            }
+        } else {
+            if (more && alive) gather_x(gn, sn, buf ^ 1);
+        }
+        if (tracer) a.trace[(long)p * 8 + 3] = clock64();
+        // ================================ publish =========================================================================
+        if (w < 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0 && alive) {
+                if (__hip_atomic_fetch_add(&sArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1u) {
+                    __hip_atomic_store(&sArrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    xcd_store_flag(a.flags + gg * 32 + c, (unsigned)(s + 1), local);
+                }
+            }
+            if (tracer) a.trace[(long)p * 8 + 4] = clock64();
+            // the histories of the backward pass / the output head: after the flag, off the critical path
+            if (saved) {
+                if (w == 0) {
+                    const int t = s - 2;
+                    const size_t u = 16 * c + b;
+                    ((float *)(a.ws + a.h2_off))[(((size_t)(t + 1) * RB + rb) * 128 + (u >> 2)) * 128 + (cb + j) * 4 + (u & 3)] = hsave;
+                    if (TRAIN) {
+                        ((float *)(a.ws + a.c2_off))[(((size_t)(t + 1) * RB + rb) * 512 + u) * 32 + cb + j] = cc;
+                        ((float4 *)(a.ws + a.g2_off))[(((size_t)t * RB + rb) * 512 + u) * 32 + cb + j] = gs;
+                    }
+                } else {
+                    const int t = s;
+                    const size_t u = 8 * c + b;
+                    ((float *)(a.ws + a.h1_off))[(((size_t)(t + 1) * RB + rb) * 64 + (u >> 2)) * 128 + (cb + j) * 4 + (u & 3)] = hsave;
+                    if (TRAIN) {
+                        ((float *)(a.ws + a.c1_off))[(((size_t)(t + 1) * RB + rb) * 256 + u) * 32 + cb + j] = cc;
+                        ((float4 *)(a.ws + a.g1_off))[(((size_t)t * RB + rb) * 256 + u) * 32 + cb + j] = gs;
+                    }
+                }
+            }
+        }
+        // ================================ next phase's gather =============================================================
+        if (more && alive && w != 2) {
+            if (sn > 0) alive = xcd_wait_flags(a.flags + (gn * 8 + x) * 32, (unsigned)sn, a.status, p);
+            if (tracer) a.trace[(long)p * 8 + 5] = clock64();
+            if (alive) gather_h(gn, sn, buf ^ 1);
+            else sAbort = 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tracer) a.trace[(long)p * 8 + 6] = clock64();
+        __syncthreads();                        // barrier 2: the next phase's inputs have landed
+        if (tracer) a.trace[(long)p * 8 + 7] = clock64();
+        if (sAbort) return;
+        gi = gn;
+        s = sn;
+    }
+}
+
+// y staging [RB*32][T] float4 = W_out h2[t] (prediction_layer, learned_models.py:33,47) from the h2 history; one workgroup per
+// (t, row block): thread (r, clip) walks k-quads r, r + 8, ...; the 8 partials are summed in fixed order.  An aborted persistent
+// launch (status[0] != 0) poisons y with NaN.
+__global__ void __launch_bounds__(256) opnet_xcd4_out_head(const Xcd4Args a)
+{
+    __shared__ float sw[4][512];
+    __shared__ __attribute__((aligned(16))) float4 red[8][32];
+    const int t = blockIdx.x, rb = blockIdx.y, tid = threadIdx.x, T = a.T;
+    const float *wo = a.woutp;                 // [H2/16][64][4]: lane l = row l & 15, k = 16 q + 4 (l >> 4) + e
+    for (int i = tid; i < 4 * 512; i += 256) {
+        const int o = i / 512, k = i % 512;
+        sw[o][k] = wo[(((k >> 4) * 64) + o + 16 * ((k & 15) >> 2)) * 4 + (k & 3)];
+    }
+    __syncthreads();
+    const int r = tid >> 5, clip = tid & 31;
+    const float4 *h = (const float4 *)(a.ws + a.h2_off) + ((size_t)(t + 1) * a.RB + rb) * (128 * 32);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kq = r; kq < 128; kq += 8) {
+        const float4 hv = h[kq * 32 + clip];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            acc[o] = fmaf(sw[o][4 * kq + 0], hv.x, acc[o]);
+            acc[o] = fmaf(sw[o][4 * kq + 1], hv.y, acc[o]);
+            acc[o] = fmaf(sw[o][4 * kq + 2], hv.z, acc[o]);
+            acc[o] = fmaf(sw[o][4 * kq + 3], hv.w, acc[o]);
+        }
+    }
+    red[r][clip] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (tid < 32) {
+        float4 sum = red[0][tid];
+        for (int i = 1; i < 8; ++i) {
+            const float4 v = red[i][tid];
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        if (a.status[0] != 0u) sum = make_float4(NAN, NAN, NAN, NAN);
+        ((float4 *)(a.ws + a.ys_off))[((size_t)rb * 32 + tid) * T + t] = sum;
+    }
+}

@@ -1,0 +1,97 @@
+"""GPU parity of the 4-clip per-XCD persistent training step (csrc/opnet_xcd4_kernels.hip) - the form
+opnet_train_forward_f32 / opnet_train_backward_f32 take for batches of up to 32 clips on a whole MI355X - against the
+launch chain (OPNET_XCD4=0), the fp64 port of the reference (oracle/torch_port.py) and the reference's own autograd
+goldens (tests/test_train_gpu.py runs on it by default)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth, torch_port
+
+pytestmark = pytest.mark.gpu
+
+REAL_CFG = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
+
+
+def _model():
+    from objectpermanence_amd import ModelsFactory
+    m = ModelsFactory.get_model("opnet", REAL_CFG)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.opnet_synth_params(REAL_CFG).items()})
+    return m.to("cuda:0").train(True)
+
+
+def _run(m, boxes, labels):
+    from objectpermanence_amd import l1_mean
+    m.zero_grad(set_to_none=True)
+    y, logits = m(torch.from_numpy(boxes).cuda())
+    loss = l1_mean(y, torch.from_numpy(labels).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    return (float(loss.item()), y.detach().cpu().numpy(), logits.detach().cpu().numpy(),
+            {k: p.grad.cpu().numpy().copy() for k, p in m.named_parameters()})
+
+
+def _supported():
+    from objectpermanence_amd import _lib
+    return bool(_lib.load().opnet_xcd_supported(256, 512))
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (4, 7), (20, 9), (32, 12), (31, 40)])
+def test_persistent_step_matches_chain_and_port(B, T, monkeypatch):
+    if not _supported():
+        pytest.skip("needs a whole MI355X (8 XCDs x 32 CUs)")
+    boxes, labels = synth.make_batch(300 + B, B, T)
+    m = _model()
+    monkeypatch.setenv("OPNET_XCD4", "1")
+    loss_x, y_x, lg_x, g_x = _run(m, boxes, labels)
+    loss_x2, y_x2, lg_x2, g_x2 = _run(m, boxes, labels)
+    monkeypatch.setenv("OPNET_XCD4", "0")
+    loss_c, y_c, lg_c, g_c = _run(m, boxes, labels)
+    assert np.isfinite(y_x).all()
+    # run to run: the same bits
+    assert np.array_equal(y_x, y_x2) and np.array_equal(lg_x, lg_x2)
+    for k in g_x:
+        assert np.array_equal(g_x[k], g_x2[k]), k
+    # against the launch chain: another summation order of the same fp32 products
+    assert np.abs(y_x - y_c).max() < 2e-5
+    assert np.abs(lg_x - lg_c).max() < 5e-5
+    assert loss_x == pytest.approx(loss_c, abs=2e-6)
+    for k in g_x:
+        assert np.abs(g_x[k] - g_c[k]).max() <= 2e-4 * max(1e-2, np.abs(g_c[k]).max()), k
+    # against the fp64 port of the reference
+    ref_loss, ref_grads, y_ref = torch_port.loss_and_grads(boxes, labels, synth.opnet_synth_params(REAL_CFG), dtype=torch.float64)
+    assert np.abs(y_x - y_ref).max() < 2e-5
+    assert loss_x == pytest.approx(ref_loss, abs=2e-6)
+    for k, gr in g_x.items():
+        assert np.abs(gr - ref_grads[k]).max() <= 1e-4 * max(1e-2, np.abs(ref_grads[k]).max()), k
+
+
+def test_full_size_step_matches_chain(monkeypatch):
+    """BASELINE config 2: 32 clips x 300 frames."""
+    if not _supported():
+        pytest.skip("needs a whole MI355X (8 XCDs x 32 CUs)")
+    boxes, labels = synth.make_batch(7, 32, 300)
+    m = _model()
+    monkeypatch.setenv("OPNET_XCD4", "1")
+    loss_x, y_x, lg_x, g_x = _run(m, boxes, labels)
+    monkeypatch.setenv("OPNET_XCD4", "0")
+    loss_c, y_c, lg_c, g_c = _run(m, boxes, labels)
+    assert np.isfinite(y_x).all()
+    assert np.abs(y_x - y_c).max() < 1e-4
+    assert loss_x == pytest.approx(loss_c, abs=1e-5)
+    for k in g_x:
+        assert np.abs(g_x[k] - g_c[k]).max() <= 2e-3 * max(1e-2, np.abs(g_c[k]).max()), k
+
+
+def test_write_through_protocol_gives_the_same_bits(monkeypatch):
+    if not _supported():
+        pytest.skip("needs a whole MI355X (8 XCDs x 32 CUs)")
+    boxes, labels = synth.make_batch(11, 32, 20)
+    m = _model()
+    monkeypatch.setenv("OPNET_XCD4", "1")
+    _, y_a, lg_a, g_a = _run(m, boxes, labels)
+    monkeypatch.setenv("OPNET_XCD_SAFE", "1")
+    _, y_b, lg_b, g_b = _run(m, boxes, labels)
+    assert np.array_equal(y_a, y_b) and np.array_equal(lg_a, lg_b)
+    for k in g_a:
+        assert np.array_equal(g_a[k], g_b[k]), k

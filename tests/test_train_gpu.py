@@ -105,8 +105,21 @@ def test_train_forward_equals_inference_forward():
     with torch.no_grad():
         y_i, l_i = m(x)
     torch.cuda.synchronize()
-    assert torch.equal(y_t.detach(), y_i) and torch.equal(l_t, l_i)
+    # 6 clips train on the 4-clip persistent step (another summation order than the inference chain's)
+    assert (y_t.detach() - y_i).abs().max() < 2e-5 and (l_t - l_i).abs().max() < 5e-5
     assert y_t.requires_grad and not l_t.requires_grad
+
+
+def test_train_forward_equals_inference_forward_on_the_chain(monkeypatch):
+    monkeypatch.setenv("OPNET_XCD4", "0")
+    boxes, _ = synth.make_batch(5, 6, 50)
+    m = _model(REAL_CFG)
+    x = torch.from_numpy(boxes).cuda()
+    y_t, l_t = m(x)
+    with torch.no_grad():
+        y_i, l_i = m(x)
+    torch.cuda.synchronize()
+    assert torch.equal(y_t.detach(), y_i) and torch.equal(l_t, l_i)
 
 
 def test_backward_after_second_forward_is_refused():
