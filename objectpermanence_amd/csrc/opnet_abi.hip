@@ -2,8 +2,8 @@
 // Plain pointers and sizes in, HIP launches on the caller's stream out; no torch types.
 #include "opnet_kernels.hip"
 #include "opnet_xcd_kernels.hip"
-#include "opnet_xcd4_kernels.hip"
 #include "opnet_train_kernels.hip"
+#include "opnet_xcd4_kernels.hip"
 #include "seq_kernels.hip"
 #include "conv_kernels.hip"
 #include "attn_kernels.hip"
@@ -622,7 +622,7 @@ extern "C" int opnet_plan_forward(opnet_plan *p, const float *boxes, const float
 // training: forward with saved history, backward, loss, optimiser
 // ------------------------------------------------------------------------------------------------
 struct TrainPackedLayout {  // offsets in floats; the inference layout comes first
-    size_t fwd_total, w2bt, w1bt, wih2t, wsel, wout, x4fwd, total;   // x4fwd: register images of opnet_xcd4_forward (reference sizes only)
+    size_t fwd_total, w2bt, w1bt, wih2t, wsel, wout, x4fwd, x4bwd, total;   // x4*: register images of the 4-clip persistent kernels (reference sizes only)
 };
 
 static bool x4_dims(int H1, int H2) { return H1 == XCD_H1 && H2 == XCD_H2; }
@@ -639,13 +639,14 @@ static TrainPackedLayout train_packed_layout(int H1, int H2)
     L.wsel = o;  o += align_up((size_t)OPNET_SLOTS * H1, 4);
     L.wout = o;  o += align_up((size_t)4 * H2, 4);
     L.x4fwd = o; o += x4_dims(H1, H2) ? x4_packed_layout().total : 0;
+    L.x4bwd = o; o += x4_dims(H1, H2) ? x4b_packed_layout().total : 0;
     L.total = o;
     return L;
 }
 
 struct TrainWorkspaceLayout {  // offsets in bytes
     size_t io, xp, state, h1all, c1all, h2all, c2all, state_end, x2all, g1, g2, psave, ystage, lgstage,
-        dyp, dlall, dhpart2, dhpart1, dx2part, dcz, dc2, dc1, dcz_end, l1part, x4h1x, x4h2x, x4flags, x4status, total;
+        dyp, dlall, dhpart2, dhpart1, dx2part, dcz, dc2, dc1, dcz_end, l1part, x4h1x, x4h2x, x4flags, x4status, x4da1x, x4da2x, x4dfx, x4flags2, total;
 };
 
 // the 4-clip persistent step carries up to X4_NGMAX row blocks; its exchange buffers exist only for such batches
@@ -686,6 +687,10 @@ static TrainWorkspaceLayout train_workspace_layout(int B, int T, int H1, int H2)
     L.x4h2x = o;   o += NG * (TT + 1) * 8192;
     L.x4flags = o; o += align_up(NG * 32 * 4, 256);
     L.x4status = o; o += NG ? 2048 : 0;
+    L.x4flags2 = o; o += align_up(NG * 32 * 4, 256);
+    L.x4da1x = o;  o += NG * (TT + 1) * 16384;
+    L.x4da2x = o;  o += NG * (TT + 1) * 32768;
+    L.x4dfx = o;   o += NG * (TT + 1) * 4096;
     L.total = align_up(o, 256);
     return L;
 }
@@ -720,7 +725,10 @@ extern "C" int opnet_train_pack_weights_f32(const float *w_ih1, const float *w_h
     opnet_pack_tiles_t<<<blocks((size_t)(H2 / 4) * 256), 256, 0, st>>>(packed + L.wih2t, w_ih2, H2, OPNET_FEATS, 1, 1);
     opnet_copy_f32<<<blocks((size_t)OPNET_SLOTS * H1), 256, 0, st>>>(packed + L.wsel, w_sel, (long)OPNET_SLOTS * H1);
     opnet_copy_f32<<<blocks((size_t)4 * H2), 256, 0, st>>>(packed + L.wout, w_out, (long)4 * H2);
-    if (x4_dims(H1, H2)) opnet_xcd4_pack_fwd<<<1024, 256, 0, st>>>(packed + L.x4fwd, w_ih1, w_hh1, w_sel, w_ih2, w_hh2);
+    if (x4_dims(H1, H2)) {
+        opnet_xcd4_pack_fwd<<<1024, 256, 0, st>>>(packed + L.x4fwd, w_ih1, w_hh1, w_sel, w_ih2, w_hh2);
+        opnet_xcd4_pack_bwd<<<1024, 256, 0, st>>>(packed + L.x4bwd, w_hh1, w_sel, w_ih2, w_hh2, w_out);
+    }
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }
@@ -824,6 +832,26 @@ static int make_x4_args(Xcd4Args *x, const float *packed, void *ws, int B, int T
     return OPNET_OK;
 }
 
+static void make_x4b_args(Xcd4BArgs *x, const float *packed, void *ws, int B, int T, int H1, int H2)
+{
+    const TrainWorkspaceLayout W = train_workspace_layout(B, T, H1, H2);
+    const TrainPackedLayout TP = train_packed_layout(H1, H2);
+    memset(x, 0, sizeof(*x));
+    x->B = B; x->T = T; x->RB = (B + 31) / 32;
+    x->pk = packed + TP.x4bwd;
+    x->ws = (char *)ws;
+    x->xp_off = (unsigned)W.xp;
+    x->c1_off = (unsigned)W.c1all; x->c2_off = (unsigned)W.c2all;
+    x->g1_off = (unsigned)W.g1; x->g2_off = (unsigned)W.g2;
+    x->ps_off = (unsigned)W.psave; x->dy_off = (unsigned)W.dyp; x->dl_off = (unsigned)W.dlall;
+    x->da1x_off = (unsigned)W.x4da1x; x->da2x_off = (unsigned)W.x4da2x; x->dfx_off = (unsigned)W.x4dfx;
+    x->flags = (unsigned *)((char *)ws + W.x4flags);
+    x->flags2 = (unsigned *)((char *)ws + W.x4flags2);
+    x->status = (unsigned *)((char *)ws + W.x4status);
+    x->force_safe = env_int("OPNET_XCD_SAFE", 0);
+    x->trace = g_x4_trace;
+}
+
 extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
                                        void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
                                        void *stream)
@@ -910,7 +938,19 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
     // leave most of the chip idle (measured per step, fused / split: B=96 6.72 / 7.17 ms, B=128 7.79 / 7.92, B=256 12.97 / 12.38).
     const char *mode = getenv("OPNET_BWD_MODE");          // "fused" / "split": measurement override
     const bool fused = mode ? strcmp(mode, "fused") == 0 : RB <= 4;
-    if (fused) {
+    if (!mlp && x4_use(B, T, H1, H2) && env_int("OPNET_XCD4_BWD", 1) != 0) {
+        // small batch on a whole device: the 4-clip persistent reverse recurrence (opnet_xcd4_kernels.hip)
+        Xcd4BArgs x;
+        make_x4b_args(&x, packed, workspace, B, T, H1, H2);
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        opnet_xcd4_init_bwd<<<8, 256, 0, st>>>(x);
+        std::lock_guard<std::mutex> lock(g_xcd_mu);
+        if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
+        else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
+        opnet_xcd4_backward<<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(x);
+        HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
+    } else if (fused) {
         const dim3 gfused(2 * (H2 / 16 + H1 / 16 + 1), RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
         for (int n = 0; n <= T + 1; ++n) opnet_bwd_fused<<<gfused, FUSED_THREADS, 0, st>>>(bw, n);
     } else {

@@ -515,3 +515,489 @@ __global__ void __launch_bounds__(256) opnet_xcd4_out_head(const Xcd4Args a)
         ((float4 *)(a.ws + a.ys_off))[((size_t)rb * 32 + tid) * T + t] = sum;
     }
 }
+
+// ====================================================================================================================
+// backward: the reverse recurrence of opnet_train_backward_f32 (reference: torch autograd through learned_models.py:35-52
+// under training_main.py:216; restated in oracle/torch_port.py), same placement and protocol as the forward above.
+//     dh2_t = W_out^T dy_t + W_hh2^T da2_{t+1};   (da2_t, dc2) = cell backward           (opnet_train_kernels.hip cell_backward)
+//     dfb_t = W_ih2^T da2_t;  dp = boxes_t . dfb_t;  dl_t = p_t * (dp - <p_t, dp>)          (einsum + softmax backward)
+//     dh1_t = W_sel^T dl_t + W_hh1^T da1_{t+1};   (da1_t, dc1) = cell backward
+// da_t overwrites the saved gates (g2 / g1, the launch chain's layout) and dl_t goes to dlall, so that opnet_wgrad runs on
+// the result unchanged.
+// CU c owns the dh rows of ITS units (16 of LSTM2, 8 of LSTM1) and holds the matching rows of W_hh^T: K = 4H gate columns,
+// MFMA blocks = (row quad, k subset): LSTM2 16 rows x 4 k x 4 clips per instruction, LSTM1 8 rows x 8 k x 4 clips; B = the
+// (unit', clip) float4 of da (its four gates = four consecutive k), so one ds_read_b128 feeds four instructions.
+// Phase (row block gi, n), T + 2 of them:  LSTM2 cell at t2 = T-1-n | head backward at th = T-n | LSTM1 cell at t1 = T+1-n.
+//     gather: da2_{T-n} (32 KB), da1_{T+2-n} (16 KB) of the group;
+//     wave 0: dh2 sum + cell -> da2_{t2} -> exchange, flag; then the CU's part of dfb_{t2} (8 MFMAs on the da registers,
+//             summed over the CU's units through LDS) -> exchange, second flag; then g2;
+//     wave 1: dh1 sum + W_sel^T dl_{t1} (dl from LDS, left there by wave 2 one phase earlier) + cell -> da1_{t1};
+//     wave 2: sums the 32 CUs' dfb parts of step th, dp, dl_{th} -> LDS (+ dlall by one CU);
+//     wave 3: most of the next gather.
+// ====================================================================================================================
+#define X4D_DA2 0              // LDS gather buffer of a backward phase, float4 units: da2 [512 units][4 clips]
+#define X4D_DA1 2048           //                                                      da1 [256 units][4 clips]
+#define X4D_F4 3072            // 48 KB
+
+struct X4BPacked { size_t b2, b1, bx, bo, bs, total; };    // offsets in floats
+__host__ __device__ inline X4BPacked x4b_packed_layout()
+{
+    X4BPacked P;
+    size_t o = 0;
+    P.b2 = o; o += (size_t)32 * 4 * 32 * 256;    // [cu][wave][m][lane] float4   W_hh2^T
+    P.b1 = o; o += (size_t)32 * 4 * 8 * 256;     // [cu][wave][m][lane]          W_hh1^T
+    P.bx = o; o += (size_t)32 * 2 * 256;         // [cu][f quad][lane]           W_ih2^T of the CU's units
+    P.bo = o; o += (size_t)32 * 256;             // [cu][lane]                   W_out^T of the lane's unit
+    P.bs = o; o += (size_t)32 * 4 * 256;         // [cu][slot quad][lane]        W_sel^T of the lane's unit
+    P.total = o;
+    return P;
+}
+
+struct Xcd4BArgs {
+    int B, T, RB;
+    const float *pk;           // x4b_packed_layout image
+    char *ws;
+    unsigned xp_off;           // [T][RB][24][32] float4
+    unsigned c1_off, c2_off;   // [T+1][RB][H][32] float
+    unsigned g1_off, g2_off;   // [T][RB][H][32] float4: gates in, da out
+    unsigned ps_off;           // [T][RB][4][32] float4
+    unsigned dy_off;           // [T][RB][32] float4
+    unsigned dl_off;           // [T][RB][4][32] float4 out
+    unsigned da1x_off, da2x_off;   // exchange [RB*8][T+1][H][4] float4, slot t = step t, slot T = 0
+    unsigned dfx_off;          // exchange [RB*8][T+1][32 CUs][8 features][4 clips] float
+    unsigned *flags, *flags2;  // [RB*8][32] each
+    unsigned *status;
+    int force_safe;
+    unsigned long long *trace;
+};
+
+__global__ void __launch_bounds__(256) opnet_xcd4_pack_bwd(float *__restrict__ out, const float *__restrict__ w_hh1,
+                                                           const float *__restrict__ w_sel, const float *__restrict__ w_ih2,
+                                                           const float *__restrict__ w_hh2, const float *__restrict__ w_out)
+{
+    const X4BPacked P = x4b_packed_layout();
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < P.total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, b = lane >> 2, i = lane & 3;
+        float v = 0.f;
+        if (idx < P.b1) {
+            const size_t r = idx >> 8;
+            const int m = r % 32, w = (r / 32) % 4, cu = r / 128;
+            const int u = 16 * cu + 4 * (b & 3) + i, unit = 128 * w + 4 * m + (b >> 2);
+            v = w_hh2[(size_t)(e * 512 + unit) * 512 + u];
+        } else if (idx < P.bx) {
+            const size_t r = (idx - P.b1) >> 8;
+            const int m = r % 8, w = (r / 8) % 4, cu = r / 32;
+            const int u = 8 * cu + 4 * (b & 1) + i, unit = 64 * w + 8 * m + (b >> 1);
+            v = w_hh1[(size_t)(e * 256 + unit) * 256 + u];
+        } else if (idx < P.bo) {
+            const size_t r = (idx - P.bx) >> 8;
+            const int q = r % 2, cu = r / 2;
+            const int f = 4 * q + i;                // row of the MFMA block of unit 16 cu + b; k = gate e
+            v = f < OPNET_FEATS_ ? w_ih2[(size_t)(e * 512 + 16 * cu + b) * OPNET_FEATS_ + f] : 0.f;
+        } else if (idx < P.bs) {
+            const size_t cu = (idx - P.bo) >> 8;
+            v = w_out[(size_t)e * 512 + 16 * cu + b];            // lane (b, any i): W_out[e][unit]
+        } else {
+            const size_t r = (idx - P.bs) >> 8;
+            const int q = r % 4, cu = r / 4;
+            const int slot = 4 * q + e;
+            v = slot < OPNET_SLOTS_ ? w_sel[(size_t)slot * 256 + 8 * cu + (b & 7)] : 0.f;
+        }
+        out[idx] = v;
+    }
+}
+
+// flags, status, the zero slot T of the da exchange buffers
+__global__ void __launch_bounds__(256) opnet_xcd4_init_bwd(Xcd4BArgs a)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
+    const int NG = a.RB * 8;
+    for (int i = tid; i < NG * 32; i += n) { a.flags[i] = 0u; a.flags2[i] = 0u; }
+    if (tid < 8) a.status[tid] = 0u;
+    for (int i = tid; i < 256; i += n) a.status[8 + i] = 0xffffffffu;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 *d1 = (float4 *)(a.ws + a.da1x_off), *d2 = (float4 *)(a.ws + a.da2x_off);
+    for (int i = tid; i < NG * 1024; i += n) d1[((size_t)(i >> 10) * (a.T + 1) + a.T) * 1024 + (i & 1023)] = z;
+    for (int i = tid; i < NG * 2048; i += n) d2[((size_t)(i >> 11) * (a.T + 1) + a.T) * 2048 + (i & 2047)] = z;
+}
+
+__global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
+{
+    __shared__ __attribute__((aligned(1024))) float4 sbuf[2][X4D_F4];
+    __shared__ __attribute__((aligned(16))) float4 sP[4][2][64];       // K-split partials: dh2 | dh1
+    __shared__ __attribute__((aligned(16))) float4 sX[2][64];          // per-unit parts of dfb: features 0..3 | 4..7
+    __shared__ float sDC2[X4_NGMAX][64];
+    __shared__ float sDC1[X4_NGMAX][32];
+    __shared__ __attribute__((aligned(16))) float sDL[X4_NGMAX][2][4][16];   // dl of the group's head steps, by phase parity: [clip][slot]
+    __shared__ float sDFB[2][32];
+    __shared__ __attribute__((aligned(16))) float4 sHX[X4_NGMAX][2][28][4];   // the head step's boxes (24 k-quads) and p (4 slot quads) x 4 clips, by step parity
+    __shared__ volatile int sAbort, sLocal;
+    __shared__ unsigned sArrive;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = blockIdx.x & 7, c = blockIdx.x >> 3;
+    const int T = a.T, RB = a.RB, ng = a.RB;
+    const int b = lane >> 2, j = lane & 3;
+    if (w == 0) {
+        const int loc = xcd_group_is_local(a.status, x);
+        if (lane == 0) {
+            sLocal = loc > 0 && a.force_safe == 0;
+            sAbort = loc < 0;
+            sArrive = 0u;
+            if (loc == 0 && c == 0) atomicAdd(a.status + 3, 1u);
+        }
+    }
+    for (int i = tid; i < X4_NGMAX * 64; i += 256) { (&sDC2[0][0])[i] = 0.f; (&sDL[0][0][0][0])[i] = 0.f; (&sDL[0][0][0][0])[X4_NGMAX * 64 + i] = 0.f; }
+    for (int i = tid; i < X4_NGMAX * 32; i += 256) (&sDC1[0][0])[i] = 0.f;
+
+    // ---- resident weights ------------------------------------------------------------------------------------------------
+    const X4BPacked P = x4b_packed_layout();
+    float4 b2[32], b1[8], bxa, bxb, wo, wsl[4];
+    {
+        const float4 *p2 = (const float4 *)(a.pk + P.b2) + ((size_t)(c * 4 + w) * 32) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) b2[q] = p2[q * 64];
+        const float4 *p1 = (const float4 *)(a.pk + P.b1) + ((size_t)(c * 4 + w) * 8) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) b1[q] = p1[q * 64];
+        const float4 *px = (const float4 *)(a.pk + P.bx) + (size_t)(c * 2) * 64 + lane;
+        bxa = px[0];
+        bxb = px[64];
+        wo = ((const float4 *)(a.pk + P.bo))[(size_t)c * 64 + lane];
+        const float4 *ps = (const float4 *)(a.pk + P.bs) + (size_t)(c * 4) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wsl[q] = ps[q * 64];
+    }
+
+    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void *)a.ws, 0, 0x7fffffff, 0x00020000);
+    const unsigned lds0 = (unsigned)(unsigned long long)(const void *)&sbuf[0][0];
+    const unsigned cb = 4 * x;
+    const unsigned lane16 = lane * 16;
+    bool alive = true;
+
+    // The gather of phase (gi, n): 48 pieces of 1 KB (16 units x 4 clips) - 32 of da2_{T-n}, 16 of da1_{T+2-n} - twelve per wave,
+    // THROUGH REGISTERS: sc1 loads (L2-served, never this CU's L1) issued back to back, one round trip, then ds_write_b128.
+    // (LDS-DMA pieces cost ~180 cycles each here - every piece rewrites M0 - measured 6 700 cycles for 24 pieces on one wave.)
+    auto gather_issue = [&](int gi, int n, xcd_u32x4 (&r)[12]) {
+        const unsigned gg = gi * 8 + x;
+        const int s2 = T - n >= 0 ? T - n : 0;
+        const int s1 = n >= 2 ? (T + 2 - n >= 0 ? T + 2 - n : 0) : T;
+        // wave w: pieces 12 w .. 12 w + 11 (waves 0, 1: da2 0..23; wave 2: da2 24..31 + da1 0..3; wave 3: da1 4..15)
+        const unsigned o2 = a.da2x_off + (gg * (T + 1) + s2) * 32768 + 12 * w * 1024;
+        const unsigned o1 = a.da1x_off + (gg * (T + 1) + s1) * 16384 + (w == 2 ? 0 : 4 * 1024);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const bool is2 = w < 2 || (w == 2 && q < 8);
+            const unsigned so = is2 ? o2 + q * 1024 : o1 + (w == 2 ? q - 8 : q) * 1024;
+            r[q] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, __builtin_amdgcn_readfirstlane(so), 16);
+        }
+    };
+    auto gather_land = [&](int buf, const xcd_u32x4 (&r)[12]) {
+        float4 *S = &sbuf[buf][0] + lane;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const bool is2 = w < 2 || (w == 2 && q < 8);
+            const int piece = is2 ? 12 * w + q : (w == 2 ? q - 8 : 4 + q);
+            float4 v;
+            v.x = __uint_as_float(r[q].x); v.y = __uint_as_float(r[q].y); v.z = __uint_as_float(r[q].z); v.w = __uint_as_float(r[q].w);
+            S[(is2 ? X4D_DA2 : X4D_DA1) + piece * 64] = v;
+        }
+    };
+
+    // the saved activations a cell needs (gates, c_t, c_{t-1}, wave 0: dy), fetched one phase ahead - they come from HBM / the
+    // Infinity Cache
+    float4 cg = make_float4(0.f, 0.f, 0.f, 0.f), cdy = cg, ng_ = cg, ndy = cg;      // gates, dy of the current / next phase
+    float cct = 0.f, ccp = 0.f, nct = 0.f, ncp = 0.f;                                   // c_t, c_{t-1}
+    auto fetch = [&](int gi, int n, float4 &g, float4 &dy, float &ct, float &cp) {
+        const int rb = gi;
+        if (w == 0) {
+            const int t = T - 1 - n;
+            if (t >= 0 && t < T) {
+                const size_t u = 16 * c + b;
+                g = ((const float4 *)(a.ws + a.g2_off))[(((size_t)t * RB + rb) * 512 + u) * 32 + cb + j];
+                dy = ((const float4 *)(a.ws + a.dy_off))[((size_t)t * RB + rb) * 32 + cb + j];
+                ct = ((const float *)(a.ws + a.c2_off))[(((size_t)(t + 1) * RB + rb) * 512 + u) * 32 + cb + j];
+                cp = ((const float *)(a.ws + a.c2_off))[(((size_t)t * RB + rb) * 512 + u) * 32 + cb + j];
+            }
+        } else if (w == 1) {
+            const int t = T + 1 - n;
+            if (t >= 0 && t < T && lane < 32) {
+                const size_t u = 8 * c + b;
+                g = ((const float4 *)(a.ws + a.g1_off))[(((size_t)t * RB + rb) * 256 + u) * 32 + cb + j];
+                ct = ((const float *)(a.ws + a.c1_off))[(((size_t)(t + 1) * RB + rb) * 256 + u) * 32 + cb + j];
+                cp = ((const float *)(a.ws + a.c1_off))[(((size_t)t * RB + rb) * 256 + u) * 32 + cb + j];
+            }
+        }
+    };
+
+    {
+        xcd_u32x4 r0[12];
+        gather_issue(0, 0, r0);
+        gather_land(0, r0);
+    }
+    fetch(0, 0, cg, cdy, cct, ccp);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (sAbort) return;
+    const bool local = __builtin_amdgcn_readfirstlane(sLocal) != 0;
+    const bool tracer = a.trace && blockIdx.x == 0 && tid == 0;
+    const int nph = (T + 2) * ng;
+    const bool tracer3 = a.trace && blockIdx.x == 0 && tid == 192;     // wave 3's stamps follow wave 0's: [nph][8]
+    unsigned long long *tr3 = a.trace + (long)nph * 8;
+
+    int gi = 0, n = 0;
+    for (int p = 0; p < nph; ++p) {
+        const int buf = p & 1;
+        int gn = gi + 1, nn = n;
+        if (gn == ng) { gn = 0; ++nn; }
+        const bool more = p + 1 < nph;
+        if (tracer) a.trace[(long)p * 8 + 0] = clock64();
+        if (more) fetch(gn, nn, ng_, ndy, nct, ncp);
+        // ================================ products =======================================================================
+        {
+            const float4 *S = &sbuf[buf][0];
+            const float4 *F2 = S + X4D_DA2 + (128 * w + (b >> 2)) * 4 + j;      // unit' = 128 w + 4 m + kk: + 16 m
+            const float4 *F1 = S + X4D_DA1 + (64 * w + (b >> 1)) * 4 + j;       // unit' = 64 w + 8 m + kk: + 32 m
+            x4_f32x4 c2[4], c1[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c2[q] = (x4_f32x4){0.f, 0.f, 0.f, 0.f};
+            c1[0] = c1[1] = (x4_f32x4){0.f, 0.f, 0.f, 0.f};
+            auto frag = [&](int idx) -> const float4 * { return idx < 32 ? F2 + idx * 16 : F1 + (idx - 32) * 32; };
+            float4 bf[X4_RING];
+#pragma unroll
+            for (int i = 0; i < X4_AHEAD; ++i) bf[i] = *frag(i);
+#pragma unroll
+            for (int idx = 0; idx < 40; ++idx) {
+                if (idx + X4_AHEAD < 40) bf[(idx + X4_AHEAD) % X4_RING] = *frag(idx + X4_AHEAD);
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 bq = bf[idx % X4_RING];
+                if (idx < 32) {
+                    X4_MFMA(c2[0], b2[idx < 32 ? idx : 0].x, bq.x);
+                    X4_MFMA(c2[1], b2[idx < 32 ? idx : 0].y, bq.y);
+                    X4_MFMA(c2[2], b2[idx < 32 ? idx : 0].z, bq.z);
+                    X4_MFMA(c2[3], b2[idx < 32 ? idx : 0].w, bq.w);
+                } else {
+                    const int m = idx - 32;
+                    X4_MFMA(c1[0], b1[m].x, bq.x);
+                    X4_MFMA(c1[1], b1[m].y, bq.y);
+                    X4_MFMA(c1[0], b1[m].z, bq.z);
+                    X4_MFMA(c1[1], b1[m].w, bq.w);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float4 *pp = &sP[w][0][lane];
+            pp[0] = make_float4((c2[0][0] + c2[1][0]) + (c2[2][0] + c2[3][0]), (c2[0][1] + c2[1][1]) + (c2[2][1] + c2[3][1]),
+                                (c2[0][2] + c2[1][2]) + (c2[2][2] + c2[3][2]), (c2[0][3] + c2[1][3]) + (c2[2][3] + c2[3][3]));
+            pp[64] = make_float4(c1[0][0] + c1[1][0], c1[0][1] + c1[1][1], c1[0][2] + c1[1][2], c1[0][3] + c1[1][3]);
+        }
+        if (tracer) a.trace[(long)p * 8 + 1] = clock64();
+        __syncthreads();                        // barrier 1
+        if (tracer) a.trace[(long)p * 8 + 2] = clock64();
+        if (sAbort) return;
+        const unsigned gg = gi * 8 + x;
+        const int rb = gi;
+        const float *PF = (const float *)&sP[0][0][0];
+
+        float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool saved = false;
+        if (w == 0) {
+            // ---- LSTM2 cell backward at t = T-1-n: lane = (unit 16 c + b, clip j); its dh row sits in D register b & 3 of the
+            //      lanes (row quad b >> 2, k subset kk, clip j) of every wave --------------------------------------------------
+            const int t = T - 1 - n;
+            if (t >= 0 && t < T && alive) {
+                float rec = 0.f;
+                const float *pr = PF + (4 * (b >> 2) + j) * 4 + (b & 3);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) rec += pr[(q * 2 * 64 + 16 * kk) * 4];
+                // upstream: prediction_layer (learned_models.py:47): dh += W_out^T dy_t
+                float dh = wo.x * cdy.x;
+                dh = fmaf(wo.y, cdy.y, dh);
+                dh = fmaf(wo.z, cdy.z, dh);
+                dh = fmaf(wo.w, cdy.w, dh);
+                dh += rec;
+                float dco;
+                da = cell_backward(dh, sDC2[gi][lane], cg, cct, ccp, &dco);
+                sDC2[gi][lane] = dco;
+                saved = true;
+                xcd_store16(rws, lane16, a.da2x_off + ((gg * (T + 1) + t) * 512 + 16 * c) * 64, da, local);
+            }
+        } else if (w == 1) {
+            // ---- LSTM1 cell backward at t = T+1-n: lanes 0..31 = (unit 8 c + b, clip j) -------------------------------------
+            const int t = T + 1 - n;
+            if (t >= 0 && t < T && alive) {
+                // the 32 partials of a dh row (4 waves x 8 k subsets): each lane half sums 16 of them, then the halves meet
+                float rec = 0.f;
+                const int lq = lane & 31, lb = lq >> 2, hf = lane >> 5;
+                const float *pr = PF + (64 + 4 * (lb >> 2) + j + 32 * hf) * 4 + (lb & 3);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) rec += pr[(q * 2 * 64 + 8 * kk) * 4];
+                rec += __shfl_xor(rec, 32);
+              if (lane < 32) {
+                // upstream: object_to_track_prediction (learned_models.py:40): dh += W_sel^T dl_t
+                const float4 *dl = (const float4 *)&sDL[gi][(n + 1) & 1][j][0];   // written by wave 2 one phase ago
+                float dh = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 d = dl[q];
+                    dh = fmaf(wsl[q].x, d.x, dh);
+                    dh = fmaf(wsl[q].y, d.y, dh);
+                    dh = fmaf(wsl[q].z, d.z, dh);
+                    dh = fmaf(wsl[q].w, d.w, dh);
+                }
+                dh += rec;
+                float dco;
+                da = cell_backward(dh, sDC1[gi][lane], cg, cct, ccp, &dco);
+                sDC1[gi][lane] = dco;
+                saved = true;
+                xcd_store16(rws, lane16, a.da1x_off + ((gg * (T + 1) + t) * 256 + 8 * c) * 64, da, local);
+              }
+            }
+        }
+        if (tracer) a.trace[(long)p * 8 + 3] = clock64();
+        // ================================ publish =========================================================================
+        if (w < 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0 && alive) {
+                if (__hip_atomic_fetch_add(&sArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1u) {
+                    __hip_atomic_store(&sArrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    xcd_store_flag(a.flags + gg * 32 + c, (unsigned)(n + 1), local);
+                }
+            }
+            if (tracer) a.trace[(long)p * 8 + 4] = clock64();
+            if (w == 0) {
+                // the CU's part of dfb_t = W_ih2^T da2_t: MFMA block = unit, k = gate, B = the da registers themselves;
+                // D[unit b][feature][clip j], then the sum over the 16 units through LDS
+                x4_f32x4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
+                X4_MFMA(d1, bxa.x, da.x); X4_MFMA(d2, bxb.x, da.x);
+                X4_MFMA(d1, bxa.y, da.y); X4_MFMA(d2, bxb.y, da.y);
+                X4_MFMA(d1, bxa.z, da.z); X4_MFMA(d2, bxb.z, da.z);
+                X4_MFMA(d1, bxa.w, da.w); X4_MFMA(d2, bxb.w, da.w);
+                sX[0][lane] = make_float4(d1[0], d1[1], d1[2], d1[3]);
+                sX[1][lane] = make_float4(d2[0], d2[1], d2[2], d2[3]);
+                XCD_WAVE_LDS_SYNC();
+                if (lane < 32) {                // lane = (feature f = lane >> 2, clip j)
+                    const float *px = (const float *)&sX[lane >> 4][0] + j * 4 + ((lane >> 2) & 3);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) sum += px[u * 16];
+                    const int t = T - 1 - n;
+                    if (t >= 0 && t < T && alive)
+                        xcd_store4(rws, lane * 4, a.dfx_off + ((gg * (T + 1) + t) * 32 + c) * 128, sum, local);
+                }
+                // its flag (flags2) follows the wait at the end of the phase: nobody needs it before the next phase's finish
+            }
+        } else if (w == 2) {
+            // ---- head backward at t = T-n: dfb_t = sum of the 32 CUs' parts (published one phase ago, second flag) -------------
+            const int t = T - n;
+            if (t >= 0 && t < T && alive) {
+                alive = xcd_wait_flags(a.flags2 + gg * 32, (unsigned)n, a.status, p);
+                if (alive) {
+                    // lane = (CU half h, feature f, clip j): 16 CUs each
+                    const unsigned base = a.dfx_off + ((gg * (T + 1) + t) * 32 + 16 * (lane >> 5)) * 128;
+                    float v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        v[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rws, (lane & 31) * 4, base + q * 128, 16));   // sc1
+                    // this step's slot probabilities and boxes (lanes 0..15 = (slot quad rg, clip j)): left in LDS by wave 3 one
+                    // phase ago (they come from HBM)
+                    float4 hp = make_float4(0.f, 0.f, 0.f, 0.f), hx[6];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) hx[q] = hp;
+                    if (lane < 16) {
+                        const int rg = lane >> 2;
+                        hp = sHX[gi][n & 1][24 + rg][j];
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) hx[q] = sHX[gi][n & 1][6 * rg + q][j];
+                    }
+                    float sum = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) sum += v[q];
+                    sDFB[lane >> 5][lane & 31] = sum;
+                    XCD_WAVE_LDS_SYNC();
+                    if (lane < 16) {
+                        const int rg = lane >> 2;
+                        float dfb[OPNET_FEATS_];
+#pragma unroll
+                        for (int f = 0; f < OPNET_FEATS_; ++f) dfb[f] = sDFB[0][f * 4 + j] + sDFB[1][f * 4 + j];
+                        // einsum backward: dp[o] = sum_f boxes[o][f] dfb[f]; softmax backward: dl = p * (dp - <p, dp>)
+                        const float xf[24] = {hx[0].x, hx[0].y, hx[0].z, hx[0].w, hx[1].x, hx[1].y, hx[1].z, hx[1].w,
+                                              hx[2].x, hx[2].y, hx[2].z, hx[2].w, hx[3].x, hx[3].y, hx[3].z, hx[3].w,
+                                              hx[4].x, hx[4].y, hx[4].z, hx[4].w, hx[5].x, hx[5].y, hx[5].z, hx[5].w};
+                        const float pv[4] = {hp.x, hp.y, hp.z, hp.w};
+                        float dp[4], dot = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int f = 0; f < OPNET_FEATS_; ++f) acc = fmaf(xf[6 * r + f], dfb[f], acc);
+                            dp[r] = acc;
+                            dot = fmaf(pv[r], acc, dot);          // p of the non-existent slot 15 is 0
+                        }
+                        dot += __shfl_xor(dot, 4);
+                        dot += __shfl_xor(dot, 8);
+                        float4 dl;
+                        dl.x = pv[0] * (dp[0] - dot);
+                        dl.y = pv[1] * (dp[1] - dot);
+                        dl.z = pv[2] * (dp[2] - dot);
+                        dl.w = rg < 3 ? pv[3] * (dp[3] - dot) : 0.f;
+                        *(float4 *)&sDL[gi][n & 1][j][4 * rg] = dl;
+                        if (c == (n & 31))
+                            ((float4 *)(a.ws + a.dl_off))[(((size_t)t * RB + rb) * 4 + rg) * 32 + cb + j] = dl;
+                    }
+                } else sAbort = 1;
+            }
+        }
+        // ================================ next phase's gather =============================================================
+        float4 hxa = make_float4(0.f, 0.f, 0.f, 0.f), hxb = hxa;
+        const int tn = T - nn;                                 // the next phase's head step
+        const bool hfetch = w == 3 && more && tn >= 0 && tn < T;
+        if (tracer3) tr3[(long)p * 8 + 0] = clock64();
+        if (hfetch) {
+            // lane = (k-quad or slot quad q, clip j): boxes k-quads 0..15 | boxes k-quads 16..23 and p
+            const float4 *xs = (const float4 *)(a.ws + a.xp_off) + ((size_t)tn * RB + gn) * (OPNET_KXQ * 32) + cb + j;
+            hxa = xs[b * 32];
+            if (b < 8) hxb = xs[(16 + b) * 32];
+            else if (b < 12) hxb = ((const float4 *)(a.ws + a.ps_off))[(((size_t)tn * RB + gn) * 4 + (b - 8)) * 32 + cb + j];
+        }
+        xcd_u32x4 gr[12];
+        bool got = false;
+        if (more && alive) {
+            if (nn > 0) alive = xcd_wait_flags(a.flags + (gn * 8 + x) * 32, (unsigned)nn, a.status, p);
+            if (tracer) a.trace[(long)p * 8 + 5] = clock64();
+            if (alive) { gather_issue(gn, nn, gr); got = true; }
+            else sAbort = 1;
+            if (tracer3) tr3[(long)p * 8 + 1] = clock64();
+        }
+        // da replaces the saved gates (the weight-gradient GEMMs read it there): under the gather's round trip
+        if (saved) {
+            if (w == 0) {
+                const int t = T - 1 - n;
+                ((float4 *)(a.ws + a.g2_off))[(((size_t)t * RB + rb) * 512 + 16 * c + b) * 32 + cb + j] = da;
+            } else {
+                const int t = T + 1 - n;
+                ((float4 *)(a.ws + a.g1_off))[(((size_t)t * RB + rb) * 256 + 8 * c + b) * 32 + cb + j] = da;
+            }
+        }
+        if (got) gather_land(buf ^ 1, gr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tracer3) tr3[(long)p * 8 + 2] = clock64();
+        if (hfetch) {
+            sHX[gn][nn & 1][b][j] = hxa;
+            if (b < 12) sHX[gn][nn & 1][16 + b][j] = hxb;
+        }
+        if (w == 0 && lane == 0 && alive) xcd_store_flag(a.flags2 + gg * 32 + c, (unsigned)(n + 1), local);   // the dfb part is out
+        if (tracer) a.trace[(long)p * 8 + 6] = clock64();
+        __syncthreads();                        // barrier 2
+        if (tracer) a.trace[(long)p * 8 + 7] = clock64();
+        if (tracer3) tr3[(long)p * 8 + 3] = clock64();
+        if (sAbort) return;
+        gi = gn;
+        n = nn;
+        cg = ng_; cdy = ndy; cct = nct; ccp = ncp;
+    }
+}

@@ -62,16 +62,31 @@ def main():
         print(f"B={B} T={T}: forward persistent {res['1'][0]:.3f} ms / chain {res['0'][0]:.3f} ms | fwd+loss+bwd persistent "
               f"{res['1'][1]:.3f} ms / chain {res['0'][1]:.3f} ms", flush=True)
         ng = (B + 31) // 32
-        tr = torch.zeros((T + 2) * ng * 8, dtype=torch.int64, device=dev)
+        tr = torch.zeros((T + 2) * ng * 8 * 2, dtype=torch.int64, device=dev)
         lib.opnet_xcd4_set_trace(tr.data_ptr())
         fwd()
         torch.cuda.synchronize()
         lib.opnet_xcd4_set_trace(None)
-        t = tr.cpu().numpy().reshape(-1, 8)
+        t = tr.cpu().numpy().reshape(-1, 8)[:(T + 2) * ng]
         ph = t[len(t) // 3: 2 * len(t) // 3]
         med = lambda v: float(np.median(v))
         parts = [med(ph[:, i + 1] - ph[:, i]) for i in range(7)] + [med(ph[1:, 0] - ph[:-1, 7])]
         print(f"  forward, block 0 wave 0, cycles (median): period {med(np.diff(ph[:, 0])):.0f} | "
+              + ", ".join(f"{n} {v:.0f}" for n, v in zip(NAMES, parts)), flush=True)
+        tr.zero_()
+        lib.opnet_xcd4_set_trace(tr.data_ptr())
+        step()          # the backward kernel stamps the same buffer after the forward
+        torch.cuda.synchronize()
+        lib.opnet_xcd4_set_trace(None)
+        t = tr.cpu().numpy().reshape(-1, 8)
+        nphase = len(t) // 2
+        t3 = t[nphase:][nphase // 3: 2 * nphase // 3]
+        t = t[:nphase]
+        ph = t[len(t) // 3: 2 * len(t) // 3]
+        print(f"  backward, wave 3 after barrier 1: gather issued {med(t3[:, 1] - t3[:, 0]):.0f}, landed {med(t3[:, 2] - t3[:, 1]):.0f}, "
+              f"barrier 2 wait {med(t3[:, 3] - t3[:, 2]):.0f}; wave 0's flag at {med(ph[:, 4] - ph[:, 2]):.0f} after barrier 1", flush=True)
+        parts = [med(ph[:, i + 1] - ph[:, i]) for i in range(7)] + [med(ph[1:, 0] - ph[:-1, 7])]
+        print(f"  backward, block 0 wave 0, cycles (median): period {med(np.diff(ph[:, 0])):.0f} | "
               + ", ".join(f"{n} {v:.0f}" for n, v in zip(NAMES, parts)), flush=True)
 
 
