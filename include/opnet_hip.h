@@ -96,6 +96,9 @@ void opnet_xcd_set_trace(void *device_buffer);
 /* tools: the same for the 4-clip persistent training kernels (opnet_train_forward_f32 / opnet_train_backward_f32 on
  * batches of up to 32 clips): >= (T+2) * ceil(B/32) * 8 uint64 */
 void opnet_xcd4_set_trace(void *device_buffer);
+/* tools / tests: status words of this process's most recent 4-clip persistent launch (synchronises the device): [0] abort
+ * code (0 = ok), [1] first failing block, [2] phase, [3] groups that ran the write-through protocol (not XCD-local) */
+int opnet_xcd4_last_status(unsigned *out4);
 
 /* ---- training (replaces torch autograd through OPNet.forward, nn.L1Loss and torch.optim.Adam as used
  *      at training_main.py:150-152,183-217) ---------------------------------------------------------

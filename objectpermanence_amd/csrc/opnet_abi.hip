@@ -646,7 +646,7 @@ static TrainPackedLayout train_packed_layout(int H1, int H2)
 
 struct TrainWorkspaceLayout {  // offsets in bytes
     size_t io, xp, state, h1all, c1all, h2all, c2all, state_end, x2all, g1, g2, psave, ystage, lgstage,
-        dyp, dlall, dhpart2, dhpart1, dx2part, dcz, dc2, dc1, dcz_end, l1part, x4h1x, x4h2x, x4flags, x4status, x4da1x, x4da2x, x4dfx, x4flags2, total;
+        dyp, dlall, dhpart2, dhpart1, dx2part, dcz, dc2, dc1, dcz_end, l1part, x4h1x, x4h2x, x4status, x4da1x, x4da2x, x4dfx, total;
 };
 
 // the 4-clip persistent step carries up to X4_NGMAX row blocks; its exchange buffers exist only for such batches
@@ -682,15 +682,13 @@ static TrainWorkspaceLayout train_workspace_layout(int B, int T, int H1, int H2)
     L.dcz_end = o;
     L.l1part = o;  o += 1024 * 4;
     o = align_up(o, 4096);
-    const size_t NG = x4_batch(B, H1, H2) ? RB * 8 : 0;     // 4-clip groups
-    L.x4h1x = o;   o += NG * (TT + 1) * 4096;
-    L.x4h2x = o;   o += NG * (TT + 1) * 8192;
-    L.x4flags = o; o += align_up(NG * 32 * 4, 256);
+    const size_t NG = x4_batch(B, H1, H2) ? RB * 8 : 0;     // 4-clip groups; exchange rings of X4_SLOTS steps
+    L.x4h1x = o;   o += NG * X4_SLOTS * 4096;
+    L.x4h2x = o;   o += NG * X4_SLOTS * 8192;
     L.x4status = o; o += NG ? 2048 : 0;
-    L.x4flags2 = o; o += align_up(NG * 32 * 4, 256);
-    L.x4da1x = o;  o += NG * (TT + 1) * 16384;
-    L.x4da2x = o;  o += NG * (TT + 1) * 32768;
-    L.x4dfx = o;   o += NG * (TT + 1) * 4096;
+    L.x4da1x = o;  o += NG * X4_SLOTS * 16384;
+    L.x4da2x = o;  o += NG * X4_SLOTS * 32768;
+    L.x4dfx = o;   o += NG * X4_SLOTS * 4096;
     L.total = align_up(o, 256);
     return L;
 }
@@ -793,6 +791,17 @@ static int make_train_args(StepArgs *a, OpnetIO *io, BwdArgs *bw, const float *b
 // tools: in-kernel timeline of block 0 of the 4-clip persistent kernels (device buffer of >= (T + 2) * row blocks * 8 u64)
 static unsigned long long *g_x4_trace = nullptr;
 extern "C" void opnet_xcd4_set_trace(void *device_buffer) { g_x4_trace = (unsigned long long *)device_buffer; }
+// tools / tests: the status words of the most recent 4-clip persistent launch of this process (synchronises the device):
+// [0] abort code (0 = ok), [1] first failing block, [2] phase, [3] groups that were not XCD-local (write-through protocol)
+static unsigned *g_x4_last_status = nullptr;
+extern "C" int opnet_xcd4_last_status(unsigned *out4)
+{
+    if (!out4) return fail(OPNET_EINVAL, "null pointer");
+    if (!g_x4_last_status) { out4[0] = out4[1] = out4[2] = out4[3] = 0u; return OPNET_OK; }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out4, g_x4_last_status, 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return OPNET_OK;
+}
 
 // Does the training step of this batch run on the 4-clip persistent kernels?  Reference hidden sizes, a whole device (8 XCDs
 // x 32 CUs), at most OPNET_XCD4_MAX_B clips (default 32: one group per XCD - larger batches serialise their row blocks and
@@ -824,10 +833,11 @@ static int make_x4_args(Xcd4Args *x, const float *packed, void *ws, int B, int T
     x->ps_off = (unsigned)W.psave; x->x2_off = (unsigned)W.x2all;
     x->lg_off = (unsigned)W.lgstage; x->ys_off = (unsigned)W.ystage;
     x->h1x_off = (unsigned)W.x4h1x; x->h2x_off = (unsigned)W.x4h2x;
-    x->flags_off = (unsigned)W.x4flags;
-    x->flags = (unsigned *)((char *)ws + W.x4flags);
     x->status = (unsigned *)((char *)ws + W.x4status);
     x->force_safe = env_int("OPNET_XCD_SAFE", 0);
+    x->delay = env_int("OPNET_X4_DELAY", 0);
+    x->debug = env_int("OPNET_X4_DEBUG", 0);
+    g_x4_last_status = x->status;
     x->trace = g_x4_trace;
     return OPNET_OK;
 }
@@ -845,11 +855,10 @@ static void make_x4b_args(Xcd4BArgs *x, const float *packed, void *ws, int B, in
     x->g1_off = (unsigned)W.g1; x->g2_off = (unsigned)W.g2;
     x->ps_off = (unsigned)W.psave; x->dy_off = (unsigned)W.dyp; x->dl_off = (unsigned)W.dlall;
     x->da1x_off = (unsigned)W.x4da1x; x->da2x_off = (unsigned)W.x4da2x; x->dfx_off = (unsigned)W.x4dfx;
-    x->flags = (unsigned *)((char *)ws + W.x4flags);
-    x->flags2 = (unsigned *)((char *)ws + W.x4flags2);
     x->status = (unsigned *)((char *)ws + W.x4status);
     x->force_safe = env_int("OPNET_XCD_SAFE", 0);
     x->trace = g_x4_trace;
+    g_x4_last_status = x->status;
 }
 
 extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, float *y, float *logits,

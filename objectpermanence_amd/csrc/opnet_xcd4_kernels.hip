@@ -1,56 +1,53 @@
-// opnet_xcd4_kernels.hip - the per-XCD persistent OPNet step for SMALL batches (the training batch of 32 clips): groups of
-// FOUR clips, one group per XCD and row block, every weight resident in registers for all T steps.
+// opnet_xcd4_kernels.hip - the per-XCD persistent OPNet TRAINING step for small batches (the reference's batch of 32 clips):
+// groups of FOUR clips, one group per XCD and row block, every weight resident in registers for all T steps - forward and
+// backward recurrence as one launch each.
 //
-// What is computed: reference baselines/learned_models.py:35-52 (forward) - the same function as opnet_kernels.hip and
-// opnet_xcd_kernels.hip - here in the TRAINING form of opnet_train_forward_f32: every step's activations are kept in the
-// launch chain's own history layouts (opnet_ctx.h StepArgs, "train"), so that the backward pass and the weight-gradient
-// GEMMs (opnet_train_kernels.hip) run on them unchanged.
+// What is computed: reference baselines/learned_models.py:35-52 (forward) and torch autograd through it under
+// training_main.py:216 (backward; restated in oracle/torch_port.py) - the same functions as opnet_kernels.hip /
+// opnet_train_kernels.hip, on the launch chain's own history layouts (opnet_ctx.h StepArgs "train", BwdArgs), so that the loss,
+// the weight-gradient GEMMs (opnet_wgrad) and Adam run on the result unchanged.
 //
 // Why a third form.  The 16-clip persistent kernel (opnet_xcd_kernels.hip) needs >= 3 groups per XCD
 // (384 clips) to hide its exchange; a 32-clip batch is 2 groups - 2 XCDs busy, 5.5 us per step - and the launch chain pays
-// a kernel boundary + a 5.68 MB weight fetch per step (4.9 us).  A 32-clip batch cut into EIGHT groups of 4 clips puts every
-// XCD to work with a quarter of the matrix work per step: v_mfma_f32_4x4x1_16b_f32 = 16 independent 4x4 outer products per
-// instruction, used as 64 gate rows x 1 k x 4 clips (measured 9.5 cycles per instruction, tools/probes/mfma4x4_probe.hip),
-// so the 188 MFMAs of a step cost ~1 800 cycles instead of 6 000 and the step is the exchange latency + that.
+// a kernel boundary + a 5.68 MB weight fetch per step (4.9 us forward, 5.1 us backward).  A 32-clip batch cut into EIGHT
+// groups of 4 clips puts every XCD to work with a quarter of the matrix work per step: v_mfma_f32_4x4x1_16b_f32 = 16
+// independent 4x4 outer products per instruction (measured 9.5 cycles per instruction, tools/probes/mfma4x4_probe.hip), so
+// the ~190 MFMAs of a step cost ~2 000 cycles instead of 6 000 and the step is that + the exchange latency.
 //
 // One workgroup = 4 waves on one CU (one per SIMD), 256 workgroups; XCD x = blockIdx.x & 7 runs clips 4x .. 4x+3 of every
-// row block (group gi = row block gi), CU c = blockIdx.x >> 3 owns
-//     LSTM2 units 16c .. 16c+15 (64 gate rows), K = 512 split over the 4 waves              128 VGPRs a wave
-//     LSTM1 units  8c ..  8c+7  (32 gate rows), K = 96 + 256 split over the 4 waves           44 VGPRs
-//     the selection head (every CU, redundantly): 16 (15) rows, K = 256 split over the waves  16 VGPRs
-//     wave 0: W_ih2 of the CU's 64 gate rows (K = 6 -> 8)                                       8 VGPRs
+// row block (group gi = row block gi), CU c = blockIdx.x >> 3 owns LSTM2 units 16c .. 16c+15 and LSTM1 units 8c .. 8c+7.
 // MFMA operand layout (probe): lane = 4 b + i holds A[block b][row i], lane 4 b + j holds B[block b][col j], D[b][i][j] sits in
-// lane 4 b + j, register i.  LSTM2: block = unit, row = gate, one k per instruction, B = h2[k][clip j] in every block (a
-// ds_read_b128 of the [k/4][clip] float4 buffer, the same address in all 16 blocks).  LSTM1: block = (unit, k half).  Head:
-// block = (slot quad, k quarter).
-// Phase (row block gi, step s), T + 2 steps:  LSTM1 step s | selection head step s-1 | LSTM2 step s-2.
-//     1. products out of the LDS gather buffer of the phase (x[s], h1[s-1], h2[s-3], x[s-1]) and the CU's own
-//        frames_boxes[s-2] (LDS) -> K-split partials to LDS, barrier;
-//     2. wave 0: LSTM2 cell (lane = unit b, clip j), wave 1: LSTM1 cell, wave 2: head sum, softmax, einsum ->
-//        frames_boxes[s-1] to LDS, wave 3: LDS-DMA of the next phase's x pieces;
-//     3. waves 0, 1 publish h into the exchange buffers ([group][slot][k/4][4 clips] float4: a CU's piece is whole 128-B
-//        lines), drain, arrive; the second one stores the CU's flag (Guideline 16 recipe R1, as in opnet_xcd_kernels.hip:
-//        XCD-local plain stores when the placement check passed, write-through otherwise); THEN the history stores the
-//        backward needs (gates, c, h, p, frames_boxes, logits - off the critical path);
-//     4. every wave polls the 32 flags of the next phase's group, issues its LDS-DMA pieces, waits, barrier.
-// Every spin is bounded (xcd_wait_flags); an aborted launch poisons y with NaN (opnet_xcd4_out_head).
+// lane 4 b + j, register i; the clip is always the column j.
 //
-// Summation order: LSTM2 gate = ((w0 + w1) + w2) + w3 over the K quarters, each quarter (c0 + c1) + (c2 + c3) over four
-// interleaved ascending-k chains (k mod 4), wave 0's chains continued by the W_ih2 part; LSTM1 gate = sum over waves of
-// (low k half + high k half), each half two chains; logits = sum over waves, over k quarters of the wave's slice.
+// The exchange between the 32 CUs of an XCD (h forward, da backward) - "the data is the flag":
+//   * ring buffers of 4 steps, [k/4 or unit][4 clips] float4, a CU's piece = whole 128-B lines; every word holds the
+//     SENTINEL 0xffffffff (a NaN no cell produces) until its step is published;
+//   * a producer just stores its piece (plain stores that stay in this XCD's L2 when the placement check passed, write-through
+//     otherwise - as in opnet_xcd_kernels.hip) and, with it, re-arms its piece of the slot two steps on with the sentinel;
+//     nothing is drained, no flag is written;
+//   * a consumer loads its pieces with sc1 (L2-served) loads into registers, and any lane that still sees a sentinel word
+//     makes the wave load that piece again (bounded: XCD_SPIN_LIMIT, then the abort word and NaN in y); then ds_write.
+//   Against payload + drain + flag + poll + gather (Guideline 16 recipe R1, the first version of this file) this takes a
+//   store-acknowledge and a flag round trip out of every step: measured 6 700 -> [see DESIGN.md] cycles per forward step.
+//   Re-arming is safe with the slot two steps ahead: a CU publishes step k only after it has gathered every CU's step k-1, i.e.
+//   after every CU has finished READING step k-2 (its gather precedes its publish), and the workgroup's end-of-phase
+//   s_waitcnt vmcnt(0) orders a CU's re-arm before its next publish, which every reader of the re-armed slot has to see first.
+//   (LDS-DMA gathers cost ~180 cycles per 1-KB piece here - each rewrites M0 - so the gather goes through registers.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "opnet_ctx.h"
 
 #define X4_NGMAX 4             // row blocks (groups per XCD) one launch carries: B <= 128
-#define X4_NBUF 6              // LDS gather buffers allocated (two are used): 96 KB keep a second workgroup off the CU
-// LDS gather buffer of one phase, float4 units: [k-quad][4 clips]
+#define X4_SENT 0xffffffffu    // "not published yet"
+#define X4_SLOTS 4             // exchange ring depth (steps)
+// LDS gather buffer of a forward phase, float4 units: [k-quad][4 clips]
 #define X4B_X0 0               // x[s]      24 k-quads
 #define X4B_H1 96              // h1[s-1]   64
 #define X4B_H2 352             // h2[s-3]  128
 #define X4B_X1 864             // x[s-1]    24 (the head's einsum)
 #define X4B_F4 1024            // 16 KB
+#define X4_NBUF 6              // buffers allocated (two are used): 96 KB keep a second workgroup off the CU
 #ifndef X4_RING
 #define X4_RING 6
 #endif
@@ -82,16 +79,69 @@ struct Xcd4Args {
     unsigned g1_off, g2_off;   // [T][RB][H][32] float4 post-activation gates
     unsigned ps_off, x2_off;   // [T][RB][4][32], [T][RB][2][32] float4
     unsigned lg_off, ys_off;   // logits / y staging
-    unsigned h1x_off, h2x_off; // exchange: [RB*8 groups][T+1][H/4][4] float4
-    unsigned flags_off;        // [RB*8][32] u32
-    unsigned *flags;
+    unsigned h1x_off, h2x_off; // exchange rings: [RB*8 groups][4][H/4][4] float4, slot (t + 1) & 3 = step t
     unsigned *status;          // as XcdArgs.status
     int force_safe;
+    int delay;                 // s_sleep units (64 cycles) a wave idles before its first try at the next phase's h (tuning)
+    int debug;                 // tools only (wrong results): bit 0 no gather, 1 no history stores, 2 no cells, 3 no head, 4 no products
     unsigned long long *trace; // optional [phases][8] s_memtime stamps of block 0, wave 0
 };
 
 typedef float x4_f32x4 __attribute__((ext_vector_type(4)));
 #define X4_MFMA(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc, 0, 0, 0)
+
+__device__ __forceinline__ float4 x4_as_float4(xcd_u32x4 r)
+{
+    return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
+__device__ __forceinline__ bool x4_unpublished(xcd_u32x4 r) { return r.x == X4_SENT || r.y == X4_SENT || r.z == X4_SENT || r.w == X4_SENT; }
+
+// every 64th round of a sentinel poll: has somebody raised the abort word, is the wait over the limit?  false = give up.
+// The wall clock (s_memrealtime: hundreds of cycles) is first read at round 64 - a poll that succeeds never pays for it.
+__device__ __forceinline__ bool x4_keep_polling(unsigned spins, long long &t0, unsigned *status, int phase)
+{
+    if ((spins & 63u) != 0) return true;
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+    const long long now = (long long)wall_clock64();
+    if (spins == 64u) t0 = now;
+    if (now - t0 > XCD_SPIN_LIMIT) {
+        if ((threadIdx.x & 63) == 0) {
+            __hip_atomic_store(status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(status + 2, (unsigned)phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return false;
+    }
+    return true;
+}
+
+// NP pieces of 1 KB (lane l: 16 B at src + 1024 q + 16 l) -> registers, reloading every piece in which some lane still sees the
+// sentinel (need: bit q = piece q is part of this phase); then into LDS at dst + 64 q float4.  false = abort (wave-uniform).
+template <int NP>
+__device__ __forceinline__ bool x4_gather(__amdgpu_buffer_rsrc_t rws, unsigned lane16, unsigned src, unsigned need, float4 *dst,
+                                          unsigned *status, int phase, unsigned long long *tr = nullptr)
+{
+    xcd_u32x4 r[NP];
+    unsigned todo = need;
+    long long t0 = 0;
+    unsigned spins = 1;
+    for (; todo; ++spins) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            if (todo & (1u << q)) r[q] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, src + q * 1024, 16);   // sc1
+        if (tr && spins == 1) tr[0] = clock64();
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            if ((todo & (1u << q)) && !__any(x4_unpublished(r[q]))) todo &= ~(1u << q);
+        if (tr && spins == 1) tr[1] = clock64();
+        if (todo && !x4_keep_polling(spins, t0, status, phase)) return false;
+    }
+    if (tr) tr[2] = spins;
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+        if (need & (1u << q)) dst[q * 64] = x4_as_float4(r[q]);
+    return true;
+}
 
 // fp32 weights -> the register images of opnet_xcd4_forward (see the layout notes above)
 __global__ void __launch_bounds__(256) opnet_xcd4_pack_fwd(float *__restrict__ out, const float *__restrict__ w_ih1,
@@ -129,18 +179,17 @@ __global__ void __launch_bounds__(256) opnet_xcd4_pack_fwd(float *__restrict__ o
     }
 }
 
-// flags, status words and the XCC sentinels; slot 0 of the exchange buffers (h(-1) = 0)
+// status words and the XCC sentinels; the exchange rings: slot 0 = the zero initial state, the others unpublished
 __global__ void __launch_bounds__(256) opnet_xcd4_init(Xcd4Args a)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
     const int NG = a.RB * 8;
-    for (int i = tid; i < NG * 32; i += n) a.flags[i] = 0u;
     if (tid < 8) a.status[tid] = 0u;
     for (int i = tid; i < 256; i += n) a.status[8 + i] = 0xffffffffu;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 *h1x = (float4 *)(a.ws + a.h1x_off), *h2x = (float4 *)(a.ws + a.h2x_off);
-    for (int i = tid; i < NG * 256; i += n) h1x[(size_t)(i >> 8) * (a.T + 1) * 256 + (i & 255)] = z;
-    for (int i = tid; i < NG * 512; i += n) h2x[(size_t)(i >> 9) * (a.T + 1) * 512 + (i & 511)] = z;
+    const xcd_u32x4 z = {0u, 0u, 0u, 0u}, sent = {X4_SENT, X4_SENT, X4_SENT, X4_SENT};
+    xcd_u32x4 *h1x = (xcd_u32x4 *)(a.ws + a.h1x_off), *h2x = (xcd_u32x4 *)(a.ws + a.h2x_off);
+    for (int i = tid; i < NG * X4_SLOTS * 256; i += n) h1x[i] = ((i >> 8) & (X4_SLOTS - 1)) == 0 ? z : sent;
+    for (int i = tid; i < NG * X4_SLOTS * 512; i += n) h2x[i] = ((i >> 9) & (X4_SLOTS - 1)) == 0 ? z : sent;
 }
 
 // lane i of every row of 16 lanes receives lane i + N of its row
@@ -153,13 +202,26 @@ __device__ __forceinline__ float x4_row_shl(float v)
 template <bool TRAIN>
 __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
 {
+    // Phase (row block gi, step s), T + 2 steps:  LSTM1 step s | selection head step s-1 | LSTM2 step s-2.
+    //   CU c: LSTM2 64 gate rows x K = 512 split over the 4 waves (128 VGPRs a wave), LSTM1 32 gate rows x K = 96 + 256 (44),
+    //   the selection head (every CU, redundantly) 16 rows x K = 256 (16), wave 0: W_ih2 of its 64 rows (8).
+    //   LSTM2: block = unit, row = gate, one k per instruction, B = h2[k][clip j] in every block (a ds_read_b128 of the
+    //   [k/4][clip] float4 buffer, the same address in all 16 blocks); LSTM1: block = (unit, k half); head: (slot quad, k quarter).
+    //   1. products out of the LDS buffer of the phase (x[s], h1[s-1], h2[s-3], x[s-1]) and the CU's own frames_boxes[s-2]
+    //      (LDS) -> K-split partials to LDS, barrier;
+    //   2. wave 0: LSTM2 cell (lane = unit b, clip j), wave 1: LSTM1 cell, wave 2: head sum, softmax, einsum -> frames_boxes[s-1]
+    //      to LDS, wave 3: the next phase's x and h1; the cell waves store h into the exchange ring, then the histories the
+    //      backward needs (gates, c, h; wave 2: p, frames_boxes, logits), then gather their pieces of the next phase's h2;
+    //   3. barrier.
+    // Summation order: LSTM2 gate = ((w0 + w1) + w2) + w3 over the K quarters, each quarter (c0 + c1) + (c2 + c3) over four
+    // interleaved ascending-k chains (k mod 4), wave 0's chains continued by the W_ih2 part; LSTM1 gate = sum over waves of
+    // (low k half + high k half), each half two chains; logits = sum over waves, over k quarters of the wave's slice.
     __shared__ __attribute__((aligned(1024))) float4 sbuf[X4_NBUF][X4B_F4];
     __shared__ __attribute__((aligned(16))) float4 sP[4][3][64];       // K-split partials: LSTM2 | LSTM1 | head
     __shared__ __attribute__((aligned(16))) float sFB[X4_NGMAX][4][8]; // frames_boxes of the group's previous head step
     __shared__ float sC2[X4_NGMAX][64];
     __shared__ float sC1[X4_NGMAX][32];
     __shared__ volatile int sAbort, sLocal;
-    __shared__ unsigned sArrive;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,7 +233,6 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
         if (lane == 0) {
             sLocal = loc > 0 && a.force_safe == 0;
             sAbort = loc < 0;
-            sArrive = 0u;
             if (loc == 0 && c == 0) atomicAdd(a.status + 3, 1u);
         }
     }
@@ -197,44 +258,44 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
     }
 
     const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void *)a.ws, 0, 0x7fffffff, 0x00020000);
-    const unsigned lds0 = (unsigned)(unsigned long long)(const void *)&sbuf[0][0];
     const unsigned cb = 4 * x;                                  // first clip of this XCD's groups within a row block
     const unsigned lane16 = lane * 16;
     const unsigned xlane = ((lane >> 2) * 32 + cb + (lane & 3)) * 16;   // [k-quad][32 clips] float4: k-quad lane >> 2, clip cb + (lane & 3)
+    const xcd_u32x4 sent4 = {X4_SENT, X4_SENT, X4_SENT, X4_SENT};
+    const float4 sentf = x4_as_float4(sent4);
     bool alive = true;
 
-    // this wave's LDS-DMA pieces (1 KB = 16 k-quads x 4 clips) of the gather of phase (gi, s) into buffer `buf`:
-    // wave 3: the four x pieces (no flag needed) and h pieces 8..11; waves 0, 1: h pieces 0..3, 4..7; wave 2 (the head) none
-    auto gather_x = [&](int gi, int s, int buf) {
-        const unsigned dst = lds0 + (unsigned)buf * (X4B_F4 * 16);
-        const int t0 = s < T ? s : T - 1, t1 = s > 0 ? (s - 1 < T ? s - 1 : T - 1) : 0;
-        const unsigned o0 = a.xp_off + (unsigned)((t0 * RB + gi) * OPNET_KXQ) * 512;
-        const unsigned o1 = a.xp_off + (unsigned)((t1 * RB + gi) * OPNET_KXQ) * 512;
-        xcd_glds16(rws, xlane, o0, dst + X4B_X0 * 16);
-        xcd_glds16(rws, xlane, o1, dst + X4B_X1 * 16);
-        if (lane < 32) {                                        // k-quads 16 .. 23
-            xcd_glds16(rws, xlane, o0 + 16 * 512, dst + X4B_X0 * 16 + 1024);
-            xcd_glds16(rws, xlane, o1 + 16 * 512, dst + X4B_X1 * 16 + 1024);
-        }
-    };
-    auto gather_h = [&](int gi, int s, int buf) {
-        const unsigned dst = lds0 + (unsigned)buf * (X4B_F4 * 16);
+    // The inputs of phase (gi, s) into LDS buffer `buf`, by wave: wave 3 x[s], x[s-1] (read-only input, no sentinel) and h1[s-1]
+    // (ring slot s & 3, 4 pieces); waves 0 / 1: the halves of h2[s-3] (ring slot (s - 2) & 3, 4 pieces each); wave 2 (the head) none.
+    // h1 is only waited for while somebody still publishes it (s <= T), h2 from s = 2 on.
+    auto gather = [&](int gi, int s, int buf, int phase) -> bool {
+        float4 *S = &sbuf[buf][0] + lane;
         const unsigned gg = gi * 8 + x;
-        const int s1 = s <= T ? s : T;                          // slot of h1[s-1]
-        const int s2 = s >= 2 ? (s - 2 <= T ? s - 2 : T) : 0;   // slot of h2[s-3]
-        const unsigned o1 = a.h1x_off + (gg * (T + 1) + s1) * 4096;
-        const unsigned o2 = a.h2x_off + (gg * (T + 1) + s2) * 8192;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int piece = 4 * (w == 3 ? 2 : w) + q;         // wave-uniform: 0..3 = h1, 4..11 = h2
-            if (piece < 4) xcd_glds16(rws, lane16, o1 + piece * 1024, dst + X4B_H1 * 16 + piece * 1024);
-            else xcd_glds16(rws, lane16, o2 + (piece - 4) * 1024, dst + X4B_H2 * 16 + (piece - 4) * 1024);
+        if (w == 3) {
+            const int t0 = s < T ? s : T - 1, t1 = s > 0 ? (s - 1 < T ? s - 1 : T - 1) : 0;
+            const unsigned o0 = a.xp_off + (unsigned)((t0 * RB + gi) * OPNET_KXQ) * 512;
+            const unsigned o1 = a.xp_off + (unsigned)((t1 * RB + gi) * OPNET_KXQ) * 512;
+            const xcd_u32x4 xa = __builtin_amdgcn_raw_buffer_load_b128(rws, xlane, o0, 0);
+            const xcd_u32x4 xb = __builtin_amdgcn_raw_buffer_load_b128(rws, xlane, o1, 0);
+            xcd_u32x4 xc = sent4, xd = sent4;
+            if (lane < 32) {                                    // k-quads 16 .. 23
+                xc = __builtin_amdgcn_raw_buffer_load_b128(rws, xlane, o0 + 16 * 512, 0);
+                xd = __builtin_amdgcn_raw_buffer_load_b128(rws, xlane, o1 + 16 * 512, 0);
+            }
+            const bool ok = x4_gather<4>(rws, lane16, a.h1x_off + (gg * X4_SLOTS + (s & 3)) * 4096, s <= T ? 0xfu : 0u,
+                                         S + X4B_H1, a.status, phase);
+            S[X4B_X0] = x4_as_float4(xa);
+            S[X4B_X1] = x4_as_float4(xb);
+            if (lane < 32) { S[X4B_X0 + 64] = x4_as_float4(xc); S[X4B_X1 + 64] = x4_as_float4(xd); }
+            return ok;
         }
+        if (w == 2) return true;
+        return x4_gather<4>(rws, lane16, a.h2x_off + (gg * X4_SLOTS + ((s + 2) & 3)) * 8192 + w * 4096, s >= 2 ? 0xfu : 0u,
+                            S + X4B_H2 + w * 256, a.status, phase,
+                            a.trace && blockIdx.x == 0 && threadIdx.x == 0 ? a.trace + ((long)(T + 2) * a.RB + phase) * 8 : nullptr);
     };
 
-    if (w == 3) gather_x(0, 0, 0);
-    if (w != 2) gather_h(0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!gather(0, 0, 0, 0)) sAbort = 1;
     __syncthreads();
     if (sAbort) return;
     const bool local = __builtin_amdgcn_readfirstlane(sLocal) != 0;
@@ -246,7 +307,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
         const int buf = p & 1;
         if (tracer) a.trace[(long)p * 8 + 0] = clock64();
         // ================================ products =======================================================================
-        {
+        if (!(a.debug & 16)) {
             const float4 *S = &sbuf[buf][0];
             const float4 *F2 = S + X4B_H2 + (32 * w) * 4 + j;
             const float4 *F1 = S + X4B_X0 + (22 * w + (b >> 3)) * 4 + j;
@@ -318,48 +379,66 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
         const int rb = gi;
 
         // ================================ finish, by wave =================================================================
-        float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);
-        float cc = 0.f, hsave = 0.f;
-        bool saved = false;
         if (w == 0) {
             // ---- LSTM2 cell of step t = s - 2 (learned_models.py:46): lane = (unit 16 c + b, clip j) ----------------------
             const int t = s - 2;
-            if (t >= 0 && t < T && alive) {
+            if (t >= 0 && t < T && !(a.debug & 4)) {
                 const float4 p0 = sP[0][0][lane], p1 = sP[1][0][lane], p2 = sP[2][0][lane], p3 = sP[3][0][lane];
-                cc = sC2[gi][lane];
+                float cc = sC2[gi][lane];
+                float4 gs;
                 const float h = lstm_cell_g(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
                                             ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w, &cc, &gs);
                 sC2[gi][lane] = cc;
-                hsave = h;
-                saved = true;
-                // exchange: float4 = units 4 q .. 4 q + 3 of clip j, by the lanes with (b & 3) == 0
+                // exchange: float4 = units 4 q .. 4 q + 3 of clip j, by the lanes with (b & 3) == 0; ring slot (t + 1) & 3 = (s - 1) & 3,
+                // and the slot two steps on is re-armed
                 const float4 hv = make_float4(h, x4_row_shl<4>(h), x4_row_shl<8>(h), x4_row_shl<12>(h));
-                if ((b & 3) == 0)
-                    xcd_store16(rws, ((b >> 2) * 4 + j) * 16, a.h2x_off + ((gg * (T + 1) + t + 1) * 128 + 4 * c) * 64, hv, local);
+                if ((b & 3) == 0) {
+                    const unsigned vo = ((b >> 2) * 4 + j) * 16;
+                    xcd_store16(rws, vo, a.h2x_off + ((gg * X4_SLOTS + ((s - 1) & 3)) * 128 + 4 * c) * 64, hv, local);
+                    xcd_store16(rws, vo, a.h2x_off + ((gg * X4_SLOTS + ((s + 1) & 3)) * 128 + 4 * c) * 64, sentf, local);
+                }
+                if (tracer) a.trace[(long)p * 8 + 3] = clock64();
+                // the histories of the backward pass / the output head
+                const size_t u = 16 * c + b;
+                if (!(a.debug & 2))
+                ((float *)(a.ws + a.h2_off))[(((size_t)(t + 1) * RB + rb) * 128 + (u >> 2)) * 128 + (cb + j) * 4 + (u & 3)] = h;
+                if (TRAIN && !(a.debug & 2)) {
+                    ((float *)(a.ws + a.c2_off))[(((size_t)(t + 1) * RB + rb) * 512 + u) * 32 + cb + j] = cc;
+                    ((float4 *)(a.ws + a.g2_off))[(((size_t)t * RB + rb) * 512 + u) * 32 + cb + j] = gs;
+                }
             }
         } else if (w == 1) {
             // ---- LSTM1 cell of step t = s (learned_models.py:39): lanes 0..31 = (unit 8 c + b, clip j) --------------------
             const int t = s;
-            if (t < T && alive && lane < 32) {
+            if (t < T && lane < 32 && !(a.debug & 4)) {
                 float g[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 lo = sP[q][1][lane], hi = sP[q][1][lane + 32];
                     g[0] += lo.x + hi.x; g[1] += lo.y + hi.y; g[2] += lo.z + hi.z; g[3] += lo.w + hi.w;
                 }
-                cc = sC1[gi][lane];
+                float cc = sC1[gi][lane];
+                float4 gs;
                 const float h = lstm_cell_g(g[0], g[1], g[2], g[3], &cc, &gs);
                 sC1[gi][lane] = cc;
-                hsave = h;
-                saved = true;
                 const float4 hv = make_float4(h, x4_row_shl<4>(h), x4_row_shl<8>(h), x4_row_shl<12>(h));
-                if ((b & 3) == 0)
-                    xcd_store16(rws, ((b >> 2) * 4 + j) * 16, a.h1x_off + ((gg * (T + 1) + t + 1) * 64 + 2 * c) * 64, hv, local);
+                if ((b & 3) == 0) {     // ring slot (t + 1) & 3
+                    const unsigned vo = ((b >> 2) * 4 + j) * 16;
+                    xcd_store16(rws, vo, a.h1x_off + ((gg * X4_SLOTS + ((s + 1) & 3)) * 64 + 2 * c) * 64, hv, local);
+                    xcd_store16(rws, vo, a.h1x_off + ((gg * X4_SLOTS + ((s + 3) & 3)) * 64 + 2 * c) * 64, sentf, local);
+                }
+                const size_t u = 8 * c + b;
+                if (!(a.debug & 2))
+                ((float *)(a.ws + a.h1_off))[(((size_t)(t + 1) * RB + rb) * 64 + (u >> 2)) * 128 + (cb + j) * 4 + (u & 3)] = h;
+                if (TRAIN && !(a.debug & 2)) {
+                    ((float *)(a.ws + a.c1_off))[(((size_t)(t + 1) * RB + rb) * 256 + u) * 32 + cb + j] = cc;
+                    ((float4 *)(a.ws + a.g1_off))[(((size_t)t * RB + rb) * 256 + u) * 32 + cb + j] = gs;
+                }
             }
         } else if (w == 2) {
             // ---- selection head of step t = s - 1 (learned_models.py:40-43,50): lanes 0..15 = (slot quad rg, clip j) ------
             const int t = s - 1;
-            if (t >= 0 && t < T && alive && lane < 16) {
+            if (t >= 0 && t < T && lane < 16 && !(a.debug & 8)) {
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -416,57 +495,24 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
                     if (TRAIN) {
                         float4 *ps = (float4 *)(a.ws + a.ps_off);
                         ps[((size_t)(t * RB + rb) * 4 + rg) * 32 + cb + j] = make_float4(pr[0], pr[1], pr[2], pr[3]);
-                    }
-                    if (rg < 2) {
-                        float4 *x2 = (float4 *)(a.ws + a.x2_off);
-                        x2[((size_t)(t * RB + rb) * 2 + rg) * 32 + cb + j] =
-                            rg == 0 ? make_float4(fbv[0], fbv[1], fbv[2], fbv[3]) : make_float4(fbv[4], fbv[5], 0.f, 0.f);
-                    }
-                }
-            }
-        } else {
-            if (more && alive) gather_x(gn, sn, buf ^ 1);
-        }
-        if (tracer) a.trace[(long)p * 8 + 3] = clock64();
-        // ================================ publish =========================================================================
-        if (w < 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0 && alive) {
-                if (__hip_atomic_fetch_add(&sArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1u) {
-                    __hip_atomic_store(&sArrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    xcd_store_flag(a.flags + gg * 32 + c, (unsigned)(s + 1), local);
-                }
-            }
-            if (tracer) a.trace[(long)p * 8 + 4] = clock64();
-            // the histories of the backward pass / the output head: after the flag, off the critical path
-            if (saved) {
-                if (w == 0) {
-                    const int t = s - 2;
-                    const size_t u = 16 * c + b;
-                    ((float *)(a.ws + a.h2_off))[(((size_t)(t + 1) * RB + rb) * 128 + (u >> 2)) * 128 + (cb + j) * 4 + (u & 3)] = hsave;
-                    if (TRAIN) {
-                        ((float *)(a.ws + a.c2_off))[(((size_t)(t + 1) * RB + rb) * 512 + u) * 32 + cb + j] = cc;
-                        ((float4 *)(a.ws + a.g2_off))[(((size_t)t * RB + rb) * 512 + u) * 32 + cb + j] = gs;
-                    }
-                } else {
-                    const int t = s;
-                    const size_t u = 8 * c + b;
-                    ((float *)(a.ws + a.h1_off))[(((size_t)(t + 1) * RB + rb) * 64 + (u >> 2)) * 128 + (cb + j) * 4 + (u & 3)] = hsave;
-                    if (TRAIN) {
-                        ((float *)(a.ws + a.c1_off))[(((size_t)(t + 1) * RB + rb) * 256 + u) * 32 + cb + j] = cc;
-                        ((float4 *)(a.ws + a.g1_off))[(((size_t)t * RB + rb) * 256 + u) * 32 + cb + j] = gs;
+                        if (rg < 2) {
+                            float4 *x2 = (float4 *)(a.ws + a.x2_off);
+                            x2[((size_t)(t * RB + rb) * 2 + rg) * 32 + cb + j] =
+                                rg == 0 ? make_float4(fbv[0], fbv[1], fbv[2], fbv[3]) : make_float4(fbv[4], fbv[5], 0.f, 0.f);
+                        }
                     }
                 }
             }
         }
-        // ================================ next phase's gather =============================================================
-        if (more && alive && w != 2) {
-            if (sn > 0) alive = xcd_wait_flags(a.flags + (gn * 8 + x) * 32, (unsigned)sn, a.status, p);
-            if (tracer) a.trace[(long)p * 8 + 5] = clock64();
-            if (alive) gather_h(gn, sn, buf ^ 1);
-            else sAbort = 1;
+        if (tracer) a.trace[(long)p * 8 + 4] = clock64();
+        // ================================ the next phase's inputs ==========================================================
+        if (more && alive && !(a.debug & 1)) {
+            for (int d = 0; d < a.delay; ++d) __builtin_amdgcn_s_sleep(1);
+            alive = gather(gn, sn, buf ^ 1, p);
+            if (!alive) sAbort = 1;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tracer) a.trace[(long)p * 8 + 5] = clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // orders this phase's re-arm stores before the next publish
         if (tracer) a.trace[(long)p * 8 + 6] = clock64();
         __syncthreads();                        // barrier 2: the next phase's inputs have landed
         if (tracer) a.trace[(long)p * 8 + 7] = clock64();
@@ -517,8 +563,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_out_head(const Xcd4Args a)
 }
 
 // ====================================================================================================================
-// backward: the reverse recurrence of opnet_train_backward_f32 (reference: torch autograd through learned_models.py:35-52
-// under training_main.py:216; restated in oracle/torch_port.py), same placement and protocol as the forward above.
+// backward: the reverse recurrence of opnet_train_backward_f32, same placement and exchange protocol as the forward above.
 //     dh2_t = W_out^T dy_t + W_hh2^T da2_{t+1};   (da2_t, dc2) = cell backward           (opnet_train_kernels.hip cell_backward)
 //     dfb_t = W_ih2^T da2_t;  dp = boxes_t . dfb_t;  dl_t = p_t * (dp - <p_t, dp>)          (einsum + softmax backward)
 //     dh1_t = W_sel^T dl_t + W_hh1^T da1_{t+1};   (da1_t, dc1) = cell backward
@@ -528,15 +573,16 @@ __global__ void __launch_bounds__(256) opnet_xcd4_out_head(const Xcd4Args a)
 // MFMA blocks = (row quad, k subset): LSTM2 16 rows x 4 k x 4 clips per instruction, LSTM1 8 rows x 8 k x 4 clips; B = the
 // (unit', clip) float4 of da (its four gates = four consecutive k), so one ds_read_b128 feeds four instructions.
 // Phase (row block gi, n), T + 2 of them:  LSTM2 cell at t2 = T-1-n | head backward at th = T-n | LSTM1 cell at t1 = T+1-n.
-//     gather: da2_{T-n} (32 KB), da1_{T+2-n} (16 KB) of the group;
-//     wave 0: dh2 sum + cell -> da2_{t2} -> exchange, flag; then the CU's part of dfb_{t2} (8 MFMAs on the da registers,
-//             summed over the CU's units through LDS) -> exchange, second flag; then g2;
-//     wave 1: dh1 sum + W_sel^T dl_{t1} (dl from LDS, left there by wave 2 one phase earlier) + cell -> da1_{t1};
+//     inputs: da2_{T-n} (32 KB, ring slot (T-n) & 3), da1_{T+2-n} (16 KB) of the group: 48 pieces, 12 per wave;
+//     wave 0: dh2 sum + cell -> da2_{t2} -> exchange; then the CU's part of dfb_{t2} (8 MFMAs on the da registers, summed over
+//             the CU's units through LDS) -> exchange (its own ring, re-armed THREE steps on: its reader, wave 2, runs beside
+//             the publishing waves of its phase); then g2;
+//     wave 1: dh1 sum + W_sel^T dl_{t1} (dl from LDS, left there by wave 2 one phase earlier) + cell -> da1_{t1}; g1;
 //     wave 2: sums the 32 CUs' dfb parts of step th, dp, dl_{th} -> LDS (+ dlall by one CU);
-//     wave 3: most of the next gather.
+//     wave 3: the next head step's p and boxes (HBM) -> LDS.
 // ====================================================================================================================
-#define X4D_DA2 0              // LDS gather buffer of a backward phase, float4 units: da2 [512 units][4 clips]
-#define X4D_DA1 2048           //                                                      da1 [256 units][4 clips]
+#define X4D_DA2 0              // LDS buffer of a backward phase, float4 units: da2 [512 units][4 clips]
+#define X4D_DA1 2048           //                                               da1 [256 units][4 clips]
 #define X4D_F4 3072            // 48 KB
 
 struct X4BPacked { size_t b2, b1, bx, bo, bs, total; };    // offsets in floats
@@ -563,9 +609,8 @@ struct Xcd4BArgs {
     unsigned ps_off;           // [T][RB][4][32] float4
     unsigned dy_off;           // [T][RB][32] float4
     unsigned dl_off;           // [T][RB][4][32] float4 out
-    unsigned da1x_off, da2x_off;   // exchange [RB*8][T+1][H][4] float4, slot t = step t, slot T = 0
-    unsigned dfx_off;          // exchange [RB*8][T+1][32 CUs][8 features][4 clips] float
-    unsigned *flags, *flags2;  // [RB*8][32] each
+    unsigned da1x_off, da2x_off;   // exchange rings [RB*8][4][H][4] float4, slot t & 3 = step t (T & 3: the zero da_T at the start)
+    unsigned dfx_off;          // exchange ring [RB*8][4][32 CUs][8 features][4 clips] float
     unsigned *status;
     int force_safe;
     unsigned long long *trace;
@@ -607,18 +652,19 @@ __global__ void __launch_bounds__(256) opnet_xcd4_pack_bwd(float *__restrict__ o
     }
 }
 
-// flags, status, the zero slot T of the da exchange buffers
+// status, the exchange rings: slot T & 3 of da = the zero da_T, everything else unpublished
 __global__ void __launch_bounds__(256) opnet_xcd4_init_bwd(Xcd4BArgs a)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
     const int NG = a.RB * 8;
-    for (int i = tid; i < NG * 32; i += n) { a.flags[i] = 0u; a.flags2[i] = 0u; }
     if (tid < 8) a.status[tid] = 0u;
     for (int i = tid; i < 256; i += n) a.status[8 + i] = 0xffffffffu;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 *d1 = (float4 *)(a.ws + a.da1x_off), *d2 = (float4 *)(a.ws + a.da2x_off);
-    for (int i = tid; i < NG * 1024; i += n) d1[((size_t)(i >> 10) * (a.T + 1) + a.T) * 1024 + (i & 1023)] = z;
-    for (int i = tid; i < NG * 2048; i += n) d2[((size_t)(i >> 11) * (a.T + 1) + a.T) * 2048 + (i & 2047)] = z;
+    const xcd_u32x4 z = {0u, 0u, 0u, 0u}, sent = {X4_SENT, X4_SENT, X4_SENT, X4_SENT};
+    const int zs = a.T & (X4_SLOTS - 1);
+    xcd_u32x4 *d1 = (xcd_u32x4 *)(a.ws + a.da1x_off), *d2 = (xcd_u32x4 *)(a.ws + a.da2x_off), *df = (xcd_u32x4 *)(a.ws + a.dfx_off);
+    for (int i = tid; i < NG * X4_SLOTS * 1024; i += n) d1[i] = ((i >> 10) & (X4_SLOTS - 1)) == zs ? z : sent;
+    for (int i = tid; i < NG * X4_SLOTS * 2048; i += n) d2[i] = ((i >> 11) & (X4_SLOTS - 1)) == zs ? z : sent;
+    for (int i = tid; i < NG * X4_SLOTS * 256; i += n) df[i] = sent;
 }
 
 __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
@@ -632,7 +678,6 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     __shared__ float sDFB[2][32];
     __shared__ __attribute__((aligned(16))) float4 sHX[X4_NGMAX][2][28][4];   // the head step's boxes (24 k-quads) and p (4 slot quads) x 4 clips, by step parity
     __shared__ volatile int sAbort, sLocal;
-    __shared__ unsigned sArrive;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -644,7 +689,6 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         if (lane == 0) {
             sLocal = loc > 0 && a.force_safe == 0;
             sAbort = loc < 0;
-            sArrive = 0u;
             if (loc == 0 && c == 0) atomicAdd(a.status + 3, 1u);
         }
     }
@@ -671,38 +715,24 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     }
 
     const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void *)a.ws, 0, 0x7fffffff, 0x00020000);
-    const unsigned lds0 = (unsigned)(unsigned long long)(const void *)&sbuf[0][0];
     const unsigned cb = 4 * x;
     const unsigned lane16 = lane * 16;
+    const xcd_u32x4 sent4 = {X4_SENT, X4_SENT, X4_SENT, X4_SENT};
+    const float4 sentf = x4_as_float4(sent4);
     bool alive = true;
 
-    // The gather of phase (gi, n): 48 pieces of 1 KB (16 units x 4 clips) - 32 of da2_{T-n}, 16 of da1_{T+2-n} - twelve per wave,
-    // THROUGH REGISTERS: sc1 loads (L2-served, never this CU's L1) issued back to back, one round trip, then ds_write_b128.
-    // (LDS-DMA pieces cost ~180 cycles each here - every piece rewrites M0 - measured 6 700 cycles for 24 pieces on one wave.)
-    auto gather_issue = [&](int gi, int n, xcd_u32x4 (&r)[12]) {
-        const unsigned gg = gi * 8 + x;
-        const int s2 = T - n >= 0 ? T - n : 0;
-        const int s1 = n >= 2 ? (T + 2 - n >= 0 ? T + 2 - n : 0) : T;
-        // wave w: pieces 12 w .. 12 w + 11 (waves 0, 1: da2 0..23; wave 2: da2 24..31 + da1 0..3; wave 3: da1 4..15)
-        const unsigned o2 = a.da2x_off + (gg * (T + 1) + s2) * 32768 + 12 * w * 1024;
-        const unsigned o1 = a.da1x_off + (gg * (T + 1) + s1) * 16384 + (w == 2 ? 0 : 4 * 1024);
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            const bool is2 = w < 2 || (w == 2 && q < 8);
-            const unsigned so = is2 ? o2 + q * 1024 : o1 + (w == 2 ? q - 8 : q) * 1024;
-            r[q] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, __builtin_amdgcn_readfirstlane(so), 16);
-        }
-    };
-    auto gather_land = [&](int buf, const xcd_u32x4 (&r)[12]) {
+    // The inputs of phase (gi, n): 48 pieces of 1 KB (16 units x 4 clips) - 32 of da2_{T-n} (waited for while LSTM2 still runs:
+    // n <= T - 1), 16 of da1_{T+2-n} (2 <= n) - twelve per wave: waves 0, 1 da2 0..23; wave 2 da2 24..31 + da1 0..3; wave 3 da1 4..15
+    auto gather = [&](int gi, int n, int buf, int phase) -> bool {
         float4 *S = &sbuf[buf][0] + lane;
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            const bool is2 = w < 2 || (w == 2 && q < 8);
-            const int piece = is2 ? 12 * w + q : (w == 2 ? q - 8 : 4 + q);
-            float4 v;
-            v.x = __uint_as_float(r[q].x); v.y = __uint_as_float(r[q].y); v.z = __uint_as_float(r[q].z); v.w = __uint_as_float(r[q].w);
-            S[(is2 ? X4D_DA2 : X4D_DA1) + piece * 64] = v;
-        }
+        const unsigned gg = gi * 8 + x;
+        const unsigned o2 = a.da2x_off + (gg * X4_SLOTS + ((T - n) & 3)) * 32768;
+        const unsigned o1 = a.da1x_off + (gg * X4_SLOTS + ((T + 2 - n) & 3)) * 16384;
+        const unsigned n2 = n <= T - 1 ? 0xfffu : 0u, n1 = n >= 2 ? 0xfffu : 0u;
+        if (w < 2) return x4_gather<12>(rws, lane16, o2 + w * 12288, n2, S + X4D_DA2 + w * 768, a.status, phase);
+        if (w == 3) return x4_gather<12>(rws, lane16, o1 + 4096, n1, S + X4D_DA1 + 256, a.status, phase);
+        return x4_gather<8>(rws, lane16, o2 + 24576, n2 & 0xffu, S + X4D_DA2 + 1536, a.status, phase) &&
+               x4_gather<4>(rws, lane16, o1, n1 & 0xfu, S + X4D_DA1, a.status, phase);
     };
 
     // the saved activations a cell needs (gates, c_t, c_{t-1}, wave 0: dy), fetched one phase ahead - they come from HBM / the
@@ -731,20 +761,13 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         }
     };
 
-    {
-        xcd_u32x4 r0[12];
-        gather_issue(0, 0, r0);
-        gather_land(0, r0);
-    }
+    if (!gather(0, 0, 0, 0)) sAbort = 1;
     fetch(0, 0, cg, cdy, cct, ccp);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (sAbort) return;
     const bool local = __builtin_amdgcn_readfirstlane(sLocal) != 0;
     const bool tracer = a.trace && blockIdx.x == 0 && tid == 0;
     const int nph = (T + 2) * ng;
-    const bool tracer3 = a.trace && blockIdx.x == 0 && tid == 192;     // wave 3's stamps follow wave 0's: [nph][8]
-    unsigned long long *tr3 = a.trace + (long)nph * 8;
 
     int gi = 0, n = 0;
     for (int p = 0; p < nph; ++p) {
@@ -799,13 +822,11 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         const int rb = gi;
         const float *PF = (const float *)&sP[0][0][0];
 
-        float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool saved = false;
         if (w == 0) {
             // ---- LSTM2 cell backward at t = T-1-n: lane = (unit 16 c + b, clip j); its dh row sits in D register b & 3 of the
             //      lanes (row quad b >> 2, k subset kk, clip j) of every wave --------------------------------------------------
             const int t = T - 1 - n;
-            if (t >= 0 && t < T && alive) {
+            if (t >= 0 && t < T) {
                 float rec = 0.f;
                 const float *pr = PF + (4 * (b >> 2) + j) * 4 + (b & 3);
 #pragma unroll
@@ -819,57 +840,11 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                 dh = fmaf(wo.w, cdy.w, dh);
                 dh += rec;
                 float dco;
-                da = cell_backward(dh, sDC2[gi][lane], cg, cct, ccp, &dco);
+                const float4 da = cell_backward(dh, sDC2[gi][lane], cg, cct, ccp, &dco);
                 sDC2[gi][lane] = dco;
-                saved = true;
-                xcd_store16(rws, lane16, a.da2x_off + ((gg * (T + 1) + t) * 512 + 16 * c) * 64, da, local);
-            }
-        } else if (w == 1) {
-            // ---- LSTM1 cell backward at t = T+1-n: lanes 0..31 = (unit 8 c + b, clip j) -------------------------------------
-            const int t = T + 1 - n;
-            if (t >= 0 && t < T && alive) {
-                // the 32 partials of a dh row (4 waves x 8 k subsets): each lane half sums 16 of them, then the halves meet
-                float rec = 0.f;
-                const int lq = lane & 31, lb = lq >> 2, hf = lane >> 5;
-                const float *pr = PF + (64 + 4 * (lb >> 2) + j + 32 * hf) * 4 + (lb & 3);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) rec += pr[(q * 2 * 64 + 8 * kk) * 4];
-                rec += __shfl_xor(rec, 32);
-              if (lane < 32) {
-                // upstream: object_to_track_prediction (learned_models.py:40): dh += W_sel^T dl_t
-                const float4 *dl = (const float4 *)&sDL[gi][(n + 1) & 1][j][0];   // written by wave 2 one phase ago
-                float dh = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 d = dl[q];
-                    dh = fmaf(wsl[q].x, d.x, dh);
-                    dh = fmaf(wsl[q].y, d.y, dh);
-                    dh = fmaf(wsl[q].z, d.z, dh);
-                    dh = fmaf(wsl[q].w, d.w, dh);
-                }
-                dh += rec;
-                float dco;
-                da = cell_backward(dh, sDC1[gi][lane], cg, cct, ccp, &dco);
-                sDC1[gi][lane] = dco;
-                saved = true;
-                xcd_store16(rws, lane16, a.da1x_off + ((gg * (T + 1) + t) * 256 + 8 * c) * 64, da, local);
-              }
-            }
-        }
-        if (tracer) a.trace[(long)p * 8 + 3] = clock64();
-        // ================================ publish =========================================================================
-        if (w < 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0 && alive) {
-                if (__hip_atomic_fetch_add(&sArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1u) {
-                    __hip_atomic_store(&sArrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    xcd_store_flag(a.flags + gg * 32 + c, (unsigned)(n + 1), local);
-                }
-            }
-            if (tracer) a.trace[(long)p * 8 + 4] = clock64();
-            if (w == 0) {
+                xcd_store16(rws, lane16, a.da2x_off + ((gg * X4_SLOTS + (t & 3)) * 512 + 16 * c) * 64, da, local);
+                xcd_store16(rws, lane16, a.da2x_off + ((gg * X4_SLOTS + ((t + 2) & 3)) * 512 + 16 * c) * 64, sentf, local);
+                if (tracer) a.trace[(long)p * 8 + 3] = clock64();
                 // the CU's part of dfb_t = W_ih2^T da2_t: MFMA block = unit, k = gate, B = the da registers themselves;
                 // D[unit b][feature][clip j], then the sum over the 16 units through LDS
                 x4_f32x4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
@@ -885,24 +860,66 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                     float sum = 0.f;
 #pragma unroll
                     for (int u = 0; u < 16; ++u) sum += px[u * 16];
-                    const int t = T - 1 - n;
-                    if (t >= 0 && t < T && alive)
-                        xcd_store4(rws, lane * 4, a.dfx_off + ((gg * (T + 1) + t) * 32 + c) * 128, sum, local);
+                    xcd_store4(rws, lane * 4, a.dfx_off + ((gg * X4_SLOTS + (t & 3)) * 32 + c) * 128, sum, local);
+                    xcd_store4(rws, lane * 4, a.dfx_off + ((gg * X4_SLOTS + ((t + 3) & 3)) * 32 + c) * 128, sentf.x, local);
                 }
-                // its flag (flags2) follows the wait at the end of the phase: nobody needs it before the next phase's finish
+                // da replaces the saved gates (the weight-gradient GEMMs read it there)
+                ((float4 *)(a.ws + a.g2_off))[(((size_t)t * RB + rb) * 512 + 16 * c + b) * 32 + cb + j] = da;
+            }
+        } else if (w == 1) {
+            // ---- LSTM1 cell backward at t = T+1-n: lanes 0..31 = (unit 8 c + b, clip j) -------------------------------------
+            const int t = T + 1 - n;
+            if (t >= 0 && t < T) {
+                // the 32 partials of a dh row (4 waves x 8 k subsets): each lane half sums 16 of them, then the halves meet
+                float rec = 0.f;
+                const int lq = lane & 31, lb = lq >> 2, hf = lane >> 5;
+                const float *pr = PF + (64 + 4 * (lb >> 2) + j + 32 * hf) * 4 + (lb & 3);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) rec += pr[(q * 2 * 64 + 8 * kk) * 4];
+                rec += __shfl_xor(rec, 32);
+                if (lane < 32) {
+                    // upstream: object_to_track_prediction (learned_models.py:40): dh += W_sel^T dl_t
+                    const float4 *dl = (const float4 *)&sDL[gi][(n + 1) & 1][j][0];   // written by wave 2 one phase ago
+                    float dh = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 d = dl[q];
+                        dh = fmaf(wsl[q].x, d.x, dh);
+                        dh = fmaf(wsl[q].y, d.y, dh);
+                        dh = fmaf(wsl[q].z, d.z, dh);
+                        dh = fmaf(wsl[q].w, d.w, dh);
+                    }
+                    dh += rec;
+                    float dco;
+                    const float4 da = cell_backward(dh, sDC1[gi][lane], cg, cct, ccp, &dco);
+                    sDC1[gi][lane] = dco;
+                    xcd_store16(rws, lane16, a.da1x_off + ((gg * X4_SLOTS + (t & 3)) * 256 + 8 * c) * 64, da, local);
+                    xcd_store16(rws, lane16, a.da1x_off + ((gg * X4_SLOTS + ((t + 2) & 3)) * 256 + 8 * c) * 64, sentf, local);
+                    ((float4 *)(a.ws + a.g1_off))[(((size_t)t * RB + rb) * 256 + 8 * c + b) * 32 + cb + j] = da;
+                }
             }
         } else if (w == 2) {
-            // ---- head backward at t = T-n: dfb_t = sum of the 32 CUs' parts (published one phase ago, second flag) -------------
+            // ---- head backward at t = T-n: dfb_t = sum of the 32 CUs' parts (published one phase ago) -------------------------
             const int t = T - n;
             if (t >= 0 && t < T && alive) {
-                alive = xcd_wait_flags(a.flags2 + gg * 32, (unsigned)n, a.status, p);
-                if (alive) {
-                    // lane = (CU half h, feature f, clip j): 16 CUs each
-                    const unsigned base = a.dfx_off + ((gg * (T + 1) + t) * 32 + 16 * (lane >> 5)) * 128;
-                    float v[16];
+                // lane = (CU half h, feature f, clip j): 16 CUs each
+                const unsigned base = a.dfx_off + ((gg * X4_SLOTS + (t & 3)) * 32 + 16 * (lane >> 5)) * 128;
+                float sum = 0.f;
+                long long t0 = 0;
+                for (unsigned spins = 1;; ++spins) {
+                    unsigned v[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        v[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rws, (lane & 31) * 4, base + q * 128, 16));   // sc1
+                    for (int q = 0; q < 16; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b32(rws, (lane & 31) * 4, base + q * 128, 16);   // sc1
+                    bool bad = false;
+                    sum = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { bad |= v[q] == X4_SENT; sum += __uint_as_float(v[q]); }
+                    if (!__any(bad)) break;
+                    if (!x4_keep_polling(spins, t0, a.status, p)) { alive = false; break; }
+                }
+                if (alive) {
                     // this step's slot probabilities and boxes (lanes 0..15 = (slot quad rg, clip j)): left in LDS by wave 3 one
                     // phase ago (they come from HBM)
                     float4 hp = make_float4(0.f, 0.f, 0.f, 0.f), hx[6];
@@ -914,9 +931,6 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
 #pragma unroll
                         for (int q = 0; q < 6; ++q) hx[q] = sHX[gi][n & 1][6 * rg + q][j];
                     }
-                    float sum = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) sum += v[q];
                     sDFB[lane >> 5][lane & 31] = sum;
                     XCD_WAVE_LDS_SYNC();
                     if (lane < 16) {
@@ -952,11 +966,11 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                 } else sAbort = 1;
             }
         }
-        // ================================ next phase's gather =============================================================
+        if (tracer) a.trace[(long)p * 8 + 4] = clock64();
+        // ================================ the next phase's inputs ==========================================================
         float4 hxa = make_float4(0.f, 0.f, 0.f, 0.f), hxb = hxa;
         const int tn = T - nn;                                 // the next phase's head step
         const bool hfetch = w == 3 && more && tn >= 0 && tn < T;
-        if (tracer3) tr3[(long)p * 8 + 0] = clock64();
         if (hfetch) {
             // lane = (k-quad or slot quad q, clip j): boxes k-quads 0..15 | boxes k-quads 16..23 and p
             const float4 *xs = (const float4 *)(a.ws + a.xp_off) + ((size_t)tn * RB + gn) * (OPNET_KXQ * 32) + cb + j;
@@ -964,37 +978,19 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
             if (b < 8) hxb = xs[(16 + b) * 32];
             else if (b < 12) hxb = ((const float4 *)(a.ws + a.ps_off))[(((size_t)tn * RB + gn) * 4 + (b - 8)) * 32 + cb + j];
         }
-        xcd_u32x4 gr[12];
-        bool got = false;
         if (more && alive) {
-            if (nn > 0) alive = xcd_wait_flags(a.flags + (gn * 8 + x) * 32, (unsigned)nn, a.status, p);
-            if (tracer) a.trace[(long)p * 8 + 5] = clock64();
-            if (alive) { gather_issue(gn, nn, gr); got = true; }
-            else sAbort = 1;
-            if (tracer3) tr3[(long)p * 8 + 1] = clock64();
+            alive = gather(gn, nn, buf ^ 1, p);
+            if (!alive) sAbort = 1;
         }
-        // da replaces the saved gates (the weight-gradient GEMMs read it there): under the gather's round trip
-        if (saved) {
-            if (w == 0) {
-                const int t = T - 1 - n;
-                ((float4 *)(a.ws + a.g2_off))[(((size_t)t * RB + rb) * 512 + 16 * c + b) * 32 + cb + j] = da;
-            } else {
-                const int t = T + 1 - n;
-                ((float4 *)(a.ws + a.g1_off))[(((size_t)t * RB + rb) * 256 + 8 * c + b) * 32 + cb + j] = da;
-            }
-        }
-        if (got) gather_land(buf ^ 1, gr);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tracer3) tr3[(long)p * 8 + 2] = clock64();
+        if (tracer) a.trace[(long)p * 8 + 5] = clock64();
         if (hfetch) {
             sHX[gn][nn & 1][b][j] = hxa;
             if (b < 12) sHX[gn][nn & 1][16 + b][j] = hxb;
         }
-        if (w == 0 && lane == 0 && alive) xcd_store_flag(a.flags2 + gg * 32 + c, (unsigned)(n + 1), local);   // the dfb part is out
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // orders this phase's re-arm stores before the next publish
         if (tracer) a.trace[(long)p * 8 + 6] = clock64();
         __syncthreads();                        // barrier 2
         if (tracer) a.trace[(long)p * 8 + 7] = clock64();
-        if (tracer3) tr3[(long)p * 8 + 3] = clock64();
         if (sAbort) return;
         gi = gn;
         n = nn;

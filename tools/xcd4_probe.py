@@ -1,6 +1,7 @@
 """Timing and in-kernel timeline of the 4-clip persistent training step (csrc/opnet_xcd4_kernels.hip).
     python tools/xcd4_probe.py [--batches 32] [--frames 300] [--reps 5]"""
 import argparse
+import ctypes
 import os
 import sys
 
@@ -12,7 +13,7 @@ from objectpermanence_amd import ModelsFactory, _lib, l1_mean  # noqa: E402
 from synthdata import opnet as synth  # noqa: E402
 
 CFG = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
-NAMES = ["products", "barrier 1", "finish (cell + exchange stores issued)", "drain + flag", "poll", "gather issue+land", "barrier 2", "loop"]
+NAMES = ["products", "barrier 1", "cell + exchange store", "history stores (wave 0: + dfb part)", "gather (poll until published)", "drain", "barrier 2", "loop"]
 
 
 def timed(fn, reps):
@@ -61,6 +62,9 @@ def main():
         os.environ["OPNET_XCD4"] = "1"
         print(f"B={B} T={T}: forward persistent {res['1'][0]:.3f} ms / chain {res['0'][0]:.3f} ms | fwd+loss+bwd persistent "
               f"{res['1'][1]:.3f} ms / chain {res['0'][1]:.3f} ms", flush=True)
+        st = (ctypes.c_uint * 4)()
+        lib.opnet_xcd4_last_status(st)
+        print(f"  status of the last persistent launch: {list(st)}", flush=True)
         ng = (B + 31) // 32
         tr = torch.zeros((T + 2) * ng * 8 * 2, dtype=torch.int64, device=dev)
         lib.opnet_xcd4_set_trace(tr.data_ptr())
@@ -73,18 +77,17 @@ def main():
         parts = [med(ph[:, i + 1] - ph[:, i]) for i in range(7)] + [med(ph[1:, 0] - ph[:-1, 7])]
         print(f"  forward, block 0 wave 0, cycles (median): period {med(np.diff(ph[:, 0])):.0f} | "
               + ", ".join(f"{n} {v:.0f}" for n, v in zip(NAMES, parts)), flush=True)
+        tg = tr.cpu().numpy().reshape(-1, 8)[(T + 2) * ng:][len(t) // 3: 2 * len(t) // 3]
+        print(f"  forward gather of wave 0: loads issued {med(tg[:, 0] - ph[:, 4]):.0f} after the finish, first answers after "
+              f"{med(tg[:, 1] - tg[:, 0]):.0f}, tries median {med(tg[:, 2]):.0f} max {tg[:, 2].max():.0f}, return after {med(ph[:, 5] - tg[:, 1]):.0f}", flush=True)
         tr.zero_()
         lib.opnet_xcd4_set_trace(tr.data_ptr())
         step()          # the backward kernel stamps the same buffer after the forward
         torch.cuda.synchronize()
         lib.opnet_xcd4_set_trace(None)
         t = tr.cpu().numpy().reshape(-1, 8)
-        nphase = len(t) // 2
-        t3 = t[nphase:][nphase // 3: 2 * nphase // 3]
-        t = t[:nphase]
+        t = t[:(T + 2) * ng]
         ph = t[len(t) // 3: 2 * len(t) // 3]
-        print(f"  backward, wave 3 after barrier 1: gather issued {med(t3[:, 1] - t3[:, 0]):.0f}, landed {med(t3[:, 2] - t3[:, 1]):.0f}, "
-              f"barrier 2 wait {med(t3[:, 3] - t3[:, 2]):.0f}; wave 0's flag at {med(ph[:, 4] - ph[:, 2]):.0f} after barrier 1", flush=True)
         parts = [med(ph[:, i + 1] - ph[:, i]) for i in range(7)] + [med(ph[1:, 0] - ph[:-1, 7])]
         print(f"  backward, block 0 wave 0, cycles (median): period {med(np.diff(ph[:, 0])):.0f} | "
               + ", ".join(f"{n} {v:.0f}" for n, v in zip(NAMES, parts)), flush=True)
