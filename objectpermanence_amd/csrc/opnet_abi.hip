@@ -686,8 +686,8 @@ static TrainWorkspaceLayout train_workspace_layout(int B, int T, int H1, int H2)
     L.x4h1x = o;   o += NG * X4_SLOTS * 4096;
     L.x4h2x = o;   o += NG * X4_SLOTS * 8192;
     L.x4status = o; o += NG ? 2048 : 0;
-    L.x4da1x = o;  o += NG * X4_SLOTS * 16384;
-    L.x4da2x = o;  o += NG * X4_SLOTS * 32768;
+    L.x4da1x = o;  o += NG * X4_SLOTS * 131072;   // partial dh1: [32 owners][32 producers][128 B]
+    L.x4da2x = o;  o += NG * X4_SLOTS * 262144;   // partial dh2: [32 owners][32 producers][256 B]
     L.x4dfx = o;   o += NG * X4_SLOTS * 4096;
     L.total = align_up(o, 256);
     return L;
@@ -854,7 +854,8 @@ static void make_x4b_args(Xcd4BArgs *x, const float *packed, void *ws, int B, in
     x->c1_off = (unsigned)W.c1all; x->c2_off = (unsigned)W.c2all;
     x->g1_off = (unsigned)W.g1; x->g2_off = (unsigned)W.g2;
     x->ps_off = (unsigned)W.psave; x->dy_off = (unsigned)W.dyp; x->dl_off = (unsigned)W.dlall;
-    x->da1x_off = (unsigned)W.x4da1x; x->da2x_off = (unsigned)W.x4da2x; x->dfx_off = (unsigned)W.x4dfx;
+    x->p1x_off = (unsigned)W.x4da1x; x->p2x_off = (unsigned)W.x4da2x; x->dfx_off = (unsigned)W.x4dfx;
+    x->debug = env_int("OPNET_X4_DEBUG_BWD", 0);
     x->status = (unsigned *)((char *)ws + W.x4status);
     x->force_safe = env_int("OPNET_XCD_SAFE", 0);
     x->trace = g_x4_trace;
@@ -953,7 +954,7 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
         make_x4b_args(&x, packed, workspace, B, T, H1, H2);
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
-        opnet_xcd4_init_bwd<<<8, 256, 0, st>>>(x);
+        opnet_xcd4_init_bwd<<<256, 256, 0, st>>>(x);
         std::lock_guard<std::mutex> lock(g_xcd_mu);
         if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
         else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));

@@ -569,29 +569,35 @@ __global__ void __launch_bounds__(256) opnet_xcd4_out_head(const Xcd4Args a)
 //     dh1_t = W_sel^T dl_t + W_hh1^T da1_{t+1};   (da1_t, dc1) = cell backward
 // da_t overwrites the saved gates (g2 / g1, the launch chain's layout) and dl_t goes to dlall, so that opnet_wgrad runs on
 // the result unchanged.
-// CU c owns the dh rows of ITS units (16 of LSTM2, 8 of LSTM1) and holds the matching rows of W_hh^T: K = 4H gate columns,
-// MFMA blocks = (row quad, k subset): LSTM2 16 rows x 4 k x 4 clips per instruction, LSTM1 8 rows x 8 k x 4 clips; B = the
-// (unit', clip) float4 of da (its four gates = four consecutive k), so one ds_read_b128 feeds four instructions.
+// The recurrent product contracts over the 4H gate columns.  A CU that owned complete dh rows would have to gather ALL of da
+// (48 KB a step: the first version of this kernel, 14 000 cycles a step); instead CU c keeps the gate columns of ITS units - the
+// same 64 + 32 rows of W_hh it holds in the forward, read the other way - multiplies them by ITS OWN da (from LDS: no exchange on
+// the way in) into partial dh rows of EVERY unit, and the exchange is a reduce-scatter: every CU stores 32 x 384 B of partials,
+// one chunk per owner, and gathers the 32 chunks of its own 16 + 8 units (12 KB, as in the forward), which its cell waves sum.
+// MFMA blocks = row quads, one k per instruction (64 rows x 1 k x 4 clips), B = the (unit', clip) float4 of da - its four gates
+// are four consecutive k - the same address in all 16 blocks.
 // Phase (row block gi, n), T + 2 of them:  LSTM2 cell at t2 = T-1-n | head backward at th = T-n | LSTM1 cell at t1 = T+1-n.
-//     inputs: da2_{T-n} (32 KB, ring slot (T-n) & 3), da1_{T+2-n} (16 KB) of the group: 48 pieces, 12 per wave;
-//     wave 0: dh2 sum + cell -> da2_{t2} -> exchange; then the CU's part of dfb_{t2} (8 MFMAs on the da registers, summed over
-//             the CU's units through LDS) -> exchange (its own ring, re-armed THREE steps on: its reader, wave 2, runs beside
-//             the publishing waves of its phase); then g2;
-//     wave 1: dh1 sum + W_sel^T dl_{t1} (dl from LDS, left there by wave 2 one phase earlier) + cell -> da1_{t1}; g1;
-//     wave 2: sums the 32 CUs' dfb parts of step th, dp, dl_{th} -> LDS (+ dlall by one CU);
-//     wave 3: the next head step's p and boxes (HBM) -> LDS.
+//     1. wave 0: dh2 = sum of the 32 partial chunks + W_out^T dy -> cell -> da2_{t2} -> LDS, g2; then the CU's part of dfb_{t2}
+//                (8 MFMAs on the da registers, summed over the CU's units through LDS) -> its exchange ring;
+//        wave 1: dh1 = sum of the chunks + W_sel^T dl_{t1} (dl from LDS, left by wave 2 one phase earlier) -> cell -> da1 -> LDS, g1;
+//        wave 3: the next head step's p and boxes (HBM) -> LDS;      barrier;
+//     2. every wave: its 128 + 64 rows of the partial products out of the CU's da, stored to the owners' chunks (ring slot t & 3;
+//        the slot two steps on re-armed);
+//     3. waves 0, 1, 3: four 1-KB pieces each of the next phase's chunks (sentinel-polled); wave 2 meanwhile: the head backward
+//        of step th - sums the 32 CUs' dfb parts (published a phase ago), dp, dl_{th} -> LDS (+ dlall by one CU);      barrier.
 // ====================================================================================================================
-#define X4D_DA2 0              // LDS buffer of a backward phase, float4 units: da2 [512 units][4 clips]
-#define X4D_DA1 2048           //                                               da1 [256 units][4 clips]
-#define X4D_F4 3072            // 48 KB
+#define X4D_P2 0               // LDS buffer of a backward phase, float4 units: [32 producers][4 unit quads][4 clips] of dh2
+#define X4D_P1 512             //                                               [32 producers][2 unit quads][4 clips] of dh1
+#define X4D_F4 768             // 12 KB
+#define X4D_NBUF 8             // buffers allocated (two are used): 96 KB keep a second workgroup off the CU
 
 struct X4BPacked { size_t b2, b1, bx, bo, bs, total; };    // offsets in floats
 __host__ __device__ inline X4BPacked x4b_packed_layout()
 {
     X4BPacked P;
     size_t o = 0;
-    P.b2 = o; o += (size_t)32 * 4 * 32 * 256;    // [cu][wave][m][lane] float4   W_hh2^T
-    P.b1 = o; o += (size_t)32 * 4 * 8 * 256;     // [cu][wave][m][lane]          W_hh1^T
+    P.b2 = o; o += (size_t)32 * 4 * 32 * 256;    // [cu][wave][set 2 x unit' 16][lane] float4   W_hh2 columns
+    P.b1 = o; o += (size_t)32 * 4 * 8 * 256;     // [cu][wave][unit' 8][lane]                   W_hh1 columns
     P.bx = o; o += (size_t)32 * 2 * 256;         // [cu][f quad][lane]           W_ih2^T of the CU's units
     P.bo = o; o += (size_t)32 * 256;             // [cu][lane]                   W_out^T of the lane's unit
     P.bs = o; o += (size_t)32 * 4 * 256;         // [cu][slot quad][lane]        W_sel^T of the lane's unit
@@ -609,10 +615,12 @@ struct Xcd4BArgs {
     unsigned ps_off;           // [T][RB][4][32] float4
     unsigned dy_off;           // [T][RB][32] float4
     unsigned dl_off;           // [T][RB][4][32] float4 out
-    unsigned da1x_off, da2x_off;   // exchange rings [RB*8][4][H][4] float4, slot t & 3 = step t (T & 3: the zero da_T at the start)
+    unsigned p1x_off, p2x_off; // exchange rings of partial dh: [RB*8][4][32 owners][32 producers][2 | 4 unit quads][4 clips] float4;
+                               // slot t & 3 = the products of da_t (slot T & 3 starts as zeros: da_T = 0)
     unsigned dfx_off;          // exchange ring [RB*8][4][32 CUs][8 features][4 clips] float
     unsigned *status;
     int force_safe;
+    int debug;                 // tools only (wrong results): bit 0 no gather, 1 no history stores, 2 no cells, 3 no head, 4 no products
     unsigned long long *trace;
 };
 
@@ -625,15 +633,14 @@ __global__ void __launch_bounds__(256) opnet_xcd4_pack_bwd(float *__restrict__ o
         const int e = idx & 3, lane = (idx >> 2) & 63, b = lane >> 2, i = lane & 3;
         float v = 0.f;
         if (idx < P.b1) {
+            // lane (block b, row i) of (set, unit' m): dh row 128 w + 64 set + 4 b + i, k = (unit 16 cu + m, gate e)
             const size_t r = idx >> 8;
-            const int m = r % 32, w = (r / 32) % 4, cu = r / 128;
-            const int u = 16 * cu + 4 * (b & 3) + i, unit = 128 * w + 4 * m + (b >> 2);
-            v = w_hh2[(size_t)(e * 512 + unit) * 512 + u];
+            const int m = r % 16, set = (r / 16) % 2, w = (r / 32) % 4, cu = r / 128;
+            v = w_hh2[(size_t)(e * 512 + 16 * cu + m) * 512 + 128 * w + 64 * set + 4 * b + i];
         } else if (idx < P.bx) {
             const size_t r = (idx - P.b1) >> 8;
             const int m = r % 8, w = (r / 8) % 4, cu = r / 32;
-            const int u = 8 * cu + 4 * (b & 1) + i, unit = 64 * w + 8 * m + (b >> 1);
-            v = w_hh1[(size_t)(e * 256 + unit) * 256 + u];
+            v = w_hh1[(size_t)(e * 256 + 8 * cu + m) * 256 + 64 * w + 4 * b + i];
         } else if (idx < P.bo) {
             const size_t r = (idx - P.bx) >> 8;
             const int q = r % 2, cu = r / 2;
@@ -652,25 +659,26 @@ __global__ void __launch_bounds__(256) opnet_xcd4_pack_bwd(float *__restrict__ o
     }
 }
 
-// status, the exchange rings: slot T & 3 of da = the zero da_T, everything else unpublished
+// status, the exchange rings: slot T & 3 of the partials = zeros (da_T = 0), everything else unpublished
 __global__ void __launch_bounds__(256) opnet_xcd4_init_bwd(Xcd4BArgs a)
 {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
-    const int NG = a.RB * 8;
+    const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, n = (long)gridDim.x * blockDim.x;
+    const long NG = a.RB * 8;
     if (tid < 8) a.status[tid] = 0u;
-    for (int i = tid; i < 256; i += n) a.status[8 + i] = 0xffffffffu;
+    for (long i = tid; i < 256; i += n) a.status[8 + i] = 0xffffffffu;
     const xcd_u32x4 z = {0u, 0u, 0u, 0u}, sent = {X4_SENT, X4_SENT, X4_SENT, X4_SENT};
-    const int zs = a.T & (X4_SLOTS - 1);
-    xcd_u32x4 *d1 = (xcd_u32x4 *)(a.ws + a.da1x_off), *d2 = (xcd_u32x4 *)(a.ws + a.da2x_off), *df = (xcd_u32x4 *)(a.ws + a.dfx_off);
-    for (int i = tid; i < NG * X4_SLOTS * 1024; i += n) d1[i] = ((i >> 10) & (X4_SLOTS - 1)) == zs ? z : sent;
-    for (int i = tid; i < NG * X4_SLOTS * 2048; i += n) d2[i] = ((i >> 11) & (X4_SLOTS - 1)) == zs ? z : sent;
-    for (int i = tid; i < NG * X4_SLOTS * 256; i += n) df[i] = sent;
+    const long zs = a.T & (X4_SLOTS - 1);
+    xcd_u32x4 *d1 = (xcd_u32x4 *)(a.ws + a.p1x_off), *d2 = (xcd_u32x4 *)(a.ws + a.p2x_off), *df = (xcd_u32x4 *)(a.ws + a.dfx_off);
+    for (long i = tid; i < NG * X4_SLOTS * 8192; i += n) d1[i] = ((i >> 13) & (X4_SLOTS - 1)) == zs ? z : sent;
+    for (long i = tid; i < NG * X4_SLOTS * 16384; i += n) d2[i] = ((i >> 14) & (X4_SLOTS - 1)) == zs ? z : sent;
+    for (long i = tid; i < NG * X4_SLOTS * 256; i += n) df[i] = sent;
 }
 
 __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
 {
-    __shared__ __attribute__((aligned(1024))) float4 sbuf[2][X4D_F4];
-    __shared__ __attribute__((aligned(16))) float4 sP[4][2][64];       // K-split partials: dh2 | dh1
+    __shared__ __attribute__((aligned(1024))) float4 sbuf[X4D_NBUF][X4D_F4];
+    __shared__ __attribute__((aligned(16))) float4 sDA2[16][4];        // the CU's da2 of the phase: [unit'][clip] -> (i, f, g, o)
+    __shared__ __attribute__((aligned(16))) float4 sDA1[8][4];
     __shared__ __attribute__((aligned(16))) float4 sX[2][64];          // per-unit parts of dfb: features 0..3 | 4..7
     __shared__ float sDC2[X4_NGMAX][64];
     __shared__ float sDC1[X4_NGMAX][32];
@@ -694,6 +702,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     }
     for (int i = tid; i < X4_NGMAX * 64; i += 256) { (&sDC2[0][0])[i] = 0.f; (&sDL[0][0][0][0])[i] = 0.f; (&sDL[0][0][0][0])[X4_NGMAX * 64 + i] = 0.f; }
     for (int i = tid; i < X4_NGMAX * 32; i += 256) (&sDC1[0][0])[i] = 0.f;
+    if (tid < 64) (&sDA2[0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 32) (&sDA1[0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // ---- resident weights ------------------------------------------------------------------------------------------------
     const X4BPacked P = x4b_packed_layout();
@@ -720,19 +730,19 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     const xcd_u32x4 sent4 = {X4_SENT, X4_SENT, X4_SENT, X4_SENT};
     const float4 sentf = x4_as_float4(sent4);
     bool alive = true;
+    float hsum = 0.f;                           // wave 2: its lane's share of the next head step's dfb
 
-    // The inputs of phase (gi, n): 48 pieces of 1 KB (16 units x 4 clips) - 32 of da2_{T-n} (waited for while LSTM2 still runs:
-    // n <= T - 1), 16 of da1_{T+2-n} (2 <= n) - twelve per wave: waves 0, 1 da2 0..23; wave 2 da2 24..31 + da1 0..3; wave 3 da1 4..15
+    // The inputs of phase (gi, n): this CU's chunks of the partial products of da2_{T-n} (8 KB; waited for while LSTM2 still runs:
+    // n <= T - 1) and of da1_{T+2-n} (4 KB; n >= 2): twelve 1-KB pieces, four each by waves 0, 1 (dh2) and 3 (dh1)
     auto gather = [&](int gi, int n, int buf, int phase) -> bool {
+        if (w == 2) return true;
         float4 *S = &sbuf[buf][0] + lane;
         const unsigned gg = gi * 8 + x;
-        const unsigned o2 = a.da2x_off + (gg * X4_SLOTS + ((T - n) & 3)) * 32768;
-        const unsigned o1 = a.da1x_off + (gg * X4_SLOTS + ((T + 2 - n) & 3)) * 16384;
-        const unsigned n2 = n <= T - 1 ? 0xfffu : 0u, n1 = n >= 2 ? 0xfffu : 0u;
-        if (w < 2) return x4_gather<12>(rws, lane16, o2 + w * 12288, n2, S + X4D_DA2 + w * 768, a.status, phase);
-        if (w == 3) return x4_gather<12>(rws, lane16, o1 + 4096, n1, S + X4D_DA1 + 256, a.status, phase);
-        return x4_gather<8>(rws, lane16, o2 + 24576, n2 & 0xffu, S + X4D_DA2 + 1536, a.status, phase) &&
-               x4_gather<4>(rws, lane16, o1, n1 & 0xfu, S + X4D_DA1, a.status, phase);
+        if (w == 3)
+            return x4_gather<4>(rws, lane16, a.p1x_off + ((gg * X4_SLOTS + ((T + 2 - n) & 3)) * 32 + c) * 4096, n >= 2 ? 0xfu : 0u,
+                                S + X4D_P1, a.status, phase);
+        return x4_gather<4>(rws, lane16, a.p2x_off + ((gg * X4_SLOTS + ((T - n) & 3)) * 32 + c) * 8192 + w * 4096,
+                            n <= T - 1 ? 0xfu : 0u, S + X4D_P2 + w * 256, a.status, phase);
     };
 
     // the saved activations a cell needs (gates, c_t, c_{t-1}, wave 0: dy), fetched one phase ahead - they come from HBM / the
@@ -775,78 +785,38 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         int gn = gi + 1, nn = n;
         if (gn == ng) { gn = 0; ++nn; }
         const bool more = p + 1 < nph;
-        if (tracer) a.trace[(long)p * 8 + 0] = clock64();
-        if (more) fetch(gn, nn, ng_, ndy, nct, ncp);
-        // ================================ products =======================================================================
-        {
-            const float4 *S = &sbuf[buf][0];
-            const float4 *F2 = S + X4D_DA2 + (128 * w + (b >> 2)) * 4 + j;      // unit' = 128 w + 4 m + kk: + 16 m
-            const float4 *F1 = S + X4D_DA1 + (64 * w + (b >> 1)) * 4 + j;       // unit' = 64 w + 8 m + kk: + 32 m
-            x4_f32x4 c2[4], c1[2];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c2[q] = (x4_f32x4){0.f, 0.f, 0.f, 0.f};
-            c1[0] = c1[1] = (x4_f32x4){0.f, 0.f, 0.f, 0.f};
-            auto frag = [&](int idx) -> const float4 * { return idx < 32 ? F2 + idx * 16 : F1 + (idx - 32) * 32; };
-            float4 bf[X4_RING];
-#pragma unroll
-            for (int i = 0; i < X4_AHEAD; ++i) bf[i] = *frag(i);
-#pragma unroll
-            for (int idx = 0; idx < 40; ++idx) {
-                if (idx + X4_AHEAD < 40) bf[(idx + X4_AHEAD) % X4_RING] = *frag(idx + X4_AHEAD);
-                __builtin_amdgcn_sched_barrier(0);
-                const float4 bq = bf[idx % X4_RING];
-                if (idx < 32) {
-                    X4_MFMA(c2[0], b2[idx < 32 ? idx : 0].x, bq.x);
-                    X4_MFMA(c2[1], b2[idx < 32 ? idx : 0].y, bq.y);
-                    X4_MFMA(c2[2], b2[idx < 32 ? idx : 0].z, bq.z);
-                    X4_MFMA(c2[3], b2[idx < 32 ? idx : 0].w, bq.w);
-                } else {
-                    const int m = idx - 32;
-                    X4_MFMA(c1[0], b1[m].x, bq.x);
-                    X4_MFMA(c1[1], b1[m].y, bq.y);
-                    X4_MFMA(c1[0], b1[m].z, bq.z);
-                    X4_MFMA(c1[1], b1[m].w, bq.w);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            float4 *pp = &sP[w][0][lane];
-            pp[0] = make_float4((c2[0][0] + c2[1][0]) + (c2[2][0] + c2[3][0]), (c2[0][1] + c2[1][1]) + (c2[2][1] + c2[3][1]),
-                                (c2[0][2] + c2[1][2]) + (c2[2][2] + c2[3][2]), (c2[0][3] + c2[1][3]) + (c2[2][3] + c2[3][3]));
-            pp[64] = make_float4(c1[0][0] + c1[1][0], c1[0][1] + c1[1][1], c1[0][2] + c1[1][2], c1[0][3] + c1[1][3]);
-        }
-        if (tracer) a.trace[(long)p * 8 + 1] = clock64();
-        __syncthreads();                        // barrier 1
-        if (tracer) a.trace[(long)p * 8 + 2] = clock64();
-        if (sAbort) return;
         const unsigned gg = gi * 8 + x;
         const int rb = gi;
-        const float *PF = (const float *)&sP[0][0][0];
-
+        if (tracer) a.trace[(long)p * 8 + 0] = clock64();
+        if (more) fetch(gn, nn, ng_, ndy, nct, ncp);
+        // ================================ the cells (and the head backward), by wave ========================================
+        const float *PF = (const float *)&sbuf[buf][0];
         if (w == 0) {
-            // ---- LSTM2 cell backward at t = T-1-n: lane = (unit 16 c + b, clip j); its dh row sits in D register b & 3 of the
-            //      lanes (row quad b >> 2, k subset kk, clip j) of every wave --------------------------------------------------
+            // ---- LSTM2 cell backward at t = T-1-n: lane = (unit 16 c + b, clip j): component b & 3 of the float4 (unit quad b >> 2,
+            //      clip j) of every producer's chunk ---------------------------------------------------------------------------
             const int t = T - 1 - n;
-            if (t >= 0 && t < T) {
-                float rec = 0.f;
-                const float *pr = PF + (4 * (b >> 2) + j) * 4 + (b & 3);
+            float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < T && !(a.debug & 4)) {
+                float r0 = 0.f, r1 = 0.f;
+                const float *pr = PF + X4D_P2 * 4 + ((b >> 2) * 4 + j) * 4 + (b & 3);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) rec += pr[(q * 2 * 64 + 16 * kk) * 4];
+                for (int q = 0; q < 32; q += 2) { r0 += pr[q * 64]; r1 += pr[(q + 1) * 64]; }
                 // upstream: prediction_layer (learned_models.py:47): dh += W_out^T dy_t
                 float dh = wo.x * cdy.x;
                 dh = fmaf(wo.y, cdy.y, dh);
                 dh = fmaf(wo.z, cdy.z, dh);
                 dh = fmaf(wo.w, cdy.w, dh);
-                dh += rec;
+                dh += r0 + r1;
                 float dco;
-                const float4 da = cell_backward(dh, sDC2[gi][lane], cg, cct, ccp, &dco);
+                da = cell_backward(dh, sDC2[gi][lane], cg, cct, ccp, &dco);
                 sDC2[gi][lane] = dco;
-                xcd_store16(rws, lane16, a.da2x_off + ((gg * X4_SLOTS + (t & 3)) * 512 + 16 * c) * 64, da, local);
-                xcd_store16(rws, lane16, a.da2x_off + ((gg * X4_SLOTS + ((t + 2) & 3)) * 512 + 16 * c) * 64, sentf, local);
-                if (tracer) a.trace[(long)p * 8 + 3] = clock64();
+                sDA2[b][j] = da;
+                // da replaces the saved gates (the weight-gradient GEMMs read it there)
+                if (!(a.debug & 2))
+                ((float4 *)(a.ws + a.g2_off))[(((size_t)t * RB + rb) * 512 + 16 * c + b) * 32 + cb + j] = da;
                 // the CU's part of dfb_t = W_ih2^T da2_t: MFMA block = unit, k = gate, B = the da registers themselves;
-                // D[unit b][feature][clip j], then the sum over the 16 units through LDS
+                // D[unit b][feature][clip j], then the sum over the 16 units through LDS; re-armed THREE steps on (its reader,
+                // wave 2, runs beside the publishing waves of its phase)
                 x4_f32x4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
                 X4_MFMA(d1, bxa.x, da.x); X4_MFMA(d2, bxb.x, da.x);
                 X4_MFMA(d1, bxa.y, da.y); X4_MFMA(d2, bxb.y, da.y);
@@ -863,21 +833,17 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                     xcd_store4(rws, lane * 4, a.dfx_off + ((gg * X4_SLOTS + (t & 3)) * 32 + c) * 128, sum, local);
                     xcd_store4(rws, lane * 4, a.dfx_off + ((gg * X4_SLOTS + ((t + 3) & 3)) * 32 + c) * 128, sentf.x, local);
                 }
-                // da replaces the saved gates (the weight-gradient GEMMs read it there)
-                ((float4 *)(a.ws + a.g2_off))[(((size_t)t * RB + rb) * 512 + 16 * c + b) * 32 + cb + j] = da;
-            }
+            } else sDA2[b][j] = da;
         } else if (w == 1) {
-            // ---- LSTM1 cell backward at t = T+1-n: lanes 0..31 = (unit 8 c + b, clip j) -------------------------------------
+            // ---- LSTM1 cell backward at t = T+1-n: lanes 0..31 = (unit 8 c + b, clip j); each lane half sums 16 producers ------
             const int t = T + 1 - n;
-            if (t >= 0 && t < T) {
-                // the 32 partials of a dh row (4 waves x 8 k subsets): each lane half sums 16 of them, then the halves meet
+            float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < T && !(a.debug & 4)) {
                 float rec = 0.f;
                 const int lq = lane & 31, lb = lq >> 2, hf = lane >> 5;
-                const float *pr = PF + (64 + 4 * (lb >> 2) + j + 32 * hf) * 4 + (lb & 3);
+                const float *pr = PF + X4D_P1 * 4 + (16 * hf * 8 + (lb >> 2) * 4 + j) * 4 + (lb & 3);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) rec += pr[(q * 2 * 64 + 8 * kk) * 4];
+                for (int q = 0; q < 16; ++q) rec += pr[q * 32];
                 rec += __shfl_xor(rec, 32);
                 if (lane < 32) {
                     // upstream: object_to_track_prediction (learned_models.py:40): dh += W_sel^T dl_t
@@ -893,33 +859,19 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                     }
                     dh += rec;
                     float dco;
-                    const float4 da = cell_backward(dh, sDC1[gi][lane], cg, cct, ccp, &dco);
+                    da = cell_backward(dh, sDC1[gi][lane], cg, cct, ccp, &dco);
                     sDC1[gi][lane] = dco;
-                    xcd_store16(rws, lane16, a.da1x_off + ((gg * X4_SLOTS + (t & 3)) * 256 + 8 * c) * 64, da, local);
-                    xcd_store16(rws, lane16, a.da1x_off + ((gg * X4_SLOTS + ((t + 2) & 3)) * 256 + 8 * c) * 64, sentf, local);
+                    if (!(a.debug & 2))
                     ((float4 *)(a.ws + a.g1_off))[(((size_t)t * RB + rb) * 256 + 8 * c + b) * 32 + cb + j] = da;
                 }
             }
-        } else if (w == 2) {
-            // ---- head backward at t = T-n: dfb_t = sum of the 32 CUs' parts (published one phase ago) -------------------------
+            if (lane < 32) sDA1[b][j] = da;
+        }
+        if (w == 2) {
+            // ---- head backward at t = T-n (dfb_t was summed at the end of the previous phase): dp, dl_t -> LDS for wave 1 one phase on --
             const int t = T - n;
-            if (t >= 0 && t < T && alive) {
-                // lane = (CU half h, feature f, clip j): 16 CUs each
-                const unsigned base = a.dfx_off + ((gg * X4_SLOTS + (t & 3)) * 32 + 16 * (lane >> 5)) * 128;
-                float sum = 0.f;
-                long long t0 = 0;
-                for (unsigned spins = 1;; ++spins) {
-                    unsigned v[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b32(rws, (lane & 31) * 4, base + q * 128, 16);   // sc1
-                    bool bad = false;
-                    sum = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) { bad |= v[q] == X4_SENT; sum += __uint_as_float(v[q]); }
-                    if (!__any(bad)) break;
-                    if (!x4_keep_polling(spins, t0, a.status, p)) { alive = false; break; }
-                }
-                if (alive) {
+            if (t >= 0 && t < T && !(a.debug & 8)) {
+                const float sum = hsum;
                     // this step's slot probabilities and boxes (lanes 0..15 = (slot quad rg, clip j)): left in LDS by wave 3 one
                     // phase ago (they come from HBM)
                     float4 hp = make_float4(0.f, 0.f, 0.f, 0.f), hx[6];
@@ -963,13 +915,11 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                         if (c == (n & 31))
                             ((float4 *)(a.ws + a.dl_off))[(((size_t)t * RB + rb) * 4 + rg) * 32 + cb + j] = dl;
                     }
-                } else sAbort = 1;
             }
         }
-        if (tracer) a.trace[(long)p * 8 + 4] = clock64();
-        // ================================ the next phase's inputs ==========================================================
+        // wave 3: the next head step's boxes and p, from HBM into registers now, into LDS at the end of the phase
         float4 hxa = make_float4(0.f, 0.f, 0.f, 0.f), hxb = hxa;
-        const int tn = T - nn;                                 // the next phase's head step
+        const int tn = T - nn;
         const bool hfetch = w == 3 && more && tn >= 0 && tn < T;
         if (hfetch) {
             // lane = (k-quad or slot quad q, clip j): boxes k-quads 0..15 | boxes k-quads 16..23 and p
@@ -978,19 +928,98 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
             if (b < 8) hxb = xs[(16 + b) * 32];
             else if (b < 12) hxb = ((const float4 *)(a.ws + a.ps_off))[(((size_t)tn * RB + gn) * 4 + (b - 8)) * 32 + cb + j];
         }
-        if (more && alive) {
+        if (tracer) a.trace[(long)p * 8 + 1] = clock64();
+        __syncthreads();                        // barrier 1: the CU's da of the phase is in LDS
+        if (tracer) a.trace[(long)p * 8 + 2] = clock64();
+        if (sAbort) return;
+        // ================================ products: the CU's gate columns x its da -> partial dh rows of every unit ==========
+        if (!(a.debug & 16)) {
+            const float4 *F2 = &sDA2[0][0] + j, *F1 = &sDA1[0][0] + j;
+            x4_f32x4 d2a = {0.f, 0.f, 0.f, 0.f}, d2b = d2a, d1 = d2a;
+            float4 bf[X4_RING];
+            // 24 B fragments: 16 of da2 (each feeds set 0 and set 1: 8 MFMAs) | 8 of da1 (4 MFMAs), X4_AHEAD ahead
+            auto frag = [&](int idx) -> const float4 * { return idx < 16 ? F2 + idx * 4 : F1 + (idx - 16) * 4; };
+#pragma unroll
+            for (int i = 0; i < X4_AHEAD; ++i) bf[i] = *frag(i);
+#pragma unroll
+            for (int idx = 0; idx < 24; ++idx) {
+                if (idx + X4_AHEAD < 24) bf[(idx + X4_AHEAD) % X4_RING] = *frag(idx + X4_AHEAD);
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 bq = bf[idx % X4_RING];
+                if (idx < 16) {
+                    const float4 wa = b2[idx < 16 ? idx : 0], wb = b2[idx < 16 ? 16 + idx : 16];
+                    X4_MFMA(d2a, wa.x, bq.x); X4_MFMA(d2b, wb.x, bq.x);
+                    X4_MFMA(d2a, wa.y, bq.y); X4_MFMA(d2b, wb.y, bq.y);
+                    X4_MFMA(d2a, wa.z, bq.z); X4_MFMA(d2b, wb.z, bq.z);
+                    X4_MFMA(d2a, wa.w, bq.w); X4_MFMA(d2b, wb.w, bq.w);
+                } else {
+                    const float4 wc = b1[idx - 16];
+                    X4_MFMA(d1, wc.x, bq.x);
+                    X4_MFMA(d1, wc.y, bq.y);
+                    X4_MFMA(d1, wc.z, bq.z);
+                    X4_MFMA(d1, wc.w, bq.w);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // lane (block bb, clip j) holds rows 4 bb .. 4 bb + 3 of its row set = one float4 of the owner's chunk:
+            //   dh2 row 128 w + 64 set + 4 bb + i -> owner 8 w + 4 set + (bb >> 2), unit quad bb & 3
+            //   dh1 row  64 w + 4 bb + i          -> owner 8 w + (bb >> 1),         unit quad bb & 1
+            const int t2 = T - 1 - n, t1 = T + 1 - n;
+            if (t2 >= 0 && t2 < T) {
+                const unsigned vo = (((b >> 2) * 32) * 16 + (b & 3) * 4 + j) * 16;       // owner stride 32 producers x 16 float4
+                const unsigned so = a.p2x_off + (((gg * X4_SLOTS + (t2 & 3)) * 32 + 8 * w) * 32 + c) * 256;
+                const unsigned sr = a.p2x_off + (((gg * X4_SLOTS + ((t2 + 2) & 3)) * 32 + 8 * w) * 32 + c) * 256;
+                xcd_store16(rws, vo, so, make_float4(d2a[0], d2a[1], d2a[2], d2a[3]), local);
+                xcd_store16(rws, vo, so + 4 * 32 * 256, make_float4(d2b[0], d2b[1], d2b[2], d2b[3]), local);
+                xcd_store16(rws, vo, sr, sentf, local);
+                xcd_store16(rws, vo, sr + 4 * 32 * 256, sentf, local);
+            }
+            if (t1 >= 0 && t1 < T) {
+                const unsigned vo = (((b >> 1) * 32) * 8 + (b & 1) * 4 + j) * 16;        // owner stride 32 producers x 8 float4
+                const unsigned so = a.p1x_off + (((gg * X4_SLOTS + (t1 & 3)) * 32 + 8 * w) * 32 + c) * 128;
+                const unsigned sr = a.p1x_off + (((gg * X4_SLOTS + ((t1 + 2) & 3)) * 32 + 8 * w) * 32 + c) * 128;
+                xcd_store16(rws, vo, so, make_float4(d1[0], d1[1], d1[2], d1[3]), local);
+                xcd_store16(rws, vo, sr, sentf, local);
+            }
+        }
+        if (tracer) a.trace[(long)p * 8 + 3] = clock64();
+        // ================================ wave 2: the next head step's dfb = sum of the 32 CUs' parts (published in this phase's
+        //                                  first half, i.e. long ago), fetched now so that the head backward is pure arithmetic ====
+        if (w == 2 && more && alive && !(a.debug & 8)) {
+            const int t = T - nn;
+            hsum = 0.f;
+            if (t >= 0 && t < T) {
+                // lane = (CU half h, feature f, clip j): 16 CUs each
+                const unsigned base = a.dfx_off + (((gn * 8 + x) * X4_SLOTS + (t & 3)) * 32) * 128;   // wave-uniform: the lane half goes into the lane offset
+                const unsigned hvo = (lane & 31) * 4 + (lane >> 5) * (16 * 128);
+                long long t0 = 0;
+                for (unsigned spins = 1;; ++spins) {
+                    unsigned v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b32(rws, hvo, base + q * 128, 16);   // sc1
+                    bool bad = false;
+                    hsum = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { bad |= v[q] == X4_SENT; hsum += __uint_as_float(v[q]); }
+                    if (!__any(bad)) break;
+                    if (!x4_keep_polling(spins, t0, a.status, p)) { alive = false; sAbort = 1; break; }
+                }
+            }
+        }
+        // ================================ the next phase's inputs ==========================================================
+        if (more && alive && !(a.debug & 1)) {
             alive = gather(gn, nn, buf ^ 1, p);
             if (!alive) sAbort = 1;
         }
-        if (tracer) a.trace[(long)p * 8 + 5] = clock64();
+        if (tracer) a.trace[(long)p * 8 + 4] = clock64();
         if (hfetch) {
             sHX[gn][nn & 1][b][j] = hxa;
             if (b < 12) sHX[gn][nn & 1][16 + b][j] = hxb;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // orders this phase's re-arm stores before the next publish
+        if (tracer) a.trace[(long)p * 8 + 5] = clock64();
+        __syncthreads();                        // barrier 2: the next phase's chunks have landed
         if (tracer) a.trace[(long)p * 8 + 6] = clock64();
-        __syncthreads();                        // barrier 2
-        if (tracer) a.trace[(long)p * 8 + 7] = clock64();
         if (sAbort) return;
         gi = gn;
         n = nn;
