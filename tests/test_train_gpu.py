@@ -157,10 +157,12 @@ def test_l1_mean_and_adam_match_torch():
     assert torch.allclose(p1, p2, rtol=0, atol=2e-7)
 
 
-def test_inference_after_fused_adam_uses_updated_weights():
+@pytest.mark.parametrize("xcd4", ["0", "1"])
+def test_inference_after_fused_adam_uses_updated_weights(xcd4, monkeypatch):
     """Regression: FusedAdam updates parameters outside torch's view; the inference path's packed-weight
     cache is keyed on the parameter version and must notice."""
     from objectpermanence_amd import FusedAdam, l1_mean
+    monkeypatch.setenv("OPNET_XCD4", xcd4)
     boxes, labels = synth.make_batch(9, 4, 20)
     m = _model(REAL_CFG)
     x, lab = torch.from_numpy(boxes).cuda(), torch.from_numpy(labels).cuda()
@@ -177,7 +179,10 @@ def test_inference_after_fused_adam_uses_updated_weights():
     yt, _ = m(x)                          # training path (always repacks)
     torch.cuda.synchronize()
     assert not torch.equal(y0, y1)
-    assert torch.equal(y1, yt.detach())
+    if xcd4 == "0":
+        assert torch.equal(y1, yt.detach())
+    else:       # 4 clips train on the 4-clip persistent step: another summation order than the inference chain's
+        assert (y1 - yt.detach()).abs().max() < 2e-5 and (y0 - y1).abs().max() > 1e-3
 
 
 def test_smooth_l1_matches_torch():

@@ -23,7 +23,7 @@ def step():
     y, _ = m(x)
     l1_mean(y, lab).backward()
 base = None
-for dbg, name in [(0, "full"), (1, "no gather"), (2, "no history stores"), (8, "no head"), (16, "no products"), (17, "no products, no gather"), (4, "no cells (and so no dfb parts: head off too)")]:
+for dbg, name in [(0, "full"), (1, "no gather"), (2, "no history stores"), (8, "no head"), (16, "no products"), (17, "no products, no gather"), (4, "no cells (and so no dfb parts: head off too)"), (29, "nothing (loop, barriers, prefetches)")]:
     os.environ["OPNET_X4_DEBUG_BWD"] = str(dbg | (8 if dbg & 4 else 0))
     t = timed(step)
     base = base or t
