@@ -115,31 +115,28 @@ __device__ __forceinline__ bool x4_keep_polling(unsigned spins, long long &t0, u
     return true;
 }
 
-// NP pieces of 1 KB (lane l: 16 B at src + 1024 q + 16 l) -> registers, reloading every piece in which some lane still sees the
-// sentinel (need: bit q = piece q is part of this phase); then into LDS at dst + 64 q float4.  false = abort (wave-uniform).
+// NP pieces of 1 KB (lane l: 16 B at src + 1024 q + 16 l) -> registers -> LDS at dst + 64 q float4; while any lane of the wave still
+// sees a sentinel word, all of them are loaded again (straight-line code: per-piece bookkeeping compiled to ~30 scalar branches a
+// call).  wait = false: this phase does not use the pieces (nobody publishes them any more / yet): nothing is loaded.
+// false = abort (wave-uniform).
 template <int NP>
-__device__ __forceinline__ bool x4_gather(__amdgpu_buffer_rsrc_t rws, unsigned lane16, unsigned src, unsigned need, float4 *dst,
-                                          unsigned *status, int phase, unsigned long long *tr = nullptr)
+__device__ __forceinline__ bool x4_gather(__amdgpu_buffer_rsrc_t rws, unsigned lane16, unsigned src, bool wait, float4 *dst,
+                                          unsigned *status, int phase)
 {
+    if (!wait) return true;
     xcd_u32x4 r[NP];
-    unsigned todo = need;
     long long t0 = 0;
-    unsigned spins = 1;
-    for (; todo; ++spins) {
+    for (unsigned spins = 1;; ++spins) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q)
-            if (todo & (1u << q)) r[q] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, src + q * 1024, 16);   // sc1
-        if (tr && spins == 1) tr[0] = clock64();
+        for (int q = 0; q < NP; ++q) r[q] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, src + q * 1024, 16);   // sc1
+        bool bad = false;
 #pragma unroll
-        for (int q = 0; q < NP; ++q)
-            if ((todo & (1u << q)) && !__any(x4_unpublished(r[q]))) todo &= ~(1u << q);
-        if (tr && spins == 1) tr[1] = clock64();
-        if (todo && !x4_keep_polling(spins, t0, status, phase)) return false;
+        for (int q = 0; q < NP; ++q) bad |= x4_unpublished(r[q]);
+        if (!__any(bad)) break;
+        if (!x4_keep_polling(spins, t0, status, phase)) return false;
     }
-    if (tr) tr[2] = spins;
 #pragma unroll
-    for (int q = 0; q < NP; ++q)
-        if (need & (1u << q)) dst[q * 64] = x4_as_float4(r[q]);
+    for (int q = 0; q < NP; ++q) dst[q * 64] = x4_as_float4(r[q]);
     return true;
 }
 
@@ -282,7 +279,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
                 xc = __builtin_amdgcn_raw_buffer_load_b128(rws, xlane, o0 + 16 * 512, 0);
                 xd = __builtin_amdgcn_raw_buffer_load_b128(rws, xlane, o1 + 16 * 512, 0);
             }
-            const bool ok = x4_gather<4>(rws, lane16, a.h1x_off + (gg * X4_SLOTS + (s & 3)) * 4096, s <= T ? 0xfu : 0u,
+            const bool ok = x4_gather<4>(rws, lane16, a.h1x_off + (gg * X4_SLOTS + (s & 3)) * 4096, s <= T,
                                          S + X4B_H1, a.status, phase);
             S[X4B_X0] = x4_as_float4(xa);
             S[X4B_X1] = x4_as_float4(xb);
@@ -290,9 +287,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
             return ok;
         }
         if (w == 2) return true;
-        return x4_gather<4>(rws, lane16, a.h2x_off + (gg * X4_SLOTS + ((s + 2) & 3)) * 8192 + w * 4096, s >= 2 ? 0xfu : 0u,
-                            S + X4B_H2 + w * 256, a.status, phase,
-                            a.trace && blockIdx.x == 0 && threadIdx.x == 0 ? a.trace + ((long)(T + 2) * a.RB + phase) * 8 : nullptr);
+        return x4_gather<4>(rws, lane16, a.h2x_off + (gg * X4_SLOTS + ((s + 2) & 3)) * 8192 + w * 4096, s >= 2,
+                            S + X4B_H2 + w * 256, a.status, phase);
     };
 
     if (!gather(0, 0, 0, 0)) sAbort = 1;
@@ -739,10 +735,10 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         float4 *S = &sbuf[buf][0] + lane;
         const unsigned gg = gi * 8 + x;
         if (w == 3)
-            return x4_gather<4>(rws, lane16, a.p1x_off + ((gg * X4_SLOTS + ((T + 2 - n) & 3)) * 32 + c) * 4096, n >= 2 ? 0xfu : 0u,
+            return x4_gather<4>(rws, lane16, a.p1x_off + ((gg * X4_SLOTS + ((T + 2 - n) & 3)) * 32 + c) * 4096, n >= 2,
                                 S + X4D_P1, a.status, phase);
         return x4_gather<4>(rws, lane16, a.p2x_off + ((gg * X4_SLOTS + ((T - n) & 3)) * 32 + c) * 8192 + w * 4096,
-                            n <= T - 1 ? 0xfu : 0u, S + X4D_P2 + w * 256, a.status, phase);
+                            n <= T - 1, S + X4D_P2 + w * 256, a.status, phase);
     };
 
     // the saved activations a cell needs (gates, c_t, c_{t-1}, wave 0: dy), fetched one phase ahead - they come from HBM / the
