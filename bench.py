@@ -171,6 +171,14 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank == 0:
+        from objectpermanence_amd import _lib
+        persistent = (B <= int(os.environ.get("OPNET_XCD4_MAX_B", "32")) and os.environ.get("OPNET_XCD4", "1") != "0"
+                      and bool(_lib.load().opnet_xcd_supported(CFG["object_to_track_hidden_dim"], CFG["videos_hidden_dim"])))
+        engine = "xcd4" if persistent else "chain"
+        kernels = ("opnet_xcd4_forward + opnet_xcd4_backward (the whole recurrence as ONE persistent launch each, 4-clip groups "
+                   "per XCD, weights resident in registers) + opnet_wgrad" if persistent else
+                   "opnet_step + opnet_bwd_fused (the 2 launches of a time step; opnet_bwd_gemm + opnet_bwd_cell above 128 clips) "
+                   "+ opnet_wgrad")
         # algorithmic bytes of one training step under the per-time-step streaming model: the
         # forward streams the weights once per step and moves each clip's state (+ the saved history: gates 4x, h, c per
         # unit), the backward streams W_hh^T / W_ih2^T / the heads once per reverse step and reads the history back
@@ -212,9 +220,13 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
                        "parallelism": f"dp{world}", "loss": args.loss},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "opnet_step + opnet_bwd_fused (the 2 launches of a time step; opnet_bwd_gemm + opnet_bwd_cell "
-                                   "above 128 clips) + opnet_wgrad; algorithmic bytes of the whole step / GPU time",
+                         "kernel": kernels + "; algorithmic bytes of the whole step (north_star's per-time-step weight-streaming model) / GPU time",
                          "alg_bytes_per_step": alg},
+            # forward 852.7 MFLOP per clip, backward twice that, over the fp32 MFMA peak
+            "roofline_mfma": {"bound": "mfma", "achieved": round(3 * FLOP_PER_CLIP * B * args.steps / (gpu_ms * 1e-3) / 1e12, 2),
+                              "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": round(3 * FLOP_PER_CLIP * B * args.steps / (gpu_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)},
+            "engine": engine,
             "cpu_baseline": cpu,
             "final_loss": float(loss.item())})
     if dist is not None:

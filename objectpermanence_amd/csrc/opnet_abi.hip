@@ -705,29 +705,80 @@ extern "C" size_t opnet_train_workspace_bytes(int B, int T, int H1, int H2)
     return train_workspace_layout(B, T, H1, H2).total;
 }
 
-extern "C" int opnet_train_pack_weights_f32(const float *w_ih1, const float *w_hh1, const float *w_sel,
-                                            const float *w_ih2, const float *w_hh2, const float *w_out,
-                                            float *packed, size_t packed_bytes, int H1, int H2, void *stream)
+// The launch chain's training layouts (the inference layout + W^T tiles + raw heads: 9 small launches) are only read by the
+// launch-chain step; a batch that trains on the 4-clip persistent kernels reads the x4 images and the output-head tiles.
+// opnet_train_pack_weights_f32 therefore packs those three eagerly and leaves the rest to the first launch-chain call that
+// follows (train_chain_layouts) - the caller's weight pointers are remembered per packed buffer until then.
+struct TrainPackState { const float *w[6]; int H1, H2; bool chain_stale; };
+static std::mutex g_tp_mu;
+static std::map<const float *, TrainPackState> g_tp;
+
+static int pack_chain_train_layouts(const float *w_ih1, const float *w_hh1, const float *w_sel, const float *w_ih2,
+                                    const float *w_hh2, const float *w_out, float *packed, int H1, int H2, hipStream_t st)
 {
-    if (int rc = check_dims(1, 1, H1, H2)) return rc;
     const TrainPackedLayout L = train_packed_layout(H1, H2);
-    if (packed_bytes < L.total * sizeof(float))
-        return fail(OPNET_EWORKSPACE, "packed buffer %zu B < %zu B", packed_bytes, L.total * sizeof(float));
     if (int rc = opnet_pack_weights_f32(w_ih1, w_hh1, w_sel, w_ih2, w_hh2, w_out, packed,
-                                        L.fwd_total * sizeof(float), H1, H2, stream))
+                                        L.fwd_total * sizeof(float), H1, H2, st))
         return rc;
-    hipStream_t st = (hipStream_t)stream;
     auto blocks = [](size_t n) { return (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256); };
     opnet_pack_tiles_t<<<blocks((size_t)(H2 / 16) * (H2 / 4) * 256), 256, 0, st>>>(packed + L.w2bt, w_hh2, H2, 0, 0, H2 / 16);
     opnet_pack_tiles_t<<<blocks((size_t)(H1 / 16) * (H1 / 4) * 256), 256, 0, st>>>(packed + L.w1bt, w_hh1, H1, 0, 0, H1 / 16);
     opnet_pack_tiles_t<<<blocks((size_t)(H2 / 4) * 256), 256, 0, st>>>(packed + L.wih2t, w_ih2, H2, OPNET_FEATS, 1, 1);
     opnet_copy_f32<<<blocks((size_t)OPNET_SLOTS * H1), 256, 0, st>>>(packed + L.wsel, w_sel, (long)OPNET_SLOTS * H1);
     opnet_copy_f32<<<blocks((size_t)4 * H2), 256, 0, st>>>(packed + L.wout, w_out, (long)4 * H2);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+// before a launch-chain training launch: pack what opnet_train_pack_weights_f32 left out
+static int train_chain_layouts(const float *packed, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(g_tp_mu);
+    auto it = g_tp.find(packed);
+    if (it == g_tp.end() || !it->second.chain_stale) return OPNET_OK;
+    TrainPackState &t = it->second;
+    if (int rc = pack_chain_train_layouts(t.w[0], t.w[1], t.w[2], t.w[3], t.w[4], t.w[5], (float *)packed, t.H1, t.H2, st)) return rc;
+    t.chain_stale = false;
+    return OPNET_OK;
+}
+
+static bool x4_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    return xcd_device_cus(dev) >= XCD_COUNT * XCD_CUS;
+}
+
+extern "C" int opnet_train_pack_weights_f32(const float *w_ih1, const float *w_hh1, const float *w_sel,
+                                            const float *w_ih2, const float *w_hh2, const float *w_out,
+                                            float *packed, size_t packed_bytes, int H1, int H2, void *stream)
+{
+    if (int rc = check_dims(1, 1, H1, H2)) return rc;
+    if (!w_ih1 || !w_hh1 || !w_sel || !w_ih2 || !w_hh2 || !w_out || !packed) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(packed)) return fail(OPNET_EINVAL, "packed must be 16-byte aligned");
+    const TrainPackedLayout L = train_packed_layout(H1, H2);
+    if (packed_bytes < L.total * sizeof(float))
+        return fail(OPNET_EWORKSPACE, "packed buffer %zu B < %zu B", packed_bytes, L.total * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    const bool lazy = x4_dims(H1, H2) && env_int("OPNET_XCD4", 1) != 0 && x4_device();
+    if (!lazy) {
+        if (int rc = pack_chain_train_layouts(w_ih1, w_hh1, w_sel, w_ih2, w_hh2, w_out, packed, H1, H2, st)) return rc;
+    } else {
+        const PackedLayout P = packed_layout(H1, H2);
+        opnet_pack_tiles<<<(unsigned)(((size_t)(H2 / 16) * 256 + 255) / 256), 256, 0, st>>>(
+            packed + P.woutp, nullptr, w_out, 0, 0, H2, 0, 4, 1, 1);                // the output head's tiles (opnet_xcd4_out_head)
+    }
     if (x4_dims(H1, H2)) {
         opnet_xcd4_pack_fwd<<<1024, 256, 0, st>>>(packed + L.x4fwd, w_ih1, w_hh1, w_sel, w_ih2, w_hh2);
         opnet_xcd4_pack_bwd<<<1024, 256, 0, st>>>(packed + L.x4bwd, w_hh1, w_sel, w_ih2, w_hh2, w_out);
     }
     HIP_TRY(hipGetLastError());
+    {
+        std::lock_guard<std::mutex> lock(g_tp_mu);
+        if (g_tp.size() > 64) g_tp.clear();          // buffers come and go with their modules: forgetting one only costs a full pack
+        TrainPackState t = {{w_ih1, w_hh1, w_sel, w_ih2, w_hh2, w_out}, H1, H2, lazy};
+        g_tp[packed] = t;
+    }
     return OPNET_OK;
 }
 
@@ -893,6 +944,7 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
         HIP_TRY(hipGetLastError());
         return OPNET_OK;
     }
+    if (int rc = train_chain_layouts(packed, st)) return rc;
     const dim3 grid = step_grid(a);
     const opnet_step_fn stepk = step_kernel(a);
     for (int s = 0; s < T + 3; ++s) stepk<<<grid, step_threads(a), 0, st>>>(a, s);
@@ -960,6 +1012,8 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
         else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
         opnet_xcd4_backward<<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(x);
         HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
+    } else if (int rc = train_chain_layouts(packed, st)) {
+        return rc;
     } else if (fused) {
         const dim3 gfused(2 * (H2 / 16 + H1 / 16 + 1), RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
         for (int n = 0; n <= T + 1; ++n) opnet_bwd_fused<<<gfused, FUSED_THREADS, 0, st>>>(bw, n);
