@@ -93,6 +93,21 @@ int opnet_xcd_profile(int enable);
 int opnet_xcd_profile_read(double *kernel_ms_total, int *launches);
 /* tools: device buffer of >= (T+1) * ceil(B/128) * 8 uint64 receiving s_memtime stamps of block 0 (NULL = off) */
 void opnet_xcd_set_trace(void *device_buffer);
+/* ---- one small request as ONE persistent launch: groups of FOUR clips, one per XCD (csrc/opnet_xcd4_kernels.hip) -------------
+ * The same function as opnet_forward_f32 for B <= opnet_xcd4_max_batch() clips (built for B <= 32: the reference's inference
+ * batch_size is 16, configs/inference_config.json:2, its training batch 32) at the reference hidden sizes on a whole MI355X
+ * (opnet_xcd_supported): every weight resident in registers for all T steps, h exchanged through the XCD's L2 with sentinel-armed
+ * rings (no flags).  A 32-clip forward takes 0.75 ms against 1.2 ms through the launch chain.  `packed` is its own image
+ * (opnet_xcd4_pack_weights_f32); the workspace holds the packed input, the h2 history (for the output head) and the rings.
+ * Same error / stream / never-allocate conventions as above; an aborted launch (bounded polls) leaves NaN in y. */
+int opnet_xcd4_max_batch(void);
+size_t opnet_xcd4_packed_weights_bytes(int H1, int H2);
+size_t opnet_xcd4_workspace_bytes(int B, int T, int H1, int H2);
+int opnet_xcd4_pack_weights_f32(const float *w_ih1, const float *w_hh1, const float *w_sel, const float *w_ih2,
+                                const float *w_hh2, const float *w_out, float *packed, size_t packed_bytes,
+                                int H1, int H2, void *stream);
+int opnet_xcd4_forward_f32(const float *boxes, const float *packed, float *y, float *logits, void *workspace,
+                           size_t workspace_bytes, int B, int T, int H1, int H2, void *stream);
 /* tools: the same for the 4-clip persistent training kernels (opnet_train_forward_f32 / opnet_train_backward_f32 on
  * batches of up to 32 clips): >= (T+2) * ceil(B/32) * 8 uint64 */
 void opnet_xcd4_set_trace(void *device_buffer);

@@ -854,6 +854,134 @@ extern "C" int opnet_xcd4_last_status(unsigned *out4)
     return OPNET_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// inference on the 4-clip persistent forward (one small request: the reference's inference batch_size is 16,
+// configs/inference_config.json:2): opnet_xcd4_forward<false> = the training forward without the backward's histories
+// ------------------------------------------------------------------------------------------------
+struct X4InferPacked { size_t x4fwd, woutp, total; };      // floats
+static X4InferPacked x4_infer_packed_layout()
+{
+    X4InferPacked L;
+    L.x4fwd = 0;
+    L.woutp = x4_packed_layout().total;
+    L.total = L.woutp + (size_t)(XCD_H2 / 16) * 256;
+    return L;
+}
+struct X4InferLayout { size_t io, xp, h2all, ystage, lgstage, h1x, h2x, status, total; };   // bytes
+static X4InferLayout x4_infer_layout(int B, int T)
+{
+    const size_t RB = (B + 31) / 32, TT = T, NG = RB * 8;
+    X4InferLayout L;
+    size_t o = 0;
+    L.io = o;      o += align_up(sizeof(OpnetIO), 256);
+    L.xp = o;      o += TT * RB * OPNET_KXQ * 32 * 16;
+    L.h2all = o;   o += (TT + 1) * RB * (size_t)XCD_H2 * 32 * 4;
+    L.ystage = o;  o += RB * 32 * TT * 16;
+    L.lgstage = o; o += RB * 32 * TT * OPNET_SLOTS * 4;
+    o = align_up(o, 4096);
+    L.h1x = o;     o += NG * X4_SLOTS * 4096;
+    L.h2x = o;     o += NG * X4_SLOTS * 8192;
+    L.status = o;  o += 2048;
+    L.total = align_up(o, 256);
+    return L;
+}
+static int check_x4_infer(int B, int T, int H1, int H2)
+{
+    if (B <= 0 || T <= 0) return fail(OPNET_ESHAPE, "B=%d T=%d must be positive", B, T);
+    if (!x4_dims(H1, H2))
+        return fail(OPNET_ESHAPE, "the 4-clip persistent forward is built for H1=%d, H2=%d (got %d, %d); use opnet_forward_f32",
+                    XCD_H1, XCD_H2, H1, H2);
+    if ((B + 31) / 32 > X4_NGMAX) return fail(OPNET_ESHAPE, "B=%d > %d clips per launch: use opnet_xcd_forward_f32", B, 32 * X4_NGMAX);
+    if (x4_infer_layout(B, T).total >= ((size_t)1 << 31))
+        return fail(OPNET_ESHAPE, "B=%d x T=%d: the workspace exceeds the 2 GiB one buffer descriptor addresses", B, T);
+    return OPNET_OK;
+}
+extern "C" int opnet_xcd4_max_batch(void) { return 32 * X4_NGMAX; }
+extern "C" size_t opnet_xcd4_packed_weights_bytes(int H1, int H2)
+{
+    return x4_dims(H1, H2) ? x4_infer_packed_layout().total * sizeof(float) : 0;
+}
+extern "C" size_t opnet_xcd4_workspace_bytes(int B, int T, int H1, int H2)
+{
+    if (check_x4_infer(B, T, H1, H2)) return 0;
+    return x4_infer_layout(B, T).total;
+}
+extern "C" int opnet_xcd4_pack_weights_f32(const float *w_ih1, const float *w_hh1, const float *w_sel, const float *w_ih2,
+                                           const float *w_hh2, const float *w_out, float *packed, size_t packed_bytes,
+                                           int H1, int H2, void *stream)
+{
+    if (!x4_dims(H1, H2)) return fail(OPNET_ESHAPE, "the 4-clip persistent forward is built for H1=%d, H2=%d", XCD_H1, XCD_H2);
+    if (!w_ih1 || !w_hh1 || !w_sel || !w_ih2 || !w_hh2 || !w_out || !packed) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(packed)) return fail(OPNET_EINVAL, "packed must be 16-byte aligned");
+    const X4InferPacked L = x4_infer_packed_layout();
+    if (packed_bytes < L.total * sizeof(float)) return fail(OPNET_EWORKSPACE, "packed buffer %zu B < %zu B", packed_bytes, L.total * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    opnet_xcd4_pack_fwd<<<1024, 256, 0, st>>>(packed + L.x4fwd, w_ih1, w_hh1, w_sel, w_ih2, w_hh2);
+    opnet_pack_tiles<<<(unsigned)(((size_t)(H2 / 16) * 256 + 255) / 256), 256, 0, st>>>(packed + L.woutp, nullptr, w_out, 0, 0, H2, 0, 4, 1, 1);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+/* y [B][T][4], logits [B][15][T] for B <= opnet_xcd4_max_batch() clips as ONE persistent launch on a whole MI355X
+ * (opnet_xcd_supported); packed: opnet_xcd4_pack_weights_f32 image */
+extern "C" int opnet_xcd4_forward_f32(const float *boxes, const float *packed, float *y, float *logits, void *workspace,
+                                      size_t workspace_bytes, int B, int T, int H1, int H2, void *stream)
+{
+    if (int rc = check_x4_infer(B, T, H1, H2)) return rc;
+    if (!boxes || !packed || !y || !logits || !workspace) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(packed) || !aligned16(y) || !aligned16(workspace) || (((uintptr_t)boxes) & 7u))
+        return fail(OPNET_EINVAL, "packed/y/workspace must be 16-byte and boxes 8-byte aligned");
+    const X4InferLayout L = x4_infer_layout(B, T);
+    if (workspace_bytes < L.total) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", workspace_bytes, L.total);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (xcd_device_cus(dev) < XCD_COUNT * XCD_CUS)
+        return fail(OPNET_ESHAPE, "device %d exposes %d CUs; the persistent forward needs %d resident workgroups", dev,
+                    xcd_device_cus(dev), XCD_COUNT * XCD_CUS);
+    hipStream_t st = (hipStream_t)stream;
+    char *w = (char *)workspace;
+    const X4InferPacked PK = x4_infer_packed_layout();
+    const int RB = (B + 31) / 32;
+    OpnetIO io;
+    memset(&io, 0, sizeof(io));
+    io.B = B; io.T = T; io.RB = RB;
+    io.boxes = boxes; io.y = y; io.logits = logits;
+    io.xp = (float4 *)(w + L.xp);
+    io.ystage = (const float4 *)(w + L.ystage);
+    io.lgstage = (const float *)(w + L.lgstage);
+    io.state = (float4 *)(w + L.h2all);
+    io.state_f4 = 0;                                    // nothing to zero: the initial state lives in the exchange rings
+    Xcd4Args x;
+    memset(&x, 0, sizeof(x));
+    x.B = B; x.T = T; x.RB = RB;
+    x.pk = packed + PK.x4fwd;
+    x.woutp = packed + PK.woutp;
+    x.ws = w;
+    x.xp_off = (unsigned)L.xp;
+    x.h2_off = (unsigned)L.h2all;
+    x.lg_off = (unsigned)L.lgstage; x.ys_off = (unsigned)L.ystage;
+    x.h1x_off = (unsigned)L.h1x; x.h2x_off = (unsigned)L.h2x;
+    x.status = (unsigned *)(w + L.status);
+    x.force_safe = env_int("OPNET_XCD_SAFE", 0);
+    x.delay = 0;
+    x.debug = 0;
+    x.trace = g_x4_trace;
+    g_x4_last_status = x.status;
+    OpnetIO *dio = (OpnetIO *)(w + L.io);
+    opnet_set_io<<<1, 1, 0, st>>>(dio, io);
+    opnet_pack_input<<<dim3(T, RB), 256, 0, st>>>(dio);
+    opnet_xcd4_init<<<8, 256, 0, st>>>(x);
+    std::lock_guard<std::mutex> lock(g_xcd_mu);
+    if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
+    else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
+    opnet_xcd4_forward<false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(x);
+    HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
+    opnet_xcd4_out_head<<<dim3(T, RB), 256, 0, st>>>(x);
+    opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
 // Does the training step of this batch run on the 4-clip persistent kernels?  Reference hidden sizes, a whole device (8 XCDs
 // x 32 CUs), at most OPNET_XCD4_MAX_B clips (default 32: one group per XCD - larger batches serialise their row blocks and
 // the launch chain's wide step wins again), OPNET_XCD4 = 0 switches it off.

@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
                     xcd_store16(rws, vo, a.h1x_off + ((gg * X4_SLOTS + ((s + 3) & 3)) * 64 + 2 * c) * 64, sentf, local);
                 }
                 const size_t u = 8 * c + b;
-                if (!(a.debug & 2))
+                if (TRAIN && !(a.debug & 2))
                 ((float *)(a.ws + a.h1_off))[(((size_t)(t + 1) * RB + rb) * 64 + (u >> 2)) * 128 + (cb + j) * 4 + (u & 3)] = h;
                 if (TRAIN && !(a.debug & 2)) {
                     ((float *)(a.ws + a.c1_off))[(((size_t)(t + 1) * RB + rb) * 256 + u) * 32 + cb + j] = cc;

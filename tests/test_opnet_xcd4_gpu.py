@@ -1,7 +1,10 @@
-"""GPU parity of the 4-clip per-XCD persistent training step (csrc/opnet_xcd4_kernels.hip) - the form
-opnet_train_forward_f32 / opnet_train_backward_f32 take for batches of up to 32 clips on a whole MI355X - against the
-launch chain (OPNET_XCD4=0), the fp64 port of the reference (oracle/torch_port.py) and the reference's own autograd
-goldens (tests/test_train_gpu.py runs on it by default)."""
+"""GPU parity of the 4-clip per-XCD persistent kernels (csrc/opnet_xcd4_kernels.hip) - the form opnet_train_forward_f32 /
+opnet_train_backward_f32 take for batches of up to 32 clips on a whole MI355X, and opnet_xcd4_forward_f32, the inference
+forward of one small request - against the launch chain (OPNET_XCD4=0 / use_xcd4 = "0"), the reference's goldens, the
+oracle, and the fp64 port of the reference (oracle/torch_port.py); tests/test_train_gpu.py runs on them by default."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -95,3 +98,62 @@ def test_write_through_protocol_gives_the_same_bits(monkeypatch):
     assert np.array_equal(y_a, y_b) and np.array_equal(lg_a, lg_b)
     for k in g_a:
         assert np.array_equal(g_a[k], g_b[k]), k
+
+
+# ---- inference: opnet_xcd4_forward_f32 (OPNet.forward without grad, up to 32 clips) -----------------------------------------
+def _infer(m, boxes, mode):
+    m.use_xcd4 = mode
+    with torch.no_grad():
+        y, lg = m(torch.from_numpy(boxes).cuda())
+    torch.cuda.synchronize()
+    return y.cpu().numpy(), lg.cpu().numpy()
+
+
+def test_inference_matches_reference_golden(golden_dir):
+    """the reference's own OPNet.forward on 4 clips x 300 frames (tests/golden/opnet_real.npz)"""
+    if not _supported():
+        pytest.skip("needs a whole MI355X (8 XCDs x 32 CUs)")
+    g = np.load(os.path.join(golden_dir, "opnet_real.npz"))
+    boxes, _ = synth.make_batch(0, int(g["n_clips"]), int(g["t_frames"]))
+    m = _model().eval()
+    y, lg = _infer(m, boxes, "1")
+    from objectpermanence_amd import _lib
+    st = (_lib.ctypes.c_uint * 4)()
+    _lib.load().opnet_xcd4_last_status(st)
+    assert list(st)[:1] == [0]
+    assert np.abs(y - g["y"]).max() < 1e-4
+    assert np.abs(lg - g["logits"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (16, 300), (32, 64), (29, 33)])
+def test_inference_matches_chain_and_oracle(B, T):
+    from oracle import opnet_oracle
+    if not _supported():
+        pytest.skip("needs a whole MI355X (8 XCDs x 32 CUs)")
+    boxes, _ = synth.make_batch(500 + B, B, T)
+    m = _model().eval()
+    y_x, lg_x = _infer(m, boxes, "1")
+    y_x2, lg_x2 = _infer(m, boxes, "1")
+    y_c, lg_c = _infer(m, boxes, "0")
+    assert np.isfinite(y_x).all()
+    assert np.array_equal(y_x, y_x2) and np.array_equal(lg_x, lg_x2)          # run to run: the same bits
+    assert np.abs(y_x - y_c).max() < 2e-5 and np.abs(lg_x - lg_c).max() < 5e-5
+    if B * T <= 2000:
+        y_o, lg_o = opnet_oracle.opnet_forward(boxes, synth.opnet_synth_params(REAL_CFG), dtype=np.float64)
+        assert np.abs(y_x - y_o).max() < 2e-5 and np.abs(lg_x - lg_o).max() < 5e-5
+
+
+def test_inference_sees_weight_updates_and_other_streams():
+    if not _supported():
+        pytest.skip("needs a whole MI355X (8 XCDs x 32 CUs)")
+    boxes, _ = synth.make_batch(3, 8, 20)
+    m = _model().eval()
+    y0, _ = _infer(m, boxes, "1")
+    with torch.no_grad():
+        m.prediction_layer.weight.mul_(1.5)
+    y1, _ = _infer(m, boxes, "1")
+    assert np.abs(y1 - 1.5 * y0).max() < 1e-5
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        y2, _ = _infer(m, boxes, "1")
+    assert np.array_equal(y1, y2)
