@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
         if (tracer) a.trace[(long)p * 8 + 1] = clock64();
         __syncthreads();                        // barrier 1: the phase's partials are in sP
         if (tracer) a.trace[(long)p * 8 + 2] = clock64();
-        if (sAbort) return;
+        // (an abort can only be raised in the second half of a phase: it is looked at after barrier 2)
         // the next phase
         int gn = gi + 1, sn = s;
         if (gn == ng) { gn = 0; ++sn; }
@@ -927,7 +927,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         if (tracer) a.trace[(long)p * 8 + 1] = clock64();
         __syncthreads();                        // barrier 1: the CU's da of the phase is in LDS
         if (tracer) a.trace[(long)p * 8 + 2] = clock64();
-        if (sAbort) return;
+        // (an abort can only be raised in the second half of a phase: it is looked at after barrier 2)
         // ================================ products: the CU's gate columns x its da -> partial dh rows of every unit ==========
         if (!(a.debug & 16)) {
             const float4 *F2 = &sDA2[0][0] + j, *F1 = &sDA1[0][0] + j;
