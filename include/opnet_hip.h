@@ -147,6 +147,11 @@ int opnet_smooth_l1_loss_f32(const float *y, const float *labels, float *loss, f
  * the gradient is multiplied by grad_scale first (1/world for data-parallel sums). */
 int opnet_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,
                         float beta1, float beta2, float eps, int step, float grad_scale, void *stream);
+/* the same update for `count` (<= 16) tensors that share the hyper-parameters and the step number, as ONE launch (a model's
+ * parameters: torch.optim.Adam's per-parameter loop, training_main.py:217); arrays of `count` device pointers / element counts */
+int opnet_adam_multi_step_f32(int count, float *const *params, const float *const *grads, float *const *exp_avgs,
+                              float *const *exp_avg_sqs, const long *numels, float lr, float beta1, float beta2,
+                              float eps, int step, float grad_scale, void *stream);
 
 /* ---- sibling reasoners (reference learned_models.py:55-197) ----------------------------------------
  * OPNetLstmMlp (:55-89): OPNet whose video LSTM is relu(Linear 6->H2) (hidden_layer.weight [H2,6]);

@@ -82,6 +82,9 @@ def _declare(lib):
     lib.opnet_l1_loss_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_void_p, c_size_t, c_void_p]
     lib.opnet_smooth_l1_loss_f32.restype = c_int
     lib.opnet_smooth_l1_loss_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_float, c_void_p, c_size_t, c_void_p]
+    lib.opnet_adam_multi_step_f32.restype = c_int
+    lib.opnet_adam_multi_step_f32.argtypes = [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                              POINTER(ctypes.c_long), c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]
     lib.opnet_adam_step_f32.restype = c_int
     lib.opnet_adam_step_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_float, c_float, c_float, c_float,
                                         c_int, c_float, c_void_p]
@@ -178,7 +181,7 @@ EXPORTS = [
     "opnet_xcd4_workspace_bytes", "opnet_xcd4_pack_weights_f32", "opnet_xcd4_forward_f32",
     "opnet_xcd_profile", "opnet_xcd_profile_read",
     "opnet_train_packed_weights_bytes", "opnet_train_pack_weights_f32", "opnet_train_workspace_bytes",
-    "opnet_train_forward_f32", "opnet_train_backward_f32", "opnet_l1_loss_f32", "opnet_smooth_l1_loss_f32", "opnet_adam_step_f32",
+    "opnet_train_forward_f32", "opnet_train_backward_f32", "opnet_l1_loss_f32", "opnet_smooth_l1_loss_f32", "opnet_adam_step_f32", "opnet_adam_multi_step_f32",
     "opnet_mlp_pack_weights_f32", "opnet_mlp_forward_f32",
     "opnet_mlp_train_pack_weights_f32", "opnet_mlp_train_forward_f32", "opnet_mlp_train_backward_f32",
     "opseq_lstm_stack_packed_bytes", "opseq_lstm_stack_workspace_bytes", "opseq_lstm_stack_pack_weights_f32",

@@ -1280,6 +1280,33 @@ extern "C" int opnet_adam_step_f32(float *param, const float *grad, float *exp_a
     return OPNET_OK;
 }
 
+/* opnet_adam_step_f32 for `count` (<= 16) tensors that share the hyper-parameters and the step number, as ONE launch */
+extern "C" int opnet_adam_multi_step_f32(int count, float *const *params, const float *const *grads, float *const *exp_avgs,
+                                         float *const *exp_avg_sqs, const long *numels, float lr, float beta1, float beta2,
+                                         float eps, int step, float grad_scale, void *stream)
+{
+    if (!params || !grads || !exp_avgs || !exp_avg_sqs || !numels) return fail(OPNET_EINVAL, "null pointer");
+    if (count <= 0 || count > OPNET_ADAM_MAX) return fail(OPNET_ESHAPE, "1..%d tensors per call (count=%d)", OPNET_ADAM_MAX, count);
+    if (step <= 0) return fail(OPNET_ESHAPE, "step must be positive");
+    AdamBatch t;
+    memset(&t, 0, sizeof(t));
+    long nmax = 0;
+    for (int k = 0; k < count; ++k) {
+        if (!params[k] || !grads[k] || !exp_avgs[k] || !exp_avg_sqs[k]) return fail(OPNET_EINVAL, "null pointer (tensor %d)", k);
+        if (numels[k] <= 0) return fail(OPNET_ESHAPE, "tensor %d: n must be positive", k);
+        t.p[k] = params[k]; t.g[k] = grads[k]; t.m[k] = exp_avgs[k]; t.v[k] = exp_avg_sqs[k]; t.n[k] = numels[k];
+        if (numels[k] > nmax) nmax = numels[k];
+    }
+    t.count = count;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const unsigned nb = (unsigned)((nmax + 255) / 256 > 1024 ? 1024 : (nmax + 255) / 256);
+    opnet_adam_multi<<<dim3(nb, count), 256, 0, (hipStream_t)stream>>>(t, beta1, beta2, eps, (float)((double)lr / bc1),
+                                                                      (float)(1.0 / sqrt(bc2)), grad_scale);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // sibling reasoners: stacked LSTM + head, slot embedding, transformer encoder layer
 // ------------------------------------------------------------------------------------------------

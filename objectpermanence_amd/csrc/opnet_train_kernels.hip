@@ -723,3 +723,32 @@ __global__ void __launch_bounds__(256) opnet_adam(float *__restrict__ p, const f
         p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
     }
 }
+
+// the same update for up to OPNET_ADAM_MAX tensors in ONE launch (a model's six weights: six launches of ~5 us each otherwise)
+#define OPNET_ADAM_MAX 16
+struct AdamBatch {
+    float *p[OPNET_ADAM_MAX];
+    const float *g[OPNET_ADAM_MAX];
+    float *m[OPNET_ADAM_MAX], *v[OPNET_ADAM_MAX];
+    long n[OPNET_ADAM_MAX];
+    int count;
+};
+
+// grid (blocks per tensor, tensors)
+__global__ void __launch_bounds__(256) opnet_adam_multi(const AdamBatch t, float b1, float b2, float eps, float step_size,
+                                                        float inv_sqrt_bc2, float grad_scale)
+{
+    const int k = blockIdx.y;
+    float *__restrict__ p = t.p[k];
+    const float *__restrict__ gr = t.g[k];
+    float *__restrict__ m = t.m[k], *__restrict__ v = t.v[k];
+    const long n = t.n[k];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float g = gr[i] * grad_scale;
+        const float mi = b1 * m[i] + (1.0f - b1) * g;
+        const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    }
+}

@@ -8,6 +8,8 @@
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -66,6 +68,9 @@ class FusedAdam(torch.optim.Optimizer):
         lib = _lib.load()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            # parameters of one device that are at the same step share ONE launch (opnet_adam_multi_step_f32: up to 16 tensors)
+            batches = {}
+            keep = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -78,14 +83,24 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
                 g = p.grad.contiguous()
-                with torch.cuda.device(p.device):
-                    rc = lib.opnet_adam_step_f32(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
-                                                 st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]),
-                                                 float(b1), float(b2), float(group["eps"]), int(st["step"]),
-                                                 float(group["grad_scale"]),
-                                                 torch.cuda.current_stream(p.device).cuda_stream)
-                _lib.check(rc, "opnet_adam_step_f32")
-                # the update happened outside torch's view: bump the version counter so that consumers
-                # keyed on it (the modules' packed-weight caches) see the parameter as modified
-                torch.autograd.graph.increment_version(p)
+                keep.append(g)
+                batches.setdefault((p.device, int(st["step"])), []).append((p, g, st))
+            for (dev, step_no), items in batches.items():
+                with torch.cuda.device(dev):
+                    stream = torch.cuda.current_stream(dev).cuda_stream
+                    for lo in range(0, len(items), 16):
+                        chunk = items[lo:lo + 16]
+                        n = len(chunk)
+                        arr = lambda vals: (ctypes.c_void_p * n)(*vals)
+                        rc = lib.opnet_adam_multi_step_f32(
+                            n, arr([p.data_ptr() for p, _, _ in chunk]), arr([g.data_ptr() for _, g, _ in chunk]),
+                            arr([st["exp_avg"].data_ptr() for _, _, st in chunk]),
+                            arr([st["exp_avg_sq"].data_ptr() for _, _, st in chunk]),
+                            (ctypes.c_long * n)(*[p.numel() for p, _, _ in chunk]), float(group["lr"]), float(b1), float(b2),
+                            float(group["eps"]), step_no, float(group["grad_scale"]), stream)
+                        _lib.check(rc, "opnet_adam_multi_step_f32")
+                # the update happened outside torch's view: bump the version counters so that consumers keyed on them
+                # (the modules' packed-weight caches) see the parameters as modified
+                for p, _, _ in items:
+                    torch.autograd.graph.increment_version(p)
         return loss
