@@ -157,3 +157,28 @@ def test_inference_sees_weight_updates_and_other_streams():
     with torch.cuda.stream(side):
         y2, _ = _infer(m, boxes, "1")
     assert np.array_equal(y1, y2)
+
+
+# ---- more than one row block per launch (not the default: OPNET_XCD4_MAX_B / XCD4_MAX_BATCH raise the limit) ---------------
+@pytest.mark.parametrize("B,T", [(40, 9), (70, 6), (128, 4)])
+def test_several_row_blocks_per_launch(B, T, monkeypatch):
+    if not _supported():
+        pytest.skip("needs a whole MI355X (8 XCDs x 32 CUs)")
+    boxes, labels = synth.make_batch(700 + B, B, T)
+    m = _model()
+    monkeypatch.setenv("OPNET_XCD4", "1")
+    monkeypatch.setenv("OPNET_XCD4_MAX_B", "128")
+    loss_x, y_x, lg_x, g_x = _run(m, boxes, labels)
+    monkeypatch.setenv("OPNET_XCD4", "0")
+    loss_c, y_c, lg_c, g_c = _run(m, boxes, labels)
+    assert np.isfinite(y_x).all()
+    assert np.abs(y_x - y_c).max() < 2e-5 and np.abs(lg_x - lg_c).max() < 5e-5
+    assert loss_x == pytest.approx(loss_c, abs=2e-6)
+    for k in g_x:
+        assert np.abs(g_x[k] - g_c[k]).max() <= 2e-4 * max(1e-2, np.abs(g_c[k]).max()), k
+    # inference through the same kernel
+    m.eval()
+    m.XCD4_MAX_BATCH = 128
+    y_i, lg_i = _infer(m, boxes, "1")
+    y_j, lg_j = _infer(m, boxes, "0")
+    assert np.abs(y_i - y_j).max() < 2e-5 and np.abs(lg_i - lg_j).max() < 5e-5
