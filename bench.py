@@ -494,7 +494,7 @@ def other_batches(model, boxes, dev):
             torch.cuda.synchronize(dev)
         ms = e0.elapsed_time(e1) / 5
         res[str(b)] = {"ms_per_forward": round(ms, 3), "clips_per_s": round(b / ms * 1e3, 1),
-                       "engine": "xcd" if model._wants_xcd(b) else "xcd4" if model._wants_xcd4(b) else "chain"}
+                       "engine": "xcd4" if model._wants_xcd4(b) else "xcd" if model._wants_xcd(b) else "chain"}
     model.use_xcd = forced
     return {"reference_batch_sizes": res}
 

@@ -94,8 +94,8 @@ int opnet_xcd_profile_read(double *kernel_ms_total, int *launches);
 /* tools: device buffer of >= (T+1) * ceil(B/128) * 8 uint64 receiving s_memtime stamps of block 0 (NULL = off) */
 void opnet_xcd_set_trace(void *device_buffer);
 /* ---- one small request as ONE persistent launch: groups of FOUR clips, one per XCD (csrc/opnet_xcd4_kernels.hip) -------------
- * The same function as opnet_forward_f32 for B <= opnet_xcd4_max_batch() clips (built for B <= 32: the reference's inference
- * batch_size is 16, configs/inference_config.json:2, its training batch 32) at the reference hidden sizes on a whole MI355X
+ * The same function as opnet_forward_f32 for B <= opnet_xcd4_max_batch() clips (meant for B <= 64: the reference's inference
+ * batch_size is 16, configs/inference_config.json:2, its training batch 32; row blocks of 32 clips run one after the other) at the reference hidden sizes on a whole MI355X
  * (opnet_xcd_supported): every weight resident in registers for all T steps, h exchanged through the XCD's L2 with sentinel-armed
  * rings (no flags).  A 32-clip forward takes 0.75 ms against 1.2 ms through the launch chain.  `packed` is its own image
  * (opnet_xcd4_pack_weights_f32); the workspace holds the packed input, the h2 history (for the output head) and the rings.

@@ -280,11 +280,12 @@ class OPNet(AbstractCaterModel):
             return False
         return self.use_xcd in ("1", 1, True) or B >= self.XCD_MIN_BATCH
 
-    XCD4_MAX_BATCH = 32      # one 4-clip group per XCD: 0.75 ms for up to 32 clips against 1.2 ms through the launch chain
+    XCD4_MAX_BATCH = 64      # 4-clip groups, one (two) per XCD: 0.76 ms up to 32 clips, 1.35 ms up to 64, against 1.2 / 1.6-1.7 ms
+                             # through the launch chain and 1.65 ms for 64 clips on the 16-clip persistent forward
 
     def _wants_xcd4(self, B: int) -> bool:
-        if self.use_xcd4 in ("0", 0, False) or self.use_xcd in ("0", 0, False) or (self._h1, self._h2) != (256, 512):
-            return False
+        if self.use_xcd4 in ("0", 0, False) or self.use_xcd in ("0", "1", 0, 1, False, True) or (self._h1, self._h2) != (256, 512):
+            return False                # (use_xcd "1" forces the 16-clip form, "0" the launch chain)
         if B > self.XCD4_MAX_BATCH:
             return False
         if self._xcd_ok is None:
@@ -376,7 +377,7 @@ class OPNet(AbstractCaterModel):
         B, T = int(boxes.shape[0]), int(boxes.shape[1])
         dev = boxes.device
         with torch.cuda.device(dev):
-            if self._wants_xcd4(B) and not self._wants_xcd(B):
+            if self._wants_xcd4(B):
                 return self._forward_xcd4(boxes, _stream_ptr(dev))
             packed = self._packed_weights(dev)
             stream = _stream_ptr(dev)
