@@ -963,7 +963,6 @@ extern "C" int opnet_xcd4_forward_f32(const float *boxes, const float *packed, f
     x.h1x_off = (unsigned)L.h1x; x.h2x_off = (unsigned)L.h2x;
     x.status = (unsigned *)(w + L.status);
     x.force_safe = env_int("OPNET_XCD_SAFE", 0);
-    x.delay = 0;
     x.debug = 0;
     x.trace = g_x4_trace;
     g_x4_last_status = x.status;
@@ -1014,7 +1013,6 @@ static int make_x4_args(Xcd4Args *x, const float *packed, void *ws, int B, int T
     x->h1x_off = (unsigned)W.x4h1x; x->h2x_off = (unsigned)W.x4h2x;
     x->status = (unsigned *)((char *)ws + W.x4status);
     x->force_safe = env_int("OPNET_XCD_SAFE", 0);
-    x->delay = env_int("OPNET_X4_DELAY", 0);
     x->debug = env_int("OPNET_X4_DEBUG", 0);
     g_x4_last_status = x->status;
     x->trace = g_x4_trace;

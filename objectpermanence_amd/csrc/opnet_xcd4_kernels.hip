@@ -82,7 +82,6 @@ struct Xcd4Args {
     unsigned h1x_off, h2x_off; // exchange rings: [RB*8 groups][4][H/4][4] float4, slot (t + 1) & 3 = step t
     unsigned *status;          // as XcdArgs.status
     int force_safe;
-    int delay;                 // s_sleep units (64 cycles) a wave idles before its first try at the next phase's h (tuning)
     int debug;                 // tools only (wrong results): bit 0 no gather, 1 no history stores, 2 no cells, 3 no head, 4 no products
     unsigned long long *trace; // optional [phases][8] s_memtime stamps of block 0, wave 0
 };
@@ -503,7 +502,6 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
         if (tracer) a.trace[(long)p * 8 + 4] = clock64();
         // ================================ the next phase's inputs ==========================================================
         if (more && alive && !(a.debug & 1)) {
-            for (int d = 0; d < a.delay; ++d) __builtin_amdgcn_s_sleep(1);
             alive = gather(gn, sn, buf ^ 1, p);
             if (!alive) sAbort = 1;
         }

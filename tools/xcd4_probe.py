@@ -88,10 +88,11 @@ def main():
         t = tr.cpu().numpy().reshape(-1, 8)
         t = t[:(T + 2) * ng]
         ph = t[len(t) // 3: 2 * len(t) // 3]
-        parts = [med(ph[:, i + 1] - ph[:, i]) for i in range(7)] + [med(ph[1:, 0] - ph[:-1, 7])]
-        print(f"  backward, block 0 wave 0, cycles (median): period {med(np.diff(ph[:, 0])):.0f} | "
-              + ", ".join(f"{n} {v:.0f}" for n, v in zip(NAMES, parts)), flush=True)
-
+        BN = ["cells (wave 0: 32-chunk sum, cell, dfb part)", "barrier 1", "products + partial stores", "gather (poll until published)",
+              "drain", "barrier 2"]
+        parts = [med(ph[:, i + 1] - ph[:, i]) for i in range(6)] + [med(ph[1:, 0] - ph[:-1, 6])]
+        print(f"  backward, block 0 wave 0, cycles (median; each stamp costs ~200): period {med(np.diff(ph[:, 0])):.0f} | "
+              + ", ".join(f"{n} {v:.0f}" for n, v in zip(BN + ["loop"], parts)), flush=True)
 
 if __name__ == "__main__":
     main()
