@@ -49,10 +49,10 @@
 #define X4B_F4 1024            // 16 KB
 #define X4_NBUF 6              // buffers allocated (two are used): 96 KB keep a second workgroup off the CU
 #ifndef X4_RING
-#define X4_RING 6
+#define X4_RING 4
 #endif
 #ifndef X4_AHEAD
-#define X4_AHEAD 5
+#define X4_AHEAD 3
 #endif
 
 struct X4Packed { size_t a2, a1, as, ax, total; };     // offsets in floats
