@@ -157,18 +157,21 @@ __device__ __forceinline__ bool xcd_flags_ready(const unsigned *flags, unsigned 
     return __all(v >= need);
 }
 
-// bounded wait for the same; false = abort (wave-uniform)
+// bounded wait for the same; false = abort (wave-uniform).  The wall clock (s_memrealtime: ~600 cycles) is first read at round 64:
+// a wait that ends within a few polls - the common case - never pays for it.
 __device__ __forceinline__ bool xcd_wait_flags(const unsigned *flags, unsigned need, unsigned *status, int phase)
 {
     if (xcd_flags_ready(flags, need)) return true;
     const int lane = threadIdx.x & 63;
-    const long long t0 = wall_clock64();
+    long long t0 = 0;
     for (unsigned spins = 1;; ++spins) {
         __builtin_amdgcn_s_sleep(4);
         if (xcd_flags_ready(flags, need)) return true;
         if ((spins & 63u) == 0) {
             if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if ((long long)wall_clock64() - t0 > XCD_SPIN_LIMIT) {
+            const long long now = (long long)wall_clock64();
+            if (spins == 64u) t0 = now;
+            if (now - t0 > XCD_SPIN_LIMIT) {
                 if (lane == 0) {
                     __hip_atomic_store(status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(status + 2, (unsigned)phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
