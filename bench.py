@@ -437,6 +437,7 @@ def main():
     if rank == 0:
         out.update(accuracy_block(dev))
         out.update(other_batches(model, boxes, dev))
+        out.update(training_block(params, boxes, labels, dev))
         if world == 1 and not args.no_cpu_baseline:
             cb, y_cpu = cpu_baseline(boxes_np, params, args.cpu_seconds)
             out["cpu_baseline"] = cb
@@ -472,6 +473,33 @@ def _line(args, world, B, clips_per_s, elapsed, workload, extra_cfg):
         # launch gaps) is inside this one
         "whole_job_mfma_frac": round(clips_per_s / world * FLOP_PER_CLIP / (MFMA_F32_PEAK_TF * 1e12), 4),
     }
+
+
+def training_block(params, boxes, labels, dev):
+    """BASELINE.json config 2 next to the headline (outside the timed region; `--mode train` is the full measurement): a few
+    training steps - forward + L1 + backward + Adam - of this rank's batch on a fresh copy of the model."""
+    from objectpermanence_amd import FusedAdam, ModelsFactory, _lib
+    from objectpermanence_amd.training import train_step
+    m = ModelsFactory.get_model("opnet", CFG)
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()})
+    m = m.to(dev).train(True)
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    B = int(boxes.shape[0])
+    for _ in range(2):
+        train_step("opnet", m, opt, boxes, labels, n_global=B, comm_stream=None, loss_kind="l1")
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        train_step("opnet", m, opt, boxes, labels, n_global=B, comm_stream=None, loss_kind="l1")
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / 5
+    persistent = (B <= int(os.environ.get("OPNET_XCD4_MAX_B", "32")) and os.environ.get("OPNET_XCD4", "1") != "0"
+                  and bool(_lib.load().opnet_xcd_supported(CFG["object_to_track_hidden_dim"], CFG["videos_hidden_dim"])))
+    return {"training_step": {"batch": B, "ms_per_step": round(ms, 3), "clips_per_s": round(B / ms * 1e3, 1), "loss": "l1",
+                              "engine": "xcd4 (forward and reverse recurrence as one persistent launch each)" if persistent
+                              else "chain (one launch per time step)"}}
 
 
 def other_batches(model, boxes, dev):
