@@ -963,7 +963,7 @@ extern "C" int opnet_xcd4_forward_f32(const float *boxes, const float *packed, f
     x.h1x_off = (unsigned)L.h1x; x.h2x_off = (unsigned)L.h2x;
     x.status = (unsigned *)(w + L.status);
     x.force_safe = env_int("OPNET_XCD_SAFE", 0);
-    x.debug = 0;
+    x.debug = env_int("OPNET_X4_DEBUG", 0);           // tools / the abort test only
     x.trace = g_x4_trace;
     g_x4_last_status = x.status;
     OpnetIO *dio = (OpnetIO *)(w + L.io);

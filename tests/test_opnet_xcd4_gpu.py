@@ -182,3 +182,69 @@ def test_several_row_blocks_per_launch(B, T, monkeypatch):
     y_i, lg_i = _infer(m, boxes, "1")
     y_j, lg_j = _infer(m, boxes, "0")
     assert np.abs(y_i - y_j).max() < 2e-5 and np.abs(lg_i - lg_j).max() < 5e-5
+
+
+def test_under_concurrent_load_and_mixed_with_the_16_clip_form():
+    """A second stream keeps streaming kernels running while the persistent launches are resident; small (4-clip groups) and
+    large (16-clip groups) persistent forwards and a training step are issued from different streams - the library chains
+    every persistent launch of a device through one event, so no two of them are ever co-resident."""
+    if not _supported():
+        pytest.skip("needs a whole MI355X (8 XCDs x 32 CUs)")
+    small, labels = synth.make_batch(31, 24, 40)
+    large, _ = synth.make_batch(32, 200, 40)
+    m = _model().eval()
+    y_s, lg_s = _infer(m, small, "1")
+    with torch.no_grad():
+        y_l, _ = m(torch.from_numpy(large).cuda())
+    torch.cuda.synchronize()
+    y_l = y_l.cpu().numpy()
+    m.train(True)
+    _, y_t, _, g_t = _run(m, small, labels)
+    xs, xl, lab = torch.from_numpy(small).cuda(), torch.from_numpy(large).cuda(), torch.from_numpy(labels).cuda()
+    big = torch.empty(64 << 20, dtype=torch.float32, device="cuda:0")
+    s1, s2, s3, s4 = (torch.cuda.Stream() for _ in range(4))
+    torch.cuda.synchronize()
+    from objectpermanence_amd import l1_mean
+    outs = []
+    for it in range(3):
+        with torch.cuda.stream(s3):
+            for _ in range(20):
+                big.mul_(1.0001)
+        m.eval()
+        with torch.no_grad():
+            with torch.cuda.stream(s1):
+                outs.append(("small", m(xs)[0]))
+            with torch.cuda.stream(s2):
+                outs.append(("large", m(xl)[0]))
+        m.train(True)
+        with torch.cuda.stream(s4):
+            m.zero_grad(set_to_none=True)
+            yt, _ = m(xs)
+            l1_mean(yt, lab).backward()
+            outs.append(("train", yt.detach()))
+    torch.cuda.synchronize()
+    for name, y in outs:
+        ref = {"small": y_s, "large": y_l, "train": y_t}[name]
+        assert np.array_equal(y.cpu().numpy(), ref), name
+    for k, p in m.named_parameters():
+        assert np.array_equal(p.grad.cpu().numpy(), g_t[k]), k
+
+
+def test_a_stuck_exchange_aborts_with_nan_and_the_next_launch_is_clean(monkeypatch):
+    """OPNET_X4_DEBUG=4 switches the cells (the publishers) off: every consumer polls a sentinel that never goes away, the
+    bounded wait (1.5 s) raises the abort word, every workgroup leaves, y is NaN - and nothing is left behind."""
+    if not _supported():
+        pytest.skip("needs a whole MI355X (8 XCDs x 32 CUs)")
+    from objectpermanence_amd import _lib
+    boxes, _ = synth.make_batch(41, 8, 6)
+    m = _model().eval()
+    y_ok, _ = _infer(m, boxes, "1")
+    monkeypatch.setenv("OPNET_X4_DEBUG", "4")
+    y_bad, _ = _infer(m, boxes, "1")
+    st = (_lib.ctypes.c_uint * 4)()
+    _lib.load().opnet_xcd4_last_status(st)
+    assert st[0] == 1 and np.isnan(y_bad).all()
+    monkeypatch.delenv("OPNET_X4_DEBUG")
+    y_again, _ = _infer(m, boxes, "1")
+    _lib.load().opnet_xcd4_last_status(st)
+    assert st[0] == 0 and np.array_equal(y_again, y_ok)
