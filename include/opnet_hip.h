@@ -123,7 +123,12 @@ int opnet_xcd4_last_status(unsigned *out4);
  * weight gradients in the state_dict layouts (`boxes` never requires grad; the logits output is not
  * differentiated - no reference loss uses it, training_main.py:186-210).  `packed` must come from
  * opnet_train_pack_weights_f32 (inference tiles + transposed tiles for the backward recurrence).
- * One workspace holds ONE forward's history: call backward before the next train forward. */
+ * One workspace holds ONE forward's history: call backward before the next train forward.
+ * On a whole MI355X at the reference hidden sizes batches of up to 32 clips run both recurrences as one persistent launch each
+ * (4-clip groups, one per XCD) - same arguments, same histories.  There opnet_train_pack_weights_f32 packs only what
+ * those launches read and leaves the launch chain's layouts to the first forward / backward that needs them: the six weight
+ * pointers must stay valid and unchanged from the pack call until that step's backward has been enqueued (they are anyway:
+ * the optimiser runs after it). */
 size_t opnet_train_packed_weights_bytes(int H1, int H2);
 int opnet_train_pack_weights_f32(const float *w_ih1, const float *w_hh1, const float *w_sel,
                                  const float *w_ih2, const float *w_hh2, const float *w_out,

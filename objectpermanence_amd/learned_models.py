@@ -231,8 +231,7 @@ class OPNet(AbstractCaterModel):
         self._xcd_ok = None
         # one small request (up to XCD4_MAX_BATCH clips) as one persistent launch of 4-clip groups: "auto" / "1" / "0"
         self.use_xcd4 = os.environ.get("OPNET_XCD4", "auto")
-        self._x4packed = None
-        self._x4packed_key = None
+        self._x4packed: Dict[int, Tuple[tuple, torch.Tensor]] = {}     # per stream: (weights key, packed image)
         self._x4ws: Dict[Tuple[int, int, int, int], torch.Tensor] = {}
 
     # -- weights ------------------------------------------------------------------------------
@@ -297,8 +296,10 @@ class OPNet(AbstractCaterModel):
         lib = _lib.load()
         B, T, dev = int(boxes.shape[0]), int(boxes.shape[1]), boxes.device
         ws_ = self._weights()
-        key = tuple((w.data_ptr(), w._version) for w in ws_) + (str(dev), stream)
-        if self._x4packed is None or self._x4packed_key != key:
+        key = tuple((w.data_ptr(), w._version) for w in ws_) + (str(dev),)
+        # one packed image per stream (a re-pack on one stream must not rewrite what another stream's launch is reading)
+        entry = self._x4packed.get(stream) if isinstance(self._x4packed, dict) else None
+        if entry is None or entry[0] != key:
             for w in ws_:
                 if w.device != dev or w.dtype != torch.float32 or not w.is_contiguous():
                     raise RuntimeError("OPNet parameters must be contiguous fp32 on the input's device "
@@ -306,11 +307,18 @@ class OPNet(AbstractCaterModel):
             nbytes = lib.opnet_xcd4_packed_weights_bytes(self._h1, self._h2)
             if nbytes == 0:
                 _lib.check(-2, "opnet_xcd4_packed_weights_bytes")
-            if self._x4packed is None or self._x4packed.device != dev:
-                self._x4packed = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-            _lib.check(lib.opnet_xcd4_pack_weights_f32(*(w.data_ptr() for w in ws_), self._x4packed.data_ptr(), nbytes,
+            if not isinstance(self._x4packed, dict):
+                self._x4packed = {}
+            if entry is None or entry[1].device != dev:
+                if len(self._x4packed) >= 4:
+                    self._x4packed.pop(next(iter(self._x4packed)))
+                buf = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            else:
+                buf = entry[1]
+            _lib.check(lib.opnet_xcd4_pack_weights_f32(*(w.data_ptr() for w in ws_), buf.data_ptr(), nbytes,
                                                        self._h1, self._h2, stream), "opnet_xcd4_pack_weights_f32")
-            self._x4packed_key = key            # keyed by the stream too: another stream re-packs (ordered on itself)
+            self._x4packed[stream] = (key, buf)
+        x4packed = self._x4packed[stream][1]
         wkey = (B, T, dev.index if dev.index is not None else torch.cuda.current_device(), stream)
         if wkey not in self._x4ws:
             nbytes = lib.opnet_xcd4_workspace_bytes(B, T, self._h1, self._h2)
@@ -322,7 +330,7 @@ class OPNet(AbstractCaterModel):
         ws = self._x4ws[wkey]
         y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
         logits = torch.empty((B, 15, T), dtype=torch.float32, device=dev)
-        _lib.check(lib.opnet_xcd4_forward_f32(boxes.data_ptr(), self._x4packed.data_ptr(), y.data_ptr(), logits.data_ptr(),
+        _lib.check(lib.opnet_xcd4_forward_f32(boxes.data_ptr(), x4packed.data_ptr(), y.data_ptr(), logits.data_ptr(),
                                               ws.data_ptr(), ws.numel(), B, T, self._h1, self._h2, stream),
                    "opnet_xcd4_forward_f32")
         return y, logits
