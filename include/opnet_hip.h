@@ -86,6 +86,12 @@ size_t opnet_xcd_workspace_bytes(int B, int T, int H1, int H2);
 int opnet_xcd_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
                           void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
                           void *stream);
+/* the same launch over `nreq` (<= 64) request tensors boxes[r] = [counts[r]][T][90] (device pointers in a HOST array; the table
+ * travels in the kernel arguments): the launch's clips are the requests' clips in order, y / logits are [sum counts][..] - a
+ * server's pending requests (serving.ReasonerServer; the reference feeds its model one DataLoader minibatch at a time,
+ * inference_main.py:191-217) without a concatenation copy */
+int opnet_xcd_forward_multi_f32(const float *const *boxes, const int *counts, int nreq, const float *packed, float *y,
+                                float *logits, void *workspace, size_t workspace_bytes, int T, int H1, int H2, void *stream);
 /* measurement: with profiling enabled every launch of the persistent kernel (not the input pack / output head around
  * it) is bracketed by HIP events on the caller's stream; opnet_xcd_profile_read waits for them (host sync) and returns
  * the summed kernel time and the number of launches since the last read. */

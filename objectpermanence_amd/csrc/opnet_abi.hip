@@ -400,14 +400,14 @@ extern "C" int opnet_xcd_supported(int H1, int H2)
     return xcd_device_cus(dev) >= XCD_COUNT * XCD_CUS ? 1 : 0;
 }
 
-extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
-                                     void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
-                                     void *stream)
+static int xcd_forward_impl(const XcdSources &src, const float *packed, float *y, float *logits,
+                            void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
+                            void *stream)
 {
     if (int rc = check_xcd(B, T, H1, H2)) return rc;
-    if (!boxes || !packed || !y || !logits || !workspace) return fail(OPNET_EINVAL, "null pointer");
-    if (!aligned16(packed) || !aligned16(y) || !aligned16(workspace) || (((uintptr_t)boxes) & 7u))
-        return fail(OPNET_EINVAL, "packed/y/workspace must be 16-byte and boxes 8-byte aligned");
+    if (!packed || !y || !logits || !workspace) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(packed) || !aligned16(y) || !aligned16(workspace))
+        return fail(OPNET_EINVAL, "packed/y/workspace must be 16-byte aligned");
     const XcdWorkspaceLayout L = xcd_workspace_layout(B, T);
     if (workspace_bytes < L.total) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", workspace_bytes, L.total);
     int dev = 0;
@@ -435,7 +435,7 @@ extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, fl
         return fail(OPNET_ESHAPE, "device %d exposes %d CUs; the persistent forward needs %d resident workgroups", dev,
                     cus, XCD_COUNT * XCD_CUS);
     std::lock_guard<std::mutex> lock(g_xcd_mu);
-    opnet_xcd_pack_input<<<dim3(T + 2, L.NGT), 384, 0, st>>>(boxes, a);
+    opnet_xcd_pack_input<<<dim3(T + 2, L.NGT), 384, 0, st>>>(src, a);
     if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
     else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
     std::pair<hipEvent_t, hipEvent_t> pe{};
@@ -459,6 +459,43 @@ extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, fl
     opnet_xcd_out_head<<<dim3(T, L.NGT), 256, 0, st>>>(a, y);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
+}
+
+extern "C" int opnet_xcd_forward_f32(const float *boxes, const float *packed, float *y, float *logits,
+                                     void *workspace, size_t workspace_bytes, int B, int T, int H1, int H2,
+                                     void *stream)
+{
+    if (!boxes) return fail(OPNET_EINVAL, "null pointer");
+    if (((uintptr_t)boxes) & 7u) return fail(OPNET_EINVAL, "boxes must be 8-byte aligned");
+    XcdSources src;
+    memset(&src, 0, sizeof(src));
+    src.p[0] = boxes; src.start[0] = 0; src.start[1] = B; src.n = 1;
+    return xcd_forward_impl(src, packed, y, logits, workspace, workspace_bytes, B, T, H1, H2, stream);
+}
+
+/* The same launch over `nreq` (<= 64) request tensors boxes[r] = [counts[r]][T][90] (device pointers in a HOST array): the
+ * launch's clips are the requests' clips in order, y / logits are [sum counts][...] - a server's pending requests without a
+ * concatenation copy (serving.ReasonerServer). */
+extern "C" int opnet_xcd_forward_multi_f32(const float *const *boxes, const int *counts, int nreq, const float *packed, float *y,
+                                           float *logits, void *workspace, size_t workspace_bytes, int T, int H1, int H2,
+                                           void *stream)
+{
+    if (!boxes || !counts) return fail(OPNET_EINVAL, "null pointer");
+    if (nreq < 1 || nreq > XCD_MAX_SOURCES) return fail(OPNET_ESHAPE, "1..%d requests per launch (nreq=%d)", XCD_MAX_SOURCES, nreq);
+    XcdSources src;
+    memset(&src, 0, sizeof(src));
+    int B = 0;
+    for (int r = 0; r < nreq; ++r) {
+        if (!boxes[r]) return fail(OPNET_EINVAL, "null pointer (request %d)", r);
+        if (((uintptr_t)boxes[r]) & 7u) return fail(OPNET_EINVAL, "boxes must be 8-byte aligned (request %d)", r);
+        if (counts[r] <= 0) return fail(OPNET_ESHAPE, "request %d: %d clips", r, counts[r]);
+        src.p[r] = boxes[r];
+        src.start[r] = B;
+        B += counts[r];
+    }
+    src.start[nreq] = B;
+    src.n = nreq;
+    return xcd_forward_impl(src, packed, y, logits, workspace, workspace_bytes, B, T, H1, H2, stream);
 }
 
 // OPNetLstmMlp (learned_models.py:55-89): same packed layout; w_hidden [H2][6] takes the place of the

@@ -119,9 +119,19 @@ __device__ __forceinline__ void xcd_store_flag(unsigned *p, unsigned v, bool loc
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// boxes [B][T][90] -> xp; zero slot 0 / T+1 of xp, slot 0 of the histories, the flags and the status words.
+// Where the clips of a launch come from: up to XCD_MAX_SOURCES request tensors [n_r][T][90], clip b of the launch = clip
+// b - start[r] of request r (start[r] <= b < start[r + 1]); by value in the kernarg segment, so that a server can run its
+// pending requests as one launch without concatenating them first.
+#define XCD_MAX_SOURCES 64
+struct XcdSources {
+    const float *p[XCD_MAX_SOURCES];
+    int start[XCD_MAX_SOURCES + 1];
+    int n;
+};
+
+// boxes -> xp; zero slot 0 / T+1 of xp, slot 0 of the histories, the flags and the status words.
 // grid (T + 2, NGT), 384 threads (24 k-quads x 16 clips)
-__global__ void __launch_bounds__(384) opnet_xcd_pack_input(const float *__restrict__ boxes, XcdArgs a)
+__global__ void __launch_bounds__(384) opnet_xcd_pack_input(const XcdSources src, XcdArgs a)
 {
     const int slot = blockIdx.x, gg = blockIdx.y;
     const int T = a.T, tid = threadIdx.x;
@@ -131,10 +141,12 @@ __global__ void __launch_bounds__(384) opnet_xcd_pack_input(const float *__restr
         const int b = gg * 16 + clip, t = slot - 1;
         float4 v = z;
         if (b < a.B && t >= 0 && t < T) {
-            const float2 *src = (const float2 *)(boxes + ((long)b * T + t) * OPNET_KX + kq * 4);   // rows are 360 B apart
+            int r = 0;
+            while (r + 1 < src.n && b >= src.start[r + 1]) ++r;
+            const float2 *s2 = (const float2 *)(src.p[r] + ((long)(b - src.start[r]) * T + t) * OPNET_KX + kq * 4);   // rows are 360 B apart
             const int k = kq * 4;
-            if (k + 1 < OPNET_KX) { float2 p = src[0]; v.x = p.x; v.y = p.y; }
-            if (k + 3 < OPNET_KX) { float2 q = src[1]; v.z = q.x; v.w = q.y; }
+            if (k + 1 < OPNET_KX) { float2 p = s2[0]; v.x = p.x; v.y = p.y; }
+            if (k + 3 < OPNET_KX) { float2 q = s2[1]; v.z = q.x; v.w = q.y; }
         }
         ((float4 *)a.xp)[(((long)gg * (T + 2) + slot) * OPNET_KXQ + kq) * 16 + clip] = v;
     }

@@ -363,6 +363,43 @@ class OPNet(AbstractCaterModel):
             _lib.check(rc, "opnet_xcd_forward_f32")
         return y, logits
 
+    def forward_requests(self, requests):
+        """The forward of several request tensors [b_r, T, 15, 6] as ONE batch (serving.ReasonerServer): equal to
+        `self(torch.cat(requests))`, without the concatenation copy when the batch runs as one 16-clip persistent launch
+        (opnet_xcd_forward_multi_f32 reads the requests where they lie)."""
+        lib = _lib.load()
+        B = sum(int(r.shape[0]) for r in requests)
+        ok = (len(requests) > 1 and len(requests) <= 64 and not torch.is_grad_enabled() and all(r.is_cuda for r in requests)
+              and not self._wants_xcd4(B) and self._wants_xcd(B) and B <= int(lib.opnet_xcd_max_batch())
+              and all(r.dim() == 4 and r.shape[1:] == requests[0].shape[1:] and r.device == requests[0].device for r in requests))
+        if not ok:
+            return self(requests[0] if len(requests) == 1 else torch.cat(list(requests), dim=0))
+        reqs = [r.contiguous().float() for r in requests]
+        T, dev = int(reqs[0].shape[1]), reqs[0].device
+        if reqs[0].shape[2] != 15 or reqs[0].shape[3] != 6:
+            raise ValueError(f"boxes must be [B, T, 15, 6], got {tuple(reqs[0].shape)}")
+        with torch.cuda.device(dev):
+            packed = self._packed_weights(dev)
+            stream = _stream_ptr(dev)
+            nbytes = lib.opnet_xcd_workspace_bytes(B, T, self._h1, self._h2)
+            if nbytes == 0:     # a history beyond one buffer descriptor: the chunked path
+                return self(torch.cat(reqs, dim=0))
+            key = (B, T, dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+            if key not in self._xws:
+                if len(self._xws) >= 8:
+                    self._xws.pop(next(iter(self._xws)))
+                self._xws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ws = self._xws[key]
+            y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+            logits = torch.empty((B, 15, T), dtype=torch.float32, device=dev)
+            n = len(reqs)
+            ptrs = (_lib.c_void_p * n)(*[r.data_ptr() for r in reqs])
+            counts = (_lib.ctypes.c_int * n)(*[int(r.shape[0]) for r in reqs])
+            _lib.check(lib.opnet_xcd_forward_multi_f32(ptrs, counts, n, packed.data_ptr(), y.data_ptr(), logits.data_ptr(),
+                                                       ws.data_ptr(), ws.numel(), T, self._h1, self._h2, stream),
+                       "opnet_xcd_forward_multi_f32")
+        return y, logits
+
     def xcd_status(self):
         """{abort code, block, phase} of the last persistent launches (synchronises); code 0 = completed"""
         return {k: ws[:12].view(torch.int32).tolist() for k, ws in self._xws.items()}

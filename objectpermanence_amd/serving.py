@@ -6,7 +6,8 @@ forward (csrc/opnet_xcd_kernels.hip) wants at least two 16-clip groups on each o
 and gives 99 k clips/s there against 26 k for one 32-clip batch alone.  Clips are independent
 (SURVEY.md 8-e1), so concurrent requests can simply be concatenated: `ReasonerServer` collects submitted minibatches,
 runs them as ONE forward when `max_clips` are pending (or on `flush()`), and hands every request its own slice of the
-outputs.  Results are bit-identical to running the concatenation through `model(...)` directly.
+outputs.  Results are bit-identical to running the concatenation through `model(...)` directly (OPNet's persistent launch
+reads the request tensors where they lie: no concatenation copy).
 
 TransformerLstm is deliberately refused: its attention spans all clips of a minibatch, so merging
 requests would change its results.
@@ -65,12 +66,14 @@ class ReasonerServer:
         if not self._queue:
             return
         queue, self._queue, self._pending = self._queue, [], 0
-        x = queue[0][0] if len(queue) == 1 else torch.cat([q[0] for q in queue], dim=0)
-        out = self.model(x)
+        if len(queue) > 1 and hasattr(self.model, "forward_requests"):
+            out = self.model.forward_requests([q[0] for q in queue])     # OPNet: one launch over the requests where they lie
+        else:
+            out = self.model(queue[0][0] if len(queue) == 1 else torch.cat([q[0] for q in queue], dim=0))
         double = isinstance(out, tuple)
         self.last_output = out if double else (out,)
         self.forwards += 1
-        self.clips += int(x.shape[0])
+        self.clips += sum(h.n_clips for _, h in queue)
         lo = 0
         for boxes, h in queue:
             hi = lo + h.n_clips

@@ -184,3 +184,31 @@ def test_launch_that_cannot_complete_aborts_instead_of_hanging(monkeypatch, B):
     monkeypatch.delenv("OPNET_XCD_DEBUG")
     y2, _ = _run(m, boxes)                  # and the next launch is healthy again
     assert np.isfinite(y2).all()
+
+
+def test_requests_are_read_where_they_lie():
+    """opnet_xcd_forward_multi_f32 (OPNet.forward_requests, ReasonerServer.flush): one launch over several request tensors
+    = the launch over their concatenation, bit for bit."""
+    from objectpermanence_amd.serving import ReasonerServer
+    m, _ = _model(True)
+    sizes = [32, 7, 100, 1, 48]
+    boxes, _ = synth.make_batch(77, sum(sizes), 25)
+    xs = torch.from_numpy(boxes).to("cuda:0")
+    parts, lo = [], 0
+    for n in sizes:
+        parts.append(xs[lo:lo + n].clone())
+        lo += n
+    with torch.no_grad():
+        y_cat, lg_cat = m(xs)
+        y_req, lg_req = m.forward_requests(parts)
+    torch.cuda.synchronize()
+    assert torch.equal(y_cat, y_req) and torch.equal(lg_cat, lg_req)
+    server = ReasonerServer(m, "opnet", max_clips=1024)
+    handles = [server.submit(p) for p in parts]
+    server.flush()
+    lo = 0
+    for n, h in zip(sizes, handles):
+        y, lg = h.result()
+        assert torch.equal(y, y_cat[lo:lo + n]) and torch.equal(lg, lg_cat[lo:lo + n])
+        lo += n
+    assert server.forwards == 1 and server.clips == sum(sizes)
