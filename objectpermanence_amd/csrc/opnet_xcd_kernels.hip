@@ -452,11 +452,15 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             hd_[0] = make_float4(acc2a[0] + acc2b[0], acc2a[1] + acc2b[1], acc2a[2] + acc2b[2], acc2a[3] + acc2b[3]);
             hd_[64] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
             if (!HO) hd_[128] = make_float4(accH[0], accH[1], accH[2], accH[3]);
-            __syncthreads();                    // barrier p
-            if (sAbort) return;
+            // barrier p.  No look at the abort word here (an LDS read and its wait per phase): when the finish waves leave
+            // on an abort, the barrier only counts the waves that are still alive, and this wave runs its remaining phases
+            // on whatever is in LDS - it stores nothing to memory - and ends.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             if (ng == 1) {                      // exposed exchange: wait for this phase's finish + the next gather
-                __syncthreads();
-                if (sAbort) return;
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
             }
         }
         return;
