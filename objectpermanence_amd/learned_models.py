@@ -374,7 +374,7 @@ class OPNet(AbstractCaterModel):
               and all(r.dim() == 4 and r.shape[1:] == requests[0].shape[1:] and r.device == requests[0].device for r in requests))
         if not ok:
             return self(requests[0] if len(requests) == 1 else torch.cat(list(requests), dim=0))
-        reqs = [r.contiguous().float() for r in requests]
+        reqs = [r if (r.is_contiguous() and r.dtype == torch.float32) else r.contiguous().float() for r in requests]
         T, dev = int(reqs[0].shape[1]), reqs[0].device
         if reqs[0].shape[2] != 15 or reqs[0].shape[3] != 6:
             raise ValueError(f"boxes must be [B, T, 15, 6], got {tuple(reqs[0].shape)}")

@@ -6,8 +6,7 @@ forward (csrc/opnet_xcd_kernels.hip) wants at least two 16-clip groups on each o
 and gives 99 k clips/s there against 26 k for one 32-clip batch alone.  Clips are independent
 (SURVEY.md 8-e1), so concurrent requests can simply be concatenated: `ReasonerServer` collects submitted minibatches,
 runs them as ONE forward when `max_clips` are pending (or on `flush()`), and hands every request its own slice of the
-outputs.  Results are bit-identical to running the concatenation through `model(...)` directly (OPNet's persistent launch
-reads the request tensors where they lie: no concatenation copy).
+outputs.  Results are bit-identical to running the concatenation through `model(...)` directly.
 
 TransformerLstm is deliberately refused: its attention spans all clips of a minibatch, so merging
 requests would change its results.
@@ -38,11 +37,16 @@ class PendingResult:
 
 
 class ReasonerServer:
-    def __init__(self, model: torch.nn.Module, model_name: str = "opnet", max_clips: int = 1024):
+    def __init__(self, model: torch.nn.Module, model_name: str = "opnet", max_clips: int = 1024, concat: bool = True):
         if type(model).__name__ == "TransformerLstm":
             raise ValueError("TransformerLstm couples the clips of a minibatch (sequence-first attention): requests "
                              "cannot be merged without changing its outputs")
         self.model, self.model_name, self.max_clips = model, model_name, int(max_clips)
+        # concat = False: OPNet's persistent launch reads the request tensors where they lie (OPNet.forward_requests) instead
+        # of one torch.cat - it saves the 108 KB/clip copy, but the pack kernel then walks up to 64 sources and the host
+        # builds the pointer table: measured 118-122 k clips/s against 120-124 k for twenty 32-clip requests, so the copy stays
+        # the default
+        self.concat = bool(concat)
         self._queue: List[Tuple[torch.Tensor, PendingResult]] = []
         self._pending = 0
         self.last_output = None      # the whole output of the last forward (callers that post-process per launch)
@@ -66,7 +70,7 @@ class ReasonerServer:
         if not self._queue:
             return
         queue, self._queue, self._pending = self._queue, [], 0
-        if len(queue) > 1 and hasattr(self.model, "forward_requests"):
+        if len(queue) > 1 and not self.concat and hasattr(self.model, "forward_requests"):
             out = self.model.forward_requests([q[0] for q in queue])     # OPNet: one launch over the requests where they lie
         else:
             out = self.model(queue[0][0] if len(queue) == 1 else torch.cat([q[0] for q in queue], dim=0))

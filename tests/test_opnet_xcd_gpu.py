@@ -203,7 +203,7 @@ def test_requests_are_read_where_they_lie():
         y_req, lg_req = m.forward_requests(parts)
     torch.cuda.synchronize()
     assert torch.equal(y_cat, y_req) and torch.equal(lg_cat, lg_req)
-    server = ReasonerServer(m, "opnet", max_clips=1024)
+    server = ReasonerServer(m, "opnet", max_clips=1024, concat=False)
     handles = [server.submit(p) for p in parts]
     server.flush()
     lo = 0
