@@ -1,13 +1,14 @@
-// opnet_xcd4_kernels.hip - the per-XCD persistent OPNet TRAINING step for small batches (the reference's batch of 32 clips):
-// groups of FOUR clips, one group per XCD and row block, every weight resident in registers for all T steps - forward and
-// backward recurrence as one launch each.
+// opnet_xcd4_kernels.hip - the per-XCD persistent OPNet step for SMALL batches: the training step of the reference's 32-clip
+// batch (forward and reverse recurrence as one launch each) and the inference forward of one small request (its shipped
+// inference batch is 16).  Groups of FOUR clips, one group per XCD and row block, every weight resident in registers for all
+// T steps.
 //
 // What is computed: reference baselines/learned_models.py:35-52 (forward) and torch autograd through it under
 // training_main.py:216 (backward; restated in oracle/torch_port.py) - the same functions as opnet_kernels.hip /
 // opnet_train_kernels.hip, on the launch chain's own history layouts (opnet_ctx.h StepArgs "train", BwdArgs), so that the loss,
 // the weight-gradient GEMMs (opnet_wgrad) and Adam run on the result unchanged.
 //
-// Why a third form (DESIGN.md section 3b).  The 16-clip persistent kernel (opnet_xcd_kernels.hip) needs >= 3 groups per XCD
+// Why a third form (DESIGN.md section 9a).  The 16-clip persistent kernel (opnet_xcd_kernels.hip) needs >= 3 groups per XCD
 // (384 clips) to hide its exchange; a 32-clip batch is 2 groups - 2 XCDs busy, 5.5 us per step - and the launch chain pays
 // a kernel boundary + a 5.68 MB weight fetch per step (4.9 us forward, 5.1 us backward).  A 32-clip batch cut into EIGHT
 // groups of 4 clips puts every XCD to work with a quarter of the matrix work per step: v_mfma_f32_4x4x1_16b_f32 = 16
@@ -26,7 +27,9 @@
 //     otherwise - as in opnet_xcd_kernels.hip) and, with it, re-arms its piece of the slot two steps on with the sentinel;
 //     nothing is drained, no flag is written;
 //   * a consumer loads its pieces with sc1 (L2-served) loads into registers, and any lane that still sees a sentinel word
-//     makes the wave load that piece again (bounded: XCD_SPIN_LIMIT, then the abort word and NaN in y); then ds_write.
+//     makes the wave load its pieces again (bounded: XCD_SPIN_LIMIT, then the abort word and NaN in y); then ds_write.
+//     (A lane would also wait for a genuine value with that bit pattern - a NaN with an all-ones payload can only come from
+//     an input or weight that already holds it - and the launch would end in the same abort, NaN in y.)
 //   Against payload + drain + flag + poll + gather (Guideline 16 recipe R1, the first version of this file) this takes a
 //   store-acknowledge and a flag round trip out of every step: measured 0.91 -> 0.72 ms per 32-clip forward.
 //   Re-arming is safe with the slot two steps ahead: a CU publishes step k only after it has gathered every CU's step k-1, i.e.
