@@ -433,3 +433,20 @@ def test_grid_classes_match_reference_proj_utils(golden_dir):
     Hd, _ = homography.find_homography_dlt(pu.project_3d_point(pts3), pts3[:, :2])
     back = homography.perspective_transform(pu.project_3d_point(pts3).reshape(-1, 1, 2), Hd).reshape(-1, 2)
     assert np.abs(back - pts3[:, :2]).max() < 1e-9
+
+
+def test_small_batch_persistent_form_sizes_and_limits():
+    """host-only entry points of the 4-clip persistent kernels (no GPU needed): workspace / packed sizes, the batch limit, the
+    refusal of other hidden sizes"""
+    from objectpermanence_amd import _lib
+    lib = _lib.load()
+    assert lib.opnet_xcd4_max_batch() == 128
+    assert lib.opnet_xcd4_packed_weights_bytes(256, 512) == (2048 * 512 + 1024 * 352 + 16 * 256 + 2048 * 8 + 32 * 256) * 4
+    assert lib.opnet_xcd4_packed_weights_bytes(128, 512) == 0
+    w16, w32, w33 = (lib.opnet_xcd4_workspace_bytes(b, 300, 256, 512) for b in (16, 32, 33))
+    assert 0 < w16 == w32 < w33                       # whole row blocks of 32 clips
+    assert lib.opnet_xcd4_workspace_bytes(129, 300, 256, 512) == 0
+    assert lib.opnet_xcd4_workspace_bytes(32, 300, 256, 256) == 0
+    # the training workspace carries the exchange rings of the persistent step for batches it can serve
+    t32, t256 = lib.opnet_train_workspace_bytes(32, 300, 256, 512), lib.opnet_train_workspace_bytes(256, 300, 256, 512)
+    assert t32 > 32 * 5_000_000 and t256 > 7 * t32 * 0.9
