@@ -142,6 +142,28 @@ __device__ __forceinline__ bool x4_gather(__amdgpu_buffer_rsrc_t rws, unsigned l
     return true;
 }
 
+// The same for four pieces that are only ever needed as their SUM (the backward's partial dh rows): (r0 + r1) + (r2 + r3) per lane
+// goes to LDS as one piece - the consumer then adds 8 values instead of 32.
+__device__ __forceinline__ bool x4_gather_sum4(__amdgpu_buffer_rsrc_t rws, unsigned lane16, unsigned src, bool wait, float4 *dst,
+                                               unsigned *status, int phase)
+{
+    if (!wait) return true;
+    xcd_u32x4 r[4];
+    long long t0 = 0;
+    for (unsigned spins = 1;; ++spins) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, src + q * 1024, 16);   // sc1
+        bool bad = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bad |= x4_unpublished(r[q]);
+        if (!__any(bad)) break;
+        if (!x4_keep_polling(spins, t0, status, phase)) return false;
+    }
+    const float4 a = x4_as_float4(r[0]), b = x4_as_float4(r[1]), c = x4_as_float4(r[2]), d = x4_as_float4(r[3]);
+    *dst = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+    return true;
+}
+
 // fp32 weights -> the register images of opnet_xcd4_forward (see the layout notes above)
 __global__ void __launch_bounds__(256) opnet_xcd4_pack_fwd(float *__restrict__ out, const float *__restrict__ w_ih1,
                                                            const float *__restrict__ w_hh1, const float *__restrict__ w_sel,
@@ -570,7 +592,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_out_head(const Xcd4Args a)
 // (48 KB a step: the first version of this kernel, 14 000 cycles a step); instead CU c keeps the gate columns of ITS units - the
 // same 64 + 32 rows of W_hh it holds in the forward, read the other way - multiplies them by ITS OWN da (from LDS: no exchange on
 // the way in) into partial dh rows of EVERY unit, and the exchange is a reduce-scatter: every CU stores 32 x 384 B of partials,
-// one chunk per owner, and gathers the 32 chunks of its own 16 + 8 units (12 KB, as in the forward), which its cell waves sum.
+// one chunk per owner, and gathers the 32 chunks of its own 16 + 8 units (12 KB, as in the forward); they are summed in fixed
+// order - four by four by the gathering waves (registers), the rest by the cell waves.
 // MFMA blocks = row quads, one k per instruction (64 rows x 1 k x 4 clips), B = the (unit', clip) float4 of da - its four gates
 // are four consecutive k - the same address in all 16 blocks.
 // Phase (row block gi, n), T + 2 of them:  LSTM2 cell at t2 = T-1-n | head backward at th = T-n | LSTM1 cell at t1 = T+1-n.
@@ -583,8 +606,9 @@ __global__ void __launch_bounds__(256) opnet_xcd4_out_head(const Xcd4Args a)
 //     3. waves 0, 1, 3: four 1-KB pieces each of the next phase's chunks (sentinel-polled); wave 2 meanwhile: the head backward
 //        of step th - sums the 32 CUs' dfb parts (published a phase ago), dp, dl_{th} -> LDS (+ dlall by one CU);      barrier.
 // ====================================================================================================================
-#define X4D_P2 0               // LDS buffer of a backward phase, float4 units: [32 producers][4 unit quads][4 clips] of dh2
-#define X4D_P1 512             //                                               [32 producers][2 unit quads][4 clips] of dh1
+// LDS buffer of a backward phase, float4 units; the gathering waves add their four 1-KB pieces before they store them:
+#define X4D_P2 0               // dh2: [wave 0 | 1][lane]: the sum over q of the chunk of producer 16 wave + 4 q + (lane >> 4), float4 lane & 15
+#define X4D_P1 128             // dh1: [lane]: the sum over q of the chunk of producer 8 q + (lane >> 3), float4 lane & 7
 #define X4D_F4 768             // 12 KB
 #define X4D_NBUF 8             // buffers allocated (two are used): 96 KB keep a second workgroup off the CU
 
@@ -736,10 +760,10 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         float4 *S = &sbuf[buf][0] + lane;
         const unsigned gg = gi * 8 + x;
         if (w == 3)
-            return x4_gather<4>(rws, lane16, a.p1x_off + ((gg * X4_SLOTS + ((T + 2 - n) & 3)) * 32 + c) * 4096, n >= 2,
-                                S + X4D_P1, a.status, phase);
-        return x4_gather<4>(rws, lane16, a.p2x_off + ((gg * X4_SLOTS + ((T - n) & 3)) * 32 + c) * 8192 + w * 4096,
-                            n <= T - 1, S + X4D_P2 + w * 256, a.status, phase);
+            return x4_gather_sum4(rws, lane16, a.p1x_off + ((gg * X4_SLOTS + ((T + 2 - n) & 3)) * 32 + c) * 4096, n >= 2,
+                                  S + X4D_P1, a.status, phase);
+        return x4_gather_sum4(rws, lane16, a.p2x_off + ((gg * X4_SLOTS + ((T - n) & 3)) * 32 + c) * 8192 + w * 4096,
+                              n <= T - 1, S + X4D_P2 + w * 64, a.status, phase);
     };
 
     // the saved activations a cell needs (gates, c_t, c_{t-1}, wave 0: dy), fetched one phase ahead - they come from HBM / the
@@ -794,10 +818,11 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
             const int t = T - 1 - n;
             float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t >= 0 && t < T && !(a.debug & 4)) {
+                // the 32 producers' partials: the gathering waves have added them four by four - 2 waves x 4 lane groups are left
                 float r0 = 0.f, r1 = 0.f;
                 const float *pr = PF + X4D_P2 * 4 + ((b >> 2) * 4 + j) * 4 + (b & 3);
 #pragma unroll
-                for (int q = 0; q < 32; q += 2) { r0 += pr[q * 64]; r1 += pr[(q + 1) * 64]; }
+                for (int q = 0; q < 4; ++q) { r0 += pr[q * 64]; r1 += pr[256 + q * 64]; }
                 // upstream: prediction_layer (learned_models.py:47): dh += W_out^T dy_t
                 float dh = wo.x * cdy.x;
                 dh = fmaf(wo.y, cdy.y, dh);
@@ -832,16 +857,15 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                 }
             } else sDA2[b][j] = da;
         } else if (w == 1) {
-            // ---- LSTM1 cell backward at t = T+1-n: lanes 0..31 = (unit 8 c + b, clip j); each lane half sums 16 producers ------
+            // ---- LSTM1 cell backward at t = T+1-n: lanes 0..31 = (unit 8 c + b, clip j) ------------------------------------------
             const int t = T + 1 - n;
             float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t >= 0 && t < T && !(a.debug & 4)) {
                 float rec = 0.f;
-                const int lq = lane & 31, lb = lq >> 2, hf = lane >> 5;
-                const float *pr = PF + X4D_P1 * 4 + (16 * hf * 8 + (lb >> 2) * 4 + j) * 4 + (lb & 3);
+                const int lb = (lane & 31) >> 2;
+                const float *pr = PF + X4D_P1 * 4 + ((lb >> 2) * 4 + j) * 4 + (lb & 3);       // 8 lane groups of the summed piece
 #pragma unroll
-                for (int q = 0; q < 16; ++q) rec += pr[q * 32];
-                rec += __shfl_xor(rec, 32);
+                for (int q = 0; q < 8; ++q) rec += pr[q * 32];
                 if (lane < 32) {
                     // upstream: object_to_track_prediction (learned_models.py:40): dh += W_sel^T dl_t
                     const float4 *dl = (const float4 *)&sDL[gi][(n + 1) & 1][j][0];   // written by wave 2 one phase ago
