@@ -596,9 +596,10 @@ __global__ void __launch_bounds__(256) opnet_xcd4_out_head(const Xcd4Args a)
 // order - four by four by the gathering waves (registers), the rest by the cell waves.
 // MFMA blocks = row quads, one k per instruction (64 rows x 1 k x 4 clips), B = the (unit', clip) float4 of da - its four gates
 // are four consecutive k - the same address in all 16 blocks.
-// Phase (row block gi, n), T + 2 of them:  LSTM2 cell at t2 = T-1-n | head backward at th = T-n | LSTM1 cell at t1 = T+1-n.
-//     1. wave 0: dh2 = sum of the 32 partial chunks + W_out^T dy -> cell -> da2_{t2} -> LDS, g2; then the CU's part of dfb_{t2}
-//                (8 MFMAs on the da registers, summed over the CU's units through LDS) -> its exchange ring;
+// Phase (row block gi, n), T + 3 of them:  LSTM2 cell at t2 = T-1-n | head backward at th = T+1-n | LSTM1 cell at t1 = T+2-n.
+//     1. wave 0: dh2 = sum of the 32 partial chunks + W_out^T dy -> cell -> da2_{t2} -> LDS, g2;
+//        wave 3: the CU's part of dfb of the PREVIOUS phase's da2 (8 MFMAs, summed over the CU's units through LDS) -> its exchange
+//                ring - beside wave 0's cell instead of after it, which is why the head runs two steps behind LSTM2;
 //        wave 1: dh1 = sum of the chunks + W_sel^T dl_{t1} (dl from LDS, left by wave 2 one phase earlier) -> cell -> da1 -> LDS, g1;
 //        wave 3: the next head step's p and boxes (HBM) -> LDS;      barrier;
 //     2. every wave: its 128 + 64 rows of the partial products out of the CU's da, stored to the owners' chunks (ring slot t & 3;
@@ -698,7 +699,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_init_bwd(Xcd4BArgs a)
 __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
 {
     __shared__ __attribute__((aligned(1024))) float4 sbuf[X4D_NBUF][X4D_F4];
-    __shared__ __attribute__((aligned(16))) float4 sDA2[16][4];        // the CU's da2 of the phase: [unit'][clip] -> (i, f, g, o)
+    __shared__ __attribute__((aligned(16))) float4 sDA2[2][16][4];     // the CU's da2 of the phase (by phase parity: wave 3 turns the previous
+                                                                       // phase's into its dfb part): [unit'][clip] -> (i, f, g, o)
     __shared__ __attribute__((aligned(16))) float4 sDA1[8][4];
     __shared__ __attribute__((aligned(16))) float4 sX[2][64];          // per-unit parts of dfb: features 0..3 | 4..7
     __shared__ float sDC2[X4_NGMAX][64];
@@ -723,7 +725,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     }
     for (int i = tid; i < X4_NGMAX * 64; i += 256) { (&sDC2[0][0])[i] = 0.f; (&sDL[0][0][0][0])[i] = 0.f; (&sDL[0][0][0][0])[X4_NGMAX * 64 + i] = 0.f; }
     for (int i = tid; i < X4_NGMAX * 32; i += 256) (&sDC1[0][0])[i] = 0.f;
-    if (tid < 64) (&sDA2[0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 128) (&sDA2[0][0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 32) (&sDA1[0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // ---- resident weights ------------------------------------------------------------------------------------------------
@@ -754,13 +756,13 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     float hsum = 0.f;                           // wave 2: its lane's share of the next head step's dfb
 
     // The inputs of phase (gi, n): this CU's chunks of the partial products of da2_{T-n} (8 KB; waited for while LSTM2 still runs:
-    // n <= T - 1) and of da1_{T+2-n} (4 KB; n >= 2): twelve 1-KB pieces, four each by waves 0, 1 (dh2) and 3 (dh1)
+    // n <= T - 1) and of da1_{T+3-n} (4 KB; n >= 3): twelve 1-KB pieces, four each by waves 0, 1 (dh2) and 3 (dh1)
     auto gather = [&](int gi, int n, int buf, int phase) -> bool {
         if (w == 2) return true;
         float4 *S = &sbuf[buf][0] + lane;
         const unsigned gg = gi * 8 + x;
         if (w == 3)
-            return x4_gather_sum4(rws, lane16, a.p1x_off + ((gg * X4_SLOTS + ((T + 2 - n) & 3)) * 32 + c) * 4096, n >= 2,
+            return x4_gather_sum4(rws, lane16, a.p1x_off + ((gg * X4_SLOTS + ((T + 3 - n) & 3)) * 32 + c) * 4096, n >= 3,
                                   S + X4D_P1, a.status, phase);
         return x4_gather_sum4(rws, lane16, a.p2x_off + ((gg * X4_SLOTS + ((T - n) & 3)) * 32 + c) * 8192 + w * 4096,
                               n <= T - 1, S + X4D_P2 + w * 64, a.status, phase);
@@ -782,7 +784,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                 cp = ((const float *)(a.ws + a.c2_off))[(((size_t)t * RB + rb) * 512 + u) * 32 + cb + j];
             }
         } else if (w == 1) {
-            const int t = T + 1 - n;
+            const int t = T + 2 - n;
             if (t >= 0 && t < T && lane < 32) {
                 const size_t u = 8 * c + b;
                 g = ((const float4 *)(a.ws + a.g1_off))[(((size_t)t * RB + rb) * 256 + u) * 32 + cb + j];
@@ -798,9 +800,9 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     if (sAbort) return;
     const bool local = __builtin_amdgcn_readfirstlane(sLocal) != 0;
     const bool tracer = a.trace && blockIdx.x == 0 && tid == 0;
-    const int nph = (T + 2) * ng;
+    const int nph = (T + 3) * ng;
 
-    int gi = 0, n = 0;
+    int gi = 0, n = 0, gprev = 0, nprev = -1;      // (gprev, nprev): the previous phase
     for (int p = 0; p < nph; ++p) {
         const int buf = p & 1;
         int gn = gi + 1, nn = n;
@@ -832,33 +834,14 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                 float dco;
                 da = cell_backward(dh, sDC2[gi][lane], cg, cct, ccp, &dco);
                 sDC2[gi][lane] = dco;
-                sDA2[b][j] = da;
+                sDA2[buf][b][j] = da;
                 // da replaces the saved gates (the weight-gradient GEMMs read it there)
                 if (!(a.debug & 2))
                 ((float4 *)(a.ws + a.g2_off))[(((size_t)t * RB + rb) * 512 + 16 * c + b) * 32 + cb + j] = da;
-                // the CU's part of dfb_t = W_ih2^T da2_t: MFMA block = unit, k = gate, B = the da registers themselves;
-                // D[unit b][feature][clip j], then the sum over the 16 units through LDS; re-armed THREE steps on (its reader,
-                // wave 2, runs beside the publishing waves of its phase)
-                x4_f32x4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
-                X4_MFMA(d1, bxa.x, da.x); X4_MFMA(d2, bxb.x, da.x);
-                X4_MFMA(d1, bxa.y, da.y); X4_MFMA(d2, bxb.y, da.y);
-                X4_MFMA(d1, bxa.z, da.z); X4_MFMA(d2, bxb.z, da.z);
-                X4_MFMA(d1, bxa.w, da.w); X4_MFMA(d2, bxb.w, da.w);
-                sX[0][lane] = make_float4(d1[0], d1[1], d1[2], d1[3]);
-                sX[1][lane] = make_float4(d2[0], d2[1], d2[2], d2[3]);
-                XCD_WAVE_LDS_SYNC();
-                if (lane < 32) {                // lane = (feature f = lane >> 2, clip j)
-                    const float *px = (const float *)&sX[lane >> 4][0] + j * 4 + ((lane >> 2) & 3);
-                    float sum = 0.f;
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) sum += px[u * 16];
-                    xcd_store4(rws, lane * 4, a.dfx_off + ((gg * X4_SLOTS + (t & 3)) * 32 + c) * 128, sum, local);
-                    xcd_store4(rws, lane * 4, a.dfx_off + ((gg * X4_SLOTS + ((t + 3) & 3)) * 32 + c) * 128, sentf.x, local);
-                }
-            } else sDA2[b][j] = da;
+            } else sDA2[buf][b][j] = da;
         } else if (w == 1) {
-            // ---- LSTM1 cell backward at t = T+1-n: lanes 0..31 = (unit 8 c + b, clip j) ------------------------------------------
-            const int t = T + 1 - n;
+            // ---- LSTM1 cell backward at t = T+2-n: lanes 0..31 = (unit 8 c + b, clip j) ------------------------------------------
+            const int t = T + 2 - n;
             float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t >= 0 && t < T && !(a.debug & 4)) {
                 float rec = 0.f;
@@ -889,8 +872,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
             if (lane < 32) sDA1[b][j] = da;
         }
         if (w == 2) {
-            // ---- head backward at t = T-n (dfb_t was summed at the end of the previous phase): dp, dl_t -> LDS for wave 1 one phase on --
-            const int t = T - n;
+            // ---- head backward at t = T+1-n (dfb_t was summed at the end of the previous phase): dp, dl_t -> LDS for wave 1 one phase on --
+            const int t = T + 1 - n;
             if (t >= 0 && t < T && !(a.debug & 8)) {
                 const float sum = hsum;
                     // this step's slot probabilities and boxes (lanes 0..15 = (slot quad rg, clip j)): left in LDS by wave 3 one
@@ -938,9 +921,36 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                     }
             }
         }
+        if (w == 3 && nprev >= 0) {
+            // ---- the CU's part of dfb_t = W_ih2^T da2_t of the PREVIOUS phase's LSTM2 step (its da2 is still in LDS): MFMA block = unit,
+            //      k = gate, B = da2; D[unit b][feature][clip j], then the sum over the 16 units through LDS.  Kept off wave 0's
+            //      path to the barrier (-700 cycles there), which is why the head runs two steps behind LSTM2.  Re-armed THREE steps
+            //      on (its reader, wave 2, runs beside the publishing waves of its phase).
+            const int t = T - 1 - nprev;
+            if (t >= 0 && t < T && !(a.debug & 4)) {
+                const unsigned gp = gprev * 8 + x;
+                const float4 da = sDA2[buf ^ 1][b][j];
+                x4_f32x4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
+                X4_MFMA(d1, bxa.x, da.x); X4_MFMA(d2, bxb.x, da.x);
+                X4_MFMA(d1, bxa.y, da.y); X4_MFMA(d2, bxb.y, da.y);
+                X4_MFMA(d1, bxa.z, da.z); X4_MFMA(d2, bxb.z, da.z);
+                X4_MFMA(d1, bxa.w, da.w); X4_MFMA(d2, bxb.w, da.w);
+                sX[0][lane] = make_float4(d1[0], d1[1], d1[2], d1[3]);
+                sX[1][lane] = make_float4(d2[0], d2[1], d2[2], d2[3]);
+                XCD_WAVE_LDS_SYNC();
+                if (lane < 32) {                // lane = (feature f = lane >> 2, clip j)
+                    const float *px = (const float *)&sX[lane >> 4][0] + j * 4 + ((lane >> 2) & 3);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) sum += px[u * 16];
+                    xcd_store4(rws, lane * 4, a.dfx_off + ((gp * X4_SLOTS + (t & 3)) * 32 + c) * 128, sum, local);
+                    xcd_store4(rws, lane * 4, a.dfx_off + ((gp * X4_SLOTS + ((t + 3) & 3)) * 32 + c) * 128, sentf.x, local);
+                }
+            }
+        }
         // wave 3: the next head step's boxes and p, from HBM into registers now, into LDS at the end of the phase
         float4 hxa = make_float4(0.f, 0.f, 0.f, 0.f), hxb = hxa;
-        const int tn = T - nn;
+        const int tn = T + 1 - nn;
         const bool hfetch = w == 3 && more && tn >= 0 && tn < T;
         if (hfetch) {
             // lane = (k-quad or slot quad q, clip j): boxes k-quads 0..15 | boxes k-quads 16..23 and p
@@ -955,7 +965,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         // (an abort can only be raised in the second half of a phase: it is looked at after barrier 2)
         // ================================ products: the CU's gate columns x its da -> partial dh rows of every unit ==========
         if (!(a.debug & 16)) {
-            const float4 *F2 = &sDA2[0][0] + j, *F1 = &sDA1[0][0] + j;
+            const float4 *F2 = &sDA2[buf][0][0] + j, *F1 = &sDA1[0][0] + j;
             x4_f32x4 d2a = {0.f, 0.f, 0.f, 0.f}, d2b = d2a, d1 = d2a;
             float4 bf[X4_RING];
             // 24 B fragments: 16 of da2 (each feeds set 0 and set 1: 8 MFMAs) | 8 of da1 (4 MFMAs), X4_AHEAD ahead
@@ -985,7 +995,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
             // lane (block bb, clip j) holds rows 4 bb .. 4 bb + 3 of its row set = one float4 of the owner's chunk:
             //   dh2 row 128 w + 64 set + 4 bb + i -> owner 8 w + 4 set + (bb >> 2), unit quad bb & 3
             //   dh1 row  64 w + 4 bb + i          -> owner 8 w + (bb >> 1),         unit quad bb & 1
-            const int t2 = T - 1 - n, t1 = T + 1 - n;
+            const int t2 = T - 1 - n, t1 = T + 2 - n;
             if (t2 >= 0 && t2 < T) {
                 const unsigned vo = (((b >> 2) * 32) * 16 + (b & 3) * 4 + j) * 16;       // owner stride 32 producers x 16 float4
                 const unsigned so = a.p2x_off + (((gg * X4_SLOTS + (t2 & 3)) * 32 + 8 * w) * 32 + c) * 256;
@@ -1007,7 +1017,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         // ================================ wave 2: the next head step's dfb = sum of the 32 CUs' parts (published in this phase's
         //                                  first half, i.e. long ago), fetched now so that the head backward is pure arithmetic ====
         if (w == 2 && more && alive && !(a.debug & 8)) {
-            const int t = T - nn;
+            const int t = T + 1 - nn;
             hsum = 0.f;
             if (t >= 0 && t < T) {
                 // lane = (CU half h, feature f, clip j): 16 CUs each
@@ -1042,6 +1052,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         __syncthreads();                        // barrier 2: the next phase's chunks have landed
         if (tracer) a.trace[(long)p * 8 + 6] = clock64();
         if (sAbort) return;
+        gprev = gi;
+        nprev = n;
         gi = gn;
         n = nn;
         cg = ng_; cdy = ndy; cct = nct; ccp = ncp;
