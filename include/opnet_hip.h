@@ -115,7 +115,7 @@ int opnet_xcd4_pack_weights_f32(const float *w_ih1, const float *w_hh1, const fl
 int opnet_xcd4_forward_f32(const float *boxes, const float *packed, float *y, float *logits, void *workspace,
                            size_t workspace_bytes, int B, int T, int H1, int H2, void *stream);
 /* tools: the same for the 4-clip persistent training kernels (opnet_train_forward_f32 / opnet_train_backward_f32 on
- * batches of up to 32 clips): >= (T+2) * ceil(B/32) * 8 uint64 */
+ * batches of up to 32 clips): >= (T+3) * ceil(B/32) * 8 uint64 */
 void opnet_xcd4_set_trace(void *device_buffer);
 /* tools / tests: status words of this process's most recent 4-clip persistent launch (synchronises the device): [0] abort
  * code (0 = ok), [1] first failing block, [2] phase, [3] groups that ran the write-through protocol (not XCD-local) */

@@ -13,7 +13,7 @@ from objectpermanence_amd import ModelsFactory, _lib, l1_mean  # noqa: E402
 from synthdata import opnet as synth  # noqa: E402
 
 CFG = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
-NAMES = ["products", "barrier 1", "cell + exchange store", "history stores (wave 0: + dfb part)", "gather (poll until published)", "drain", "barrier 2", "loop"]
+NAMES = ["products", "barrier 1", "cell + exchange store", "history stores", "gather (poll until published)", "drain", "barrier 2", "loop"]
 
 
 def timed(fn, reps):
@@ -66,7 +66,7 @@ def main():
         lib.opnet_xcd4_last_status(st)
         print(f"  status of the last persistent launch: {list(st)}", flush=True)
         ng = (B + 31) // 32
-        tr = torch.zeros((T + 2) * ng * 8 * 2, dtype=torch.int64, device=dev)
+        tr = torch.zeros((T + 3) * ng * 8, dtype=torch.int64, device=dev)
         lib.opnet_xcd4_set_trace(tr.data_ptr())
         fwd()
         torch.cuda.synchronize()
@@ -77,18 +77,15 @@ def main():
         parts = [med(ph[:, i + 1] - ph[:, i]) for i in range(7)] + [med(ph[1:, 0] - ph[:-1, 7])]
         print(f"  forward, block 0 wave 0, cycles (median): period {med(np.diff(ph[:, 0])):.0f} | "
               + ", ".join(f"{n} {v:.0f}" for n, v in zip(NAMES, parts)), flush=True)
-        tg = tr.cpu().numpy().reshape(-1, 8)[(T + 2) * ng:][len(t) // 3: 2 * len(t) // 3]
-        print(f"  forward gather of wave 0: loads issued {med(tg[:, 0] - ph[:, 4]):.0f} after the finish, first answers after "
-              f"{med(tg[:, 1] - tg[:, 0]):.0f}, tries median {med(tg[:, 2]):.0f} max {tg[:, 2].max():.0f}, return after {med(ph[:, 5] - tg[:, 1]):.0f}", flush=True)
         tr.zero_()
         lib.opnet_xcd4_set_trace(tr.data_ptr())
         step()          # the backward kernel stamps the same buffer after the forward
         torch.cuda.synchronize()
         lib.opnet_xcd4_set_trace(None)
         t = tr.cpu().numpy().reshape(-1, 8)
-        t = t[:(T + 2) * ng]
+        t = t[:(T + 3) * ng]
         ph = t[len(t) // 3: 2 * len(t) // 3]
-        BN = ["cells (wave 0: 32-chunk sum, cell, dfb part)", "barrier 1", "products + partial stores", "gather (poll until published)",
+        BN = ["cells (wave 0: chunk sum, cell)", "barrier 1", "products + partial stores", "gather (poll until published)",
               "drain", "barrier 2"]
         parts = [med(ph[:, i + 1] - ph[:, i]) for i in range(6)] + [med(ph[1:, 0] - ph[:-1, 6])]
         print(f"  backward, block 0 wave 0, cycles (median; each stamp costs ~200): period {med(np.diff(ph[:, 0])):.0f} | "
