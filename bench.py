@@ -55,6 +55,22 @@ W_BYTES = 5_684_224            # all six fp32 weight tensors
 STATE_BYTES_PER_CLIP = 12_672  # per clip per time step: x_t + h,c read + h,c write of both LSTMs (8-d4)
 
 
+def pmc_traffic(kernel, clips_per_launch):
+    """`roofline.traffic`: HBM-side bytes per launch of `kernel`.  PMC counters cannot be sampled from inside the process
+    that is being timed, so this is the figure of the committed rocprofv3 --pmc passes of this same command
+    (profiles/r3_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes, per launch, keyed by
+    kernel and clips per launch); null when no pass of this build and shape is committed."""
+    path = os.path.join(REPO, "profiles", "r3_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(kernel, {}).get(str(int(clips_per_launch)))
+    except (OSError, ValueError):
+        rec = None
+    if not rec:
+        return {"traffic": None}
+    return {"traffic": rec["bytes_per_launch"], "traffic_source": f"profiles/r3_pmc_traffic.json ({rec.get('note', 'rocprofv3 --pmc')})"}
+
+
 def accuracy_block(dev):
     """mean-IoU / mAP@0.5 of the HIP path with TRAINED weights on 16 held-out synthetic clips, next to the
     values the reference's own model + ResultsAnalyzer produce for the same weights and clips
@@ -106,6 +122,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the N > 1 exchange path even with one rank")
     ap.add_argument("--loss", choices=["l1", "smooth_l1"], default="smooth_l1",
                     help="--mode train: BASELINE.json config 2 names SmoothL1; the reference's own training uses l1")
+    ap.add_argument("--repeats", type=int, default=15,
+                    help="the timed region (exactly --steps steps between barrier + synchronize) is run this many times; the line "
+                         "reports the MEDIAN (value_min / value_max alongside): one 5 ms region is box-to-box noise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
@@ -151,25 +170,23 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
     for _ in range(args.warmup):
         train_step("opnet", model, opt, boxes, labels, n_global=world * B, comm_stream=comm, loss_kind=args.loss)
     torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        loss = train_step("opnet", model, opt, boxes, labels, n_global=world * B, comm_stream=comm, loss_kind=args.loss)
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    comm_events, last = [], {}
+
+    def region():
+        ev0.record()
+        for _ in range(args.steps):
+            last["loss"] = train_step("opnet", model, opt, boxes, labels, n_global=world * B, comm_stream=comm,
+                                      loss_kind=args.loss, comm_events=comm_events if world > 1 or args.force_dist else None)
+        ev1.record()
+
+    elapsed, t_min, t_max, _all = timed_repeats(args, dev, dist, world, region)
+    loss = last["loss"]
+    gpu_ms = ev0.elapsed_time(ev1)             # the last repeat
+    from objectpermanence_amd.training import step_aborted
+    if step_aborted(model):
+        raise SystemExit("bench: a persistent launch of a training step aborted; no line is printed for such a run")
+    comm_ms = sum(a.elapsed_time(b) for a, b in comm_events) / max(len(comm_events), 1) if comm_events else None
     if rank == 0:
         from objectpermanence_amd import _lib
         persistent = (B <= int(os.environ.get("OPNET_XCD4_MAX_B", "32")) and os.environ.get("OPNET_XCD4", "1") != "0"
@@ -214,10 +231,16 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
             "metric": "CATER clips/sec OPNet training step (fwd + loss + bwd + Adam)",
             "value": round(world * B * args.steps / elapsed, 1), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "repeats": max(1, args.repeats), "value_is": "median over the repeats of the timed region",
+            "value_min": round(world * B * args.steps / t_max, 1), "value_max": round(world * B * args.steps / t_min, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"opnet training, batch={B} clips/GPU x 300 frames x 15 slots (10 objects), "
-                                   f"{args.loss} bbox loss, Adam lr 1e-3", "global_batch": world * B,
-                       "parallelism": f"dp{world}", "loss": args.loss},
+            "config": {"workload": f"opnet training (BASELINE.json config {5 if world > 1 else 2}), batch={B} clips/GPU x 300 "
+                                   f"frames x 15 slots (10 objects), {args.loss} bbox loss, Adam lr 1e-3"
+                                   + (f", data parallel over {world} GPUs: one RCCL all-reduce of the flat {W_BYTES + 16} B gradient "
+                                      "bucket per step on a side stream" if world > 1 else ""),
+                       "global_batch": world * B, "parallelism": f"dp{world}", "loss": args.loss},
+            # the gradient all-reduce alone: HIP events around the collective on the comm stream, mean per step
+            "allreduce_ms_per_step": None if comm_ms is None else round(comm_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": kernels + "; algorithmic bytes of the whole step (north_star's per-time-step weight-streaming model) / GPU time",
@@ -355,8 +378,10 @@ def launch_ranks(args) -> int:
     return subprocess.call(cmd)
 
 
-def launcher_selftest(world, rank):
-    """rendezvous + one collective on gloo: what `--gpus N` has to get right before any GPU work (CPU test)"""
+def launcher_selftest(world, rank, mode="infer", batch=32):
+    """rendezvous + one collective on gloo: what `--gpus N` has to get right before any GPU work (CPU test).  --mode train
+    additionally runs config 5's exchange - the flat OPNet gradient bucket (1 421 056 floats + the guard slot) through
+    parallel.GradBucket.all_reduce, weighted n_local / n_global - on CPU tensors, and reports the line's config block."""
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
@@ -364,8 +389,22 @@ def launcher_selftest(world, rank):
     t = torch.ones(1)
     dist.all_reduce(t)
     assert int(t.item()) == dist.get_world_size() == world
+    out = {"launcher_selftest": True, "n_gpus": world, "ranks_seen": int(t.item())}
+    if mode == "train":
+        from objectpermanence_amd import ModelsFactory, parallel
+        model = ModelsFactory.get_model("opnet", CFG)
+        bucket = parallel.GradBucket(model.parameters())
+        for i in range(len(bucket.params)):
+            bucket.view(i).fill_(float(rank + 1))
+        bucket.guard.fill_(1.0 if rank == world - 1 else 0.0)          # "the last rank's persistent launch gave up"
+        bucket.all_reduce(batch, world * batch)
+        want = sum(r + 1 for r in range(world)) / world
+        assert bucket.flat.numel() == W_BYTES // 4 and torch.allclose(bucket.flat, torch.full_like(bucket.flat, want))
+        assert float(bucket.guard) == 1.0                               # every rank sees that SOME rank aborted
+        out.update({"mode": "train", "grad_bucket_floats": int(bucket.flat.numel()), "guard_after_allreduce": float(bucket.guard),
+                    "config": {"global_batch": world * batch, "parallelism": f"dp{world}"}})
     if rank == 0:
-        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": int(t.item())}), flush=True)
+        print(json.dumps(out), flush=True)
     dist.destroy_process_group()
 
 
@@ -379,7 +418,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if args.launcher_selftest:
-        return launcher_selftest(world, rank)
+        return launcher_selftest(world, rank, args.mode, args.batch or 32)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     dev = torch.device("cuda", local_rank)
@@ -441,11 +480,38 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cb, y_cpu = cpu_baseline(boxes_np, params, args.cpu_seconds)
             out["cpu_baseline"] = cb
-            err = float(np.abs(y.cpu().numpy() - y_cpu).max())
+            # every timed step is the same B clips: EVERY B-clip slice of the last launch's output is held against the port
+            y_np = y.cpu().numpy()
+            err = max(float(np.abs(y_np[lo:lo + B] - y_cpu).max()) for lo in range(0, y_np.shape[0], B))
+            out["parity_clips_checked"] = int(y_np.shape[0])
             out["parity_max_abs_dy_vs_cpu_port"] = err
             if not err < 1e-4 and not os.environ.get("OPNET_HIP_LIB"):
                 raise SystemExit(f"bench: HIP output of the last timed step differs from the CPU port by {err}")
         emit(out)
+
+
+def timed_repeats(args, dev, dist, world, region):
+    """Run `region()` (enqueue exactly --steps steps) --repeats times, each bracketed by barrier + synchronize on both sides;
+    per repeat the MAX over ranks; returns (median, min, max, all) in seconds."""
+    times = []
+    for _ in range(max(1, args.repeats)):
+        torch.cuda.synchronize(dev)
+        if dist is not None and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        region()
+        torch.cuda.synchronize(dev)
+        if dist is not None and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        times.append(time.perf_counter() - t0)
+    if dist is not None and world > 1:
+        tt = torch.tensor(times, dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        times = [float(v) for v in tt.tolist()]
+    srt = sorted(times)
+    return srt[len(srt) // 2], srt[0], srt[-1], times
 
 
 def emit(out):
@@ -459,12 +525,17 @@ def emit(out):
     print(json.dumps(out), flush=True)
 
 
-def _line(args, world, B, clips_per_s, elapsed, workload, extra_cfg):
+def _line(args, world, B, clips_per_s, elapsed, workload, extra_cfg, spread=None):
+    rep = {}
+    if spread is not None:      # (min time -> max rate)
+        t_min, t_max = spread
+        rep = {"repeats": max(1, args.repeats), "value_is": "median over the repeats of the timed region",
+               "value_min": round(world * B * args.steps / t_max, 1), "value_max": round(world * B * args.steps / t_min, 1)}
     return {
         "metric": "CATER clips/sec (300f x 10obj) OPNet inference",
         "value": round(clips_per_s, 1), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), **rep,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "global_batch": world * B, "frames": T_FRAMES, "parallelism": f"dp{world}",
@@ -508,7 +579,7 @@ def other_batches(model, boxes, dev):
     Outside the timed region."""
     res = {}
     forced, model.use_xcd = model.use_xcd, "auto"
-    for b in (16, 400):
+    for b in (16, 32, 400):      # 32 = one request of the bench's own batch ALONE (a latency, not 1 / throughput)
         reps = (b + boxes.shape[0] - 1) // boxes.shape[0]
         x = boxes.repeat(reps, 1, 1, 1)[:b].contiguous()
         with torch.no_grad():
@@ -545,10 +616,13 @@ def bench_infer_xcd(args, model, boxes, world, rank, dev, dist):
     model.use_xcd = "1"
     server = ReasonerServer(model, "opnet", max_clips=per_launch * B)
     exchange = dist is not None
-    state = {"y": None, "pred": None, "seen": 0}
+    state = {"y": None, "pred": None, "seen": 0, "gathered": []}
+    comm = torch.cuda.Stream(device=dev) if exchange else None
 
     def after_flush():
-        # one post-process (+ one collective) per launch, on the stream the forward was enqueued on
+        # one post-process per launch on the stream the forward was enqueued on; the all-gather of its int32 predictions
+        # (3 MB for 640 clips) runs on a SIDE stream behind an event, so the next launch's input concatenation and
+        # recurrence do not wait for the collective (north_star: "overlapped ... on a side HIP stream")
         if server.forwards == state["seen"]:
             return
         state["seen"] = server.forwards
@@ -556,7 +630,11 @@ def bench_infer_xcd(args, model, boxes, world, rank, dev, dist):
         pred_px, _, _ = metrics.postprocess_and_iou(y)
         if exchange:
             gathered = torch.empty((world * pred_px.shape[0],) + tuple(pred_px.shape[1:]), dtype=pred_px.dtype, device=dev)
-            dist.all_gather_into_tensor(gathered, pred_px)
+            comm.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(comm):
+                dist.all_gather_into_tensor(gathered, pred_px)
+            pred_px.record_stream(comm)
+            state["gathered"] = (state["gathered"] + [gathered])[-4:]       # kept alive until the collectives are done
         state["y"], state["pred"] = y, pred_px
 
     def run(n):
@@ -565,6 +643,8 @@ def bench_infer_xcd(args, model, boxes, world, rank, dev, dist):
             after_flush()
         server.flush()
         after_flush()
+        if exchange:
+            torch.cuda.current_stream(dev).wait_stream(comm)       # the step is done when its predictions are everywhere
 
     # untimed: the W warm-up steps, then one launch of every shape the timed region will issue (the remainder launch, then
     # the full one), so that their history workspaces exist and are mapped - a steady-state server has them - and the
@@ -574,35 +654,24 @@ def bench_infer_xcd(args, model, boxes, world, rank, dev, dist):
     for shape_steps in sorted({args.steps % per_launch, per_launch} - {0}):
         run(shape_steps)
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
     lib.opnet_xcd_profile(1)
     f0 = server.forwards
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    elapsed, t_min, t_max, _all = timed_repeats(args, dev, dist, world, lambda: run(args.steps))
     kms, nl = ctypes.c_double(0.0), ctypes.c_int(0)
     _lib.check(lib.opnet_xcd_profile_read(ctypes.byref(kms), ctypes.byref(nl)), "opnet_xcd_profile_read")
     lib.opnet_xcd_profile(0)
-    for key, st in model.xcd_status().items():
-        if st[0] != 0:
-            raise SystemExit(f"bench: persistent launch {key} aborted (block {st[1]}, phase {st[2]})")
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # an aborted persistent launch was re-run on the chain by the model (launch_monitor.py): a bench line must not be
+    # quoted on such a run
+    if model.verify_launches() or model._monitor.aborted:
+        raise SystemExit(f"bench: {model._monitor.aborted} persistent launch(es) aborted: {model.xcd_status()}")
     if rank != 0:
         return None, None
+    R = max(1, args.repeats)
     clips = B * args.steps
     clips_per_s = world * clips / elapsed
-    launches = server.forwards - f0
-    assert launches == nl.value, (launches, nl.value)
-    kernel_s = kms.value * 1e-3
+    launches = (server.forwards - f0) // R
+    assert (server.forwards - f0) == nl.value, (server.forwards - f0, nl.value)
+    kernel_s = kms.value * 1e-3 / R            # the kernel's mean duration per timed region (HIP events around every launch)
     tf = clips * FLOP_PER_CLIP / kernel_s / 1e12
     # north_star's streaming model (every time step streams all weights once per B-clip batch and moves
     # each clip's state): what the launch-per-step design had to move for these clips, over this kernel's time.  It is a
@@ -613,17 +682,17 @@ def bench_infer_xcd(args, model, boxes, world, rank, dev, dist):
                 "15 slots (10 objects) x 6 features, precomputed bbox input resident in HBM, int32 pixel-box post-process on "
                 f"device; steps are requests to a ReasonerServer that runs up to {per_launch} pending batches "
                 f"({per_launch * B} clips) as one per-XCD persistent forward",
-                {"engine": "xcd", "batches_per_launch": per_launch, "launches": launches})
+                {"engine": "xcd", "batches_per_launch": per_launch, "launches": launches}, spread=(t_min, t_max))
     out["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                       "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
-                       "kernel": "opnet_xcd_forward", "launch_ms": round(kms.value / max(launches, 1), 4),
+                       "frac": round(tf / MFMA_F32_PEAK_TF, 4), **pmc_traffic("opnet_xcd_forward", clips // max(launches, 1)),
+                       "kernel": "opnet_xcd_forward", "launch_ms": round(kms.value / max(launches * R, 1), 4),
                        "launches": launches, "alg_flop_per_launch": int(clips * FLOP_PER_CLIP / max(launches, 1)),
                        "timing": "HIP events around every launch of the kernel on its stream (opnet_xcd_profile)"}
     out["roofline_hbm_model"] = {"bound": "hbm", "achieved": round(model_bytes / kernel_s / 1e9, 1), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(model_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                                  "note": "SURVEY.md 8-d4 streaming-model bytes of the same clips (weights once per time step per "
                                          f"{B}-clip batch) over the kernel time; not bytes this kernel moves"}
-    return out, state["y"][-B:]
+    return out, state["y"]
 
 
 def bench_infer_chain(args, model, boxes, world, rank, dev, dist):
@@ -706,25 +775,22 @@ def bench_infer_chain(args, model, boxes, world, rank, dev, dist):
         step(i)
     drain()
     torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(main_stream)
-    for st in streams:
-        if st is not main_stream:
-            st.wait_stream(main_stream)
-    for i in range(args.steps):
-        y, pred_px = step(i)
-    drain()
-    ev1.record(main_stream)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)  # HIP events bracketing all launch streams: the kernels only
+    last = {}
+
+    def region():
+        ev0.record(main_stream)
+        for st in streams:
+            if st is not main_stream:
+                st.wait_stream(main_stream)
+        for i in range(args.steps):
+            last["y"], last["pred"] = step(i)
+        drain()
+        ev1.record(main_stream)
+
+    elapsed, t_min, t_max, _all = timed_repeats(args, dev, dist, world, region)
+    y = last["y"]
+    gpu_ms = ev0.elapsed_time(ev1)  # HIP events bracketing all launch streams of the last repeat: the kernels only
     # ONE launch's own duration: a single-stream pass (nothing overlaps it), HIP events on that stream
     single = streams[:1]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -736,10 +802,6 @@ def bench_infer_chain(args, model, boxes, world, rank, dev, dist):
         e1.record(single[0])
     torch.cuda.synchronize(dev)
     single_launch_us = e0.elapsed_time(e1) * 1e3 / (10 * (T_FRAMES + 3))
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     if rank != 0:
         return None, None
     clips_per_s = world * B * args.steps / elapsed
@@ -754,7 +816,7 @@ def bench_infer_chain(args, model, boxes, world, rank, dev, dist):
                 f"opnet (configs/opnet_model_config.json: H1=256, H2=512) inference, batch={B} clips/GPU/step x 300 frames x "
                 "15 slots (10 objects) x 6 features, precomputed bbox input resident in HBM, int32 pixel-box post-process on "
                 f"device; independent steps spread over {S} HIP streams",
-                {"engine": "chain", "streams": S})
+                {"engine": "chain", "streams": S}, spread=(t_min, t_max))
     out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "opnet_step",
                        "launch_us": round(single_launch_us, 3), "alg_bytes_per_launch": int(alg_bytes_per_launch),

@@ -120,6 +120,17 @@ void opnet_xcd4_set_trace(void *device_buffer);
 /* tools / tests: status words of this process's most recent 4-clip persistent launch (synchronises the device): [0] abort
  * code (0 = ok), [1] first failing block, [2] phase, [3] groups that ran the write-through protocol (not XCD-local) */
 int opnet_xcd4_last_status(unsigned *out4);
+/* Where a persistent launch keeps its 4 status words inside the caller's workspace (byte offset; (size_t)-1 = this shape never
+ * runs a persistent kernel), so that a host caller can mirror them behind the launch (one 16-byte async copy to pinned memory)
+ * and re-run an aborted batch on the launch chain instead of consuming NaN.  opnet_xcd_forward_f32: offset 0.  The training
+ * words are sticky from opnet_train_forward_f32 to opnet_train_backward_f32 of the same step (either may raise them); after
+ * an abort the weight gradients are NaN and a guarded Adam step (below) leaves the parameters untouched. */
+size_t opnet_xcd4_status_offset(int B, int T, int H1, int H2);
+size_t opnet_train_status_offset(int B, int T, int H1, int H2);
+/* run-time switch of the 4-clip persistent kernels (training step and small inference request): 0 = launch chain only.
+ * Replaces nothing in the reference; it is how a caller falls back after an aborted persistent launch. */
+void opnet_xcd4_enable(int on);
+int opnet_xcd4_enabled(void);
 
 /* ---- training (replaces torch autograd through OPNet.forward, nn.L1Loss and torch.optim.Adam as used
  *      at training_main.py:150-152,183-217) ---------------------------------------------------------
@@ -163,6 +174,14 @@ int opnet_adam_step_f32(float *param, const float *grad, float *exp_avg, float *
 int opnet_adam_multi_step_f32(int count, float *const *params, const float *const *grads, float *const *exp_avgs,
                               float *const *exp_avg_sqs, const long *numels, float lr, float beta1, float beta2,
                               float eps, int step, float grad_scale, void *stream);
+/* the same with device-side guards (each may be NULL): the whole update is skipped - parameters and moments untouched, no host
+ * round trip - when *abort_u32 != 0 (status word of the persistent launches that produced the gradients), when *loss_f32 is
+ * not finite, or when *guard_f32 != 0 (data parallel: the sum over ranks of their abort flags, carried by the gradient
+ * all-reduce).  torch.optim.Adam (training_main.py:217) has no such guard: it would write NaN into every weight. */
+int opnet_adam_multi_step_guarded_f32(int count, float *const *params, const float *const *grads, float *const *exp_avgs,
+                                      float *const *exp_avg_sqs, const long *numels, float lr, float beta1, float beta2,
+                                      float eps, int step, float grad_scale, const unsigned *abort_u32, const float *loss_f32,
+                                      const float *guard_f32, void *stream);
 
 /* ---- sibling reasoners (reference learned_models.py:55-197) ----------------------------------------
  * OPNetLstmMlp (:55-89): OPNet whose video LSTM is relu(Linear 6->H2) (hidden_layer.weight [H2,6]);

@@ -13,6 +13,7 @@ from . import build as _build
 _LIB = None
 
 OPNET_OK = 0
+NO_OFFSET = ctypes.c_size_t(-1).value      # opnet_*_status_offset: "this shape never runs a persistent kernel"
 
 
 class OpnetHipError(RuntimeError):
@@ -88,6 +89,16 @@ def _declare(lib):
     lib.opnet_adam_multi_step_f32.restype = c_int
     lib.opnet_adam_multi_step_f32.argtypes = [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                               POINTER(ctypes.c_long), c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]
+    lib.opnet_adam_multi_step_guarded_f32.restype = c_int
+    lib.opnet_adam_multi_step_guarded_f32.argtypes = lib.opnet_adam_multi_step_f32.argtypes[:-1] + [fp, fp, fp, c_void_p]
+    lib.opnet_xcd4_status_offset.restype = c_size_t
+    lib.opnet_xcd4_status_offset.argtypes = [c_int, c_int, c_int, c_int]
+    lib.opnet_train_status_offset.restype = c_size_t
+    lib.opnet_train_status_offset.argtypes = [c_int, c_int, c_int, c_int]
+    lib.opnet_xcd4_enable.restype = None
+    lib.opnet_xcd4_enable.argtypes = [c_int]
+    lib.opnet_xcd4_enabled.restype = c_int
+    lib.opnet_xcd4_enabled.argtypes = []
     lib.opnet_adam_step_f32.restype = c_int
     lib.opnet_adam_step_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_float, c_float, c_float, c_float,
                                         c_int, c_float, c_void_p]
@@ -185,6 +196,7 @@ EXPORTS = [
     "opnet_xcd_profile", "opnet_xcd_profile_read",
     "opnet_train_packed_weights_bytes", "opnet_train_pack_weights_f32", "opnet_train_workspace_bytes",
     "opnet_train_forward_f32", "opnet_train_backward_f32", "opnet_l1_loss_f32", "opnet_smooth_l1_loss_f32", "opnet_adam_step_f32", "opnet_adam_multi_step_f32",
+    "opnet_adam_multi_step_guarded_f32", "opnet_xcd4_status_offset", "opnet_train_status_offset", "opnet_xcd4_enable", "opnet_xcd4_enabled",
     "opnet_mlp_pack_weights_f32", "opnet_mlp_forward_f32",
     "opnet_mlp_train_pack_weights_f32", "opnet_mlp_train_forward_f32", "opnet_mlp_train_backward_f32",
     "opseq_lstm_stack_packed_bytes", "opseq_lstm_stack_workspace_bytes", "opseq_lstm_stack_pack_weights_f32",

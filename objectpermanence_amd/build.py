@@ -10,7 +10,14 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libopnet_hip.so")
 SOURCES = ["opnet_abi.hip", "opdet_abi.hip"]
-DEPS = ["opnet_abi.hip", "opdet_abi.hip", "det_head_kernels.hip", "attn_kernels.hip", "enc_train_kernels.hip", "opnet_kernels.hip", "opnet_xcd_kernels.hip", "opnet_train_kernels.hip", "seq_kernels.hip", "conv_kernels.hip", "opnet_ctx.h", os.path.join("..", "..", "include", "opnet_hip.h")]
+
+
+def _deps():
+    """every source the two translation units can include: all of csrc/ plus the public header (a hand-kept list went stale
+    when opnet_xcd4_kernels.hip was added - an edited kernel file must always make the library stale)"""
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".hpp"))]
+    out.append(os.path.join(PKG, "..", "include", "opnet_hip.h"))
+    return out
 
 
 def _hipcc() -> str:
@@ -24,7 +31,7 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in _deps() if os.path.exists(d))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

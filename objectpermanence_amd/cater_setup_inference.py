@@ -16,6 +16,7 @@ import torch
 from torch.utils import data
 
 from .datasets import DatasetsFactory
+from .launch_monitor import verify_launches
 from .models_factory import ModelsFactory
 from .proj_utils import get_class_predictions
 from .supported_models import DOUBLE_OUTPUT_MODELS
@@ -50,6 +51,7 @@ def cater_setup_inference(model_name: str, results_dir: str, inference_config_pa
     with torch.no_grad():
         for (boxes, _index_to_track), _y, video_names in loader:
             out = model(boxes.to(device))
+            verify_launches(model)       # (the .cpu() below synchronises anyway) an aborted persistent launch is re-run first
             output = out[0] if model_name in DOUBLE_OUTPUT_MODELS else out
             last.append(output[:, -1, :].cpu().numpy().reshape(-1, 4))                 # :77
             names.extend(video_names)

@@ -15,6 +15,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <new>
@@ -779,6 +780,12 @@ static int train_chain_layouts(const float *packed, hipStream_t st)
     return OPNET_OK;
 }
 
+// Run-time switch of the 4-clip persistent kernels (host callers fall back to the launch chain after an aborted launch)
+static std::atomic<int> g_x4_enabled{1};
+extern "C" void opnet_xcd4_enable(int on) { g_x4_enabled.store(on ? 1 : 0); }
+extern "C" int opnet_xcd4_enabled(void) { return g_x4_enabled.load(); }
+static bool x4_on() { return g_x4_enabled.load() != 0 && env_int("OPNET_XCD4", 1) != 0; }
+
 static bool x4_device()
 {
     int dev = 0;
@@ -797,7 +804,7 @@ extern "C" int opnet_train_pack_weights_f32(const float *w_ih1, const float *w_h
     if (packed_bytes < L.total * sizeof(float))
         return fail(OPNET_EWORKSPACE, "packed buffer %zu B < %zu B", packed_bytes, L.total * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
-    const bool lazy = x4_dims(H1, H2) && env_int("OPNET_XCD4", 1) != 0 && x4_device();
+    const bool lazy = x4_dims(H1, H2) && x4_on() && x4_device();
     if (!lazy) {
         if (int rc = pack_chain_train_layouts(w_ih1, w_hh1, w_sel, w_ih2, w_hh2, w_out, packed, H1, H2, st)) return rc;
     } else {
@@ -934,6 +941,19 @@ static int check_x4_infer(int B, int T, int H1, int H2)
     return OPNET_OK;
 }
 extern "C" int opnet_xcd4_max_batch(void) { return 32 * X4_NGMAX; }
+/* Byte offset of the 4 status words {abort code, block, phase, groups on the write-through path} of a persistent launch
+ * inside its workspace, for callers that mirror them to the host behind the launch; (size_t)-1: this shape never runs a
+ * persistent kernel.  (opnet_xcd_forward_f32: offset 0 of its workspace.) */
+extern "C" size_t opnet_xcd4_status_offset(int B, int T, int H1, int H2)
+{
+    if (check_x4_infer(B, T, H1, H2)) return (size_t)-1;
+    return x4_infer_layout(B, T).status;
+}
+extern "C" size_t opnet_train_status_offset(int B, int T, int H1, int H2)
+{
+    if (check_dims(B, T, H1, H2) || !x4_batch(B, H1, H2)) return (size_t)-1;
+    return train_workspace_layout(B, T, H1, H2).x4status;
+}
 extern "C" size_t opnet_xcd4_packed_weights_bytes(int H1, int H2)
 {
     return x4_dims(H1, H2) ? x4_infer_packed_layout().total * sizeof(float) : 0;
@@ -1023,7 +1043,7 @@ extern "C" int opnet_xcd4_forward_f32(const float *boxes, const float *packed, f
 // the launch chain's wide step wins again), OPNET_XCD4 = 0 switches it off.
 static bool x4_use(int B, int T, int H1, int H2)
 {
-    if (!x4_batch(B, H1, H2) || env_int("OPNET_XCD4", 1) == 0) return false;
+    if (!x4_batch(B, H1, H2) || !x4_on()) return false;
     if (B > env_int("OPNET_XCD4_MAX_B", 32)) return false;
     if (train_workspace_layout(B, T, H1, H2).total >= ((size_t)1 << 31)) return false;   // one buffer descriptor
     int dev = 0;
@@ -1108,6 +1128,9 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
         return OPNET_OK;
     }
     if (int rc = train_chain_layouts(packed, st)) return rc;
+    // the status words of the 4-clip kernels are sticky from the forward to the weight-gradient launch and the optimiser's
+    // guard: a forward on the launch chain has to say "nothing aborted" itself
+    if (x4_batch(B, H1, H2)) HIP_TRY(hipMemsetAsync((char *)workspace + W.x4status, 0, 32, st));
     const dim3 grid = step_grid(a);
     const opnet_step_fn stepk = step_kernel(a);
     for (int s = 0; s < T + 3; ++s) stepk<<<grid, step_threads(a), 0, st>>>(a, s);
@@ -1175,7 +1198,7 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
         else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
         opnet_xcd4_backward<<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(x);
         HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
-    } else if (int rc = train_chain_layouts(packed, st)) {
+    } else if (int rc = mlp ? OPNET_OK : train_chain_layouts(packed, st)) {      // (the mlp image is always packed eagerly)
         return rc;
     } else if (fused) {
         const dim3 gfused(2 * (H2 / 16 + H1 / 16 + 1), RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
@@ -1217,6 +1240,8 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
         wb.job[j].tile_begin = 0x7fffffff;
         wb.job[j].tiles_m = 1;
     }
+    // a forward or reverse recurrence that gave up (4-clip persistent kernels) left partial histories: every dW becomes NaN
+    wb.abort = x4_batch(B, H1, H2) ? (const unsigned *)(w + W.x4status) : nullptr;
     opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
@@ -1234,6 +1259,12 @@ extern "C" int opnet_mlp_train_pack_weights_f32(const float *w_ih1, const float 
     if (packed_bytes < L.total * sizeof(float)) return fail(OPNET_EWORKSPACE, "packed buffer too small");
     if (int rc = opnet_mlp_pack_weights_f32(w_ih1, w_hh1, w_sel, w_hidden, w_out, packed, L.fwd_total * sizeof(float), H1, H2, stream))
         return rc;
+    {
+        // this buffer now holds an OPNetLstmMlp image: a deferred OPNet chain pack remembered for the same address (a freed
+        // module's buffer handed out again by the caching allocator) must never run over it
+        std::lock_guard<std::mutex> lock(g_tp_mu);
+        g_tp.erase(packed);
+    }
     hipStream_t st = (hipStream_t)stream;
     auto blocks = [](size_t n) { return (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256); };
     // "W_ih2" [4H2][6] = [hidden_layer.weight ; 0 ; 0 ; 0]
@@ -1262,6 +1293,7 @@ extern "C" int opnet_mlp_train_forward_f32(const float *boxes, const float *pack
     OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
+    if (x4_batch(B, H1, H2)) HIP_TRY(hipMemsetAsync((char *)workspace + W.x4status, 0, 32, st));   // (see opnet_train_forward_f32)
     const dim3 grid = step_grid(a);
     const opnet_step_fn stepk = step_kernel(a);
     for (int s = 0; s < T + 3; ++s) stepk<<<grid, step_threads(a), 0, st>>>(a, s);
@@ -1315,10 +1347,24 @@ extern "C" int opnet_adam_step_f32(float *param, const float *grad, float *exp_a
     return OPNET_OK;
 }
 
-/* opnet_adam_step_f32 for `count` (<= 16) tensors that share the hyper-parameters and the step number, as ONE launch */
+/* opnet_adam_step_f32 for `count` (<= 16) tensors that share the hyper-parameters and the step number, as ONE launch.
+ * The guarded form skips the whole update on device (no host round trip) when *abort_u32 != 0 (a persistent recurrence gave
+ * up: its gradients are NaN), when *loss_f32 is not finite, or when *guard_f32 != 0 (data parallel: some rank aborted). */
+extern "C" int opnet_adam_multi_step_guarded_f32(int count, float *const *params, const float *const *grads, float *const *exp_avgs,
+                                                 float *const *exp_avg_sqs, const long *numels, float lr, float beta1, float beta2,
+                                                 float eps, int step, float grad_scale, const unsigned *abort_u32,
+                                                 const float *loss_f32, const float *guard_f32, void *stream);
 extern "C" int opnet_adam_multi_step_f32(int count, float *const *params, const float *const *grads, float *const *exp_avgs,
                                          float *const *exp_avg_sqs, const long *numels, float lr, float beta1, float beta2,
                                          float eps, int step, float grad_scale, void *stream)
+{
+    return opnet_adam_multi_step_guarded_f32(count, params, grads, exp_avgs, exp_avg_sqs, numels, lr, beta1, beta2, eps, step,
+                                             grad_scale, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int opnet_adam_multi_step_guarded_f32(int count, float *const *params, const float *const *grads, float *const *exp_avgs,
+                                                 float *const *exp_avg_sqs, const long *numels, float lr, float beta1, float beta2,
+                                                 float eps, int step, float grad_scale, const unsigned *abort_u32,
+                                                 const float *loss_f32, const float *guard_f32, void *stream)
 {
     if (!params || !grads || !exp_avgs || !exp_avg_sqs || !numels) return fail(OPNET_EINVAL, "null pointer");
     if (count <= 0 || count > OPNET_ADAM_MAX) return fail(OPNET_ESHAPE, "1..%d tensors per call (count=%d)", OPNET_ADAM_MAX, count);
@@ -1333,6 +1379,7 @@ extern "C" int opnet_adam_multi_step_f32(int count, float *const *params, const 
         if (numels[k] > nmax) nmax = numels[k];
     }
     t.count = count;
+    t.abort_u32 = abort_u32; t.loss_f32 = loss_f32; t.guard_f32 = guard_f32;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const unsigned nb = (unsigned)((nmax + 255) / 256 > 1024 ? 1024 : (nmax + 255) / 256);
@@ -1835,7 +1882,8 @@ extern "C" int opseq_lstm_stack_train_backward_f32(const float *dy, const float 
                 wb.job[j].tiles_m = 1;
             }
         }
-        opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
+        wb.abort = nullptr;       // (the stack's recurrences are launch chains: nothing can give up)
+    opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
     }
     if (dx0) {
         // dx0 [B*T][KX] = da0 [B*T][4H] . W_ih0 [4H][KX]  (k = 4*unit + gate on both sides) via the tiled GEMM

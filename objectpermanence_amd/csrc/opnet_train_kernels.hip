@@ -582,6 +582,8 @@ struct WgradArgs {
 #define OPNET_WGRAD_JOBS 6
 struct WgradBatch {
     WgradArgs job[OPNET_WGRAD_JOBS];
+    const unsigned *abort;     // status word of the persistent recurrences that wrote the histories (null: launch chain);
+                               // nonzero = they gave up, the histories are partial -> every dW is NaN, never a plausible number
 };
 
 __global__ void __launch_bounds__(256) opnet_wgrad(const WgradBatch batch)
@@ -651,7 +653,8 @@ __global__ void __launch_bounds__(256) opnet_wgrad(const WgradBatch batch)
     for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
         const int l = idx & 63, ar = idx >> 6;
         const int r = ar & 3, y = (ar >> 2) & 3, x = ar >> 4;
-        const float v = ((red[0][ar][l] + red[1][ar][l]) + red[2][ar][l]) + red[3][ar][l];
+        float v = ((red[0][ar][l] + red[1][ar][l]) + red[2][ar][l]) + red[3][ar][l];
+        if (batch.abort && *batch.abort != 0u) v = NAN;
         // D layout of 16x16x4: lane l holds column j = l&15, rows 4*(l>>4) + r
         const int m = 4 * (mq0 + 4 * (l >> 4) + r) + x;
         const int nn = 4 * (nq0 + (l & 15)) + y;
@@ -732,12 +735,21 @@ struct AdamBatch {
     float *m[OPNET_ADAM_MAX], *v[OPNET_ADAM_MAX];
     long n[OPNET_ADAM_MAX];
     int count;
+    // guards (each may be null): the update is SKIPPED - parameters and moments untouched - when the abort word of the
+    // persistent launches that made the gradients is nonzero, when the loss is not finite, or when the data-parallel guard
+    // (the sum over ranks of their abort flags, carried through the gradient all-reduce) is nonzero
+    const unsigned *abort_u32;
+    const float *loss_f32;
+    const float *guard_f32;
 };
 
 // grid (blocks per tensor, tensors)
 __global__ void __launch_bounds__(256) opnet_adam_multi(const AdamBatch t, float b1, float b2, float eps, float step_size,
                                                         float inv_sqrt_bc2, float grad_scale)
 {
+    if (t.abort_u32 && *t.abort_u32 != 0u) return;
+    if (t.loss_f32 && !isfinite(*t.loss_f32)) return;
+    if (t.guard_f32 && *t.guard_f32 != 0.f) return;
     const int k = blockIdx.y;
     float *__restrict__ p = t.p[k];
     const float *__restrict__ gr = t.g[k];

@@ -686,7 +686,9 @@ __global__ void __launch_bounds__(256) opnet_xcd4_init_bwd(Xcd4BArgs a)
 {
     const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, n = (long)gridDim.x * blockDim.x;
     const long NG = a.RB * 8;
-    if (tid < 8) a.status[tid] = 0u;
+    // status[0..2] (abort code, block, phase) are STICKY from the forward of this step: an aborted forward makes the
+    // reverse recurrence leave at once, and the weight-gradient launch and the optimiser's guard still see the abort word
+    if (tid >= 3 && tid < 8) a.status[tid] = 0u;
     for (long i = tid; i < 256; i += n) a.status[8 + i] = 0xffffffffu;
     const xcd_u32x4 z = {0u, 0u, 0u, 0u}, sent = {X4_SENT, X4_SENT, X4_SENT, X4_SENT};
     const long zs = a.T & (X4_SLOTS - 1);
@@ -710,6 +712,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     __shared__ __attribute__((aligned(16))) float4 sHX[X4_NGMAX][2][28][4];   // the head step's boxes (24 k-quads) and p (4 slot quads) x 4 clips, by step parity
     __shared__ volatile int sAbort, sLocal;
 
+    // the forward of this step gave up (sticky abort word, see opnet_xcd4_init_bwd): its histories are partial - leave
+    if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x = blockIdx.x & 7, c = blockIdx.x >> 3;

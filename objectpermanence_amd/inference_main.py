@@ -26,6 +26,7 @@ from torch.utils import data
 
 from . import metrics, parallel
 from .datasets import DatasetsFactory
+from .launch_monitor import verify_launches
 from .models_factory import ModelsFactory
 from .serving import ReasonerServer, output_boxes
 
@@ -64,20 +65,22 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
     names: List[str] = []
     pending, preds, gts, ious = [], [], [], []
 
-    def finish(handle, labels_dev):
-        output = output_boxes(model_name, handle.result() if server is not None else handle)
-        pred_px, gt_px, iou = metrics.postprocess_and_iou(output, labels_dev)
-        preds.append(pred_px); gts.append(gt_px); ious.append(iou)
-
     with torch.no_grad():
         for (boxes, _index_to_track), (labels, _), video_names in loader:
             names.extend(video_names)
             if server is None:
-                finish(model(boxes.to(device)), labels.to(device))
+                pending.append((model(boxes.to(device)), labels.to(device)))
             else:
                 pending.append((server.submit(boxes.to(device)), labels.to(device)))
+        if server is not None:
+            server.flush()
+        # The sync point of this driver.  A persistent launch that gave up (bounded spins, NaN outputs) is re-run on the
+        # launch chain into the same output tensors here - NaN never reaches the int32 post-process or the JSON files.
+        verify_launches(model)
         for handle, labels_dev in pending:
-            finish(handle, labels_dev)
+            output = output_boxes(model_name, handle.result() if server is not None else handle)
+            pred_px, gt_px, iou = metrics.postprocess_and_iou(output, labels_dev)
+            preds.append(pred_px); gts.append(gt_px); ious.append(iou)
     t_frames = preds[0].shape[1] if preds else 300
     local_pred = torch.cat(preds) if preds else torch.zeros((0, t_frames, 4), dtype=torch.int32, device=device)
     local_iou = torch.cat(ious) if ious else torch.zeros((0, t_frames), dtype=torch.float64, device=device)

@@ -1,0 +1,80 @@
+"""Host-side watch over the persistent kernels' abort words.
+
+A persistent launch (csrc/opnet_xcd_kernels.hip, opnet_xcd4_kernels.hip, seq_xcd_kernels.hip) bounds every spin: a workgroup
+that cannot see its producers for 1.5 s raises an abort word in the launch's workspace, every poller leaves and the outputs
+are NaN.  The reference's model call (baselines/inference_main.py:203-207, training_main.py:186) cannot fail that way, so the
+callers here must never consume such an output: behind every persistent launch the module enqueues one 16-byte copy of the
+status words into pinned host memory and an event (`watch`); at the next point where the caller synchronises anyway it calls
+`verify`, which re-runs every aborted batch through the launch-per-step chain INTO THE SAME OUTPUT TENSORS (results the caller
+already holds views of are healed in place) and warns once.  Nothing here synchronises on the hot path.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Callable, List, Optional, Tuple
+
+import torch
+
+_SLOTS = 64
+_warned = False
+
+
+class LaunchMonitor:
+    def __init__(self):
+        self._host: Optional[torch.Tensor] = None          # pinned [SLOTS, 4] int32
+        self._next = 0
+        self._pending: List[Tuple[torch.cuda.Event, int, Optional[Callable[[], None]], str]] = []
+        self.aborted = 0                                   # launches found aborted so far
+        self.healed = 0                                    # ... of which re-run on the chain
+
+    def watch(self, workspace: torch.Tensor, offset: int, redo: Optional[Callable[[], None]], what: str) -> None:
+        """call right after the persistent launch was enqueued on the current stream; `workspace` is the launch's uint8
+        workspace, `offset` the byte offset of its status words; `redo()` re-runs the batch on the chain into the same outputs"""
+        if self._host is None:
+            self._host = torch.zeros((_SLOTS, 4), dtype=torch.int32).pin_memory()
+        if len(self._pending) >= _SLOTS - 1:
+            self.verify(limit=1)                           # the oldest launch is long done: frees its slot
+        slot = self._next
+        self._next = (self._next + 1) % _SLOTS
+        self._host[slot].copy_(workspace[offset:offset + 16].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(workspace.device))
+        self._pending.append((ev, slot, redo, what))
+
+    def pending(self) -> int:
+        return len(self._pending)
+
+    def verify(self, limit: Optional[int] = None) -> int:
+        """wait for the watched launches (oldest first; at most `limit` of them) and heal the aborted ones; returns how many
+        were aborted.  An aborted launch without a redo raises."""
+        global _warned
+        n_bad = 0
+        todo = self._pending if limit is None else self._pending[:limit]
+        self._pending = [] if limit is None else self._pending[limit:]
+        for ev, slot, redo, what in todo:
+            ev.synchronize()
+            code, block, phase, _ = (int(v) for v in self._host[slot])
+            if code == 0:
+                continue
+            n_bad += 1
+            self.aborted += 1
+            if not _warned:
+                _warned = True
+                warnings.warn(f"objectpermanence_amd: a persistent launch ({what}) gave up (code {code}, block {block}, phase "
+                              f"{phase}); the batch is re-run on the launch-per-step chain", RuntimeWarning, stacklevel=2)
+            if redo is None:
+                raise RuntimeError(f"persistent launch ({what}) aborted (code {code}, block {block}, phase {phase}) and "
+                                   "cannot be re-run here")
+            redo()
+            self.healed += 1
+        return n_bad
+
+
+def verify_launches(model: torch.nn.Module) -> int:
+    """verify every launch monitor found on `model` (and its runners); 0 when the model has none"""
+    n = 0
+    for owner in (model, getattr(model, "_runner", None)):
+        mon = getattr(owner, "_monitor", None)
+        if mon is not None:
+            n += mon.verify()
+    return n

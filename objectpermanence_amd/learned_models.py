@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .launch_monitor import LaunchMonitor
 
 
 class AbstractCaterModel(nn.Module):
@@ -117,9 +118,13 @@ class _OPNetTrainFunction(torch.autograd.Function):
         grad_y = grad_y.contiguous().float()
         # with a gradient bucket on the module (data-parallel training, parallel.GradBucket) the six weight gradients are
         # written straight into its flat buffer: the all-reduce then needs no gather copy
+        # - but only while no parameter holds a gradient: a p.grad that is still set (zero_grad(set_to_none=False), gradient
+        # accumulation, a second backward) aliases the same slices after GradBucket.collect(), and AccumulateGrad would then
+        # compute p.grad += new on aliased memory (2 x new instead of old + new)
         bucket = getattr(module, "_grad_bucket", None)
         if bucket is not None and len(bucket.params) == len(ctx.wshapes) and bucket.flat.device == dev and \
-                all(tuple(p.shape) == s for p, s in zip(bucket.params, ctx.wshapes)):
+                all(tuple(p.shape) == s for p, s in zip(bucket.params, ctx.wshapes)) and \
+                all(p.grad is None for p in bucket.params):
             grads = [bucket.view(i) for i in range(len(ctx.wshapes))]
         else:
             grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.wshapes]
@@ -128,6 +133,11 @@ class _OPNetTrainFunction(torch.autograd.Function):
                                               module._tws.numel(), *(g.data_ptr() for g in grads), B, T,
                                               module._h1, module._h2, _stream_ptr(dev))
         _lib.check(rc, "opnet_train_backward_f32")
+        # the abort words of the step's two persistent launches (sticky from the forward): mirrored to the host behind the
+        # backward; training.finish_step / OPNet.training_step_aborted() look at them at the caller's next sync point
+        off = lib.opnet_train_status_offset(B, T, module._h1, module._h2)
+        if off != _lib.NO_OFFSET and lib.opnet_xcd4_enabled():
+            module._monitor.watch(module._tws, off, module._note_training_abort, "opnet_xcd4_forward/backward (training step)")
         return (None, None) + tuple(grads)
 
 
@@ -214,9 +224,7 @@ class OPNet(AbstractCaterModel):
         self.video_LSTM = LSTMWeights(self.bb_in_dim, h2)
         self.prediction_layer = LinearWeight(h2, self.bb_out_dim)
         self._h1, self._h2 = h1, h2
-        self._packed = None
-        self._packed_key = None
-        self._packed_event, self._packed_stream = None, None
+        self._packed: Dict[int, Tuple[tuple, torch.Tensor]] = {}      # per stream: (weights key, packed image)
         self._plans: Dict[Tuple[int, int, int, int], Tuple[int, torch.Tensor]] = {}
         self._retired = []
         self._tpacked = None     # training: inference tiles + transposed tiles
@@ -233,6 +241,42 @@ class OPNet(AbstractCaterModel):
         self.use_xcd4 = os.environ.get("OPNET_XCD4", "auto")
         self._x4packed: Dict[int, Tuple[tuple, torch.Tensor]] = {}     # per stream: (weights key, packed image)
         self._x4ws: Dict[Tuple[int, int, int, int], torch.Tensor] = {}
+        self._monitor = LaunchMonitor()      # abort words of the persistent launches (launch_monitor.py)
+        self._train_aborted = False
+
+    # -- aborted persistent launches -------------------------------------------------------------
+    def verify_launches(self) -> int:
+        """Wait for the persistent launches issued so far and re-run every aborted one through the launch chain into the
+        output tensors it returned (healed in place); returns the number of aborted launches.  The drivers call this at
+        the sync point they already have, before anything reads the outputs on the host."""
+        return self._monitor.verify()
+
+    def _note_training_abort(self) -> None:
+        self._train_aborted = True
+
+    def training_step_aborted(self) -> bool:
+        """after a sync: did a persistent launch of the training steps issued so far give up?  (Their gradients are NaN and
+        a guarded FusedAdam step left the weights untouched.)  Switches this process to the launch chain and clears the flag."""
+        self._monitor.verify()
+        bad, self._train_aborted = self._train_aborted, False
+        if bad:
+            _lib.load().opnet_xcd4_enable(0)
+        return bad
+
+    def launch_guard(self):
+        """device address of the abort word the current training workspace's persistent launches raise (None: no such
+        launches for this shape) - FusedAdam's guard"""
+        if self._tws is None or self._tws_key is None:
+            return None
+        B, T, _ = self._tws_key
+        off = _lib.load().opnet_train_status_offset(B, T, self._h1, self._h2)
+        return None if off == _lib.NO_OFFSET else self._tws.data_ptr() + off
+
+    def _redo_on_chain(self, boxes: torch.Tensor, y: torch.Tensor, logits: torch.Tensor) -> None:
+        with torch.no_grad(), torch.cuda.device(boxes.device):
+            y2, lg2 = self._forward_chain(boxes)
+            y.copy_(y2)
+            logits.copy_(lg2)
 
     # -- weights ------------------------------------------------------------------------------
     def _weights(self):
@@ -241,10 +285,16 @@ class OPNet(AbstractCaterModel):
                 self.video_LSTM.weight_hh_l0, self.prediction_layer.weight)
 
     def _packed_weights(self, device: torch.device) -> torch.Tensor:
+        """the packed image for launches on the CURRENT stream.  One image per stream (at most 8): forwards of this module
+        may be in flight on several streams, and a re-pack after a weight update must not rewrite an image that another
+        stream's earlier launches are still reading - a pack and the launches that read it are always ordered by their
+        own stream (the 4-clip form keeps its images the same way)."""
         lib = _lib.load()
         ws = self._weights()
+        stream = _stream_ptr(device)
         key = tuple((w.data_ptr(), w._version) for w in ws) + (str(device),)
-        if self._packed is None or self._packed_key != key:
+        entry = self._packed.get(stream)
+        if entry is None or entry[0] != key:
             for w in ws:
                 if w.device != device or w.dtype != torch.float32 or not w.is_contiguous():
                     raise RuntimeError("OPNet parameters must be contiguous fp32 on the input's device "
@@ -252,20 +302,18 @@ class OPNet(AbstractCaterModel):
             nbytes = lib.opnet_packed_weights_bytes(self._h1, self._h2)
             if nbytes == 0:
                 _lib.check(-2, "opnet_packed_weights_bytes")
-            if self._packed is None or self._packed.device != device:
-                self._packed = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
-            rc = lib.opnet_pack_weights_f32(*(w.data_ptr() for w in ws), self._packed.data_ptr(),
-                                            nbytes, self._h1, self._h2, _stream_ptr(device))
+            if entry is None or entry[1].device != device:
+                if len(self._packed) >= 8:
+                    # (the evicted image may still be read by launches on ITS stream: the caching allocator hands a block
+                    # back to the stream it was allocated on, so whatever reuses it is ordered behind them)
+                    self._packed.pop(next(iter(self._packed)))
+                buf = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+            else:
+                buf = entry[1]
+            rc = lib.opnet_pack_weights_f32(*(w.data_ptr() for w in ws), buf.data_ptr(), nbytes, self._h1, self._h2, stream)
             _lib.check(rc, "opnet_pack_weights_f32")
-            self._packed_key = key
-            # forwards of this module may be in flight on several streams: the others must not read the packed image
-            # before (or while) this stream's pack kernels have written it
-            self._packed_event = torch.cuda.Event()
-            self._packed_event.record(torch.cuda.current_stream(device))
-            self._packed_stream = _stream_ptr(device)
-        elif self._packed_event is not None and self._packed_stream != _stream_ptr(device):
-            torch.cuda.current_stream(device).wait_event(self._packed_event)
-        return self._packed
+            self._packed[stream] = (key, buf)
+        return self._packed[stream][1]
 
     XCD_MIN_BATCH = 64       # measured: 38.3 k clips/s against 37.4 k through the launch chain at 64 clips, 74 k against 49 k at 128
     MAX_PLANS = 16           # (shape, device, stream) launch plans kept alive
@@ -333,6 +381,8 @@ class OPNet(AbstractCaterModel):
         _lib.check(lib.opnet_xcd4_forward_f32(boxes.data_ptr(), x4packed.data_ptr(), y.data_ptr(), logits.data_ptr(),
                                               ws.data_ptr(), ws.numel(), B, T, self._h1, self._h2, stream),
                    "opnet_xcd4_forward_f32")
+        self._monitor.watch(ws, lib.opnet_xcd4_status_offset(B, T, self._h1, self._h2),
+                            lambda: self._redo_on_chain(boxes, y, logits), "opnet_xcd4_forward")
         return y, logits
 
     def _forward_xcd(self, boxes: torch.Tensor, packed: torch.Tensor, stream: int):
@@ -354,6 +404,9 @@ class OPNet(AbstractCaterModel):
                 if nbytes == 0:
                     _lib.check(-2, "opnet_xcd_workspace_bytes")
                 if len(self._xws) >= 8:
+                    # dropped at once, unlike the chain's plans (a hipGraph must be destroyed by hand, a tensor must not):
+                    # the key holds the stream, the buffer was allocated on it, and the caching allocator only hands a block
+                    # back to its own stream - whatever reuses it runs behind the launch that may still be using it
                     self._xws.pop(next(iter(self._xws)))
                 self._xws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             ws = self._xws[key]
@@ -361,6 +414,8 @@ class OPNet(AbstractCaterModel):
                                            logits[lo:lo + n].data_ptr(), ws.data_ptr(), ws.numel(), n, T,
                                            self._h1, self._h2, stream)
             _lib.check(rc, "opnet_xcd_forward_f32")
+            self._monitor.watch(ws, 0, lambda b=boxes[lo:lo + n], yy=y[lo:lo + n], ll=logits[lo:lo + n]:
+                                self._redo_on_chain(b, yy, ll), "opnet_xcd_forward")
         return y, logits
 
     def forward_requests(self, requests):
@@ -398,6 +453,7 @@ class OPNet(AbstractCaterModel):
             _lib.check(lib.opnet_xcd_forward_multi_f32(ptrs, counts, n, packed.data_ptr(), y.data_ptr(), logits.data_ptr(),
                                                        ws.data_ptr(), ws.numel(), T, self._h1, self._h2, stream),
                        "opnet_xcd_forward_multi_f32")
+            self._monitor.watch(ws, 0, lambda: self._redo_on_chain(torch.cat(reqs, dim=0), y, logits), "opnet_xcd_forward")
         return y, logits
 
     def xcd_status(self):
@@ -428,6 +484,16 @@ class OPNet(AbstractCaterModel):
             stream = _stream_ptr(dev)
             if self._wants_xcd(B):
                 return self._forward_xcd(boxes, packed, stream)
+            return self._forward_chain(boxes)
+
+    def _forward_chain(self, boxes: torch.Tensor):
+        """the launch-per-step form (csrc/opnet_kernels.hip): one hipGraph of T + 3 step launches"""
+        lib = _lib.load()
+        B, T = int(boxes.shape[0]), int(boxes.shape[1])
+        dev = boxes.device
+        with torch.cuda.device(dev):
+            packed = self._packed_weights(dev)
+            stream = _stream_ptr(dev)
             # one workspace + graph per (shape, device, stream): forwards enqueued on different HIP
             # streams run concurrently (the step kernel leaves most of a CU idle at small batches)
             key = (B, T, dev.index if dev.index is not None else torch.cuda.current_device(), stream)

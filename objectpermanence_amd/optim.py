@@ -58,6 +58,19 @@ def smooth_l1_mean(y: torch.Tensor, labels: torch.Tensor, beta: float = 1.0) -> 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, grad_scale=grad_scale))
+        # device-side guards of the next step() (opnet_adam_multi_step_guarded_f32; set by training.train_step, None = off):
+        # abort word of the persistent launches behind the gradients | the loss (skip if not finite) | data-parallel guard
+        self.abort_ptr = None
+        self.loss_ptr = None
+        self.guard_ptr = None
+        self._last_stepped = []
+
+    def rollback_step_count(self) -> None:
+        """undo the step COUNTERS of the last step(): for a step whose update the device-side guard skipped (parameters and
+        moments untouched) and that the caller is about to repeat"""
+        for st in self._last_stepped:
+            st["step"] -= 1
+        self._last_stepped = []
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -66,6 +79,7 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        self._last_stepped = []
         for group in self.param_groups:
             b1, b2 = group["betas"]
             # parameters of one device that are at the same step share ONE launch (opnet_adam_multi_step_f32: up to 16 tensors)
@@ -82,6 +96,7 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
+                self._last_stepped.append(st)
                 g = p.grad.contiguous()
                 keep.append(g)
                 batches.setdefault((p.device, int(st["step"])), []).append((p, g, st))
@@ -92,13 +107,14 @@ class FusedAdam(torch.optim.Optimizer):
                         chunk = items[lo:lo + 16]
                         n = len(chunk)
                         arr = lambda vals: (ctypes.c_void_p * n)(*vals)
-                        rc = lib.opnet_adam_multi_step_f32(
+                        rc = lib.opnet_adam_multi_step_guarded_f32(
                             n, arr([p.data_ptr() for p, _, _ in chunk]), arr([g.data_ptr() for _, g, _ in chunk]),
                             arr([st["exp_avg"].data_ptr() for _, _, st in chunk]),
                             arr([st["exp_avg_sq"].data_ptr() for _, _, st in chunk]),
                             (ctypes.c_long * n)(*[p.numel() for p, _, _ in chunk]), float(group["lr"]), float(b1), float(b2),
-                            float(group["eps"]), step_no, float(group["grad_scale"]), stream)
-                        _lib.check(rc, "opnet_adam_multi_step_f32")
+                            float(group["eps"]), step_no, float(group["grad_scale"]), self.abort_ptr, self.loss_ptr,
+                            self.guard_ptr, stream)
+                        _lib.check(rc, "opnet_adam_multi_step_guarded_f32")
                 # the update happened outside torch's view: bump the version counters so that consumers keyed on them
                 # (the modules' packed-weight caches) see the parameters as modified
                 for p, _, _ in items:

@@ -107,7 +107,13 @@ class GradBucket:
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
-        self.flat = torch.zeros(n, dtype=torch.float32, device=ref.device)
+        # 4 extra floats behind the gradients: [n] is the GUARD - this rank's "my persistent launches gave up" flag, summed
+        # over the ranks by the same all-reduce, so that every rank's optimiser skips the step when any rank's gradients are
+        # NaN (optim.FusedAdam.guard_ptr); the rest is padding (16-byte multiple)
+        self.n_grad = n
+        self._buf = torch.zeros(n + 4, dtype=torch.float32, device=ref.device)
+        self.flat = self._buf[:n]
+        self.guard = self._buf[n:n + 1]
         self.offsets, o = [], 0
         for p in self.params:
             self.offsets.append(o)
@@ -117,12 +123,16 @@ class GradBucket:
         p, o = self.params[i], self.offsets[i]
         return self.flat[o:o + p.numel()].view_as(p)       # a fresh tensor object on the bucket's storage
 
-    def collect(self) -> None:
+    def collect(self, fill_missing: bool = True) -> None:
         """make `flat` hold the current gradients: slices the backward already wrote in place are left alone, anything
-        else (a sibling model's autograd-made gradient, a missing gradient) is copied / zeroed; then p.grad aliases it"""
+        else (a sibling model's autograd-made gradient) is copied; then p.grad aliases it.  A parameter WITHOUT a gradient:
+        fill_missing (data parallel - every rank must reduce the same elements and take the same optimiser steps) gives it
+        zeros; otherwise it keeps grad = None and the optimiser skips it, as torch.optim.Adam does (training_main.py:217)."""
         for i, p in enumerate(self.params):
             v = self.view(i)
             if p.grad is None:
+                if not fill_missing:
+                    continue
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
@@ -132,7 +142,7 @@ class GradBucket:
         """weighted n_local / n_global so that an uneven split still reproduces the single-process mean-loss gradient
         (SURVEY.md 8-e1); call on the stream the collective should run on"""
         self.flat.mul_(float(n_local) / float(n_global))
-        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)     # gradients + guard
 
 
 def all_reduce_gradients(params, n_local: int, n_global: int, group: Optional[dist.ProcessGroup] = None,

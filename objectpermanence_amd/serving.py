@@ -26,13 +26,16 @@ class PendingResult:
     def __init__(self, server: "ReasonerServer", n_clips: int):
         self._server, self.n_clips = server, n_clips
         self._value = None
+        self._error = None
 
     def done(self) -> bool:
-        return self._value is not None
+        return self._value is not None or self._error is not None
 
     def result(self):
-        if self._value is None:
+        if self._value is None and self._error is None:
             self._server.flush()
+        if self._error is not None:      # the forward this request was part of failed: every request of it says so
+            raise self._error
         return self._value
 
 
@@ -56,8 +59,13 @@ class ReasonerServer:
     def submit(self, boxes: torch.Tensor) -> PendingResult:
         """boxes [b, T, 15, F] on the model's device.  Returns a handle; the forward runs when `max_clips` clips are
         pending or on flush() / handle.result()."""
-        if self._queue and tuple(boxes.shape[1:]) != tuple(self._queue[0][0].shape[1:]):
-            self.flush()             # a different clip length cannot share a launch
+        if self._queue:
+            first = self._queue[0][0]
+            if boxes.device != first.device or boxes.dtype != first.dtype:
+                raise ValueError(f"request on {boxes.device} / {boxes.dtype} while {first.device} / {first.dtype} requests are "
+                                 "pending: requests of one server share a launch and must share device and dtype")
+            if tuple(boxes.shape[1:]) != tuple(first.shape[1:]):
+                self.flush()         # a different clip length cannot share a launch
         h = PendingResult(self, int(boxes.shape[0]))
         self._queue.append((boxes, h))
         self._pending += h.n_clips
@@ -70,10 +78,17 @@ class ReasonerServer:
         if not self._queue:
             return
         queue, self._queue, self._pending = self._queue, [], 0
-        if len(queue) > 1 and not self.concat and hasattr(self.model, "forward_requests"):
-            out = self.model.forward_requests([q[0] for q in queue])     # OPNet: one launch over the requests where they lie
-        else:
-            out = self.model(queue[0][0] if len(queue) == 1 else torch.cat([q[0] for q in queue], dim=0))
+        try:
+            if len(queue) > 1 and not self.concat and hasattr(self.model, "forward_requests"):
+                out = self.model.forward_requests([q[0] for q in queue])     # OPNet: one launch over the requests where they lie
+            else:
+                out = self.model(queue[0][0] if len(queue) == 1 else torch.cat([q[0] for q in queue], dim=0))
+        except Exception as e:
+            # a bad shape, an out-of-memory concatenation, an ABI error: the requests of this forward are not silently lost -
+            # each handle re-raises from result() (and done() turns true), the server stays usable
+            for _, h in queue:
+                h._error = e
+            raise
         double = isinstance(out, tuple)
         self.last_output = out if double else (out,)
         self.forwards += 1

@@ -21,23 +21,29 @@ from .optim import l1_mean, smooth_l1_mean
 from .supported_models import DOUBLE_OUTPUT_MODELS, NO_LABELS_MODELS
 
 
-def compute_loss(model_name: str, output: torch.Tensor, labels: torch.Tensor, mask: Optional[torch.Tensor] = None,
-                 loss_kind: str = "l1"):
-    """Returns (loss, pred_loss, consistency_loss) as training_main.py:192-210 does.  loss_kind "smooth_l1" swaps the
-    supervised L1 for torch.nn.SmoothL1Loss (BASELINE.json config 2 names it; the reference itself trains with L1)."""
+def _consistency(output: torch.Tensor) -> torch.Tensor:
     nxt, cur = output[:, 1:, :], output[:, :-1, :]
-    consistency = torch.mean(torch.norm(nxt - cur, p=2, dim=-1)) if output.shape[1] > 1 else output.new_zeros(())
+    return torch.mean(torch.norm(nxt - cur, p=2, dim=-1)) if output.shape[1] > 1 else output.new_zeros(())
+
+
+def compute_loss(model_name: str, output: torch.Tensor, labels: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                 loss_kind: str = "l1", with_consistency: bool = True):
+    """Returns (loss, pred_loss, consistency_loss) as training_main.py:192-210 does.  loss_kind "smooth_l1" swaps the
+    supervised L1 for torch.nn.SmoothL1Loss (BASELINE.json config 2 names it; the reference itself trains with L1).
+    The supervised models' loss does not contain the consistency term (the reference only PRINTS it, :213-214); a caller that
+    does not print it passes with_consistency=False and gets None - four launches less per training step."""
     if model_name in NO_LABELS_MODELS:
+        consistency = _consistency(output)
         pred = torch.mean(torch.abs(output - labels) * mask)
         return pred + 0.5 * consistency, pred, consistency
     pred = smooth_l1_mean(output, labels) if loss_kind == "smooth_l1" else l1_mean(output, labels)
-    return pred, pred, consistency.detach()
+    return pred, pred, (_consistency(output.detach()) if with_consistency else None)
 
 
 def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.Optimizer, boxes: Optional[torch.Tensor],
                labels: Optional[torch.Tensor], mask: Optional[torch.Tensor] = None, group: Optional[dist.ProcessGroup] = None,
                n_global: Optional[int] = None, comm_stream: Optional[torch.cuda.Stream] = None,
-               loss_kind: str = "l1", overlap=None) -> torch.Tensor:
+               loss_kind: str = "l1", overlap=None, comm_events: Optional[list] = None) -> torch.Tensor:
     """zero_grad -> forward -> loss -> backward -> [gradient all-reduce] -> Adam (training_main.py:183-217).
 
     Data parallel: EVERY rank calls this for every global batch - a rank whose slice of the batch is empty passes
@@ -53,15 +59,29 @@ def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.O
         bucket = model._grad_bucket = parallel.GradBucket(model.parameters())
     optimizer.zero_grad(set_to_none=True)
     n_local = 0 if boxes is None else int(boxes.shape[0])
+    guard_word = None
     if n_local > 0:
         out = model(boxes)
         output = out[0] if model_name in DOUBLE_OUTPUT_MODELS else out
-        loss, _, _ = compute_loss(model_name, output, labels, mask, loss_kind)
+        loss, _, _ = compute_loss(model_name, output, labels, mask, loss_kind, with_consistency=False)
         loss.backward()
         loss = loss.detach()
+        guard_word = model.launch_guard() if hasattr(model, "launch_guard") else None
     else:
         loss = bucket.flat.new_zeros(())
-    bucket.collect()
+    bucket.collect(fill_missing=distributed)
+    # device-side guards of the optimiser step (optim.FusedAdam): an aborted persistent launch (its gradients are NaN) or a
+    # non-finite loss must not reach the weights; the host learns of it at its next sync point (step_aborted below)
+    if hasattr(optimizer, "abort_ptr"):
+        optimizer.abort_ptr = guard_word
+        optimizer.loss_ptr = loss.data_ptr() if (loss.is_cuda and n_local > 0) else None
+        optimizer.guard_ptr = bucket.guard.data_ptr() if (distributed and bucket.flat.is_cuda) else None
+    if distributed and bucket.flat.is_cuda:
+        if guard_word is not None:      # this rank's abort word -> the guard slot the all-reduce sums over the ranks
+            off = guard_word - model._tws.data_ptr()
+            bucket.guard.copy_(model._tws[off:off + 4].view(torch.int32))
+        else:
+            bucket.guard.zero_()
     if distributed:
         n_glob = n_global if n_global is not None else n_local * dist.get_world_size(group)
         cur = torch.cuda.current_stream(bucket.flat.device) if bucket.flat.is_cuda else None
@@ -69,7 +89,13 @@ def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.O
         if cur is not None:
             st.wait_stream(cur)
             with torch.cuda.stream(st):
+                if comm_events is not None:     # measurement (bench.py): the collective's own time on its stream
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
                 bucket.all_reduce(n_local, max(n_glob, 1), group)
+                if comm_events is not None:
+                    e1.record(st)
+                    comm_events.append((e0, e1))
             if overlap is not None:
                 overlap()
             cur.wait_stream(st)
@@ -81,3 +107,19 @@ def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.O
         overlap()
     optimizer.step()
     return loss
+
+
+def step_aborted(model: torch.nn.Module, group: Optional[dist.ProcessGroup] = None) -> bool:
+    """Call after the host has synchronised with a train_step (the driver's float(loss)): did a persistent launch of that
+    step give up on any rank?  If so the guarded optimiser left parameters and moments untouched on every rank, this process
+    has switched to the launch chain, and the caller repeats the step: optimizer.rollback_step_count(); train_step(...)."""
+    fn = getattr(model, "training_step_aborted", None)
+    bad = bool(fn()) if fn is not None else False
+    bucket = getattr(model, "_grad_bucket", None)
+    if bucket is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 \
+            and bucket.flat.is_cuda and float(bucket.guard) != 0.0:
+        bad = True
+        if fn is not None:
+            from . import _lib
+            _lib.load().opnet_xcd4_enable(0)
+    return bad

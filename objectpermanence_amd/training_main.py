@@ -8,7 +8,7 @@ Adam / post-process / IoU run in the HIP library.
 
 With torch.distributed initialised (not in the reference):
   * every reference minibatch is split over the ranks in balanced contiguous slices and each rank LOADS ONLY ITS SLICE
-    (parallel.RankSliceSampler) - the input pipeline is not replicated; the gradients are exchanged by one all-reduce over
+    (a `batch_sampler` list of its own index slices, `training_batches`) - the input pipeline is not replicated; the gradients are exchanged by one all-reduce over
     the flat bucket (training.train_step), every rank joining every step even when its slice is empty;
   * transformer_lstm* couples the clips of a minibatch (sequence-first attention), so there a rank takes WHOLE reference
     batches (k*W + r) and one optimiser step spans W of them;
@@ -29,10 +29,11 @@ from torch.utils import data
 
 from . import metrics, parallel
 from .datasets import DatasetsFactory
+from .launch_monitor import verify_launches
 from .models_factory import ModelsFactory
 from .optim import FusedAdam
 from .supported_models import DOUBLE_OUTPUT_MODELS
-from .training import compute_loss, train_step
+from .training import compute_loss, step_aborted, train_step
 
 
 def save_checkpoint(model: torch.nn.Module, model_name: str, dev_iou: float, checkpoint_dir: str) -> str:
@@ -67,17 +68,21 @@ def inference_and_iou_comp(model_name: str, model: torch.nn.Module, device: torc
     loader = data.DataLoader(dataset, batch_sampler=batches, num_workers=num_workers)
     model.eval()
     loss_sum = torch.zeros((), dtype=torch.float64, device=device)
-    ious, contain = [], []
+    ious, contain, outs = [], [], []
     with torch.no_grad():
         for (boxes, _), (labels, mask), _names in loader:
             boxes, labels, mask = boxes.to(device), labels.to(device), mask.to(device)
             out = model(boxes)
-            output = out[0] if model_name in DOUBLE_OUTPUT_MODELS else out
-            loss, _, _ = compute_loss(model_name, output, labels, mask)
+            outs.append((out[0] if model_name in DOUBLE_OUTPUT_MODELS else out, labels, mask))
+        # ONE sync for the whole set: an aborted persistent launch is re-run on the launch chain (into the same output
+        # tensors) before anything is derived from its output
+        verify_launches(model)
+        for output, labels, mask in outs:
+            loss, _, _ = compute_loss(model_name, output, labels, mask, with_consistency=False)
             _, _, iou = metrics.postprocess_and_iou(output, labels)
             ious.append(iou)
             contain.append(torch.sum(mask, dim=-1).type(torch.bool))
-            loss_sum += loss.double() * boxes.shape[0]
+            loss_sum += loss.double() * output.shape[0]
     t_frames = ious[0].shape[1] if ious else 300
     iou = torch.cat(ious) if ious else torch.zeros((0, t_frames), dtype=torch.float64, device=device)
     cm = torch.cat(contain) if contain else torch.zeros((0, t_frames), dtype=torch.bool, device=device)
@@ -146,10 +151,16 @@ def training_main(model_name: str, train_config: Dict[str, Any], model_config: D
         for k, (_, n_global) in enumerate(steps):
             cur, box = nxt, {}
             # the next step's batch is fetched while the gradient all-reduce of this one is in flight
-            loss = train_step(model_name, model, optimizer, *(cur if cur is not None else (None, None, None)), n_global=n_global,
+            args = cur if cur is not None else (None, None, None)
+            loss = train_step(model_name, model, optimizer, *args, n_global=n_global,
                               comm_stream=comm, overlap=lambda: box.setdefault("n", fetch(k + 1)))
             nxt = box.get("n")
-            running += float(loss)
+            loss_value = float(loss)              # the reference's per-step .item() (training_main.py:212): the sync point
+            if step_aborted(model):
+                # a persistent launch of this step gave up: the guarded Adam kept the weights; repeat it on the launch chain
+                optimizer.rollback_step_count()
+                loss_value = float(train_step(model_name, model, optimizer, *args, n_global=n_global, comm_stream=comm))
+            running += loss_value
             if (k + 1) % train_config["print_step"] == 0:
                 print("Train Epoch: {} [{}/{}]\t Average Loss: {:.4f} Training began {} seconds ago".format(
                     epoch + 1, (k + 1) * bs, len(train_ds), running / train_config["print_step"], int(time.time() - start)))

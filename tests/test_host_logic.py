@@ -239,6 +239,22 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
 
 
+def test_bench_train_mode_launches_ranks_and_reduces_the_gradient_bucket():
+    """config 5's line without the hardware: `bench.py --gpus 2 --mode train` starts its own ranks; the self-test leg runs the
+    exchange the real run does (the flat 1 421 056-float OPNet gradient bucket + its guard slot through
+    parallel.GradBucket.all_reduce) on gloo and reports global batch / parallelism as the real line would."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--mode", "train", "--launcher-selftest"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["mode"] == "train" and out["grad_bucket_floats"] == 1_421_056 and out["guard_after_allreduce"] == 1.0
+    assert out["config"] == {"global_batch": 64, "parallelism": "dp2"}
+
+
 def test_bench_refuses_more_gpus_than_the_node_has():
     import subprocess
     import sys
@@ -329,7 +345,7 @@ def _dp_train_worker(rank, world, port, n_total, tmp):
     lo, hi = parallel.balanced_range(n_total, world, rank)
     boxes, labels = synth.make_batch(0, n_total, 8)
     old = training.compute_loss
-    training.compute_loss = lambda name, out, lab, mask=None, kind="l1": (torch.mean(torch.abs(out - lab)),) * 3
+    training.compute_loss = lambda name, out, lab, mask=None, kind="l1", **kw: (torch.mean(torch.abs(out - lab)),) * 3
     try:
         xb = torch.from_numpy(boxes[lo:hi]) if hi > lo else None
         lb = torch.from_numpy(labels[lo:hi]) if hi > lo else None

@@ -97,6 +97,23 @@ def test_persistent_forward_full_size_matches_step_launch_form_and_is_determinis
         assert np.array_equal(y2, y) and np.array_equal(lg2, lg)
 
 
+def test_bench_shape_matches_c_oracle_on_every_clip():
+    """The driver's bench shape - twenty 32-clip requests = ONE 640-clip x 300-frame persistent launch (5 groups per XCD,
+    head-once form) - against the C port of the reference algorithm (oracle/opnet_oracle.c) on ALL 640 distinct clips,
+    not on a sample: float boxes within TOL_Y, int32 pixel boxes equal up to rare 1-px truncation flips."""
+    from oracle import c_oracle
+    boxes, _ = synth.make_batch(0, 640, 300)
+    m, params = _model(True)
+    y, lg = _run(m, boxes)
+    y_ref, lg_ref = c_oracle.opnet_forward(boxes, params, c_oracle.usable_cores())
+    assert y.shape == y_ref.shape == (640, 300, 4)
+    err = np.abs(y - y_ref).reshape(640, -1).max(axis=1)
+    assert err.max() < TOL_Y, f"worst clip {int(err.argmax())}: {err.max()}"
+    assert np.abs(lg - lg_ref).max() < TOL_LOGITS
+    px, px_ref = oo.postprocess_to_pixels(y), oo.postprocess_to_pixels(y_ref)
+    assert (px != px_ref).mean() < 1e-3 and np.abs(px - px_ref).max() <= 1
+
+
 def test_persistent_forward_chunks_large_batches():
     """more clips than one launch carries (opnet_xcd_max_batch) are run as several chained launches"""
     from objectpermanence_amd import _lib
