@@ -220,6 +220,25 @@ int opseq_lstm_stack_forward_f32(const float *x, const float *packed, float *y, 
  * the library (host-side objects; opseq_graph_cache_clear() releases them). Bit-identical results. */
 int opseq_lstm_stack_forward_graph_f32(const float *x, const float *packed, float *y, void *workspace,
                                        size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream);
+/* ---- the same stack as ONE persistent launch (csrc/seq_xcd_kernels.hip) --------------------------------------------------
+ * Replaces the T + 2L - 1 step launches above for the reference's three stacked reasoners (learned_models.py:99-101,
+ * 135-137, 170-171: H = 512; L = 1 with KX = 75, L = 2 with KX = 256 or the hoisted KX = 3840) on a whole MI355X
+ * (opseq_xcd_supported): every weight of a layer resident in the registers of one XCD for all T steps, groups of four clips,
+ * layer 1 on the neighbouring XCD one or more steps behind layer 0.  B <= opseq_xcd_max_batch(L) clips per launch.  `packed`
+ * is its own image (opseq_xcd_pack_weights_f32: LSTM weights only); w_head is predictions_layer.weight [4][H] where the caller
+ * holds it.  Same error / stream / never-allocate conventions; an aborted launch (bounded polls) leaves NaN in y and raises
+ * the status words at opseq_xcd_status_offset() of the workspace. */
+int opseq_xcd_supported(int L, int KX, int H);
+void opseq_xcd_enable(int on);
+int opseq_xcd_max_batch(int L);
+size_t opseq_xcd_packed_bytes(int L, int KX, int H);
+size_t opseq_xcd_workspace_bytes(int B, int T, int L, int KX, int H);
+size_t opseq_xcd_status_offset(int B, int T, int L, int KX, int H);
+int opseq_xcd_pack_weights_f32(const float *const *w_ih, const float *const *w_hh, float *packed, size_t packed_bytes,
+                               int L, int KX, int H, void *stream);
+int opseq_xcd_forward_f32(const float *x, const float *packed, const float *w_head, float *y, void *workspace,
+                          size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream);
+
 void opseq_graph_cache_clear(void);
 /* training of the stacked LSTM: forward keeping the history in `workspace`, then BPTT + weight gradients.
  * g_ih / g_hh: HOST arrays of L device pointers (state_dict layouts); dx0 (may be NULL): gradient of x [B,T,KX]. */

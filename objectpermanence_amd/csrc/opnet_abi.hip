@@ -5,6 +5,7 @@
 #include "opnet_train_kernels.hip"
 #include "opnet_xcd4_kernels.hip"
 #include "seq_kernels.hip"
+#include "seq_xcd_kernels.hip"
 #include "conv_kernels.hip"
 #include "attn_kernels.hip"
 #include "enc_train_kernels.hip"
@@ -1633,6 +1634,157 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
     }
     const long ny = (long)B * T;
     copy_y_out<<<(unsigned)((ny + 255) / 256 > 1024 ? 1024 : (ny + 255) / 256), 256, 0, st>>>(a.ystage, (float4 *)y, ny);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+// ---- the stacked LSTM as ONE persistent launch (seq_xcd_kernels.hip) -------------------------------------------------
+// Shapes it is built for: H = 512, L = 1 or 2, layer-0 input either hoisted (KX % 16 == 0 and KX >= 2 H: NonLinearLstm) or
+// direct with KX <= 256 in the instantiated quarter widths (BaselineLstm 75 -> 5 k-quads a wave, TransformerLstm 256 -> 16).
+static int seqx_nxq0(int KX, int H) { return stack_hoists_input(KX, H) ? 0 : (KX + 15) / 16; }
+static bool seqx_dims(int L, int KX, int H)
+{
+    if (H != SX_H || L < 1 || L > 2 || KX <= 0) return false;
+    const int nxq0 = seqx_nxq0(KX, H);
+    return (L == 1 && nxq0 == 5) || (L == 2 && (nxq0 == 16 || nxq0 == 0));
+}
+static std::atomic<int> g_seqx_enabled{1};
+extern "C" void opseq_xcd_enable(int on) { g_seqx_enabled.store(on ? 1 : 0); }
+extern "C" int opseq_xcd_supported(int L, int KX, int H)
+{
+    if (!seqx_dims(L, KX, H) || g_seqx_enabled.load() == 0 || env_int("OPSEQ_XCD", 1) == 0) return 0;
+    return x4_device() ? 1 : 0;
+}
+extern "C" int opseq_xcd_max_batch(int L) { return L == 2 ? 4 * SX_NGMAX * 4 : 4 * SX_NGMAX * 8; }
+
+struct SeqXHostPacked { size_t regs, wih0g, total; };          // floats
+static SeqXHostPacked seqx_host_packed(int L, int KX, int H)
+{
+    SeqXHostPacked P;
+    P.regs = 0;
+    P.wih0g = align_up(seqx_packed_layout(L, seqx_nxq0(KX, H)).total, 64);
+    P.total = P.wih0g + (stack_hoists_input(KX, H) ? (size_t)4 * H * KX : 0);
+    return P;
+}
+struct SeqXWs { size_t status, xp, gemm, hl[2], hc[2], total; };  // bytes
+static SeqXWs seqx_ws_layout(int B, int T, int L, int KX, int H)
+{
+    const size_t RB = (B + 31) / 32, NGT = (B + 3) / 4, KXP = (size_t)((KX + 15) / 16) * 16;
+    SeqXWs W;
+    size_t o = 0;
+    W.status = o; o += 2048;
+    W.xp = o;   if (!stack_hoists_input(KX, H)) o += (size_t)T * RB * (KXP / 4) * 32 * 16;
+    o = align_up(o, 4096);
+    W.gemm = o; if (stack_hoists_input(KX, H)) o += align_up((size_t)B * T * 4 * H * 4, 4096);
+    for (int l = 0; l < 2; ++l) {
+        W.hl[l] = o; if (l < L) o += NGT * (size_t)(T + 1) * 8192;
+        W.hc[l] = o; if (l + 1 < L) o += NGT * (size_t)(T + 1) * 8192;
+    }
+    W.total = align_up(o, 4096);
+    return W;
+}
+static int check_seqx(int B, int T, int L, int KX, int H)
+{
+    if (B <= 0 || T <= 0) return fail(OPNET_ESHAPE, "B=%d T=%d must be positive", B, T);
+    if (!seqx_dims(L, KX, H))
+        return fail(OPNET_ESHAPE, "the persistent stacked LSTM is built for H=512, (L=1, KX<=80) or (L=2, KX=241..256 or a hoisted "
+                                  "input); got L=%d KX=%d H=%d - use opseq_lstm_stack_forward_f32", L, KX, H);
+    if (B > opseq_xcd_max_batch(L)) return fail(OPNET_ESHAPE, "B=%d > %d clips per launch", B, opseq_xcd_max_batch(L));
+    if (seqx_ws_layout(B, T, L, KX, H).total >= ((size_t)1 << 31))
+        return fail(OPNET_ESHAPE, "B=%d x T=%d: the workspace exceeds the 2 GiB one buffer descriptor addresses", B, T);
+    return OPNET_OK;
+}
+extern "C" size_t opseq_xcd_packed_bytes(int L, int KX, int H)
+{
+    return seqx_dims(L, KX, H) ? seqx_host_packed(L, KX, H).total * sizeof(float) : 0;
+}
+extern "C" size_t opseq_xcd_workspace_bytes(int B, int T, int L, int KX, int H)
+{
+    if (check_seqx(B, T, L, KX, H)) return 0;
+    return seqx_ws_layout(B, T, L, KX, H).total;
+}
+/* byte offset of the launch's 4 status words in its workspace (see opnet_xcd4_status_offset) */
+extern "C" size_t opseq_xcd_status_offset(int B, int T, int L, int KX, int H)
+{
+    if (check_seqx(B, T, L, KX, H)) return (size_t)-1;
+    return seqx_ws_layout(B, T, L, KX, H).status;
+}
+extern "C" int opseq_xcd_pack_weights_f32(const float *const *w_ih, const float *const *w_hh, float *packed, size_t packed_bytes,
+                                          int L, int KX, int H, void *stream)
+{
+    if (!seqx_dims(L, KX, H)) return fail(OPNET_ESHAPE, "unsupported shape for the persistent stacked LSTM (L=%d KX=%d H=%d)", L, KX, H);
+    if (!w_ih || !w_hh || !packed) return fail(OPNET_EINVAL, "null pointer");
+    for (int l = 0; l < L; ++l)
+        if (!w_ih[l] || !w_hh[l]) return fail(OPNET_EINVAL, "null weight pointer (layer %d)", l);
+    if (!aligned16(packed)) return fail(OPNET_EINVAL, "packed must be 16-byte aligned");
+    const SeqXHostPacked P = seqx_host_packed(L, KX, H);
+    if (packed_bytes < P.total * sizeof(float)) return fail(OPNET_EWORKSPACE, "packed buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    seqx_pack<<<2048, 256, 0, st>>>(packed + P.regs, w_ih[0], w_hh[0], L == 2 ? w_ih[1] : nullptr, L == 2 ? w_hh[1] : nullptr, L,
+                                    seqx_nxq0(KX, H), KX);
+    if (stack_hoists_input(KX, H)) {
+        const size_t n = (size_t)4 * H * KX;
+        stack_pack_wih_rows<<<(unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), 256, 0, st>>>(w_ih[0], packed + P.wih0g, H, KX, KX);
+    }
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+/* y [B][T][4] = head(LSTM stack(x [B][T][KX])) as ONE persistent launch (+ input pack / hoisted GEMM before, the 4-row head
+ * after).  packed: opseq_xcd_pack_weights_f32 image; w_head: predictions_layer.weight [4][H] as the caller holds it. */
+extern "C" int opseq_xcd_forward_f32(const float *x, const float *packed, const float *w_head, float *y, void *workspace,
+                                     size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream)
+{
+    if (int rc = check_seqx(B, T, L, KX, H)) return rc;
+    if (!x || !packed || !w_head || !y || !workspace) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(packed) || !aligned16(y) || !aligned16(workspace) || !aligned16(w_head))
+        return fail(OPNET_EINVAL, "packed/w_head/y/workspace must be 16-byte aligned");
+    const SeqXWs W = seqx_ws_layout(B, T, L, KX, H);
+    if (workspace_bytes < W.total) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", workspace_bytes, W.total);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (xcd_device_cus(dev) < XCD_COUNT * XCD_CUS)
+        return fail(OPNET_ESHAPE, "device %d exposes %d CUs; the persistent launch needs %d resident workgroups", dev,
+                    xcd_device_cus(dev), XCD_COUNT * XCD_CUS);
+    const SeqXHostPacked PK = seqx_host_packed(L, KX, H);
+    const int nxq0 = seqx_nxq0(KX, H);
+    hipStream_t st = (hipStream_t)stream;
+    char *w = (char *)workspace;
+    const int RB = (B + 31) / 32;
+    SeqXArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.L = L; a.NGT = (B + 3) / 4; a.RB = RB; a.KXQ = 4 * nxq0;
+    a.pk = packed + PK.regs;
+    a.whead = w_head;
+    a.ws = w;
+    a.xp_off = (unsigned)W.xp; a.g_off = (unsigned)W.gemm;
+    for (int l = 0; l < 2; ++l) { a.hl_off[l] = (unsigned)W.hl[l]; a.hc_off[l] = (unsigned)W.hc[l]; }
+    a.status = (unsigned *)(w + W.status);
+    a.ystage = (float4 *)y;
+    a.force_safe = env_int("OPNET_XCD_SAFE", 0);
+    a.debug = env_int("OPSEQ_XCD_DEBUG", 0);
+    if (nxq0 == 0) {
+        if (!aligned16(x)) return fail(OPNET_EINVAL, "x must be 16-byte aligned");
+        // G [B*T][4H] = x [B*T][KX] . W_ih0^T (a 1 x 1 "conv" over B*T pixels); the cell reads it where it lies
+        ConvArgs c = {};
+        c.X = x; c.Wt = packed + PK.wih0g; c.bias = nullptr; c.R = nullptr; c.Y = (float *)(w + W.gemm);
+        c.N = 1; c.H = 1; c.W = B * T; c.Cin = KX; c.Cout = 4 * H; c.KH = 1; c.KW = 1; c.stride = 1; c.pad = 0;
+        c.OH = 1; c.OW = B * T; c.KP = KX; c.relu = 0;
+        launch_conv_tiled(c, (long)B * T, st);
+    } else {
+        rows_to_packed<<<1024, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, RB, KX, 16 * nxq0, nullptr, 0);
+    }
+    seqx_init<<<512, 256, 0, st>>>(a);
+    {
+        std::lock_guard<std::mutex> lock(g_xcd_mu);           // two persistent grids must never be co-resident
+        if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
+        else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
+        if (L == 1) seqx_forward<5, 1, false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
+        else if (nxq0 == 16) seqx_forward<16, 2, false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
+        else seqx_forward<0, 2, false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
+        HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
+    }
+    seqx_out_head<<<dim3(T, a.NGT), 64, 0, st>>>(a);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

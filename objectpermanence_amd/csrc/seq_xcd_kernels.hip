@@ -1,0 +1,380 @@
+// seq_xcd_kernels.hip - the stacked LSTM of the sibling reasoners as ONE persistent launch per forward.
+//
+// What is computed: the nn.LSTM(bias=False, batch_first) + Linear head of reference baselines/learned_models.py
+//   BaselineLstm   :99-101, 110-115   (1 layer, 75 -> 512)
+//   NonLinearLstm  :135-137, 146-148  (2 layers, 3840 -> 512 -> 512; the 3840-wide input product is hoisted into one GEMM)
+//   TransformerLstm:170-172, 192-195  (2 layers, 256 -> 512 -> 512)
+// - the same function as lstm_stack_step (seq_kernels.hip), which stays the engine for every other shape.
+//
+// Why: one launch per time step costs 5.7 us of dependent-launch latency per step (T + 2L - 1
+// launches, the matrix pipe 6 % busy); config 3 (one clip, S = 300) is 2.0 ms of which 1.75 ms are those launches.
+// The scheme of opnet_xcd4_kernels.hip carries over: groups of FOUR clips, every weight of a layer resident in the registers
+// of ONE XCD (32 CUs x 4 waves) for all T steps, v_mfma_f32_4x4x1_16b_f32 (16 independent 4 x 4 outer products: block = hidden
+// unit, row = gate, column = clip), h exchanged between the 32 CUs through the XCD's L2 with "the data is the flag".
+//
+// Decomposition.  256 workgroups of 4 waves, one per CU; XCD x = blockIdx.x & 7, CU c = blockIdx.x >> 3 owns hidden units
+// 16 c .. 16 c + 15 (64 gate rows) of ITS XCD's layer.
+//   L = 1: XCD x runs the layer for the groups G = x, x + 8, ...           (8 groups = 32 clips side by side)
+//   L = 2: XCD 2 p runs layer 0 and XCD 2 p + 1 layer 1 of the groups G = p, p + 4, ...   (4 pairs = 16 clips side by side)
+// The two layers of a pair are a PIPELINE, not a lock step: layer 1 at step t needs h0[t] and its own h1[t-1]; layer 0 needs
+// nothing from layer 1, runs ahead, and the cross-XCD hop (write-through stores, sc1 loads: ~1 us) only delays layer 1's
+// start.  There is no ring to overrun: every exchange buffer holds the FULL history [T + 1 slots], each word written once per
+// launch (slot 0 = the zero initial state, every other word pre-armed with the sentinel 0xffffffff by seqx_init), so there is
+// no re-arming, no flow control, and the top layer's buffer is what the output head reads afterwards.
+//
+// A phase = (group gi, step t).  Wave w (one per SIMD) owns the K quarter w of both products of the CU's 64 gate rows:
+//   x side: W_ih . input[t]   input = the packed x (layer 0, K <= 256), or the lower layer's h[t] (K = 512) gathered from its
+//           cross-XCD copy; its weights sit in AGPRs (the MFMA reads an AccVGPR as its A operand directly);
+//           (hoisted layer 0: no x side - the cell adds the GEMM's gate pre-activations)
+//   h side: W_hh . h[t-1]     gathered from the layer's own exchange buffer (XCD-local stores when the placement check of
+//           opnet_xcd_kernels.hip passed, write-through otherwise); weights in VGPRs.
+// Both inputs of a wave are ITS OWN quarter of the k range: gathered by that wave into wave-private LDS, read back as B
+// operands (one ds_read_b128 = four k of one clip, the same address in all 16 blocks) - the only workgroup barrier of a phase is
+// the one between the K-split partials and the cell.  The x side does not depend on the recurrence: it is computed FIRST, while
+// the previous phase's h is still on its way (wave 0 computes the previous phase's cell, publishes, and then does its x side
+// under the exchange latency), so the serial chain of a step is  cell -> publish -> gather -> h side (128 MFMAs) -> barrier.
+// Summation order: gate = ((w0 + w1) + w2) + w3 over the K quarters [+ hoisted pre-activation]; a quarter = (c0 + c1) + (c2 + c3)
+// over four interleaved ascending-k chains (k mod 4), the x part of a chain before its h part.
+// Every poll is bounded (XCD_SPIN_LIMIT): an abort raises status[0], every poller leaves, seqx_out_head fills y with NaN.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "opnet_ctx.h"
+
+#define SX_H 512
+#define SX_NGMAX 8             // groups per XCD (pair) one launch carries
+#define SX_XQMAX 32            // k-quads of a wave's x side (K = 512: the lower layer's h)
+
+struct SeqXPacked { size_t ah[2], ax[2], total; int nxq[2]; };      // offsets in floats; nxq = x-side k-quads per wave
+__host__ __device__ inline SeqXPacked seqx_packed_layout(int L, int NXQ0)
+{
+    SeqXPacked P;
+    size_t o = 0;
+    for (int l = 0; l < 2; ++l) {
+        P.nxq[l] = l == 0 ? NXQ0 : SX_XQMAX;
+        P.ah[l] = o; if (l < L) o += (size_t)32 * 4 * 32 * 256;             // [cu][wave][q][lane] float4
+        P.ax[l] = o; if (l < L) o += (size_t)32 * 4 * P.nxq[l] * 256;
+    }
+    P.total = o;
+    return P;
+}
+
+struct SeqXArgs {
+    int B, T, L, NGT;          // NGT = ceil(B / 4) groups of 4 clips
+    int RB, KXQ;               // packed input: row blocks of 32 clips, k-quads per clip (4 * NXQ0)
+    const float *pk;           // seqx_packed_layout image
+    const float *whead;        // predictions_layer.weight [4][512], the caller's row-major tensor
+    char *ws;                  // workspace base; the offsets below are bytes into it (one buffer descriptor)
+    unsigned xp_off;           // layer 0 input, direct:  [T][RB][KXQ][32] float4
+    unsigned g_off;            // layer 0 input, hoisted: G [B * T][2048] floats, row b * T + t, column 4 * unit + gate
+    unsigned hl_off[2];        // per layer: own exchange / history [NGT][T + 1][128][4] float4, slot t + 1 = step t
+    unsigned hc_off[2];        // layer l < L - 1: the same data written through for the next layer's XCD
+    unsigned *status;          // [0] abort code, [1] block, [2] phase, [3] groups on the write-through path, [8..] XCC ids
+    float4 *ystage;            // [B][T] float4 (the caller's y)
+    int force_safe, debug;     // debug (tools / tests): bit 2 = no cells (nobody publishes: forces the abort path)
+    // training forward: the launch chain's history layouts (stack_train_ws_layout), null for inference
+    float *hall[2];            // [T + 1][RB][128][32] float4 as floats
+    float *call[2];            // [T + 1][RB][512][32]
+    float4 *gsave[2];          // [T][RB][512][32]
+};
+
+typedef float sx_f32x4 __attribute__((ext_vector_type(4)));
+
+// one k of 64 gate rows x 4 clips; A in a VGPR / in an AccVGPR
+#define SX_MFMA_V(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
+#define SX_MFMA_A(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(av), "v"(bv))
+
+// fp32 weights -> the register images (lane = 4 b + i: unit 16 cu + b, gate i; element e of quad q of wave w: k = 4 (NQ w + q) + e)
+__global__ void __launch_bounds__(256) seqx_pack(float *__restrict__ out, const float *__restrict__ w_ih0, const float *__restrict__ w_hh0,
+                                                 const float *__restrict__ w_ih1, const float *__restrict__ w_hh1, int L, int NXQ0, int KX)
+{
+    const SeqXPacked P = seqx_packed_layout(L, NXQ0);
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < P.total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, b = lane >> 2, i = lane & 3;
+        int l = (L == 2 && idx >= P.ah[1]) ? 1 : 0;
+        const bool xs = idx >= P.ax[l];
+        const size_t r = (idx - (xs ? P.ax[l] : P.ah[l])) >> 8;
+        const int nq = xs ? P.nxq[l] : 32;
+        const int q = r % nq, w = (r / nq) % 4, cu = r / (4 * nq);
+        const int k = 4 * (nq * w + q) + e;
+        const size_t row = (size_t)i * SX_H + 16 * cu + b;
+        float v;
+        if (!xs) v = (l == 0 ? w_hh0 : w_hh1)[row * SX_H + k];
+        else if (l == 0) v = k < KX ? w_ih0[row * KX + k] : 0.f;
+        else v = w_ih1[row * SX_H + k];
+        out[idx] = v;
+    }
+}
+
+// status words, XCC sentinels; every exchange buffer: slot 0 = zeros (h_{-1}), everything else "not published yet"
+__global__ void __launch_bounds__(256) seqx_init(SeqXArgs a)
+{
+    const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, n = (long)gridDim.x * blockDim.x;
+    if (tid < 8) a.status[tid] = 0u;
+    for (long i = tid; i < 256; i += n) a.status[8 + i] = 0xffffffffu;
+    const xcd_u32x4 z = {0u, 0u, 0u, 0u}, sent = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    const long per = (long)(a.T + 1) * 512, tot = (long)a.NGT * per;       // float4 per group, per buffer
+    for (int l = 0; l < a.L; ++l) {
+        xcd_u32x4 *hl = (xcd_u32x4 *)(a.ws + a.hl_off[l]);
+        for (long i = tid; i < tot; i += n) hl[i] = (i % per) < 512 ? z : sent;
+        if (l + 1 < a.L) {
+            xcd_u32x4 *hc = (xcd_u32x4 *)(a.ws + a.hc_off[l]);
+            for (long i = tid; i < tot; i += n) hc[i] = (i % per) < 512 ? z : sent;
+        }
+    }
+}
+
+__device__ __forceinline__ bool sx_unpublished(xcd_u32x4 r)
+{
+    return r.x == 0xffffffffu || r.y == 0xffffffffu || r.z == 0xffffffffu || r.w == 0xffffffffu;
+}
+
+// NP pieces of 1 KB at src (lane l: 16 B at src + 1024 q + 16 l) -> registers; while any lane still sees a sentinel word all of
+// them are loaded again (bounded).  false = abort (wave-uniform).
+template <int NP>
+__device__ __forceinline__ bool sx_poll(__amdgpu_buffer_rsrc_t rws, unsigned lane16, unsigned src, xcd_u32x4 (&r)[NP],
+                                        unsigned *status, int phase)
+{
+    long long t0 = 0;
+    for (unsigned spins = 1;; ++spins) {
+        bool bad = false;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) bad |= sx_unpublished(r[q]);
+        if (!__any(bad)) return true;
+        if (!x4_keep_polling(spins, t0, status, phase)) return false;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) r[q] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, src + q * 1024, 16);   // sc1
+    }
+}
+
+// NQ B fragments (k-quads) out of a wave-private LDS region F (already offset by the lane's clip), four MFMAs each on the four
+// chains; the fragments travel through a ring of 4 register quads, 3 ahead (opnet_xcd4_kernels.hip: one ds_read in flight per
+// 4 MFMAs exposes every LDS latency).  AG: the A operands are AccVGPRs.
+template <int NQ, bool AG, typename AT>
+__device__ __forceinline__ void sx_products(sx_f32x4 (&c)[4], const AT &A, const float4 *F)
+{
+    if (NQ == 0) return;
+    float4 bf[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (i < NQ) bf[i] = F[i * 4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q + 3 < NQ) bf[(q + 3) & 3] = F[(q + 3) * 4];
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 bq = bf[q & 3];
+        if (AG) {
+            SX_MFMA_A(c[0], A[4 * q + 0], bq.x);
+            SX_MFMA_A(c[1], A[4 * q + 1], bq.y);
+            SX_MFMA_A(c[2], A[4 * q + 2], bq.z);
+            SX_MFMA_A(c[3], A[4 * q + 3], bq.w);
+        } else {
+            SX_MFMA_V(c[0], A[4 * q + 0], bq.x);
+            SX_MFMA_V(c[1], A[4 * q + 1], bq.y);
+            SX_MFMA_V(c[2], A[4 * q + 2], bq.z);
+            SX_MFMA_V(c[3], A[4 * q + 3], bq.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// NXQ0: k-quads per wave of layer 0's direct input (0 = hoisted: the cell adds G); L: layers; TRAIN: keep the backward's histories
+template <int NXQ0, int L, bool TRAIN>
+__global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
+{
+    constexpr int NXQ1 = SX_XQMAX;
+    constexpr int NXMAX = L == 2 ? NXQ1 : (NXQ0 > 0 ? NXQ0 : 1);
+    __shared__ __attribute__((aligned(1024))) float4 sH[4][128];       // wave-private: the wave's quarter of h[t-1]
+    __shared__ __attribute__((aligned(1024))) float4 sX[4][4 * NXMAX]; // wave-private: the wave's quarter of the x-side input
+    __shared__ __attribute__((aligned(16))) float4 sP[2][4][64];       // K-split partials by phase parity
+    __shared__ float sC[SX_NGMAX][64];
+    __shared__ float4 sPad[3840];          // 60 KB never used: > 80 KB of LDS in total keep a second workgroup off the CU (every
+                                           // CU must host exactly one of the 256 workgroups, or the exchange waits for a block
+                                           // that is not resident)
+    __shared__ volatile int sAbort, sLocal;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = blockIdx.x & 7, c = blockIdx.x >> 3;
+    constexpr int NPAIR = 8 / L;
+    const int pr = x / L, l = __builtin_amdgcn_readfirstlane(x % L);
+    const int T = a.T;
+    const int ng = a.NGT > pr ? (a.NGT - pr + NPAIR - 1) / NPAIR : 0;
+    if (ng == 0) return;
+    const int b = lane >> 2, j = lane & 3;
+    if (w == 0) {
+        const int loc = xcd_group_is_local(a.status, x);
+        if (lane == 0) {
+            sLocal = loc > 0 && a.force_safe == 0;
+            sAbort = loc < 0;
+            if (loc == 0 && c == 0) atomicAdd(a.status + 3, 1u);
+        }
+    }
+    for (int i = tid; i < SX_NGMAX * 64; i += 256) (&sC[0][0])[i] = 0.f;
+    if (a.debug & 0x40000000) sPad[tid * 15] = make_float4(0.f, 0.f, 0.f, 0.f);     // (keeps the padding allocated)
+    // this XCD's layer: its buffers and histories (selected here once - indexing the kernarg arrays by l costs scratch)
+    const unsigned hl_mine = l == 0 ? a.hl_off[0] : a.hl_off[1];
+    const unsigned hc_mine = a.hc_off[0];                        // only layer 0 of L = 2 has a reader on another XCD
+    float *const hall_mine = l == 0 ? a.hall[0] : a.hall[1];
+    float *const call_mine = l == 0 ? a.call[0] : a.call[1];
+    float4 *const gsave_mine = l == 0 ? a.gsave[0] : a.gsave[1];
+    const size_t pk_ah = l == 0 ? seqx_packed_layout(L, NXQ0).ah[0] : seqx_packed_layout(L, NXQ0).ah[1];
+    const size_t pk_ax = l == 0 ? seqx_packed_layout(L, NXQ0).ax[0] : seqx_packed_layout(L, NXQ0).ax[1];
+
+    // ---- resident weights: h side in VGPRs, x side in AccVGPRs -----------------------------------------------------------
+    float ah[128];
+    float ax[4 * NXMAX];
+    {
+        const float4 *ph = (const float4 *)(a.pk + pk_ah) + ((size_t)(c * 4 + w) * 32) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const float4 v = ph[q * 64];
+            ah[4 * q] = v.x; ah[4 * q + 1] = v.y; ah[4 * q + 2] = v.z; ah[4 * q + 3] = v.w;
+        }
+        const int nq = l == 0 ? NXQ0 : NXQ1;
+        const float4 *px = (const float4 *)(a.pk + pk_ax) + ((size_t)(c * 4 + w) * nq) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < NXMAX; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < nq) v = px[q * 64];
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(ax[4 * q]) : "v"(v.x));
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(ax[4 * q + 1]) : "v"(v.y));
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(ax[4 * q + 2]) : "v"(v.z));
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(ax[4 * q + 3]) : "v"(v.w));
+        }
+    }
+
+    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void *)a.ws, 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = lane * 16;
+    __syncthreads();
+    if (sAbort) return;
+    const bool local = __builtin_amdgcn_readfirstlane(sLocal) != 0;
+    const bool top = l == L - 1;
+    const int nph = T * ng;
+    const unsigned slot_bytes = 128 * 64;                        // one step of one group: 128 k-quads x 4 clips x 16 B
+
+    int gi = 0, t = 0;              // the phase this iteration computes the products of
+    int gp = 0, tp = 0;             // the previous phase (whose cell wave 0 computes now)
+    for (int p = 0; p <= nph; ++p) {
+        const bool work = p < nph;
+        const int G = gi * NPAIR + pr;                           // group of this phase: clips 4 G .. 4 G + 3
+        // ---- (1) ask for this phase's x-side input (it does not depend on the recurrence) ---------------------------------
+        xcd_u32x4 xr[2];
+        xr[0] = xr[1] = (xcd_u32x4){0u, 0u, 0u, 0u};
+        unsigned xsrc = 0;
+        if (work) {
+            if (L == 2 && l == 1) {
+                xsrc = a.hc_off[0] + ((unsigned)(G * (T + 1) + t + 1) * 128 + 32 * w) * 64;
+                xr[0] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, xsrc, 16);
+                xr[1] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, xsrc + 1024, 16);
+            } else if (NXQ0 > 0) {
+                const int rb = (4 * G) >> 5, cb = (4 * G) & 31;
+                const unsigned o = a.xp_off + ((unsigned)((t * a.RB + rb) * a.KXQ) + NXQ0 * w) * 512;
+                if ((lane >> 2) < NXQ0) xr[0] = __builtin_amdgcn_raw_buffer_load_b128(rws, ((lane >> 2) * 32 + cb + j) * 16, o, 0);
+            }
+        }
+        // ---- (2) wave 0: the cell of the previous phase (learned_models.py:110 / 146 / 192), publish h ------------------------
+        if (w == 0 && p > 0 && !(a.debug & 4)) {
+            const int Gp = gp * NPAIR + pr;
+            float4 xg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NXQ0 == 0 && l == 0) {                           // hoisted input product: G[(clip * T + t)][4 unit .. 4 unit + 3]
+                int clip = 4 * Gp + j;
+                clip = clip < a.B ? clip : a.B - 1;
+                xg = *(const float4 *)(a.ws + a.g_off + (((size_t)clip * T + tp) * (4 * SX_H) + (size_t)(16 * c + b) * 4) * 4);
+            }
+            const float4 *pp = &sP[(p - 1) & 1][0][lane];
+            const float4 p0 = pp[0], p1 = pp[64], p2 = pp[128], p3 = pp[192];
+            float cc = sC[gp][lane];
+            float4 gs;
+            const float h = lstm_cell_g((((p0.x + p1.x) + p2.x) + p3.x) + xg.x, (((p0.y + p1.y) + p2.y) + p3.y) + xg.y,
+                                        (((p0.z + p1.z) + p2.z) + p3.z) + xg.z, (((p0.w + p1.w) + p2.w) + p3.w) + xg.w, &cc, &gs);
+            sC[gp][lane] = cc;
+            // float4 = units 4 q .. 4 q + 3 of clip j, assembled by the lanes with (b & 3) == 0; slot tp + 1 = step tp
+            const float4 hv = make_float4(h, x4_row_shl<4>(h), x4_row_shl<8>(h), x4_row_shl<12>(h));
+            if ((b & 3) == 0) {
+                const unsigned vo = ((b >> 2) * 4 + j) * 16;
+                const unsigned so = ((unsigned)(Gp * (T + 1) + tp + 1) * 128 + 4 * c) * 64;
+                xcd_store16(rws, vo, hl_mine + so, hv, local);
+                if (!top) xcd_store16(rws, vo, hc_mine + so, hv, false);
+            }
+            if (TRAIN) {
+                const int clip = 4 * Gp + j, rb = clip >> 5, cl = clip & 31, RB = a.RB;
+                const size_t u = 16 * c + b;
+                hall_mine[(((size_t)(tp + 1) * RB + rb) * 128 + (u >> 2)) * 128 + cl * 4 + (u & 3)] = h;
+                call_mine[(((size_t)(tp + 1) * RB + rb) * SX_H + u) * 32 + cl] = cc;
+                gsave_mine[(((size_t)tp * RB + rb) * SX_H + u) * 32 + cl] = gs;
+            }
+        }
+        if (!work) break;
+        bool ok = true;
+        sx_f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = (sx_f32x4){0.f, 0.f, 0.f, 0.f};
+        // ---- (3) x side ---------------------------------------------------------------------------------------------------
+        if (L == 2 && l == 1) {
+            ok = sx_poll<2>(rws, lane16, xsrc, xr, a.status, p);
+            sX[w][lane] = x4_as_float4(xr[0]);
+            sX[w][64 + lane] = x4_as_float4(xr[1]);
+            XCD_WAVE_LDS_SYNC();
+            sx_products<NXQ1, true>(acc, ax, &sX[w][0] + j);
+        } else if (NXQ0 > 0) {
+            if ((lane >> 2) < NXQ0) sX[w][lane] = x4_as_float4(xr[0]);
+            XCD_WAVE_LDS_SYNC();
+            sx_products<NXQ0, true>(acc, ax, &sX[w][0] + j);
+        }
+        // ---- (4) h side: this wave's quarter of h[t-1] (slot t) --------------------------------------------------------------
+        {
+            xcd_u32x4 hr[2];
+            const unsigned hsrc = hl_mine + ((unsigned)(G * (T + 1) + t) * 128 + 32 * w) * 64;
+            hr[0] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, hsrc, 16);
+            hr[1] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, hsrc + 1024, 16);
+            if (ok) ok = sx_poll<2>(rws, lane16, hsrc, hr, a.status, p);
+            sH[w][lane] = x4_as_float4(hr[0]);
+            sH[w][64 + lane] = x4_as_float4(hr[1]);
+            XCD_WAVE_LDS_SYNC();
+            sx_products<32, false>(acc, ah, &sH[w][0] + j);
+        }
+        sP[p & 1][w][lane] = make_float4((acc[0][0] + acc[1][0]) + (acc[2][0] + acc[3][0]), (acc[0][1] + acc[1][1]) + (acc[2][1] + acc[3][1]),
+                                         (acc[0][2] + acc[1][2]) + (acc[2][2] + acc[3][2]), (acc[0][3] + acc[1][3]) + (acc[2][3] + acc[3][3]));
+        if (!ok) sAbort = 1;
+        __syncthreads();                        // the phase's partials are in sP
+        if (sAbort) return;
+        gp = gi; tp = t;
+        if (++gi == ng) { gi = 0; ++t; }
+    }
+}
+
+// y[clip][t] = predictions_layer.weight . h_top[t] (learned_models.py:113 / 148 / 195) from the top layer's exchange history;
+// one workgroup of 64 threads per (t, group): thread (r, clip j) walks k-quads r, r + 16, ..., the 16 partials are summed in
+// fixed order.  An aborted launch (status[0] != 0) poisons y with NaN.
+__global__ void __launch_bounds__(64) seqx_out_head(const SeqXArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float4 red[16][4];
+    const int t = blockIdx.x, G = blockIdx.y, tid = threadIdx.x, r = tid >> 2, j = tid & 3;
+    const float4 *h = (const float4 *)(a.ws + a.hl_off[a.L - 1]) + ((size_t)(G * (a.T + 1) + t + 1) * 128) * 4 + j;
+    const float4 *w4 = (const float4 *)a.whead;                     // [4][128] float4
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = r; q < 128; q += 16) {
+        const float4 hv = h[q * 4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float4 wv = w4[o * 128 + q];
+            acc[o] = fmaf(hv.x, wv.x, acc[o]);
+            acc[o] = fmaf(hv.y, wv.y, acc[o]);
+            acc[o] = fmaf(hv.z, wv.z, acc[o]);
+            acc[o] = fmaf(hv.w, wv.w, acc[o]);
+        }
+    }
+    red[r][j] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (tid < 4) {
+        float4 s = red[0][tid];
+        for (int k = 1; k < 16; ++k) {
+            const float4 v = red[k][tid];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (a.status[0] != 0u) s = make_float4(NAN, NAN, NAN, NAN);
+        const int clip = 4 * G + tid;
+        if (clip < a.B) a.ystage[(size_t)clip * a.T + t] = s;
+    }
+}

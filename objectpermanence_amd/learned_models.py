@@ -659,6 +659,67 @@ class _LstmStackRunner:
         self.key = None
         self.ws = {}
         self.tpacked, self.tws, self.tws_key, self.train_gen = None, None, None, 0
+        # the whole stack as ONE persistent launch (csrc/seq_xcd_kernels.hip): "auto" = whenever the library supports the
+        # shape on this device (H = 512; the reference's three stacked reasoners) and the batch fits one launch; "0" = never
+        self.use_xcd = os.environ.get("OPSEQ_XCD", "auto")
+        self._xpacked: Dict[int, Tuple[tuple, torch.Tensor]] = {}     # per stream: (weights key, register image)
+        self._xws: Dict[tuple, torch.Tensor] = {}
+        self._monitor = LaunchMonitor()
+        self.xcd_launches = 0            # statistics: forwards that ran as one persistent launch
+
+    def _wants_xcd(self, B: int) -> bool:
+        if self.use_xcd in ("0", 0, False):
+            return False
+        lib = _lib.load()
+        return bool(lib.opseq_xcd_supported(self.L, self.KX, self.H)) and B <= int(lib.opseq_xcd_max_batch(self.L))
+
+    def _run_xcd(self, x: torch.Tensor, ws_list, head: "LinearWeight") -> torch.Tensor:
+        lib = _lib.load()
+        dev = x.device
+        B, T = int(x.shape[0]), int(x.shape[1])
+        stream = _stream_ptr(dev)
+        key = _weights_key(ws_list, dev)
+        entry = self._xpacked.get(stream)
+        if entry is None or entry[0] != key:
+            for w in ws_list:
+                if w.device != dev or w.dtype != torch.float32 or not w.is_contiguous():
+                    raise RuntimeError("parameters must be contiguous fp32 on the input's device")
+            nbytes = lib.opseq_xcd_packed_bytes(self.L, self.KX, self.H)
+            if nbytes == 0:
+                _lib.check(-2, "opseq_xcd_packed_bytes")
+            if entry is None or entry[1].device != dev:
+                if len(self._xpacked) >= 4:
+                    self._xpacked.pop(next(iter(self._xpacked)))
+                buf = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            else:
+                buf = entry[1]
+            arr = _lib.c_void_p * self.L
+            ih = arr(*[w.data_ptr() for w in ws_list[:self.L]])
+            hh = arr(*[w.data_ptr() for w in ws_list[self.L:2 * self.L]])
+            _lib.check(lib.opseq_xcd_pack_weights_f32(ih, hh, buf.data_ptr(), nbytes, self.L, self.KX, self.H, stream),
+                       "opseq_xcd_pack_weights_f32")
+            self._xpacked[stream] = (key, buf)
+        packed = self._xpacked[stream][1]
+        wkey = (B, T, str(dev), stream)
+        if wkey not in self._xws:
+            nb = lib.opseq_xcd_workspace_bytes(B, T, self.L, self.KX, self.H)
+            if nb == 0:
+                _lib.check(-2, "opseq_xcd_workspace_bytes")
+            if len(self._xws) >= 4:
+                self._xws.pop(next(iter(self._xws)))      # (stream-keyed: see OPNet._forward_xcd on dropping it at once)
+            self._xws[wkey] = torch.empty(nb, dtype=torch.uint8, device=dev)
+        ws = self._xws[wkey]
+        y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+        _lib.check(lib.opseq_xcd_forward_f32(x.data_ptr(), packed.data_ptr(), head.weight.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), B, T, self.L, self.KX, self.H, stream), "opseq_xcd_forward_f32")
+
+        def redo():          # the launch gave up: the same batch through the launch-per-step chain, into the same y
+            with torch.no_grad(), torch.cuda.device(dev):
+                y.copy_(self._run_chain(x, ws_list, head))
+
+        self._monitor.watch(ws, lib.opseq_xcd_status_offset(B, T, self.L, self.KX, self.H), redo, "seqx_forward")
+        self.xcd_launches += 1
+        return y
 
     def run_train(self, x: torch.Tensor, lstm: "LSTMWeights", head: "LinearWeight") -> torch.Tensor:
         ws_list = [getattr(lstm, f"weight_ih_l{l}") for l in range(self.L)] + \
@@ -669,11 +730,17 @@ class _LstmStackRunner:
         return _StackTrainFunction.apply(self, x.contiguous(), *ws_list)
 
     def run(self, x: torch.Tensor, lstm: "LSTMWeights", head: "LinearWeight") -> torch.Tensor:
+        ws_list = [getattr(lstm, f"weight_ih_l{l}") for l in range(self.L)] + \
+                  [getattr(lstm, f"weight_hh_l{l}") for l in range(self.L)] + [head.weight]
+        if self._wants_xcd(int(x.shape[0])):
+            return self._run_xcd(x, ws_list, head)
+        return self._run_chain(x, ws_list, head)
+
+    def _run_chain(self, x: torch.Tensor, ws_list, head: "LinearWeight") -> torch.Tensor:
+        """one launch per time step (csrc/seq_kernels.hip lstm_stack_step), T + 2 L - 1 launches as one hipGraph"""
         lib = _lib.load()
         dev = x.device
         B, T = int(x.shape[0]), int(x.shape[1])
-        ws_list = [getattr(lstm, f"weight_ih_l{l}") for l in range(self.L)] + \
-                  [getattr(lstm, f"weight_hh_l{l}") for l in range(self.L)] + [head.weight]
         stream = _stream_ptr(dev)
         key = _weights_key(ws_list, dev)
         if self.key != key:

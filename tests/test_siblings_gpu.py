@@ -20,11 +20,19 @@ def gold(golden_dir):
     return np.load(os.path.join(golden_dir, "siblings.npz"))
 
 
-def _model(name, cfg):
+def _model(name, cfg, engine="auto"):
+    """engine: "auto" = the product's choice (the persistent stack launch of csrc/seq_xcd_kernels.hip for H = 512 stacks),
+    "chain" = one launch per time step (csrc/seq_kernels.hip)"""
     from objectpermanence_amd import ModelsFactory
     m = ModelsFactory.get_model(name, cfg)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in PARAMS[name](cfg).items()})
+    if engine == "chain" and hasattr(m, "_runner"):
+        m._runner.use_xcd = "0"
     return m.eval().to("cuda:0")
+
+
+def _persistent(m):
+    return getattr(getattr(m, "_runner", None), "xcd_launches", 0)
 
 
 def _run(m, x):
@@ -39,13 +47,21 @@ CASES = [("baseline_lstm", "tiny"), ("baseline_lstm", "real"), ("non_linear_lstm
          ("transformer_lstm", "real_b1"), ("transformer_lstm", "real_b2"), ("transformer_lstm", "heads4_b1")]
 
 
+@pytest.mark.parametrize("engine", ["auto", "chain"])
 @pytest.mark.parametrize("name,tag", CASES)
-def test_matches_reference_golden(gold, name, tag):
+def test_matches_reference_golden(gold, name, tag, engine):
+    """both engines of the stacked LSTM against the reference's own outputs: the persistent launch (what "auto" picks for the
+    real configs: H = 512) and the launch-per-step chain"""
     cfg = json.loads(str(gold[f"{name}/{tag}/cfg"]))
     n, t = (int(v) for v in gold[f"{name}/{tag}/shape"])
     boxes, _ = synth.make_batch(0, n, t)
     x = boxes if name == "opnet_lstm_mlp" else synth.boxes5(boxes)
-    out = _run(_model(name, cfg), x)
+    m = _model(name, cfg, engine)
+    out = _run(m, x)
+    real_stack = name != "opnet_lstm_mlp" and tag != "tiny"
+    assert _persistent(m) == (1 if (engine == "auto" and real_stack) else 0)
+    if hasattr(m, "_runner"):
+        assert m._runner._monitor.verify() == 0
     y = (out[0] if isinstance(out, tuple) else out).cpu().numpy()
     y_ref = gold[f"{name}/{tag}/y"]
     assert y.shape == y_ref.shape
@@ -119,3 +135,67 @@ def test_attention_core_matches_torch(S, E, nhead):
     ref = torch.cat([torch.softmax(q[h] @ k[h].T / hd ** 0.5, dim=-1) @ v[h] for h in range(nhead)], dim=1)
     err = (out.cpu().to(dt) - ref).abs().max().item()
     assert err < (2e-5 if S <= 1000 else 2e-4), err
+
+
+REAL = {"baseline_lstm": {"videos_hidden_dim": 512},
+        "non_linear_lstm": {"boxes_features_dim": 256, "videos_hidden_dim": 512},
+        "transformer_lstm": {"boxes_features_dim": 256, "num_attention_heads": 2, "num_attention_layers": 2,
+                             "num_lstm_layers": 2, "lstm_hidden_dim": 512}}
+ORACLE = {"baseline_lstm": lambda x, p, cfg: oo.baseline_lstm_forward(x, p),
+          "non_linear_lstm": lambda x, p, cfg: oo.non_linear_lstm_forward(x, p),
+          "transformer_lstm": lambda x, p, cfg: oo.transformer_lstm_forward(x, p, cfg)}
+
+
+# one clip / a ragged last group / every XCD busy / two groups per XCD (pair) / single frame, per model
+@pytest.mark.parametrize("name,B,T", [("baseline_lstm", 1, 1), ("baseline_lstm", 3, 7), ("baseline_lstm", 32, 9),
+                                      ("baseline_lstm", 37, 5), ("baseline_lstm", 70, 4), ("baseline_lstm", 256, 3),
+                                      ("non_linear_lstm", 1, 2), ("non_linear_lstm", 6, 5), ("non_linear_lstm", 17, 6),
+                                      ("non_linear_lstm", 40, 3), ("transformer_lstm", 1, 11), ("transformer_lstm", 2, 8),
+                                      ("transformer_lstm", 5, 6), ("transformer_lstm", 19, 4), ("transformer_lstm", 33, 3)])
+def test_persistent_stack_matches_oracle_ragged(name, B, T):
+    """the persistent launch of the stacked LSTM (csrc/seq_xcd_kernels.hip) on ragged shapes vs the fp64 oracle, and
+    against the launch chain on the same input (different summation order: rounding-level agreement)"""
+    cfg = REAL[name]
+    boxes, _ = synth.make_batch(500, B, T)
+    x = synth.boxes5(boxes)
+    m = _model(name, cfg)
+    y = _run(m, x).cpu().numpy()
+    assert _persistent(m) == 1 and m._runner._monitor.verify() == 0
+    y_ref = ORACLE[name](x, PARAMS[name](cfg), cfg)
+    assert np.isfinite(y).all() and np.abs(y - y_ref).max() < 3e-5, float(np.abs(y - y_ref).max())
+    y_chain = _run(_model(name, cfg, "chain"), x).cpu().numpy()
+    assert np.abs(y - y_chain).max() < 1e-5
+
+
+def test_persistent_stack_is_deterministic_and_protocol_independent(monkeypatch):
+    """run to run and XCD-local stores vs the write-through protocol (OPNET_XCD_SAFE): the same bits - a stale hand-off
+    would not reproduce"""
+    cfg = REAL["transformer_lstm"]
+    boxes, _ = synth.make_batch(7, 6, 40)
+    x = synth.boxes5(boxes)
+    m = _model("transformer_lstm", cfg)
+    y0 = _run(m, x).cpu().numpy()
+    for _ in range(3):
+        assert np.array_equal(_run(m, x).cpu().numpy(), y0)
+    monkeypatch.setenv("OPNET_XCD_SAFE", "1")
+    assert np.array_equal(_run(m, x).cpu().numpy(), y0)
+
+
+def test_persistent_stack_abort_is_healed(monkeypatch):
+    """OPSEQ_XCD_DEBUG bit 2 switches the cells (the publishers) off: the launch gives up after its bounded wait, y is NaN,
+    and verify_launches re-runs the batch on the launch chain into the same tensor"""
+    import warnings
+    from objectpermanence_amd.launch_monitor import verify_launches
+    cfg = REAL["baseline_lstm"]
+    boxes, _ = synth.make_batch(9, 5, 6)
+    x = synth.boxes5(boxes)
+    m = _model("baseline_lstm", cfg)
+    monkeypatch.setenv("OPSEQ_XCD_DEBUG", "4")
+    y = _run(m, x)
+    assert torch.isnan(y).all()
+    monkeypatch.delenv("OPSEQ_XCD_DEBUG")
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        assert verify_launches(m) == 1
+    y_ref = oo.baseline_lstm_forward(x, PARAMS["baseline_lstm"](cfg))
+    assert np.abs(y.cpu().numpy() - y_ref).max() < 3e-5
