@@ -238,6 +238,10 @@ int opseq_xcd_pack_weights_f32(const float *const *w_ih, const float *const *w_h
                                int L, int KX, int H, void *stream);
 int opseq_xcd_forward_f32(const float *x, const float *packed, const float *w_head, float *y, void *workspace,
                           size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream);
+/* opseq_lstm_stack_train_forward_f32 runs the same persistent launch on the shapes above (B <= opseq_xcd_max_batch(L)) and
+ * writes the h / c / gate histories its backward reads; its status words sit at this offset of the TRAINING workspace
+ * ((size_t)-1: this shape trains on the launch chain) */
+size_t opseq_lstm_stack_train_status_offset(int B, int T, int L, int KX, int H);
 
 void opseq_graph_cache_clear(void);
 /* training of the stacked LSTM: forward keeping the history in `workspace`, then BPTT + weight gradients.

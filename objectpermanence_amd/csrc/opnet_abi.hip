@@ -1790,7 +1790,7 @@ extern "C" int opseq_xcd_forward_f32(const float *x, const float *packed, const 
 }
 
 // ---- training of the stacked LSTM ---------------------------------------------------------------------
-struct StackTrainPacked { size_t fwd_total, whh_t[SEQ_MAX_LAYERS], wih_t[SEQ_MAX_LAYERS], whead, wih0_t, total; };
+struct StackTrainPacked { size_t fwd_total, whh_t[SEQ_MAX_LAYERS], wih_t[SEQ_MAX_LAYERS], whead, wih0_t, seqx, total; };
 
 static StackTrainPacked stack_train_packed_layout(int L, int KX, int H)
 {
@@ -1803,14 +1803,19 @@ static StackTrainPacked stack_train_packed_layout(int L, int KX, int H)
     }
     P.whead = o; o += align_up((size_t)4 * H, 4);
     P.wih0_t = o; o += align_up((size_t)(((KX + 15) / 16) * 16) * 4 * H, 4);   // W_ih0^T [KXP][4H], k = 4*unit + gate
+    o = align_up(o, 64);
+    P.seqx = o;                                    // register image of the persistent forward (seq_xcd_kernels.hip)
+    if (seqx_dims(L, KX, H)) o += seqx_packed_layout(L, seqx_nxq0(KX, H)).total;
     P.total = o;
     return P;
 }
 
 struct StackTrainWs {
     size_t xp, state, hall[SEQ_MAX_LAYERS], call[SEQ_MAX_LAYERS], state_end, g[SEQ_MAX_LAYERS], ystage, dyp,
-        rpart[SEQ_MAX_LAYERS], dxpart[SEQ_MAX_LAYERS], dcz, dc[SEQ_MAX_LAYERS], dcz_end, darows, total;
+        rpart[SEQ_MAX_LAYERS], dxpart[SEQ_MAX_LAYERS], dcz, dc[SEQ_MAX_LAYERS], dcz_end, darows,
+        sx_status, sx_hl[2], sx_hc[2], total;      // sx_*: exchange histories + status words of the persistent forward
 };
+static bool seqx_train_shape(int B, int L, int KX, int H) { return seqx_dims(L, KX, H) && B <= opseq_xcd_max_batch(L); }
 
 static StackTrainWs stack_train_ws_layout(int B, int T, int L, int KX, int H)
 {
@@ -1835,8 +1840,25 @@ static StackTrainWs stack_train_ws_layout(int B, int T, int L, int KX, int H)
     for (int l = 0; l < L; ++l) { W.dc[l] = o; o += RB * (size_t)H * 32 * 4; }
     W.dcz_end = o;
     W.darows = o; o += (size_t)B * TT * 4 * H * 4;      // da0 as rows, for the input-gradient GEMM
+    o = align_up(o, 4096);
+    W.sx_status = o;
+    for (int l = 0; l < 2; ++l) W.sx_hl[l] = W.sx_hc[l] = o;
+    if (seqx_train_shape(B, L, KX, H)) {
+        const size_t NGT = (B + 3) / 4;
+        o += 4096;
+        for (int l = 0; l < L; ++l) {
+            W.sx_hl[l] = o; o += NGT * (TT + 1) * 8192;
+            W.sx_hc[l] = o; if (l + 1 < L) o += NGT * (TT + 1) * 8192;
+        }
+    }
     W.total = align_up(o, 256);
     return W;
+}
+/* byte offset of the training forward's status words in its workspace ((size_t)-1: the shape never runs the persistent kernel) */
+extern "C" size_t opseq_lstm_stack_train_status_offset(int B, int T, int L, int KX, int H)
+{
+    if (check_stack(B, T, L, KX, H) || !seqx_train_shape(B, L, KX, H)) return (size_t)-1;
+    return stack_train_ws_layout(B, T, L, KX, H).sx_status;
 }
 
 extern "C" size_t opseq_lstm_stack_train_packed_bytes(int L, int KX, int H)
@@ -1882,6 +1904,9 @@ extern "C" int opseq_lstm_stack_train_pack_weights_f32(const float *const *w_ih,
     opnet_copy_f32<<<blocks((size_t)4 * H), 256, 0, st>>>(packed + P.whead, w_head, (long)4 * H);
     const int KXP = ((KX + 15) / 16) * 16;
     pack_wih0_t<<<blocks((size_t)KXP * 4 * H), 256, 0, st>>>(packed + P.wih0_t, w_ih[0], H, KX, KXP);
+    if (seqx_dims(L, KX, H))
+        seqx_pack<<<2048, 256, 0, st>>>(packed + P.seqx, w_ih[0], w_hh[0], L == 2 ? w_ih[1] : nullptr, L == 2 ? w_hh[1] : nullptr, L,
+                                        seqx_nxq0(KX, H), KX);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }
@@ -1944,6 +1969,7 @@ extern "C" int opseq_lstm_stack_train_forward_f32(const float *x, const float *p
     hipStream_t st = (hipStream_t)stream;
     rows_to_packed<<<2048, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, a.RB, KX, P.nhx[0] * 16,
                                           (float4 *)(w + W.state), (long)((W.state_end - W.state) / 16));
+    const bool use_sx = seqx_train_shape(B, L, KX, H) && opseq_xcd_supported(L, KX, H) && W.total < ((size_t)1 << 31);
     if (stack_hoists_input(KX, H)) {
         // same hoisted input product as the inference forward (bit-identical y); the packed x above is still needed
         // by the weight-gradient GEMM.  Scratch: G lives in the da-rows buffer (used by backward only), xg in layer
@@ -1955,12 +1981,54 @@ extern "C" int opseq_lstm_stack_train_forward_f32(const float *x, const float *p
         c.OH = 1; c.OW = B * T; c.KP = KX; c.relu = 0;
         launch_conv_tiled(c, (long)B * T, st);
         const long nx = (long)T * a.RB * 32 * H;
-        stack_xg_repack<<<(unsigned)((nx + 255) / 256 > 8192 ? 8192 : (nx + 255) / 256), 256, 0, st>>>(
-            (const float4 *)(w + W.darows), (float4 *)(w + W.g[0]), B, T, a.RB, H);
+        if (!use_sx)
+            stack_xg_repack<<<(unsigned)((nx + 255) / 256 > 8192 ? 8192 : (nx + 255) / 256), 256, 0, st>>>(
+                (const float4 *)(w + W.darows), (float4 *)(w + W.g[0]), B, T, a.RB, H);
         a.layer[0].xg = (float4 *)(w + W.g[0]);
         a.layer[0].a_skip = P.nhx[0];
         a.layer[0].nhx = 0;
     }
+    if (use_sx) {
+        // the whole recurrence as ONE persistent launch (seq_xcd_kernels.hip, TRAIN = true): the same arithmetic as the
+        // inference forward of this shape (bit-identical y) + the h / c / gate histories the backward below reads, written in
+        // the launch chain's own layouts.  (The hoisted input product: the cell reads G where the GEMM left it - W.darows.)
+        const StackTrainPacked TP = stack_train_packed_layout(L, KX, H);
+        const int nxq0 = seqx_nxq0(KX, H);
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        SeqXArgs sx;
+        memset(&sx, 0, sizeof(sx));
+        sx.B = B; sx.T = T; sx.L = L; sx.NGT = (B + 3) / 4; sx.RB = a.RB; sx.KXQ = 4 * nxq0;
+        sx.pk = packed + TP.seqx;
+        sx.whead = packed + TP.whead;
+        sx.ws = w;
+        sx.xp_off = (unsigned)W.xp; sx.g_off = (unsigned)W.darows;
+        for (int l = 0; l < 2; ++l) { sx.hl_off[l] = (unsigned)W.sx_hl[l]; sx.hc_off[l] = (unsigned)W.sx_hc[l]; }
+        sx.status = (unsigned *)(w + W.sx_status);
+        sx.ystage = (float4 *)y;
+        sx.force_safe = env_int("OPNET_XCD_SAFE", 0);
+        sx.debug = env_int("OPSEQ_XCD_DEBUG", 0);
+        for (int l = 0; l < L; ++l) {
+            sx.hall[l] = (float *)(w + W.hall[l]);
+            sx.call[l] = (float *)(w + W.call[l]);
+            sx.gsave[l] = (float4 *)(w + W.g[l]);
+        }
+        seqx_init<<<512, 256, 0, st>>>(sx);
+        {
+            std::lock_guard<std::mutex> lock(g_xcd_mu);
+            if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
+            else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
+            if (L == 1) seqx_forward<5, 1, true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sx);
+            else if (nxq0 == 16) seqx_forward<16, 2, true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sx);
+            else seqx_forward<0, 2, true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sx);
+            HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
+        }
+        seqx_out_head<<<dim3(T, sx.NGT), 64, 0, st>>>(sx);
+        HIP_TRY(hipGetLastError());
+        return OPNET_OK;
+    }
+    // (the status words a caller's optimiser guard reads: a forward on the launch chain says "nothing aborted" itself)
+    if (seqx_train_shape(B, L, KX, H)) HIP_TRY(hipMemsetAsync(w + W.sx_status, 0, 32, st));
     const dim3 grid(((2 * L - 1) * (H / 4) + 1 + 7) / 8 * 8, a.RB < OPNET_MAX_GY ? a.RB : OPNET_MAX_GY, 1);
     const stack_step_fn stepk = stack_step_kernel(a.RB);
     for (int s = 0; s < T + 2 * L - 1; ++s) stepk<<<grid, stack_step_threads(a.RB), 0, st>>>(a, s);
@@ -2140,7 +2208,12 @@ extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float 
     // C[M][N] = act(A[M][K] W[N][K]^T + b) = a 1x1 "convolution" over M pixels: the LDS-staged tiled kernel
     auto gemm = [&](const float *A, const float *Wt, const float *b, float *C, int N, int K, int act) {
         if ((long)((M + 127) / 128) * ((N + 127) / 128) < 256) {   // too few 128-tiles to fill the chip
-            gemm_bias_act<<<dim3((M + 63) / 64, (N + 63) / 64, 1), 256, 0, st>>>(A, Wt, b, C, M, N, K, act);
+            // ... and with fewer than 256 64-tiles (one clip: S = 300) even those leave CUs idle behind long serial K walks:
+            // 32 x 32 tiles with K split over the workgroup's waves
+            if ((K & 63) == 0 && (long)((M + 63) / 64) * ((N + 63) / 64) < 256 && env_int("OPSEQ_GEMM_KS", 1))
+                gemm_bias_act_ks<<<dim3((M + 31) / 32, (N + 31) / 32, 1), 256, 0, st>>>(A, Wt, b, C, M, N, K, act);
+            else
+                gemm_bias_act<<<dim3((M + 63) / 64, (N + 63) / 64, 1), 256, 0, st>>>(A, Wt, b, C, M, N, K, act);
             return;
         }
         ConvArgs c = {};

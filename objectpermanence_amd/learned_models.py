@@ -29,6 +29,15 @@ class AbstractCaterModel(nn.Module):
         self.bb_in_dim = 5
         self.bb_out_dim = 4
 
+    # the persistent-launch bookkeeping of the models whose LSTM stack runs through a _LstmStackRunner (OPNet has its own)
+    def launch_guard(self):
+        r = getattr(self, "_runner", None)
+        return r.launch_guard() if r is not None else None
+
+    def training_step_aborted(self) -> bool:
+        r = getattr(self, "_runner", None)
+        return r.training_step_aborted() if r is not None else False
+
 
 class LSTMWeights(nn.Module):
     """Parameter holder with torch.nn.LSTM's parameter names and default init (bias=False,
@@ -264,13 +273,13 @@ class OPNet(AbstractCaterModel):
         return bad
 
     def launch_guard(self):
-        """device address of the abort word the current training workspace's persistent launches raise (None: no such
-        launches for this shape) - FusedAdam's guard"""
+        """the abort word (a 1-element int32 view of the current training workspace) that the persistent launches of a
+        training step raise; None: no such launches for this shape - FusedAdam's guard"""
         if self._tws is None or self._tws_key is None:
             return None
         B, T, _ = self._tws_key
         off = _lib.load().opnet_train_status_offset(B, T, self._h1, self._h2)
-        return None if off == _lib.NO_OFFSET else self._tws.data_ptr() + off
+        return None if off == _lib.NO_OFFSET else self._tws[off:off + 4].view(torch.int32)
 
     def _redo_on_chain(self, boxes: torch.Tensor, y: torch.Tensor, logits: torch.Tensor) -> None:
         with torch.no_grad(), torch.cuda.device(boxes.device):
@@ -592,6 +601,10 @@ class _StackTrainFunction(torch.autograd.Function):
         ctx.runner, ctx.gen, ctx.shape = runner, runner.train_gen, (B, T)
         ctx.wshapes = [tuple(w.shape) for w in weights]
         ctx.need_dx = x.requires_grad
+        # the persistent training forward (H = 512 stacks): its abort words are mirrored to the host behind the launch
+        off = lib.opseq_lstm_stack_train_status_offset(B, T, L, KX, H)
+        if off != _lib.NO_OFFSET and lib.opseq_xcd_supported(L, KX, H):
+            runner._monitor.watch(runner.tws, off, runner._note_training_abort, "seqx_forward (training)")
         return y
 
     @staticmethod
@@ -666,6 +679,25 @@ class _LstmStackRunner:
         self._xws: Dict[tuple, torch.Tensor] = {}
         self._monitor = LaunchMonitor()
         self.xcd_launches = 0            # statistics: forwards that ran as one persistent launch
+
+    def _note_training_abort(self) -> None:
+        self._train_aborted = True
+
+    def training_step_aborted(self) -> bool:
+        """after a sync: did the persistent forward of a training step give up?  (y and the loss are NaN, the guarded
+        FusedAdam left the weights alone.)  Switches this process to the launch chain and clears the flag."""
+        self._monitor.verify()
+        bad, self._train_aborted = getattr(self, "_train_aborted", False), False
+        if bad:
+            _lib.load().opseq_xcd_enable(0)
+        return bad
+
+    def launch_guard(self):
+        if self.tws is None or self.tws_key is None:
+            return None
+        B, T, _ = self.tws_key
+        off = _lib.load().opseq_lstm_stack_train_status_offset(B, T, self.L, self.KX, self.H)
+        return None if off == _lib.NO_OFFSET else self.tws[off:off + 4].view(torch.int32)
 
     def _wants_xcd(self, B: int) -> bool:
         if self.use_xcd in ("0", 0, False):

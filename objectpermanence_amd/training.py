@@ -73,13 +73,12 @@ def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.O
     # device-side guards of the optimiser step (optim.FusedAdam): an aborted persistent launch (its gradients are NaN) or a
     # non-finite loss must not reach the weights; the host learns of it at its next sync point (step_aborted below)
     if hasattr(optimizer, "abort_ptr"):
-        optimizer.abort_ptr = guard_word
+        optimizer.abort_ptr = guard_word.data_ptr() if guard_word is not None else None
         optimizer.loss_ptr = loss.data_ptr() if (loss.is_cuda and n_local > 0) else None
         optimizer.guard_ptr = bucket.guard.data_ptr() if (distributed and bucket.flat.is_cuda) else None
     if distributed and bucket.flat.is_cuda:
         if guard_word is not None:      # this rank's abort word -> the guard slot the all-reduce sums over the ranks
-            off = guard_word - model._tws.data_ptr()
-            bucket.guard.copy_(model._tws[off:off + 4].view(torch.int32))
+            bucket.guard.copy_(guard_word)
         else:
             bucket.guard.zero_()
     if distributed:
@@ -119,7 +118,7 @@ def step_aborted(model: torch.nn.Module, group: Optional[dist.ProcessGroup] = No
     if bucket is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 \
             and bucket.flat.is_cuda and float(bucket.guard) != 0.0:
         bad = True
-        if fn is not None:
-            from . import _lib
-            _lib.load().opnet_xcd4_enable(0)
+        from . import _lib              # some OTHER rank's launch gave up: every rank leaves the persistent kernels together
+        _lib.load().opnet_xcd4_enable(0)
+        _lib.load().opseq_xcd_enable(0)
     return bad

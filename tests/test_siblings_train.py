@@ -59,9 +59,21 @@ def test_torch_port_matches_reference(golden_dir, name, tag):
     _check(g, pre, loss, grads, 2e-4)
 
 
+@pytest.fixture
+def stack_engine(request):
+    """"auto": the product's choice - the H = 512 stacks run their forward (inference AND training) as one persistent launch
+    (csrc/seq_xcd_kernels.hip); "chain": one launch per time step (csrc/seq_kernels.hip) for everything"""
+    from objectpermanence_amd import _lib
+    lib = _lib.load()
+    lib.opseq_xcd_enable(0 if request.param == "chain" else 1)
+    yield request.param
+    lib.opseq_xcd_enable(1)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("stack_engine", ["auto", "chain"], indirect=True)
 @pytest.mark.parametrize("name,tag", CASES)
-def test_hip_gradients_match_reference(golden_dir, name, tag):
+def test_hip_gradients_match_reference(golden_dir, name, tag, stack_engine):
     import torch
     from objectpermanence_amd import ModelsFactory, l1_mean
     g = np.load(os.path.join(golden_dir, "siblings_train.npz"))
@@ -76,6 +88,10 @@ def test_hip_gradients_match_reference(golden_dir, name, tag):
     loss.backward()
     torch.cuda.synchronize()
     _check(g, pre, float(loss.detach()), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}, 5e-4)
+    if hasattr(m, "_runner"):
+        persistent = stack_engine == "auto" and tag == "real"
+        assert m._runner._monitor.pending() == (1 if persistent else 0)     # the training forward was watched <=> persistent
+        assert not m.training_step_aborted()
     with torch.no_grad():
         y_inf = _y(m(torch.from_numpy(x).cuda()))
     if name == "transformer_lstm":      # materialised-softmax training kernels vs the flash inference kernel
