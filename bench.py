@@ -115,8 +115,11 @@ def parse():
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the independent steps are spread over (step i runs on stream i %% S); "
                          "0 = calibrate S in {1,2,3,4} on untimed steps before the warm-up and keep the fastest")
-    ap.add_argument("--mode", choices=["infer", "train", "detect"], default="infer",
-                    help="infer = the BASELINE metric (default); train = fwd + L1 + bwd + Adam step (configs 2/5)")
+    ap.add_argument("--mode", choices=["infer", "train", "detect", "transformer"], default="infer",
+                    help="infer = the BASELINE metric (default); train = fwd + L1 + bwd + Adam step (configs 2/5); "
+                         "transformer = transformer_lstm inference, one clip per step (config 3); detect = config 4's front-end")
+    ap.add_argument("--heads", type=int, default=4, help="--mode transformer: attention heads (BASELINE.json config 3 says 4; "
+                                                         "configs/transformer_lstm_model_config.json ships 2)")
     ap.add_argument("--gather-every", type=int, default=16,
                     help="N > 1: steps of a stream whose predictions are all-gathered in ONE collective (fewer, larger messages)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the N > 1 exchange path even with one rank")
@@ -364,6 +367,141 @@ def bench_detect(args, world, rank, dev, dist):
         emit(line)
 
 
+def bench_transformer(args, world, rank, dev, dist):
+    """BASELINE.json config 3: transformer_lstm (d_model 256, `--heads` heads, 2 encoder layers, 2 LSTM layers of 512),
+    one step = one forward of `--batch` clips (default ONE clip: S = 300 tokens - the reference's sequence-first encoder
+    attends over all B x 300 frames of a minibatch, so the clip count IS the sequence length).  Clips of different steps
+    are independent: weak scaling over ranks, no collective."""
+    from objectpermanence_amd import ModelsFactory, _lib
+    from synthdata import opnet as synth
+    lib = _lib.load()
+    cfg = {"boxes_features_dim": 256, "num_attention_heads": args.heads, "num_attention_layers": 2, "num_lstm_layers": 2,
+           "lstm_hidden_dim": 512}
+    B = args.batch or 1
+    params = synth.transformer_lstm_synth_params(cfg)
+    model = ModelsFactory.get_model("transformer_lstm", cfg)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model.eval().to(dev)
+    boxes_np, _ = synth.make_batch(rank * B, B, T_FRAMES)
+    x_np = synth.boxes5(boxes_np)
+    x = torch.from_numpy(x_np).to(dev)
+    last = {}
+
+    def region():
+        with torch.no_grad():
+            for _ in range(args.steps):
+                last["y"] = model(x)
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            model(x)
+    torch.cuda.synchronize(dev)
+    lib.opnet_xcd_profile(1)
+    elapsed, t_min, t_max, _all = timed_repeats(args, dev, dist, world, region)
+    prof = {}
+    for tag, name in ((1, "seqx"), (2, "attn")):
+        kms, nl = ctypes.c_double(0.0), ctypes.c_int(0)
+        _lib.check(lib.opnet_kernel_profile_read(tag, ctypes.byref(kms), ctypes.byref(nl)), "opnet_kernel_profile_read")
+        prof[name] = (kms.value, nl.value)
+    lib.opnet_xcd_profile(0)
+    from objectpermanence_amd.launch_monitor import verify_launches
+    if verify_launches(model):
+        raise SystemExit("bench: a persistent launch aborted; no line is printed for such a run")
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    S, E, H, FFN = B * T_FRAMES, 256, 512, 2048
+    clips_per_s = world * B * args.steps / elapsed
+    # algorithmic work (SURVEY.md 8-d4): the stacked LSTM 2 x T x (4H (E + H) + 4H (H + H)) flop per clip; attention 4 S^2 E
+    # per layer (Q K^T and P V); the live encoder (slot 0 only) per layer S (E 3E + E E + 2 E FFN) MAC + attention
+    stack_flop = 2 * B * T_FRAMES * (4 * H * (E + H) + 4 * H * (H + H))
+    attn_flop = 4 * S * S * E                      # one attention call
+    enc_flop = 2 * (2 * S * (E * 3 * E + E * E + 2 * E * FFN) + attn_flop)
+    stack_ms = prof["seqx"][0] / max(prof["seqx"][1], 1)
+    attn_ms = prof["attn"][0] / max(prof["attn"][1], 1)
+    persistent = prof["seqx"][1] > 0
+    line = {
+        "metric": "CATER clips/sec transformer_lstm inference (BASELINE.json config 3)",
+        "value": round(clips_per_s, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "repeats": max(1, args.repeats), "value_is": "median over the repeats of the timed region",
+        "value_min": round(world * B * args.steps / t_max, 1), "value_max": round(world * B * args.steps / t_min, 1),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"transformer_lstm inference, {B} clip(s) per step x 300 frames = one sequence of S = {S} tokens "
+                               f"(seq_len 300 per clip), d_model 256, {args.heads} heads, 2 encoder layers (FFN 2048), 2 LSTM "
+                               "layers of 512, slot-0 path (exact: slots 1..14 never reach the output), input resident in HBM",
+                   "global_batch": world * B, "frames": T_FRAMES, "parallelism": f"dp{world}", "heads": args.heads,
+                   "weights": "synthetic (synthdata/opnet.py counter RNG), fp32",
+                   "engine": "stacked LSTM as one persistent launch (seqx_forward)" if persistent else "launch per time step"},
+        "flop_per_step": {"lstm_stack": stack_flop, "encoder_live": enc_flop},
+        "whole_job_mfma_frac": round(clips_per_s / world / B * (stack_flop + enc_flop) / (MFMA_F32_PEAK_TF * 1e12), 4),
+    }
+    if persistent:
+        tf = stack_flop / (stack_ms * 1e-3) / 1e12
+        # north_star's per-time-step weight-streaming model of the same recurrence: all LSTM weights once per step per launch
+        w_bytes = 4 * (4 * H * (E + H) + 4 * H * (H + H))
+        model_gbs = T_FRAMES * (w_bytes + B * 4 * (E + 4 * H * 2)) / (stack_ms * 1e-3) / 1e9
+        line["roofline"] = {"bound": "mfma", "achieved": round(tf, 3), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": round(tf / MFMA_F32_PEAK_TF, 4), **pmc_traffic("seqx_forward", B),
+                            "kernel": "seqx_forward<16, 2> (both LSTM layers, all 300 steps, one launch; 2 of 8 XCDs busy with one "
+                                      "4-clip group - a latency chain of 300 dependent steps, not a throughput kernel)",
+                            "launch_ms": round(stack_ms, 4), "launches": prof["seqx"][1], "alg_flop_per_launch": stack_flop,
+                            "us_per_time_step": round(stack_ms * 1e3 / T_FRAMES, 3),
+                            "timing": "HIP events around every launch of the kernel on its stream (opnet_xcd_profile)"}
+        line["roofline_hbm_model"] = {"bound": "hbm", "achieved": round(model_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(model_gbs / HBM_PEAK_GBS, 4),
+                                      "note": "SURVEY.md 8-d4 streaming-model bytes (14.7 MB of LSTM weights once per time step) "
+                                              "over the kernel time; the kernel itself reads the weights once per launch"}
+    if prof["attn"][1] > 0:
+        tfa = attn_flop / (attn_ms * 1e-3) / 1e12
+        line["roofline_attention"] = {"bound": "mfma", "achieved": round(tfa, 3), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                      "frac": round(tfa / MFMA_F32_PEAK_TF, 4), "kernel": "attention_glds (+ attention_merge when the "
+                                      "key sweep is split)", "call_ms": round(attn_ms, 4), "calls": prof["attn"][1],
+                                      "alg_flop_per_call": attn_flop}
+    # other minibatch sizes (S = B x 300): one forward each, outside the timed region
+    extra = {}
+    for b in (16, 32):
+        if b == B:
+            continue
+        bx, _ = synth.make_batch(0, b, T_FRAMES)
+        xb = torch.from_numpy(synth.boxes5(bx)).to(dev)
+        with torch.no_grad():
+            model(xb)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                model(xb)
+            e1.record()
+            torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / 5
+        extra[str(b)] = {"ms_per_forward": round(ms, 3), "clips_per_s": round(b / ms * 1e3, 1), "S": b * T_FRAMES}
+    line["other_minibatches"] = extra
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_port                                   # cpu_baseline leg + parity of the last output
+        threads = max(1, min(os.cpu_count() or 1, 16))
+        torch.set_num_threads(threads)
+        pt = {k: torch.from_numpy(v) for k, v in params.items()}
+        xt = torch.from_numpy(x_np)
+        with torch.no_grad():
+            y_cpu = torch_port.transformer_lstm_forward(xt, pt, args.heads)
+            t1, n_cpu = time.perf_counter(), 0
+            while time.perf_counter() - t1 < args.cpu_seconds or n_cpu < 3:
+                torch_port.transformer_lstm_forward(xt, pt, args.heads)
+                n_cpu += 1
+            dt = time.perf_counter() - t1
+        line["cpu_baseline"] = {"value": round(n_cpu * B / dt, 2), "unit": "clips/s", "cores": threads, "kind": "port",
+                                "sample": f"{n_cpu} forwards of {B} clip(s) x 300 frames, oracle/torch_port.transformer_lstm_forward "
+                                          f"(slot-0 path on torch CPU ops, fp32), {dt:.1f} s"}
+        err = float((last["y"].cpu() - y_cpu).abs().max())
+        line["parity_max_abs_dy_vs_cpu_port"] = err
+        if not err < 1e-4:
+            raise SystemExit(f"bench: HIP output differs from the CPU port by {err}")
+    emit(line)
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one process
     per GPU, rendezvous on 127.0.0.1) and return its exit code."""
@@ -432,6 +570,10 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
 
+    if args.mode == "transformer":
+        if args.steps == 200:
+            args.steps, args.warmup = 50, 5
+        return bench_transformer(args, world, rank, dev, dist)
     if args.mode == "detect":
         args.batch = args.batch or 16     # frames per pass
         if args.steps == 200:

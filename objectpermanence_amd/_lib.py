@@ -49,6 +49,8 @@ def _declare(lib):
     lib.opnet_xcd_profile.argtypes = [c_int]
     lib.opnet_xcd_profile_read.restype = c_int
     lib.opnet_xcd_profile_read.argtypes = [POINTER(c_double), POINTER(c_int)]
+    lib.opnet_kernel_profile_read.restype = c_int
+    lib.opnet_kernel_profile_read.argtypes = [c_int, POINTER(c_double), POINTER(c_int)]
     lib.opnet_xcd_set_trace.restype = None
     lib.opnet_xcd_set_trace.argtypes = [c_void_p]
     lib.opnet_xcd4_max_batch.restype = c_int
@@ -211,7 +213,7 @@ EXPORTS = [
     "opnet_plan_destroy", "opnet_postprocess_iou",
     "opnet_xcd_max_batch", "opnet_xcd_supported", "opnet_xcd_workspace_bytes", "opnet_xcd_forward_f32", "opnet_xcd_forward_multi_f32", "opnet_xcd_set_trace", "opnet_xcd4_set_trace", "opnet_xcd4_last_status", "opnet_xcd4_max_batch", "opnet_xcd4_packed_weights_bytes",
     "opnet_xcd4_workspace_bytes", "opnet_xcd4_pack_weights_f32", "opnet_xcd4_forward_f32",
-    "opnet_xcd_profile", "opnet_xcd_profile_read",
+    "opnet_xcd_profile", "opnet_xcd_profile_read", "opnet_kernel_profile_read",
     "opnet_train_packed_weights_bytes", "opnet_train_pack_weights_f32", "opnet_train_workspace_bytes",
     "opnet_train_forward_f32", "opnet_train_backward_f32", "opnet_l1_loss_f32", "opnet_smooth_l1_loss_f32", "opnet_adam_step_f32", "opnet_adam_multi_step_f32",
     "opnet_adam_multi_step_guarded_f32", "opnet_xcd4_status_offset", "opnet_train_status_offset", "opnet_xcd4_enable", "opnet_xcd4_enabled",

@@ -347,37 +347,67 @@ static std::mutex g_xcd_mu;
 static hipEvent_t g_xcd_done[64] = {};
 static int g_xcd_cus[64] = {};
 
-// Measurement (bench.py): with profiling on, every launch of the persistent kernel is bracketed by a pair of HIP events
-// on the caller's stream; opnet_xcd_profile_read waits for them and returns the summed kernel time.
+// Measurement (bench.py): with profiling on, every launch of a profiled kernel (tag 0: opnet_xcd_forward, 1: seqx_forward,
+// 2: the attention kernel(s) of one attention call) is bracketed by a pair of HIP events on the caller's stream;
+// opnet_kernel_profile_read waits for them and returns the summed kernel time of a tag.
+#define PROF_XCD 0
+#define PROF_SEQX 1
+#define PROF_ATTN 2
+#define PROF_TAGS 3
+typedef std::pair<hipEvent_t, hipEvent_t> ProfPair;
 static bool g_xcd_prof = false;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_xcd_prof_ev;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_xcd_prof_pool;
+static std::vector<ProfPair> g_prof_ev[PROF_TAGS];
+static std::vector<ProfPair> g_prof_pool;
+static std::mutex g_prof_mu;
 
 extern "C" int opnet_xcd_profile(int enable)
 {
-    std::lock_guard<std::mutex> lock(g_xcd_mu);
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     g_xcd_prof = enable != 0;
-    for (auto &e : g_xcd_prof_ev) g_xcd_prof_pool.push_back(e);
-    g_xcd_prof_ev.clear();
+    for (auto &v : g_prof_ev) {
+        for (auto &e : v) g_prof_pool.push_back(e);
+        v.clear();
+    }
     return OPNET_OK;
 }
 
-extern "C" int opnet_xcd_profile_read(double *kernel_ms_total, int *launches)
+extern "C" int opnet_kernel_profile_read(int tag, double *kernel_ms_total, int *launches)
 {
     if (!kernel_ms_total || !launches) return fail(OPNET_EINVAL, "null pointer");
-    std::lock_guard<std::mutex> lock(g_xcd_mu);
+    if (tag < 0 || tag >= PROF_TAGS) return fail(OPNET_EINVAL, "profile tag %d out of range", tag);
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     double total = 0.0;
-    for (auto &e : g_xcd_prof_ev) {
+    for (auto &e : g_prof_ev[tag]) {
         HIP_TRY(hipEventSynchronize(e.second));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
         total += ms;
     }
     *kernel_ms_total = total;
-    *launches = (int)g_xcd_prof_ev.size();
-    for (auto &e : g_xcd_prof_ev) g_xcd_prof_pool.push_back(e);
-    g_xcd_prof_ev.clear();
+    *launches = (int)g_prof_ev[tag].size();
+    for (auto &e : g_prof_ev[tag]) g_prof_pool.push_back(e);
+    g_prof_ev[tag].clear();
     return OPNET_OK;
+}
+extern "C" int opnet_xcd_profile_read(double *kernel_ms_total, int *launches)
+{
+    return opnet_kernel_profile_read(PROF_XCD, kernel_ms_total, launches);
+}
+
+// begin / end of one profiled launch (no-ops unless profiling is on)
+static bool prof_begin(hipStream_t st, ProfPair *pe)
+{
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (!g_xcd_prof) return false;
+    if (!g_prof_pool.empty()) { *pe = g_prof_pool.back(); g_prof_pool.pop_back(); }
+    else if (hipEventCreate(&pe->first) != hipSuccess || hipEventCreate(&pe->second) != hipSuccess) return false;
+    return hipEventRecord(pe->first, st) == hipSuccess;
+}
+static void prof_end(int tag, hipStream_t st, const ProfPair &pe)
+{
+    (void)hipEventRecord(pe.second, st);
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    g_prof_ev[tag].push_back(pe);
 }
 
 static int xcd_device_cus(int dev)
@@ -440,12 +470,8 @@ static int xcd_forward_impl(const XcdSources &src, const float *packed, float *y
     opnet_xcd_pack_input<<<dim3(T + 2, L.NGT), 384, 0, st>>>(src, a);
     if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
     else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
-    std::pair<hipEvent_t, hipEvent_t> pe{};
-    if (g_xcd_prof) {
-        if (!g_xcd_prof_pool.empty()) { pe = g_xcd_prof_pool.back(); g_xcd_prof_pool.pop_back(); }
-        else { HIP_TRY(hipEventCreate(&pe.first)); HIP_TRY(hipEventCreate(&pe.second)); }
-        HIP_TRY(hipEventRecord(pe.first, st));
-    }
+    ProfPair pe{};
+    const bool prof = prof_begin(st, &pe);
     // three or more groups on the fullest XCD (they set the launch's duration): the "head once" form (the selection head on
     // one wave per XCD and phase, LSTM2 one more step behind); fewer: every CU computes the head (the exchange is on the
     // critical path there and a lone head wave lengthens it: 88 k against 106 k clips/s at 256 clips, 68 k against 75 k at
@@ -453,10 +479,7 @@ static int xcd_forward_impl(const XcdSources &src, const float *packed, float *y
     const int ho = env_int("OPNET_XCD_HO", (L.NGT + XCD_COUNT - 1) / XCD_COUNT >= 3 ? 1 : 0);
     if (ho) opnet_xcd_forward<true><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
     else opnet_xcd_forward<false><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
-    if (g_xcd_prof) {
-        HIP_TRY(hipEventRecord(pe.second, st));
-        g_xcd_prof_ev.push_back(pe);
-    }
+    if (prof) prof_end(PROF_XCD, st, pe);
     HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
     opnet_xcd_out_head<<<dim3(T, L.NGT), 256, 0, st>>>(a, y);
     HIP_TRY(hipGetLastError());
@@ -1779,9 +1802,12 @@ extern "C" int opseq_xcd_forward_f32(const float *x, const float *packed, const 
         std::lock_guard<std::mutex> lock(g_xcd_mu);           // two persistent grids must never be co-resident
         if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
         else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
+        ProfPair pe{};
+        const bool prof = prof_begin(st, &pe);
         if (L == 1) seqx_forward<5, 1, false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
         else if (nxq0 == 16) seqx_forward<16, 2, false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
         else seqx_forward<0, 2, false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
+        if (prof) prof_end(PROF_SEQX, st, pe);
         HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
     }
     seqx_out_head<<<dim3(T, a.NGT), 64, 0, st>>>(a);
@@ -2018,9 +2044,12 @@ extern "C" int opseq_lstm_stack_train_forward_f32(const float *x, const float *p
             std::lock_guard<std::mutex> lock(g_xcd_mu);
             if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
             else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
+            ProfPair pe{};
+            const bool prof = prof_begin(st, &pe);
             if (L == 1) seqx_forward<5, 1, true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sx);
             else if (nxq0 == 16) seqx_forward<16, 2, true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sx);
             else seqx_forward<0, 2, true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sx);
+            if (prof) prof_end(PROF_SEQX, st, pe);
             HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
         }
         seqx_out_head<<<dim3(T, sx.NGT), 64, 0, st>>>(sx);
@@ -2223,7 +2252,12 @@ extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float 
         launch_conv_tiled(c, M, st);
     };
     gemm(z, in_w, in_b, qkv, 3 * E, E, 0);
-    launch_attention(qkv, att, M, E, nhead, hd, hid, (size_t)S * ffn * sizeof(float), st);   // hid is free until the FFN
+    {
+        ProfPair pe{};
+        const bool prof = prof_begin(st, &pe);
+        launch_attention(qkv, att, M, E, nhead, hd, hid, (size_t)S * ffn * sizeof(float), st);   // hid is free until the FFN
+        if (prof) prof_end(PROF_ATTN, st, pe);
+    }
     gemm(att, out_w, out_b, proj, E, E, 0);
     add_layernorm<<<(M + 3) / 4, 256, 0, st>>>(z, proj, n1_w, n1_b, z1, M, E, 1e-5f);
     gemm(z1, l1_w, l1_b, hid, ffn, E, 1);
