@@ -445,7 +445,7 @@ def bench_transformer(args, world, rank, dev, dist):
         model_gbs = T_FRAMES * (w_bytes + B * 4 * (E + 4 * H * 2)) / (stack_ms * 1e-3) / 1e9
         line["roofline"] = {"bound": "mfma", "achieved": round(tf, 3), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                             "frac": round(tf / MFMA_F32_PEAK_TF, 4), **pmc_traffic("seqx_forward", B),
-                            "kernel": "seqx_forward<16, 2> (both LSTM layers, all 300 steps, one launch; 2 of 8 XCDs busy with one "
+                            "kernel": "seqx_forward<64, 2> (both LSTM layers, all 300 steps, one launch; 2 of 8 XCDs busy with one "
                                       "4-clip group - a latency chain of 300 dependent steps, not a throughput kernel)",
                             "launch_ms": round(stack_ms, 4), "launches": prof["seqx"][1], "alg_flop_per_launch": stack_flop,
                             "us_per_time_step": round(stack_ms * 1e3 / T_FRAMES, 3),

@@ -1664,12 +1664,13 @@ static int stack_forward_impl(const float *x, const float *packed, float *y, voi
 // ---- the stacked LSTM as ONE persistent launch (seq_xcd_kernels.hip) -------------------------------------------------
 // Shapes it is built for: H = 512, L = 1 or 2, layer-0 input either hoisted (KX % 16 == 0 and KX >= 2 H: NonLinearLstm) or
 // direct with KX <= 256 in the instantiated quarter widths (BaselineLstm 75 -> 5 k-quads a wave, TransformerLstm 256 -> 16).
-static int seqx_nxq0(int KX, int H) { return stack_hoists_input(KX, H) ? 0 : (KX + 15) / 16; }
+// k-quads of layer 0's direct input (K padded to 16): 20 for KX = 65..80, 64 for KX = 241..256; 0 = hoisted
+static int seqx_nxq0(int KX, int H) { return stack_hoists_input(KX, H) ? 0 : 4 * ((KX + 15) / 16); }
 static bool seqx_dims(int L, int KX, int H)
 {
     if (H != SX_H || L < 1 || L > 2 || KX <= 0) return false;
-    const int nxq0 = seqx_nxq0(KX, H);
-    return (L == 1 && nxq0 == 5) || (L == 2 && (nxq0 == 16 || nxq0 == 0));
+    const int nxt0 = seqx_nxq0(KX, H);
+    return (L == 1 && nxt0 == 20) || (L == 2 && (nxt0 == 64 || nxt0 == 0));
 }
 static std::atomic<int> g_seqx_enabled{1};
 extern "C" void opseq_xcd_enable(int on) { g_seqx_enabled.store(on ? 1 : 0); }
@@ -1776,7 +1777,7 @@ extern "C" int opseq_xcd_forward_f32(const float *x, const float *packed, const 
     const int RB = (B + 31) / 32;
     SeqXArgs a;
     memset(&a, 0, sizeof(a));
-    a.B = B; a.T = T; a.L = L; a.NGT = (B + 3) / 4; a.RB = RB; a.KXQ = 4 * nxq0;
+    a.B = B; a.T = T; a.L = L; a.NGT = (B + 3) / 4; a.RB = RB; a.KXQ = nxq0;
     a.pk = packed + PK.regs;
     a.whead = w_head;
     a.ws = w;
@@ -1795,7 +1796,7 @@ extern "C" int opseq_xcd_forward_f32(const float *x, const float *packed, const 
         c.OH = 1; c.OW = B * T; c.KP = KX; c.relu = 0;
         launch_conv_tiled(c, (long)B * T, st);
     } else {
-        rows_to_packed<<<1024, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, RB, KX, 16 * nxq0, nullptr, 0);
+        rows_to_packed<<<1024, 256, 0, st>>>(x, (float4 *)(w + W.xp), B, T, RB, KX, 4 * nxq0, nullptr, 0);
     }
     seqx_init<<<512, 256, 0, st>>>(a);
     {
@@ -1804,8 +1805,8 @@ extern "C" int opseq_xcd_forward_f32(const float *x, const float *packed, const 
         else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
         ProfPair pe{};
         const bool prof = prof_begin(st, &pe);
-        if (L == 1) seqx_forward<5, 1, false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
-        else if (nxq0 == 16) seqx_forward<16, 2, false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
+        if (L == 1) seqx_forward<20, 1, false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
+        else if (nxq0 == 64) seqx_forward<64, 2, false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
         else seqx_forward<0, 2, false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(a);
         if (prof) prof_end(PROF_SEQX, st, pe);
         HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
@@ -2024,7 +2025,7 @@ extern "C" int opseq_lstm_stack_train_forward_f32(const float *x, const float *p
         HIP_TRY(hipGetDevice(&dev));
         SeqXArgs sx;
         memset(&sx, 0, sizeof(sx));
-        sx.B = B; sx.T = T; sx.L = L; sx.NGT = (B + 3) / 4; sx.RB = a.RB; sx.KXQ = 4 * nxq0;
+        sx.B = B; sx.T = T; sx.L = L; sx.NGT = (B + 3) / 4; sx.RB = a.RB; sx.KXQ = nxq0;
         sx.pk = packed + TP.seqx;
         sx.whead = packed + TP.whead;
         sx.ws = w;
@@ -2046,8 +2047,8 @@ extern "C" int opseq_lstm_stack_train_forward_f32(const float *x, const float *p
             else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
             ProfPair pe{};
             const bool prof = prof_begin(st, &pe);
-            if (L == 1) seqx_forward<5, 1, true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sx);
-            else if (nxq0 == 16) seqx_forward<16, 2, true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sx);
+            if (L == 1) seqx_forward<20, 1, true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sx);
+            else if (nxq0 == 64) seqx_forward<64, 2, true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sx);
             else seqx_forward<0, 2, true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sx);
             if (prof) prof_end(PROF_SEQX, st, pe);
             HIP_TRY(hipEventRecord(g_xcd_done[dev], st));

@@ -22,19 +22,21 @@
 // launch (slot 0 = the zero initial state, every other word pre-armed with the sentinel 0xffffffff by seqx_init), so there is
 // no re-arming, no flow control, and the top layer's buffer is what the output head reads afterwards.
 //
-// A phase = (group gi, step t).  Wave w (one per SIMD) owns the K quarter w of both products of the CU's 64 gate rows:
-//   x side: W_ih . input[t]   input = the packed x (layer 0, K <= 256), or the lower layer's h[t] (K = 512) gathered from its
-//           cross-XCD copy; its weights sit in AGPRs (the MFMA reads an AccVGPR as its A operand directly);
-//           (hoisted layer 0: no x side - the cell adds the GEMM's gate pre-activations)
-//   h side: W_hh . h[t-1]     gathered from the layer's own exchange buffer (XCD-local stores when the placement check of
-//           opnet_xcd_kernels.hip passed, write-through otherwise); weights in VGPRs.
-// Both inputs of a wave are ITS OWN quarter of the k range: gathered by that wave into wave-private LDS, read back as B
-// operands (one ds_read_b128 = four k of one clip, the same address in all 16 blocks) - the only workgroup barrier of a phase is
-// the one between the K-split partials and the cell.  The x side does not depend on the recurrence: it is computed FIRST, while
-// the previous phase's h is still on its way (wave 0 computes the previous phase's cell, publishes, and then does its x side
-// under the exchange latency), so the serial chain of a step is  cell -> publish -> gather -> h side (128 MFMAs) -> barrier.
-// Summation order: gate = ((w0 + w1) + w2) + w3 over the K quarters [+ hoisted pre-activation]; a quarter = (c0 + c1) + (c2 + c3)
-// over four interleaved ascending-k chains (k mod 4), the x part of a chain before its h part.
+// A phase = (group gi, step t).  The two products of the CU's 64 gate rows are K-split over its four waves (one per SIMD):
+//   h side: W_hh . h[t-1]     every wave its K quarter (128 MFMAs); h gathered from the layer's own exchange buffer (XCD-local
+//           stores when the placement check of opnet_xcd_kernels.hip passed, write-through otherwise); weights in VGPRs.
+//   x side: W_ih . input[t]   waves 1..3 a THIRD of K each (wave 0 is the cell wave and has none); input = the packed x (layer 0,
+//           K <= 256) or the lower layer's h[t] (K = 512) gathered from its cross-XCD copy; the weights sit in AGPRs (the
+//           MFMA reads an AccVGPR as its A operand directly).  Hoisted layer 0: no x side - the cell adds the GEMM's output.
+// Both inputs of a wave are ITS OWN slice of the k range: gathered by that wave into wave-private LDS, read back as B operands
+// (one ds_read_b128 = four k of one clip, the same address in all 16 blocks) - the only workgroup barrier of a phase is the one
+// between the K-split partials and the cell.  The x side does not depend on the recurrence: waves 1..3 compute it FIRST, while
+// wave 0 computes the previous phase's cell and publishes h, so the serial chain of a step is
+//   cell -> publish -> [exchange] -> gather -> h side (128 MFMAs) -> barrier
+// on every layer (first version: x side split four ways with wave 0 doing its quarter after the cell - 2.17 us a step on the
+// second layer against 1.68 us on a single layer).
+// Summation order: gate = ((w0 + w1) + w2) + w3 over the waves' partials [+ hoisted pre-activation]; a wave's partial =
+// (c0 + c1) + (c2 + c3) over four interleaved ascending-k chains (k mod 4), the x part of a chain before its h part.
 // Every poll is bounded (XCD_SPIN_LIMIT): an abort raises status[0], every poller leaves, seqx_out_head fills y with NaN.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,17 +45,21 @@
 
 #define SX_H 512
 #define SX_NGMAX 8             // groups per XCD (pair) one launch carries
-#define SX_XQMAX 32            // k-quads of a wave's x side (K = 512: the lower layer's h)
+#define SX_XT1 128             // k-quads of an upper layer's x side (K = 512: the lower layer's h)
 
-struct SeqXPacked { size_t ah[2], ax[2], total; int nxq[2]; };      // offsets in floats; nxq = x-side k-quads per wave
-__host__ __device__ inline SeqXPacked seqx_packed_layout(int L, int NXQ0)
+// x side: NXT k-quads split over the three x waves; wave xi (= w - 1) owns [sx_xstart(NXT, xi), sx_xstart(NXT, xi + 1))
+__host__ __device__ constexpr int sx_xstart(int NXT, int xi) { return NXT * xi / 3; }
+__host__ __device__ constexpr int sx_xw(int NXT) { return (NXT + 2) / 3; }         // register quads an x wave holds (padded)
+
+struct SeqXPacked { size_t ah[2], ax[2], total; int nxt[2]; };      // offsets in floats; nxt = x-side k-quads of the layer
+__host__ __device__ inline SeqXPacked seqx_packed_layout(int L, int NXT0)
 {
     SeqXPacked P;
     size_t o = 0;
     for (int l = 0; l < 2; ++l) {
-        P.nxq[l] = l == 0 ? NXQ0 : SX_XQMAX;
-        P.ah[l] = o; if (l < L) o += (size_t)32 * 4 * 32 * 256;             // [cu][wave][q][lane] float4
-        P.ax[l] = o; if (l < L) o += (size_t)32 * 4 * P.nxq[l] * 256;
+        P.nxt[l] = l == 0 ? NXT0 : SX_XT1;
+        P.ah[l] = o; if (l < L) o += (size_t)32 * 4 * 32 * 256;                     // [cu][wave][q][lane] float4
+        P.ax[l] = o; if (l < L) o += (size_t)32 * 3 * sx_xw(P.nxt[l]) * 256;        // [cu][x wave][q][lane] float4
     }
     P.total = o;
     return P;
@@ -61,7 +67,7 @@ __host__ __device__ inline SeqXPacked seqx_packed_layout(int L, int NXQ0)
 
 struct SeqXArgs {
     int B, T, L, NGT;          // NGT = ceil(B / 4) groups of 4 clips
-    int RB, KXQ;               // packed input: row blocks of 32 clips, k-quads per clip (4 * NXQ0)
+    int RB, KXQ;               // packed input: row blocks of 32 clips, k-quads per clip (= NXT0)
     const float *pk;           // seqx_packed_layout image
     const float *whead;        // predictions_layer.weight [4][512], the caller's row-major tensor
     char *ws;                  // workspace base; the offsets below are bytes into it (one buffer descriptor)
@@ -84,24 +90,30 @@ typedef float sx_f32x4 __attribute__((ext_vector_type(4)));
 #define SX_MFMA_V(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
 #define SX_MFMA_A(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(av), "v"(bv))
 
-// fp32 weights -> the register images (lane = 4 b + i: unit 16 cu + b, gate i; element e of quad q of wave w: k = 4 (NQ w + q) + e)
+// fp32 weights -> the register images (lane = 4 b + i: unit 16 cu + b, gate i).  h side: element e of quad q of wave w is
+// k = 4 (32 w + q) + e; x side: element e of quad q of x wave xi is k = 4 (sx_xstart(NXT, xi) + q) + e, zero beyond the wave's share
 __global__ void __launch_bounds__(256) seqx_pack(float *__restrict__ out, const float *__restrict__ w_ih0, const float *__restrict__ w_hh0,
-                                                 const float *__restrict__ w_ih1, const float *__restrict__ w_hh1, int L, int NXQ0, int KX)
+                                                 const float *__restrict__ w_ih1, const float *__restrict__ w_hh1, int L, int NXT0, int KX)
 {
-    const SeqXPacked P = seqx_packed_layout(L, NXQ0);
+    const SeqXPacked P = seqx_packed_layout(L, NXT0);
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < P.total; idx += (size_t)gridDim.x * blockDim.x) {
         const int e = idx & 3, lane = (idx >> 2) & 63, b = lane >> 2, i = lane & 3;
-        int l = (L == 2 && idx >= P.ah[1]) ? 1 : 0;
+        const int l = (L == 2 && idx >= P.ah[1]) ? 1 : 0;
         const bool xs = idx >= P.ax[l];
         const size_t r = (idx - (xs ? P.ax[l] : P.ah[l])) >> 8;
-        const int nq = xs ? P.nxq[l] : 32;
-        const int q = r % nq, w = (r / nq) % 4, cu = r / (4 * nq);
-        const int k = 4 * (nq * w + q) + e;
-        const size_t row = (size_t)i * SX_H + 16 * cu + b;
-        float v;
-        if (!xs) v = (l == 0 ? w_hh0 : w_hh1)[row * SX_H + k];
-        else if (l == 0) v = k < KX ? w_ih0[row * KX + k] : 0.f;
-        else v = w_ih1[row * SX_H + k];
+        float v = 0.f;
+        if (!xs) {
+            const int q = r % 32, w = (r / 32) % 4, cu = r / 128;
+            const int k = 4 * (32 * w + q) + e;
+            v = (l == 0 ? w_hh0 : w_hh1)[((size_t)i * SX_H + 16 * cu + b) * SX_H + k];
+        } else {
+            const int nxt = P.nxt[l], nw = sx_xw(nxt);
+            const int q = r % nw, xi = (r / nw) % 3, cu = r / (3 * nw);
+            const int kq = sx_xstart(nxt, xi) + q;
+            const int k = 4 * kq + e;
+            const size_t rr = (size_t)i * SX_H + 16 * cu + b;
+            if (kq < sx_xstart(nxt, xi + 1)) v = l == 0 ? (k < KX ? w_ih0[rr * KX + k] : 0.f) : w_ih1[rr * SX_H + k];
+        }
         out[idx] = v;
     }
 }
@@ -178,17 +190,17 @@ __device__ __forceinline__ void sx_products(sx_f32x4 (&c)[4], const AT &A, const
     }
 }
 
-// NXQ0: k-quads per wave of layer 0's direct input (0 = hoisted: the cell adds G); L: layers; TRAIN: keep the backward's histories
-template <int NXQ0, int L, bool TRAIN>
+// NXT0: k-quads of layer 0's direct input (0 = hoisted: the cell adds G); L: layers; TRAIN: keep the backward's histories
+template <int NXT0, int L, bool TRAIN>
 __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
 {
-    constexpr int NXQ1 = SX_XQMAX;
-    constexpr int NXMAX = L == 2 ? NXQ1 : (NXQ0 > 0 ? NXQ0 : 1);
-    __shared__ __attribute__((aligned(1024))) float4 sH[4][128];       // wave-private: the wave's quarter of h[t-1]
-    __shared__ __attribute__((aligned(1024))) float4 sX[4][4 * NXMAX]; // wave-private: the wave's quarter of the x-side input
-    __shared__ __attribute__((aligned(16))) float4 sP[2][4][64];       // K-split partials by phase parity
+    constexpr int NXW0 = sx_xw(NXT0), NXW1 = sx_xw(SX_XT1);
+    constexpr int NXWMAX = L == 2 ? NXW1 : (NXW0 > 0 ? NXW0 : 1);
+    __shared__ __attribute__((aligned(1024))) float4 sH[4][128];         // wave-private: the wave's quarter of h[t-1]
+    __shared__ __attribute__((aligned(1024))) float4 sX[3][4 * NXWMAX];  // x-wave-private: its third of the x-side input
+    __shared__ __attribute__((aligned(16))) float4 sP[2][4][64];         // K-split partials by phase parity
     __shared__ float sC[SX_NGMAX][64];
-    __shared__ float4 sPad[3840];          // 60 KB never used: > 80 KB of LDS in total keep a second workgroup off the CU (every
+    __shared__ float4 sPad[4096];          // 64 KB never used: > 80 KB of LDS in total keep a second workgroup off the CU (every
                                            // CU must host exactly one of the 256 workgroups, or the exchange waits for a block
                                            // that is not resident)
     __shared__ volatile int sAbort, sLocal;
@@ -211,19 +223,24 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
         }
     }
     for (int i = tid; i < SX_NGMAX * 64; i += 256) (&sC[0][0])[i] = 0.f;
-    if (a.debug & 0x40000000) sPad[tid * 15] = make_float4(0.f, 0.f, 0.f, 0.f);     // (keeps the padding allocated)
+    if (a.debug & 0x40000000) sPad[tid * 16] = make_float4(0.f, 0.f, 0.f, 0.f);     // (keeps the padding allocated)
     // this XCD's layer: its buffers and histories (selected here once - indexing the kernarg arrays by l costs scratch)
     const unsigned hl_mine = l == 0 ? a.hl_off[0] : a.hl_off[1];
     const unsigned hc_mine = a.hc_off[0];                        // only layer 0 of L = 2 has a reader on another XCD
     float *const hall_mine = l == 0 ? a.hall[0] : a.hall[1];
     float *const call_mine = l == 0 ? a.call[0] : a.call[1];
     float4 *const gsave_mine = l == 0 ? a.gsave[0] : a.gsave[1];
-    const size_t pk_ah = l == 0 ? seqx_packed_layout(L, NXQ0).ah[0] : seqx_packed_layout(L, NXQ0).ah[1];
-    const size_t pk_ax = l == 0 ? seqx_packed_layout(L, NXQ0).ax[0] : seqx_packed_layout(L, NXQ0).ax[1];
+    const size_t pk_ah = l == 0 ? seqx_packed_layout(L, NXT0).ah[0] : seqx_packed_layout(L, NXT0).ah[1];
+    const size_t pk_ax = l == 0 ? seqx_packed_layout(L, NXT0).ax[0] : seqx_packed_layout(L, NXT0).ax[1];
+    // the x side of this wave: x wave xi = w - 1 owns k-quads [xs0, xs0 + xcnt) of the layer's NXT
+    const bool upper = L == 2 && l == 1;
+    const int nxt = upper ? SX_XT1 : NXT0;
+    const int xi = w > 0 ? w - 1 : 0;
+    const int xs0 = nxt * xi / 3, xcnt = w > 0 ? nxt * (xi + 1) / 3 - xs0 : 0;
 
     // ---- resident weights: h side in VGPRs, x side in AccVGPRs -----------------------------------------------------------
     float ah[128];
-    float ax[4 * NXMAX];
+    float ax[4 * NXWMAX];
     {
         const float4 *ph = (const float4 *)(a.pk + pk_ah) + ((size_t)(c * 4 + w) * 32) * 64 + lane;
 #pragma unroll
@@ -231,12 +248,12 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
             const float4 v = ph[q * 64];
             ah[4 * q] = v.x; ah[4 * q + 1] = v.y; ah[4 * q + 2] = v.z; ah[4 * q + 3] = v.w;
         }
-        const int nq = l == 0 ? NXQ0 : NXQ1;
-        const float4 *px = (const float4 *)(a.pk + pk_ax) + ((size_t)(c * 4 + w) * nq) * 64 + lane;
+        const int nw = upper ? NXW1 : NXW0;
+        const float4 *px = (const float4 *)(a.pk + pk_ax) + ((size_t)(c * 3 + xi) * nw) * 64 + lane;
 #pragma unroll
-        for (int q = 0; q < NXMAX; ++q) {
+        for (int q = 0; q < NXWMAX; ++q) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < nq) v = px[q * 64];
+            if (w > 0 && q < nw) v = px[q * 64];
             asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(ax[4 * q]) : "v"(v.x));
             asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(ax[4 * q + 1]) : "v"(v.y));
             asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(ax[4 * q + 2]) : "v"(v.z));
@@ -251,33 +268,38 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
     const bool local = __builtin_amdgcn_readfirstlane(sLocal) != 0;
     const bool top = l == L - 1;
     const int nph = T * ng;
-    const unsigned slot_bytes = 128 * 64;                        // one step of one group: 128 k-quads x 4 clips x 16 B
+    constexpr int NLD = (NXWMAX + 15) / 16;                      // 1-KB pieces (16 k-quads x 4 clips) an x wave loads per phase
 
     int gi = 0, t = 0;              // the phase this iteration computes the products of
     int gp = 0, tp = 0;             // the previous phase (whose cell wave 0 computes now)
     for (int p = 0; p <= nph; ++p) {
         const bool work = p < nph;
         const int G = gi * NPAIR + pr;                           // group of this phase: clips 4 G .. 4 G + 3
-        // ---- (1) ask for this phase's x-side input (it does not depend on the recurrence) ---------------------------------
-        xcd_u32x4 xr[2];
-        xr[0] = xr[1] = (xcd_u32x4){0u, 0u, 0u, 0u};
+        // ---- (1) x waves: ask for this phase's x-side input (it does not depend on the recurrence) ------------------------
+        xcd_u32x4 xr[NLD];
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) xr[r] = (xcd_u32x4){0u, 0u, 0u, 0u};
         unsigned xsrc = 0;
-        if (work) {
-            if (L == 2 && l == 1) {
-                xsrc = a.hc_off[0] + ((unsigned)(G * (T + 1) + t + 1) * 128 + 32 * w) * 64;
-                xr[0] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, xsrc, 16);
-                xr[1] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, xsrc + 1024, 16);
-            } else if (NXQ0 > 0) {
+        if (work && w > 0) {
+            if (upper) {
+                xsrc = a.hc_off[0] + ((unsigned)(G * (T + 1) + t + 1) * 128 + xs0) * 64;
+#pragma unroll
+                for (int r = 0; r < NLD; ++r)
+                    if ((lane >> 2) + 16 * r < xcnt) xr[r] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, xsrc + r * 1024, 16);
+            } else if (NXT0 > 0) {
                 const int rb = (4 * G) >> 5, cb = (4 * G) & 31;
-                const unsigned o = a.xp_off + ((unsigned)((t * a.RB + rb) * a.KXQ) + NXQ0 * w) * 512;
-                if ((lane >> 2) < NXQ0) xr[0] = __builtin_amdgcn_raw_buffer_load_b128(rws, ((lane >> 2) * 32 + cb + j) * 16, o, 0);
+                const unsigned o = a.xp_off + ((unsigned)((t * a.RB + rb) * a.KXQ) + xs0) * 512;
+#pragma unroll
+                for (int r = 0; r < NLD; ++r)
+                    if ((lane >> 2) + 16 * r < xcnt)
+                        xr[r] = __builtin_amdgcn_raw_buffer_load_b128(rws, (((lane >> 2) + 16 * r) * 32 + cb + j) * 16, o, 0);
             }
         }
         // ---- (2) wave 0: the cell of the previous phase (learned_models.py:110 / 146 / 192), publish h ------------------------
         if (w == 0 && p > 0 && !(a.debug & 4)) {
             const int Gp = gp * NPAIR + pr;
             float4 xg = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (NXQ0 == 0 && l == 0) {                           // hoisted input product: G[(clip * T + t)][4 unit .. 4 unit + 3]
+            if (NXT0 == 0 && l == 0) {                           // hoisted input product: G[(clip * T + t)][4 unit .. 4 unit + 3]
                 int clip = 4 * Gp + j;
                 clip = clip < a.B ? clip : a.B - 1;
                 xg = *(const float4 *)(a.ws + a.g_off + (((size_t)clip * T + tp) * (4 * SX_H) + (size_t)(16 * c + b) * 4) * 4);
@@ -310,17 +332,29 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
         sx_f32x4 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = (sx_f32x4){0.f, 0.f, 0.f, 0.f};
-        // ---- (3) x side ---------------------------------------------------------------------------------------------------
-        if (L == 2 && l == 1) {
-            ok = sx_poll<2>(rws, lane16, xsrc, xr, a.status, p);
-            sX[w][lane] = x4_as_float4(xr[0]);
-            sX[w][64 + lane] = x4_as_float4(xr[1]);
+        // ---- (3) x side (waves 1..3) --------------------------------------------------------------------------------------
+        if (w > 0 && (upper || NXT0 > 0)) {
+            if (upper) {
+                // the lower layer's h[t] from another XCD: wait until no lane sees the sentinel any more
+                long long t0 = 0;
+                for (unsigned spins = 1;; ++spins) {
+                    bool bad = false;
+#pragma unroll
+                    for (int r = 0; r < NLD; ++r) bad |= sx_unpublished(xr[r]);
+                    if (!__any(bad)) break;
+                    if (!x4_keep_polling(spins, t0, a.status, p)) { ok = false; break; }
+#pragma unroll
+                    for (int r = 0; r < NLD; ++r)
+                        if ((lane >> 2) + 16 * r < xcnt) xr[r] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, xsrc + r * 1024, 16);
+                }
+            }
+            float4 *SX = &sX[xi][0];
+#pragma unroll
+            for (int r = 0; r < NLD; ++r)
+                if (64 * r + lane < 4 * NXWMAX) SX[64 * r + lane] = x4_as_float4(xr[r]);      // (zeros beyond the wave's share)
             XCD_WAVE_LDS_SYNC();
-            sx_products<NXQ1, true>(acc, ax, &sX[w][0] + j);
-        } else if (NXQ0 > 0) {
-            if ((lane >> 2) < NXQ0) sX[w][lane] = x4_as_float4(xr[0]);
-            XCD_WAVE_LDS_SYNC();
-            sx_products<NXQ0, true>(acc, ax, &sX[w][0] + j);
+            if (upper) sx_products<NXW1, true>(acc, ax, SX + j);
+            else sx_products<NXW0, true>(acc, ax, SX + j);
         }
         // ---- (4) h side: this wave's quarter of h[t-1] (slot t) --------------------------------------------------------------
         {
