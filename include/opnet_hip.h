@@ -245,6 +245,8 @@ int opseq_xcd_forward_f32(const float *x, const float *packed, const float *w_he
  * writes the h / c / gate histories its backward reads; its status words sit at this offset of the TRAINING workspace
  * ((size_t)-1: this shape trains on the launch chain) */
 size_t opseq_lstm_stack_train_status_offset(int B, int T, int L, int KX, int H);
+/* tools: device buffer of >= 8 * 4 * (T * groups per XCD) * 8 uint64 receiving s_memtime stamps of CU 0 of every XCD (NULL = off) */
+void opseq_xcd_set_trace(void *device_buffer);
 
 void opseq_graph_cache_clear(void);
 /* training of the stacked LSTM: forward keeping the history in `workspace`, then BPTT + weight gradients.

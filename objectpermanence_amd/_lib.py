@@ -144,6 +144,8 @@ def _declare(lib):
     lib.opseq_xcd_forward_f32.argtypes = [fp, fp, fp, fp, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.opseq_lstm_stack_train_status_offset.restype = c_size_t
     lib.opseq_lstm_stack_train_status_offset.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    lib.opseq_xcd_set_trace.restype = None
+    lib.opseq_xcd_set_trace.argtypes = [c_void_p]
     lib.opseq_graph_cache_clear.restype = None
     lib.opseq_graph_cache_clear.argtypes = []
     lib.opseq_lstm_stack_train_packed_bytes.restype = c_size_t
@@ -222,7 +224,7 @@ EXPORTS = [
     "opseq_lstm_stack_packed_bytes", "opseq_lstm_stack_workspace_bytes", "opseq_lstm_stack_pack_weights_f32",
     "opseq_lstm_stack_forward_f32", "opseq_lstm_stack_forward_graph_f32", "opseq_graph_cache_clear",
     "opseq_xcd_supported", "opseq_xcd_enable", "opseq_xcd_max_batch", "opseq_xcd_packed_bytes", "opseq_xcd_workspace_bytes",
-    "opseq_xcd_status_offset", "opseq_xcd_pack_weights_f32", "opseq_xcd_forward_f32", "opseq_lstm_stack_train_status_offset",
+    "opseq_xcd_status_offset", "opseq_xcd_pack_weights_f32", "opseq_xcd_forward_f32", "opseq_lstm_stack_train_status_offset", "opseq_xcd_set_trace",
     "opseq_slot_embed_relu_f32", "opseq_slot_embed_relu_bwd_f32",
     "opseq_lstm_stack_train_packed_bytes", "opseq_lstm_stack_train_workspace_bytes",
     "opseq_lstm_stack_train_pack_weights_f32", "opseq_lstm_stack_train_forward_f32",

@@ -1673,6 +1673,9 @@ static bool seqx_dims(int L, int KX, int H)
     return (L == 1 && nxt0 == 20) || (L == 2 && (nxt0 == 64 || nxt0 == 0));
 }
 static std::atomic<int> g_seqx_enabled{1};
+// tools: in-kernel timeline of CU 0 of every XCD (device buffer of >= 8 * 4 * phases * 8 uint64; NULL = off)
+static unsigned long long *g_seqx_trace = nullptr;
+extern "C" void opseq_xcd_set_trace(void *device_buffer) { g_seqx_trace = (unsigned long long *)device_buffer; }
 extern "C" void opseq_xcd_enable(int on) { g_seqx_enabled.store(on ? 1 : 0); }
 extern "C" int opseq_xcd_supported(int L, int KX, int H)
 {
@@ -1787,6 +1790,7 @@ extern "C" int opseq_xcd_forward_f32(const float *x, const float *packed, const 
     a.ystage = (float4 *)y;
     a.force_safe = env_int("OPNET_XCD_SAFE", 0);
     a.debug = env_int("OPSEQ_XCD_DEBUG", 0);
+    a.trace = g_seqx_trace;
     if (nxq0 == 0) {
         if (!aligned16(x)) return fail(OPNET_EINVAL, "x must be 16-byte aligned");
         // G [B*T][4H] = x [B*T][KX] . W_ih0^T (a 1 x 1 "conv" over B*T pixels); the cell reads it where it lies

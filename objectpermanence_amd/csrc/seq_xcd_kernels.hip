@@ -36,7 +36,8 @@
 // on every layer (first version: x side split four ways with wave 0 doing its quarter after the cell - 2.17 us a step on the
 // second layer against 1.68 us on a single layer).
 // Summation order: gate = ((w0 + w1) + w2) + w3 over the waves' partials [+ hoisted pre-activation]; a wave's partial =
-// (c0 + c1) + (c2 + c3) over four interleaved ascending-k chains (k mod 4), the x part of a chain before its h part.
+// ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7)) over eight interleaved ascending-k chains (k mod 8; chain = 4 * (k-quad
+// parity) + k mod 4), the x part of a chain before its h part.
 // Every poll is bounded (XCD_SPIN_LIMIT): an abort raises status[0], every poller leaves, seqx_out_head fills y with NaN.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,9 +48,15 @@
 #define SX_NGMAX 8             // groups per XCD (pair) one launch carries
 #define SX_XT1 128             // k-quads of an upper layer's x side (K = 512: the lower layer's h)
 
-// x side: NXT k-quads split over the three x waves; wave xi (= w - 1) owns [sx_xstart(NXT, xi), sx_xstart(NXT, xi + 1))
-__host__ __device__ constexpr int sx_xstart(int NXT, int xi) { return NXT * xi / 3; }
-__host__ __device__ constexpr int sx_xw(int NXT) { return (NXT + 2) / 3; }         // register quads an x wave holds (padded)
+// x side: NXT k-quads split over the last SX_XWAVES waves; x wave xi (= w - (4 - SX_XWAVES)) owns [sx_xstart(NXT, xi),
+// sx_xstart(NXT, xi + 1)).  4 = every wave (the cell wave does its share between its publish and the arrival of the
+// others' h); 3 = the cell wave has none (measured: the three x waves then carry 300 MFMAs a phase on the upper layer and
+// the cell wave idles 2 200 cycles at the barrier: transformer_lstm one clip 0.875 ms against 0.81)
+#ifndef SX_XWAVES
+#define SX_XWAVES 4
+#endif
+__host__ __device__ constexpr int sx_xstart(int NXT, int xi) { return NXT * xi / SX_XWAVES; }
+__host__ __device__ constexpr int sx_xw(int NXT) { return (NXT + SX_XWAVES - 1) / SX_XWAVES; }   // register quads an x wave holds (padded)
 
 struct SeqXPacked { size_t ah[2], ax[2], total; int nxt[2]; };      // offsets in floats; nxt = x-side k-quads of the layer
 __host__ __device__ inline SeqXPacked seqx_packed_layout(int L, int NXT0)
@@ -59,7 +66,7 @@ __host__ __device__ inline SeqXPacked seqx_packed_layout(int L, int NXT0)
     for (int l = 0; l < 2; ++l) {
         P.nxt[l] = l == 0 ? NXT0 : SX_XT1;
         P.ah[l] = o; if (l < L) o += (size_t)32 * 4 * 32 * 256;                     // [cu][wave][q][lane] float4
-        P.ax[l] = o; if (l < L) o += (size_t)32 * 3 * sx_xw(P.nxt[l]) * 256;        // [cu][x wave][q][lane] float4
+        P.ax[l] = o; if (l < L) o += (size_t)32 * SX_XWAVES * sx_xw(P.nxt[l]) * 256;   // [cu][x wave][q][lane] float4
     }
     P.total = o;
     return P;
@@ -82,9 +89,16 @@ struct SeqXArgs {
     float *hall[2];            // [T + 1][RB][128][32] float4 as floats
     float *call[2];            // [T + 1][RB][512][32]
     float4 *gsave[2];          // [T][RB][512][32]
+    unsigned long long *trace; // tools: [8 XCDs][4 waves][phases][8] s_memtime stamps of CU 0 of every XCD (null = off)
 };
 
 typedef float sx_f32x4 __attribute__((ext_vector_type(4)));
+#ifndef SX_RING
+#define SX_RING 8
+#endif
+#ifndef SX_AHEAD
+#define SX_AHEAD 6
+#endif
 
 // one k of 64 gate rows x 4 clips; A in a VGPR / in an AccVGPR
 #define SX_MFMA_V(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
@@ -108,7 +122,7 @@ __global__ void __launch_bounds__(256) seqx_pack(float *__restrict__ out, const 
             v = (l == 0 ? w_hh0 : w_hh1)[((size_t)i * SX_H + 16 * cu + b) * SX_H + k];
         } else {
             const int nxt = P.nxt[l], nw = sx_xw(nxt);
-            const int q = r % nw, xi = (r / nw) % 3, cu = r / (3 * nw);
+            const int q = r % nw, xi = (r / nw) % SX_XWAVES, cu = r / (SX_XWAVES * nw);
             const int kq = sx_xstart(nxt, xi) + q;
             const int k = 4 * kq + e;
             const size_t rr = (size_t)i * SX_H + 16 * cu + b;
@@ -159,35 +173,43 @@ __device__ __forceinline__ bool sx_poll(__amdgpu_buffer_rsrc_t rws, unsigned lan
     }
 }
 
-// NQ B fragments (k-quads) out of a wave-private LDS region F (already offset by the lane's clip), four MFMAs each on the four
-// chains; the fragments travel through a ring of 4 register quads, 3 ahead (opnet_xcd4_kernels.hip: one ds_read in flight per
-// 4 MFMAs exposes every LDS latency).  AG: the A operands are AccVGPRs.
-template <int NQ, bool AG, typename AT>
-__device__ __forceinline__ void sx_products(sx_f32x4 (&c)[4], const AT &A, const float4 *F)
+// NQ B fragments (k-quads) out of a wave-private LDS region F (already offset by the lane's clip), four MFMAs each.  EIGHT
+// accumulator chains (fragment parity x element): measured with four, a dependent v_mfma_f32_4x4x1 issues every ~52 cycles and
+// the 128 MFMAs of the h side took 1 680 cycles (13 a piece) - the chains, not the pipe, set the pace.  The fragments travel
+// through a ring of 4 register quads, 3 ahead (opnet_xcd4_kernels.hip: one ds_read in flight per 4 MFMAs exposes every LDS
+// latency).  The fragments travel through a ring of SX_RING register quads, SX_AHEAD ahead: with 3 ahead (the 4-clip OPNet
+// kernel's ring) a fragment of four MFMAs took 53 cycles = a third of the ds_read_b128 latency instead of 4 x 9.5 - the LDS
+// round trip (~160 cycles), not the pipe, set the pace.
+// AG: the A operands are AccVGPRs.  `mid` runs once, after fragment MIDQ (the caller's early load issue).
+template <int NQ, bool AG, int MIDQ, typename AT, typename MID>
+__device__ __forceinline__ void sx_products(sx_f32x4 (&c)[8], const AT &A, const float4 *F, MID mid)
 {
-    if (NQ == 0) return;
-    float4 bf[4];
+    if (NQ == 0) { mid(); return; }
+    float4 bf[SX_RING];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < SX_AHEAD; ++i)
         if (i < NQ) bf[i] = F[i * 4];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        if (q + 3 < NQ) bf[(q + 3) & 3] = F[(q + 3) * 4];
+        if (q + SX_AHEAD < NQ) bf[(q + SX_AHEAD) % SX_RING] = F[(q + SX_AHEAD) * 4];
         __builtin_amdgcn_sched_barrier(0);
-        const float4 bq = bf[q & 3];
+        const float4 bq = bf[q % SX_RING];
+        const int o = (q & 1) * 4;
         if (AG) {
-            SX_MFMA_A(c[0], A[4 * q + 0], bq.x);
-            SX_MFMA_A(c[1], A[4 * q + 1], bq.y);
-            SX_MFMA_A(c[2], A[4 * q + 2], bq.z);
-            SX_MFMA_A(c[3], A[4 * q + 3], bq.w);
+            SX_MFMA_A(c[o + 0], A[4 * q + 0], bq.x);
+            SX_MFMA_A(c[o + 1], A[4 * q + 1], bq.y);
+            SX_MFMA_A(c[o + 2], A[4 * q + 2], bq.z);
+            SX_MFMA_A(c[o + 3], A[4 * q + 3], bq.w);
         } else {
-            SX_MFMA_V(c[0], A[4 * q + 0], bq.x);
-            SX_MFMA_V(c[1], A[4 * q + 1], bq.y);
-            SX_MFMA_V(c[2], A[4 * q + 2], bq.z);
-            SX_MFMA_V(c[3], A[4 * q + 3], bq.w);
+            SX_MFMA_V(c[o + 0], A[4 * q + 0], bq.x);
+            SX_MFMA_V(c[o + 1], A[4 * q + 1], bq.y);
+            SX_MFMA_V(c[o + 2], A[4 * q + 2], bq.z);
+            SX_MFMA_V(c[o + 3], A[4 * q + 3], bq.w);
         }
+        if (q == MIDQ) mid();
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (MIDQ >= NQ) mid();
 }
 
 // NXT0: k-quads of layer 0's direct input (0 = hoisted: the cell adds G); L: layers; TRAIN: keep the backward's histories
@@ -197,7 +219,7 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
     constexpr int NXW0 = sx_xw(NXT0), NXW1 = sx_xw(SX_XT1);
     constexpr int NXWMAX = L == 2 ? NXW1 : (NXW0 > 0 ? NXW0 : 1);
     __shared__ __attribute__((aligned(1024))) float4 sH[4][128];         // wave-private: the wave's quarter of h[t-1]
-    __shared__ __attribute__((aligned(1024))) float4 sX[3][4 * NXWMAX];  // x-wave-private: its third of the x-side input
+    __shared__ __attribute__((aligned(1024))) float4 sX[SX_XWAVES][4 * NXWMAX];  // x-wave-private: its share of the x-side input
     __shared__ __attribute__((aligned(16))) float4 sP[2][4][64];         // K-split partials by phase parity
     __shared__ float sC[SX_NGMAX][64];
     __shared__ float4 sPad[4096];          // 64 KB never used: > 80 KB of LDS in total keep a second workgroup off the CU (every
@@ -235,8 +257,10 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
     // the x side of this wave: x wave xi = w - 1 owns k-quads [xs0, xs0 + xcnt) of the layer's NXT
     const bool upper = L == 2 && l == 1;
     const int nxt = upper ? SX_XT1 : NXT0;
-    const int xi = w > 0 ? w - 1 : 0;
-    const int xs0 = nxt * xi / 3, xcnt = w > 0 ? nxt * (xi + 1) / 3 - xs0 : 0;
+    constexpr int XW0 = 4 - SX_XWAVES;                           // first x wave
+    const bool xwave = w >= XW0;
+    const int xi = xwave ? w - XW0 : 0;
+    const int xs0 = sx_xstart(nxt, xi), xcnt = xwave ? sx_xstart(nxt, xi + 1) - xs0 : 0;
 
     // ---- resident weights: h side in VGPRs, x side in AccVGPRs -----------------------------------------------------------
     float ah[128];
@@ -249,11 +273,11 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
             ah[4 * q] = v.x; ah[4 * q + 1] = v.y; ah[4 * q + 2] = v.z; ah[4 * q + 3] = v.w;
         }
         const int nw = upper ? NXW1 : NXW0;
-        const float4 *px = (const float4 *)(a.pk + pk_ax) + ((size_t)(c * 3 + xi) * nw) * 64 + lane;
+        const float4 *px = (const float4 *)(a.pk + pk_ax) + ((size_t)(c * SX_XWAVES + xi) * nw) * 64 + lane;
 #pragma unroll
         for (int q = 0; q < NXWMAX; ++q) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (w > 0 && q < nw) v = px[q * 64];
+            if (xwave && q < nw) v = px[q * 64];
             asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(ax[4 * q]) : "v"(v.x));
             asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(ax[4 * q + 1]) : "v"(v.y));
             asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(ax[4 * q + 2]) : "v"(v.z));
@@ -272,29 +296,37 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
 
     int gi = 0, t = 0;              // the phase this iteration computes the products of
     int gp = 0, tp = 0;             // the previous phase (whose cell wave 0 computes now)
+    // the x-side input of phase (g, tt): it does not depend on the recurrence, so it is asked for one phase early (under the h
+    // side's MFMAs) and only checked / asked again at its use
+    xcd_u32x4 xr[NLD];
+    unsigned xsrc = 0;
+    auto ask_x = [&](int g, int tt) {
+        const int GG = g * NPAIR + pr;
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) xr[r] = (xcd_u32x4){0u, 0u, 0u, 0u};
+        if (!xwave) return;
+        if (upper) {
+            xsrc = a.hc_off[0] + ((unsigned)(GG * (T + 1) + tt + 1) * 128 + xs0) * 64;
+#pragma unroll
+            for (int r = 0; r < NLD; ++r)
+                if ((lane >> 2) + 16 * r < xcnt) xr[r] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, xsrc + r * 1024, 16);
+        } else if (NXT0 > 0) {
+            const int rb = (4 * GG) >> 5, cb = (4 * GG) & 31;
+            const unsigned o = a.xp_off + ((unsigned)((tt * a.RB + rb) * a.KXQ) + xs0) * 512;
+#pragma unroll
+            for (int r = 0; r < NLD; ++r)
+                if ((lane >> 2) + 16 * r < xcnt)
+                    xr[r] = __builtin_amdgcn_raw_buffer_load_b128(rws, (((lane >> 2) + 16 * r) * 32 + cb + j) * 16, o, 0);
+        }
+    };
+    ask_x(0, 0);
+    unsigned long long *const tr = (a.trace && c == 0 && lane == 0) ? a.trace + ((size_t)(x * 4 + w) * nph) * 8 : nullptr;
+#define SX_STAMP(k) do { if (tr && p < nph) tr[(size_t)p * 8 + (k)] = clock64(); } while (0)
     for (int p = 0; p <= nph; ++p) {
         const bool work = p < nph;
         const int G = gi * NPAIR + pr;                           // group of this phase: clips 4 G .. 4 G + 3
-        // ---- (1) x waves: ask for this phase's x-side input (it does not depend on the recurrence) ------------------------
-        xcd_u32x4 xr[NLD];
-#pragma unroll
-        for (int r = 0; r < NLD; ++r) xr[r] = (xcd_u32x4){0u, 0u, 0u, 0u};
-        unsigned xsrc = 0;
-        if (work && w > 0) {
-            if (upper) {
-                xsrc = a.hc_off[0] + ((unsigned)(G * (T + 1) + t + 1) * 128 + xs0) * 64;
-#pragma unroll
-                for (int r = 0; r < NLD; ++r)
-                    if ((lane >> 2) + 16 * r < xcnt) xr[r] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, xsrc + r * 1024, 16);
-            } else if (NXT0 > 0) {
-                const int rb = (4 * G) >> 5, cb = (4 * G) & 31;
-                const unsigned o = a.xp_off + ((unsigned)((t * a.RB + rb) * a.KXQ) + xs0) * 512;
-#pragma unroll
-                for (int r = 0; r < NLD; ++r)
-                    if ((lane >> 2) + 16 * r < xcnt)
-                        xr[r] = __builtin_amdgcn_raw_buffer_load_b128(rws, (((lane >> 2) + 16 * r) * 32 + cb + j) * 16, o, 0);
-            }
-        }
+        SX_STAMP(0);
+        // ---- (1) the x-side input of this phase was asked for during the previous phase's h side (ask_x below) -----------------
         // ---- (2) wave 0: the cell of the previous phase (learned_models.py:110 / 146 / 192), publish h ------------------------
         if (w == 0 && p > 0 && !(a.debug & 4)) {
             const int Gp = gp * NPAIR + pr;
@@ -328,12 +360,22 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
             }
         }
         if (!work) break;
+        SX_STAMP(1);                            // (wave 0: the cell is done and published)
         bool ok = true;
-        sx_f32x4 acc[4];
+        sx_f32x4 acc[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = (sx_f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 8; ++q) acc[q] = (sx_f32x4){0.f, 0.f, 0.f, 0.f};
+        // this wave's quarter of h[t-1] (slot t): asked for by the x waves two thirds into their x side (when the cell of the
+        // previous phase has usually been published: the load's round trip - ~650 cycles - then hides under the remaining
+        // MFMAs), by wave 0 right after its cell; anybody who still sees a sentinel asks again
+        xcd_u32x4 hr[2];
+        const unsigned hsrc = hl_mine + ((unsigned)(G * (T + 1) + t) * 128 + 32 * w) * 64;
+        auto ask_h = [&]() {
+            hr[0] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, hsrc, 16);
+            hr[1] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, hsrc + 1024, 16);
+        };
         // ---- (3) x side (waves 1..3) --------------------------------------------------------------------------------------
-        if (w > 0 && (upper || NXT0 > 0)) {
+        if (xwave && (upper || NXT0 > 0)) {
             if (upper) {
                 // the lower layer's h[t] from another XCD: wait until no lane sees the sentinel any more
                 long long t0 = 0;
@@ -353,25 +395,37 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
             for (int r = 0; r < NLD; ++r)
                 if (64 * r + lane < 4 * NXWMAX) SX[64 * r + lane] = x4_as_float4(xr[r]);      // (zeros beyond the wave's share)
             XCD_WAVE_LDS_SYNC();
-            if (upper) sx_products<NXW1, true>(acc, ax, SX + j);
-            else sx_products<NXW0, true>(acc, ax, SX + j);
+            if (upper) sx_products<NXW1, true, (2 * NXW1) / 3>(acc, ax, SX + j, ask_h);
+            else sx_products<NXW0, true, (2 * NXW0) / 3>(acc, ax, SX + j, ask_h);
+        } else {
+            ask_h();
         }
-        // ---- (4) h side: this wave's quarter of h[t-1] (slot t) --------------------------------------------------------------
+        SX_STAMP(2);                            // (x waves: the x side is done)
+        // ---- (4) h side ---------------------------------------------------------------------------------------------------
         {
-            xcd_u32x4 hr[2];
-            const unsigned hsrc = hl_mine + ((unsigned)(G * (T + 1) + t) * 128 + 32 * w) * 64;
-            hr[0] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, hsrc, 16);
-            hr[1] = __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, hsrc + 1024, 16);
             if (ok) ok = sx_poll<2>(rws, lane16, hsrc, hr, a.status, p);
+            SX_STAMP(3);                        // h[t-1] has arrived
             sH[w][lane] = x4_as_float4(hr[0]);
             sH[w][64 + lane] = x4_as_float4(hr[1]);
+            {                                   // the next phase's x-side input: lands under the h side's MFMAs
+                int gn = gi + 1, tn = t;
+                if (gn == ng) { gn = 0; ++tn; }
+                if (tn < T) ask_x(gn, tn);
+            }
             XCD_WAVE_LDS_SYNC();
-            sx_products<32, false>(acc, ah, &sH[w][0] + j);
+            sx_products<32, false, 99>(acc, ah, &sH[w][0] + j, []() {});
         }
-        sP[p & 1][w][lane] = make_float4((acc[0][0] + acc[1][0]) + (acc[2][0] + acc[3][0]), (acc[0][1] + acc[1][1]) + (acc[2][1] + acc[3][1]),
-                                         (acc[0][2] + acc[1][2]) + (acc[2][2] + acc[3][2]), (acc[0][3] + acc[1][3]) + (acc[2][3] + acc[3][3]));
+        {
+            sx_f32x4 s4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                s4[r] = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + ((acc[4][r] + acc[5][r]) + (acc[6][r] + acc[7][r]));
+            sP[p & 1][w][lane] = make_float4(s4[0], s4[1], s4[2], s4[3]);
+        }
         if (!ok) sAbort = 1;
+        SX_STAMP(4);                            // products done
         __syncthreads();                        // the phase's partials are in sP
+        SX_STAMP(5);
         if (sAbort) return;
         gp = gi; tp = t;
         if (++gi == ng) { gi = 0; ++t; }
