@@ -22,6 +22,7 @@
 #define OPNET_HIP_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -185,6 +186,18 @@ int opnet_adam_multi_step_guarded_f32(int count, float *const *params, const flo
                                       float *const *exp_avg_sqs, const long *numels, float lr, float beta1, float beta2,
                                       float eps, int step, float grad_scale, const unsigned *abort_u32, const float *loss_f32,
                                       const float *guard_f32, void *stream);
+
+/* ---- input encoder (host code; replaces baselines/datasets.py:130-196 / :265-336 _normalize_and_pad_predictions and
+ *      :199-257 / :338-416 _get_closest_object_to_track_vector) -------------------------------------------------------
+ * Per-frame detections of n_clips clips -> boxes [n_clips][T][15][n_tracks] fp32 (slot order: snitch 140 first, then ascending
+ * class id; first detection of an id per frame, last for a repeated snitch; [x1/320, y1/240, x2/320, y2/240, 1(, is_cone)];
+ * a missing cone keeps its cone bit below the frame's largest rank) and the heuristic object-to-track vector [n_clips][T]
+ * (int64; may be NULL).  HOST pointers: counts [frames] detections per frame, ids [N], bb [N][4] pixels, clip c = frames
+ * clip_first_frame[c] .. + T and detections clip_first_det[c] .. clip_first_det[c + 1]; is_cone [n_classes] = the class table
+ * (object_indices.py:200-202).  n_tracks 5 or 6.  Returns 0 / negative error code; touches no GPU state. */
+int opnet_encode_clips_f32(const int32_t *counts, const int32_t *ids, const int32_t *bb, const int64_t *clip_first_frame,
+                           const int64_t *clip_first_det, int n_clips, int T, int n_tracks, const uint8_t *is_cone, int n_classes,
+                           float *boxes_out, int64_t *index_out);
 
 /* ---- sibling reasoners (reference learned_models.py:55-197) ----------------------------------------
  * OPNetLstmMlp (:55-89): OPNet whose video LSTM is relu(Linear 6->H2) (hidden_layer.weight [H2,6]);

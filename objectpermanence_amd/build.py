@@ -9,13 +9,13 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libopnet_hip.so")
-SOURCES = ["opnet_abi.hip", "opdet_abi.hip"]
+SOURCES = ["opnet_abi.hip", "opdet_abi.hip", "encode_host.cpp"]
 
 
 def _deps():
     """every source the two translation units can include: all of csrc/ plus the public header (a hand-kept list went stale
     when opnet_xcd4_kernels.hip was added - an edited kernel file must always make the library stale)"""
-    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".hpp"))]
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".hpp", ".cpp"))]
     out.append(os.path.join(PKG, "..", "include", "opnet_hip.h"))
     return out
 

@@ -13,6 +13,9 @@ datasets_factory.py.  The reference encodes a clip with nested Python loops and 
                  its cone bit (:311-318); then divide by [320,240,320,240,1(,1)] in float64 and cast to fp32.
 
 Results are bit-identical to the reference's (tests/test_datasets.py vs tests/golden/datasets.npz).
+The dataset classes run the NATIVE form of the same two functions (csrc/encode_host.cpp through the C ABI's
+opnet_encode_clips_f32: flat detection arrays in, ~15 us a clip); the numpy form below is the readable statement it is held
+to bit for bit (tests/test_datasets.py, oracle/fuzz_datasets.py) and the fallback when the library is absent.
 The heuristic "object to track" index vector (:199-257, :338-416) is sequential by nature and is restated
 as a small state machine; no loss uses it but it is part of the dataset tuple.
 """
@@ -94,6 +97,86 @@ def encode_boxes(bb: List[np.ndarray], labels: List[np.ndarray], n_tracks: int =
     return out
 
 
+_CONE_TABLE = None
+
+
+def _cone_table() -> np.ndarray:
+    global _CONE_TABLE
+    if _CONE_TABLE is None:
+        from .object_indices import NUM_CLASSES
+        t = np.zeros(NUM_CLASSES, dtype=np.uint8)
+        t[sorted(CONE_IDS)] = 1
+        _CONE_TABLE = t
+    return _CONE_TABLE
+
+
+def flatten_detections(bb: List[np.ndarray], labels: List[np.ndarray]):
+    """one clip's per-frame detection lists -> (counts int32 [T], ids int32 [N], boxes int32 [N, 4]): the flat form the native
+    encoder reads"""
+    T = len(labels)
+    counts = np.fromiter(map(len, labels), dtype=np.int32, count=T)
+    n = int(counts.sum())
+    if n == 0:
+        return counts, np.zeros(0, dtype=np.int32), np.zeros((0, 4), dtype=np.int32)
+    try:            # the files the reference writes: every frame an [n] / [n, 4] integer array (preprocess_perception_main.py:35-36)
+        ids = np.concatenate(labels)
+        boxes = np.concatenate(bb)
+        if ids.ndim != 1 or boxes.ndim != 2 or boxes.shape != (n, 4) or ids.shape[0] != n:
+            raise ValueError
+    except ValueError:   # lists, 0-d / empty frames of another rank: normalise frame by frame
+        ids = np.concatenate([np.asarray(l).reshape(-1) for l in labels])
+        boxes = np.concatenate([np.asarray(b).reshape(-1, 4) for b, c in zip(bb, counts) if c > 0])
+    return counts, np.ascontiguousarray(ids, dtype=np.int32), np.ascontiguousarray(boxes, dtype=np.int32)
+
+
+def encode_clips_native(counts: np.ndarray, ids: np.ndarray, boxes: np.ndarray, n_clips: int, T: int, n_tracks: int = 6,
+                        clip_first_det: np.ndarray = None, with_index: bool = True, out: np.ndarray = None,
+                        idx: np.ndarray = None):
+    """`n_clips` clips of T frames each as flat arrays (counts [n_clips * T], ids [N], boxes [N, 4]) -> (float32
+    [n_clips, T, 15, n_tracks], int64 [n_clips, T] | None) through the native encoder of libopnet_hip.so
+    (csrc/encode_host.cpp: host code, no GPU).  Bit-identical to encode_boxes + index_to_track."""
+    from . import _lib
+    lib = _lib.load()
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 4)
+    if counts.shape[0] != n_clips * T or ids.shape[0] != boxes.shape[0] or int(counts.sum(dtype=np.int64)) != ids.shape[0] \
+            or (counts.size and int(counts.min()) < 0):
+        raise ValueError("counts must hold n_clips * T frames and ids / boxes one row per counted detection")
+    first_frame = np.arange(n_clips, dtype=np.int64) * T
+    if clip_first_det is None:
+        per_clip = counts.reshape(n_clips, T).sum(axis=1, dtype=np.int64)
+        clip_first_det = np.concatenate([[0], np.cumsum(per_clip)]).astype(np.int64)
+    clip_first_det = np.ascontiguousarray(clip_first_det, dtype=np.int64)
+    if clip_first_det.shape != (n_clips + 1,) or clip_first_det[0] != 0 or clip_first_det[-1] != ids.shape[0] or \
+            np.any(np.diff(clip_first_det) < 0):
+        raise ValueError("clip_first_det must be n_clips + 1 non-decreasing offsets from 0 to the number of detections")
+    if out is None:         # (a steady-state loader passes its own - e.g. pinned - buffers: fresh pages cost more than the encode)
+        out = np.empty((n_clips, T, MAX_OBJECTS, n_tracks), dtype=np.float32)
+    if idx is None and with_index:
+        idx = np.empty((n_clips, T), dtype=np.int64)
+    if out.shape != (n_clips, T, MAX_OBJECTS, n_tracks) or out.dtype != np.float32 or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous float32 [n_clips, T, 15, n_tracks] array")
+    cone = _cone_table()
+    rc = lib.opnet_encode_clips_f32(counts.ctypes.data, ids.ctypes.data, boxes.ctypes.data, first_frame.ctypes.data,
+                                    clip_first_det.ctypes.data, n_clips, T, n_tracks, cone.ctypes.data, int(cone.shape[0]),
+                                    out.ctypes.data, idx.ctypes.data if with_index else None)
+    if rc != 0:
+        raise ValueError(f"opnet_encode_clips_f32 failed (code {rc}): inconsistent counts / shapes")
+    return out, idx
+
+
+def native_encoder_available() -> bool:
+    import os
+    if os.environ.get("OPNET_NATIVE_ENCODE", "1") == "0":
+        return False
+    try:
+        from . import _lib
+        return hasattr(_lib.load(), "opnet_encode_clips_f32")
+    except Exception:
+        return False
+
+
 def _closest(frame_centers: np.ndarray, last_location: np.ndarray) -> int:
     """slot whose box centre is nearest to the centre of `last_location` (argmin of the Euclidean norm, as
     datasets.py:186-196; the centres of every frame are computed once per clip)"""
@@ -167,6 +250,7 @@ class CaterAbstractDataset(Dataset):
         self.labels_dir = Path(label_dir)
         self.videos_names: List[str] = []
         self.label_paths: Dict[str, str] = {}
+        self._native = None          # decided at the first sample (in the process that encodes it - a DataLoader worker)
 
     def _init_dataset_if_not_initiated(self) -> None:
         if len(self.videos_names) == 0:
@@ -184,7 +268,14 @@ class CaterAbstractDataset(Dataset):
         labels = load_snitch_labels(self.label_paths[name])
         with open(str(self.predictions_dir / (name + ".pkl")), "rb") as f:
             data = pickle.load(f)
-        boxes = encode_boxes(data["bb"], data["labels"], self.n_tracks)
+        if self._native is None:
+            self._native = native_encoder_available()
+        if self._native:
+            # the native encoder (csrc/encode_host.cpp, ~15 us a clip): flat arrays in, fp32 boxes + index vector out
+            counts, ids, flat = flatten_detections(data["bb"], data["labels"])
+            boxes, idx = encode_clips_native(counts, ids, flat, 1, len(counts), self.n_tracks)
+            return (torch.from_numpy(boxes[0]), torch.from_numpy(idx[0]), torch.tensor(labels, dtype=torch.float32), name)
+        boxes = encode_boxes(data["bb"], data["labels"], self.n_tracks)      # the numpy statement of the same function
         idx_vec = index_to_track(boxes)
         return (torch.tensor(boxes, dtype=torch.float32), torch.tensor(idx_vec, dtype=torch.int64),
                 torch.tensor(labels, dtype=torch.float32), name)
