@@ -16,7 +16,11 @@
 //                  minimum (numpy.argmin), no fused multiply-add (numpy evaluates d0*d0 + d1*d1 in two roundings).
 // Bit-exact against tests/golden/datasets.npz and the 300-case fuzz against the reference's own classes
 // (tests/test_datasets.py, oracle/fuzz_datasets.py).  The reference takes 16.7 ms per clip, the numpy form 1.2 ms, this ~15 us.
+// (built twice: into libopnet_hip.so with hipcc - the C ABI's entry point - and alone into libopnet_encode.so with g++
+// -ffp-contract=off, which DataLoader worker processes load without paying for the HIP runtime's start-up)
+#ifdef __clang__
 #pragma clang fp contract(off)
+#endif
 
 #include <math.h>
 #include <stdint.h>

@@ -22,6 +22,7 @@ as a small state machine; no loss uses it but it is part
 from __future__ import annotations
 
 import json
+import os
 import pickle
 from pathlib import Path
 from typing import Dict, List, Tuple
@@ -135,8 +136,7 @@ def encode_clips_native(counts: np.ndarray, ids: np.ndarray, boxes: np.ndarray, 
     """`n_clips` clips of T frames each as flat arrays (counts [n_clips * T], ids [N], boxes [N, 4]) -> (float32
     [n_clips, T, 15, n_tracks], int64 [n_clips, T] | None) through the native encoder of libopnet_hip.so
     (csrc/encode_host.cpp: host code, no GPU).  Bit-identical to encode_boxes + index_to_track."""
-    from . import _lib
-    lib = _lib.load()
+    lib = _encoder_lib()
     counts = np.ascontiguousarray(counts, dtype=np.int32)
     ids = np.ascontiguousarray(ids, dtype=np.int32)
     boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 4)
@@ -166,13 +166,33 @@ def encode_clips_native(counts: np.ndarray, ids: np.ndarray, boxes: np.ndarray, 
     return out, idx
 
 
+_ENC_LIB = None
+
+
+def _encoder_lib():
+    """libopnet_encode.so: csrc/encode_host.cpp built alone (host code only).  The same entry point is exported by
+    libopnet_hip.so (the C ABI of include/opnet_hip.h); dataset workers load this sibling so that they never start the HIP
+    runtime (1.1 s per worker process before its first sample, measured)."""
+    global _ENC_LIB
+    if _ENC_LIB is None:
+        import ctypes
+        from . import build as _build
+        path = _build.ENCODE_LIB
+        if not os.path.exists(path):
+            _build.build_encoder()
+        lib = ctypes.CDLL(path)
+        vp = ctypes.c_void_p
+        lib.opnet_encode_clips_f32.restype = ctypes.c_int
+        lib.opnet_encode_clips_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]
+        _ENC_LIB = lib
+    return _ENC_LIB
+
+
 def native_encoder_available() -> bool:
-    import os
     if os.environ.get("OPNET_NATIVE_ENCODE", "1") == "0":
         return False
     try:
-        from . import _lib
-        return hasattr(_lib.load(), "opnet_encode_clips_f32")
+        return _encoder_lib() is not None
     except Exception:
         return False
 
