@@ -2297,7 +2297,21 @@ static void transpose_to(const float *src, long sld, float *dst, long dld, long 
 
 static unsigned ew_grid(long n) { return (unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256); }
 
-struct EncSaved { size_t z_in, qkv, P, att, u1, st1, x1, hid, u2, st2, total; long Sp; };   // offsets in floats
+struct EncSaved { size_t z_in, qkv, att, u1, st1, x1, hid, u2, st2, total; long Sp; };   // offsets in floats
+
+// The attention of the training step is evaluated in CHUNKS of Qc query rows (flash-style tiling at GEMM granularity): the
+// scores of a chunk [Qc][S] are computed, soft-maxed, used and dropped - in the forward AND again in the backward, which
+// recomputes them from q and k instead of reading a saved S x S matrix per head (737 MB per layer at S = 9600, 3.1 GiB per
+// step, S <= 23 000: round 2).  A chunk is sized to stay in the 256 MB Infinity Cache with its companions (~24 MB each).
+static long enc_chunk_rows(long S)
+{
+    const long Sp = (S + 15) / 16 * 16;
+    long qc = (6L << 20) / Sp / 64 * 64;            // ~24 MB of fp32 per chunk buffer
+    if (qc < 64) qc = 64;
+    const int forced = env_int("OPSEQ_ATTN_CHUNK", 0);          // tests: several chunks on a short sequence (a multiple of 16)
+    if (forced > 0) qc = (forced + 15) / 16 * 16;
+    return qc < S ? qc : S;
+}
 
 static EncSaved enc_saved_layout(long S, int E, int nhead, int ffn)
 {
@@ -2305,7 +2319,7 @@ static EncSaved enc_saved_layout(long S, int E, int nhead, int ffn)
     L.Sp = (S + 15) / 16 * 16;
     size_t o = 0;
     auto take = [&](size_t n) { const size_t at = o; o += (n + 63) / 64 * 64; return at; };
-    L.z_in = take((size_t)S * E);  L.qkv = take((size_t)S * 3 * E);  L.P = take((size_t)nhead * S * L.Sp);
+    L.z_in = take((size_t)S * E);  L.qkv = take((size_t)S * 3 * E);
     L.att = take((size_t)S * E);   L.u1 = take((size_t)S * E);        L.st1 = take((size_t)S * 2);
     L.x1 = take((size_t)S * E);    L.hid = take((size_t)S * ffn);     L.u2 = take((size_t)S * E);
     L.st2 = take((size_t)S * 2);
@@ -2313,7 +2327,7 @@ static EncSaved enc_saved_layout(long S, int E, int nhead, int ffn)
     return L;
 }
 
-struct EncScratch { size_t wt_in, wt_out, wt_l1, wt_l2, sq0, sq1, hT, t0, tA, tB, dqkv, e0, e1, e2, part, total; };
+struct EncScratch { size_t wt_in, wt_out, wt_l1, wt_l2, pc, sq0, sq1, sq2, hT, t0, tA, tB, dqkv, e0, e1, e2, part, total; };
 
 static EncScratch enc_scratch_layout(long S, int E, int nhead, int ffn)
 {
@@ -2325,7 +2339,8 @@ static EncScratch enc_scratch_layout(long S, int E, int nhead, int ffn)
     auto take = [&](size_t n) { const size_t at = o; o += (n + 63) / 64 * 64; return at; };
     L.wt_in = take((size_t)E * 3 * E);  L.wt_out = take((size_t)E * E);
     L.wt_l1 = take((size_t)E * ffn);    L.wt_l2 = take((size_t)ffn * E);
-    L.sq0 = take((size_t)S * Sp);       L.sq1 = take((size_t)S * Sp);
+    const size_t chunk = (size_t)((enc_chunk_rows(S) + 15) / 16 * 16) * Sp;    // one [Qc][S] / [S][Qc] attention chunk
+    L.pc = take(chunk);  L.sq0 = take(chunk);  L.sq1 = take(chunk);  L.sq2 = take(chunk);
     L.hT = take((size_t)4 * hd * Sp);   L.t0 = take((size_t)S * ffn);
     L.tA = take(wide * Sp);             L.tB = take(wide * Sp);
     L.dqkv = take((size_t)S * 3 * E);
@@ -2340,8 +2355,9 @@ static int check_encoder_train(long S, int E, int nhead, int ffn, float p_drop)
     if (int rc = check_encoder(S, E, nhead, ffn)) return rc;
     if ((E & 15) || (ffn & 15) || E > 64 * ENC_LN_MAX_PER_LANE) return fail(OPNET_ESHAPE, "E and ffn must be multiples of 16, E <= %d", 64 * ENC_LN_MAX_PER_LANE);
     if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(OPNET_EINVAL, "dropout probability must be in [0, 1)");
-    const long Sp = (S + 15) / 16 * 16;
-    if ((double)S * Sp * 4 >= 2147483648.0) return fail(OPNET_ESHAPE, "S=%ld: the S x S attention matrices exceed the GEMM kernel's 2 GiB operand limit", S);
+    const long wide = ffn > 3 * E ? ffn : 3 * E;
+    if ((double)S * wide * 4 >= 2147483648.0)
+        return fail(OPNET_ESHAPE, "S=%ld: an activation matrix exceeds the GEMM kernel's 2 GiB operand limit", S);
     return OPNET_OK;
 }
 
@@ -2398,15 +2414,19 @@ extern "C" int opseq_encoder_layer_train_forward_f32(const float *z_in, float *z
     float *zs = sv + SV.z_in, *qkv = sv + SV.qkv, *att = sv + SV.att;
     HIP_TRY(hipMemcpyAsync(zs, z_in, (size_t)S * E * 4, hipMemcpyDeviceToDevice, st));
     gemm_nt(zs, E, in_w, E, in_b, nullptr, qkv, 3 * E, S, 3 * E, E, 0, st);
+    const long QC = enc_chunk_rows(S);
     for (int h = 0; h < nhead; ++h) {
-        float *P = sv + SV.P + (size_t)h * S * Sp;
-        gemm_nt(qkv + h * hd, 3 * E, qkv + E + h * hd, 3 * E, nullptr, nullptr, P, Sp, S, (int)S, hd, 0, st);
-        float *Pd = D.thresh ? sc + SC.sq0 : nullptr;
-        enc_softmax_rows<<<(unsigned)S, 256, 0, st>>>(P, Pd, Sp, (int)S, scale, D.seed, 0u, (unsigned long long)h * S * S,
-                                                      D.thresh, D.inv_keep);
         float *Vt = sc + SC.hT;
         transpose_to(qkv + 2 * E + h * hd, 3 * E, Vt, Sp, S, hd, st);
-        gemm_nt(Pd ? Pd : P, Sp, Vt, Sp, nullptr, nullptr, att + h * hd, E, S, hd, (int)Sp, 0, st);
+        for (long q0 = 0; q0 < S; q0 += QC) {
+            const long qn = S - q0 < QC ? S - q0 : QC;                   // query rows of this chunk
+            float *P = sc + SC.pc;                                       // [qn][Sp] scores -> probabilities, not kept
+            gemm_nt(qkv + q0 * 3 * E + h * hd, 3 * E, qkv + E + h * hd, 3 * E, nullptr, nullptr, P, Sp, qn, (int)S, hd, 0, st);
+            float *Pd = D.thresh ? sc + SC.sq0 : nullptr;
+            enc_softmax_rows<<<(unsigned)qn, 256, 0, st>>>(P, Pd, Sp, (int)S, scale, D.seed, 0u,
+                                                           (unsigned long long)h * S * S + (unsigned long long)q0 * S, D.thresh, D.inv_keep);
+            gemm_nt(Pd ? Pd : P, Sp, Vt, Sp, nullptr, nullptr, att + q0 * E + h * hd, E, qn, hd, (int)Sp, 0, st);
+        }
     }
     float *e0 = sc + SC.e0;
     gemm_nt(att, E, out_w, E, out_b, nullptr, e0, E, S, E, E, 0, st);
@@ -2491,24 +2511,32 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
     float *Vt_unused = sc + SC.hT, *Kt = sc + SC.hT + (size_t)hd * Sp, *Qt = sc + SC.hT + (size_t)2 * hd * Sp,
           *dOt = sc + SC.hT + (size_t)3 * hd * Sp;
     (void)Vt_unused;
+    float *pc = sc + SC.pc, *sq2 = sc + SC.sq2;
+    const long QC = enc_chunk_rows(S);
     for (int h = 0; h < nhead; ++h) {
-        const float *P = sv + SV.P + (size_t)h * S * Sp;
-        const unsigned long long idx0 = (unsigned long long)h * S * S;
-        const float *Pu = P;                                             // the matrix that multiplied V in the forward
-        if (D.thresh) {
-            enc_attn_drop<<<ew_grid(S * Sp), 256, 0, st>>>(P, sq0, Sp, (int)S, S, D.seed, 0u, idx0, D.thresh, D.inv_keep);
-            Pu = sq0;
-        }
-        transpose_to(Pu, Sp, sq1, Sp, S, (int)S, st);                                       // P^T [key][query]
-        transpose_to(e2 + h * hd, E, dOt, Sp, S, hd, st);
-        gemm_nt(sq1, Sp, dOt, Sp, nullptr, nullptr, dqkv + 2 * E + h * hd, 3 * E, S, hd, (int)Sp, 0, st);        // dV
-        gemm_nt(e2 + h * hd, E, qkv + 2 * E + h * hd, 3 * E, nullptr, nullptr, sq0, Sp, S, (int)S, hd, 0, st);   // dP
-        enc_softmax_bwd_rows<<<(unsigned)S, 256, 0, st>>>(P, sq0, Sp, (int)S, scale, D.seed, 0u, idx0, D.thresh, D.inv_keep);
+        transpose_to(e2 + h * hd, E, dOt, Sp, S, hd, st);                                     // dO^T [hd][query]
         transpose_to(qkv + E + h * hd, 3 * E, Kt, Sp, S, hd, st);
-        gemm_nt(sq0, Sp, Kt, Sp, nullptr, nullptr, dqkv + h * hd, 3 * E, S, hd, (int)Sp, 0, st);                  // dQ
-        transpose_to(sq0, Sp, sq1, Sp, S, (int)S, st);                                                            // dS^T
         transpose_to(qkv + h * hd, 3 * E, Qt, Sp, S, hd, st);
-        gemm_nt(sq1, Sp, Qt, Sp, nullptr, nullptr, dqkv + E + h * hd, 3 * E, S, hd, (int)Sp, 0, st);              // dK
+        float *dQ = dqkv + h * hd, *dK = dqkv + E + h * hd, *dV = dqkv + 2 * E + h * hd;
+        for (long q0 = 0; q0 < S; q0 += QC) {
+            const long qn = S - q0 < QC ? S - q0 : QC;
+            const long qp = (qn + 15) / 16 * 16;                                              // the chunk as a K dimension
+            const unsigned long long idx0 = (unsigned long long)h * S * S + (unsigned long long)q0 * S;
+            // the chunk's probabilities again (the same two kernels as the forward: the same bits)
+            gemm_nt(qkv + q0 * 3 * E + h * hd, 3 * E, qkv + E + h * hd, 3 * E, nullptr, nullptr, pc, Sp, qn, (int)S, hd, 0, st);
+            const float *Pu = pc;                                        // the matrix that multiplied V in the forward
+            enc_softmax_rows<<<(unsigned)qn, 256, 0, st>>>(pc, D.thresh ? sq2 : nullptr, Sp, (int)S, scale, D.seed, 0u, idx0,
+                                                           D.thresh, D.inv_keep);
+            if (D.thresh) Pu = sq2;
+            const float *acc_v = q0 ? dV : nullptr, *acc_k = q0 ? dK : nullptr;               // later chunks accumulate
+            transpose_to(Pu, Sp, sq1, qp, qn, (int)S, st);                                    // P^T [key][query of the chunk]
+            gemm_nt(sq1, qp, dOt + q0, Sp, nullptr, acc_v, dV, 3 * E, S, hd, (int)qp, 0, st);             // dV += P^T dO
+            gemm_nt(e2 + q0 * E + h * hd, E, qkv + 2 * E + h * hd, 3 * E, nullptr, nullptr, sq0, Sp, qn, (int)S, hd, 0, st);   // dP
+            enc_softmax_bwd_rows<<<(unsigned)qn, 256, 0, st>>>(pc, sq0, Sp, (int)S, scale, D.seed, 0u, idx0, D.thresh, D.inv_keep);
+            gemm_nt(sq0, Sp, Kt, Sp, nullptr, nullptr, dQ + q0 * 3 * E, 3 * E, qn, hd, (int)Sp, 0, st);   // dQ rows of the chunk
+            transpose_to(sq0, Sp, sq1, qp, qn, (int)S, st);                                   // dS^T
+            gemm_nt(sq1, qp, Qt + q0, Sp, nullptr, acc_k, dK, 3 * E, S, hd, (int)qp, 0, st);              // dK += dS^T Q
+        }
     }
     // ---- in_proj ----
     colsum(dqkv, 3 * E, 3 * E, g_in_b);
