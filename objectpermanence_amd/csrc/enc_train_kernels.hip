@@ -51,9 +51,12 @@ __global__ void __launch_bounds__(256) enc_transpose(const float *__restrict__ s
 
 // rows of scores -> softmax(scale * row) in place (Psoft, saved); optionally Pdrop = Psoft * dropout multiplier.
 // One workgroup per row of n valid columns (row stride ld, padding columns zeroed).
+// stats (nullable): (row max of scale * score, 1 / sum of exp) per row, so that the backward can rebuild the same
+// probabilities in one pass (enc_softmax_from_stats)
 __global__ void __launch_bounds__(256) enc_softmax_rows(float *__restrict__ P, float *__restrict__ Pdrop, long ld, int n,
                                                         float scale, unsigned long long seed, unsigned site,
-                                                        unsigned long long idx0, unsigned thresh, float inv_keep)
+                                                        unsigned long long idx0, unsigned thresh, float inv_keep,
+                                                        float2 *__restrict__ stats = nullptr)
 {
     __shared__ float red[256];
     const long row = blockIdx.x;
@@ -78,8 +81,26 @@ __global__ void __launch_bounds__(256) enc_softmax_rows(float *__restrict__ P, f
         __syncthreads();
     }
     const float inv = 1.0f / red[0];
+    if (stats && tid == 0) stats[row] = make_float2(m, inv);
     for (int k = tid; k < ld; k += 256) {
         const float v = k < n ? __expf(p[k] * scale - m) * inv : 0.f;
+        p[k] = v;
+        if (Pdrop) Pdrop[row * ld + k] = k < n ? v * enc_keep(seed, site, idx0 + row * n + k, thresh, inv_keep) : 0.f;
+    }
+}
+
+// the same probabilities from the scores and the forward's saved (max, 1 / sum): the expression of enc_softmax_rows' last loop,
+// hence the same bits, without its two row reductions
+__global__ void __launch_bounds__(256) enc_softmax_from_stats(float *__restrict__ P, float *__restrict__ Pdrop, long ld, int n,
+                                                              float scale, unsigned long long seed, unsigned site,
+                                                              unsigned long long idx0, unsigned thresh, float inv_keep,
+                                                              const float2 *__restrict__ stats)
+{
+    const long row = blockIdx.x;
+    float *p = P + row * ld;
+    const float2 st = stats[row];
+    for (int k = threadIdx.x; k < ld; k += 256) {
+        const float v = k < n ? __expf(p[k] * scale - st.x) * st.y : 0.f;
         p[k] = v;
         if (Pdrop) Pdrop[row * ld + k] = k < n ? v * enc_keep(seed, site, idx0 + row * n + k, thresh, inv_keep) : 0.f;
     }
@@ -280,4 +301,72 @@ __global__ void __launch_bounds__(256) enc_relu_drop_bwd(float *__restrict__ dh,
 __global__ void __launch_bounds__(256) enc_add_inplace(float *__restrict__ a, const float *__restrict__ b, long n)
 {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) a[i] += b[i];
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Skinny, long-K products of the chunked attention (O_c = P_c V and dQ_c = dS_c K: [Qc x S] . [S x hd] - a handful of
+// 128 x 128 tiles whose K walk is the whole sequence): split K over gridDim.z workgroups, partial tiles to scratch, summed
+// in fixed slice order by enc_splitk_reduce (deterministic).  Operands K-contiguous, one float4 per lane per 16-k step
+// feeding four MFMAs, straight from L2 / Infinity Cache (the chunk was just written there) - no LDS staging.
+// Workgroup = 64 x 64 outputs, wave = 32 x 32.  part [z][M][N].  kc = k per slice (a multiple of 16).
+__global__ void __launch_bounds__(256) enc_gemm_nt_splitk(const float *__restrict__ X, long XS, const float *__restrict__ W, long WS,
+                                                          float *__restrict__ part, int M, int N, int K, int kc)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 64 + (w >> 1) * 32, n0 = blockIdx.y * 64 + (w & 1) * 32;
+    const int i = lane & 15, kk = lane >> 4;
+    const int k0 = blockIdx.z * kc;
+    const int k1 = min(K, k0 + kc);
+    const float4 *a_row[2], *w_row[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int m = min(m0 + f * 16 + i, M - 1), nn = min(n0 + f * 16 + i, N - 1);
+        a_row[f] = (const float4 *)(X + (long)m * XS + k0) + kk;
+        w_row[f] = (const float4 *)(W + (long)nn * WS + k0) + kk;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nhex = (k1 - k0) >> 4;
+#pragma unroll 4
+    for (int q = 0; q < nhex; ++q) {
+        const float4 av0 = a_row[0][q * 4], av1 = a_row[1][q * 4];
+        const float4 wv0 = w_row[0][q * 4], wv1 = w_row[1][q * 4];
+        const float ae[2][4] = {{av0.x, av0.y, av0.z, av0.w}, {av1.x, av1.y, av1.z, av1.w}};
+        const float we[2][4] = {{wv0.x, wv0.y, wv0.z, wv0.w}, {wv1.x, wv1.y, wv1.z, wv1.w}};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[x][e], we[y][e], acc[x][y], 0, 0, 0);
+    }
+    float *P = part + (long)blockIdx.z * M * N;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int nn = n0 + y * 16 + i;
+            if (nn >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + x * 16 + kk * 4 + r;
+                if (m < M) P[(long)m * N + nn] = acc[x][y][r];
+            }
+        }
+}
+
+// Y[m * YS + n] = sum_z part[z][m][n] in ascending z
+__global__ void __launch_bounds__(256) enc_splitk_reduce(const float *__restrict__ part, int KS, long MN, int N, float *__restrict__ Y, long YS)
+{
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < MN; idx += (long)gridDim.x * 256) {
+        float s = part[idx];
+        for (int z = 1; z < KS; ++z) s += part[(long)z * MN + idx];
+        const long m = idx / N;
+        Y[m * YS + (idx - m * N)] = s;
+    }
 }

@@ -2290,6 +2290,28 @@ static void gemm_nt(const float *X, long XS, const float *Wt, long WS, const flo
     else conv2d_nhwc_glds<64, 3><<<dim3(gx, (N + 63) / 64, 1), 256, 0, st>>>(c);
 }
 
+// the same product for a SKINNY output and a long K (the chunked attention's P_c V and dS_c K): K split over up to 32
+// workgroups per 64 x 64 tile, partials in `part` (>= KS * M * N floats), reduced in fixed order.  K % 16 == 0.
+static int splitk_slices(long M, int N, int K)
+{
+    const long tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    long ks = 512 / (tiles > 0 ? tiles : 1);                 // ~2 workgroups per CU
+    const long kmax = K / 128 > 0 ? K / 128 : 1;             // at least 128 k per slice
+    if (ks > kmax) ks = kmax;
+    if (ks > 32) ks = 32;
+    return ks < 1 ? 1 : (int)ks;
+}
+static void gemm_nt_splitk(const float *X, long XS, const float *Wt, long WS, float *Y, long YS, long M, int N, int K, float *part,
+                           hipStream_t st)
+{
+    const int KS = splitk_slices(M, N, K);
+    const int kc = ((K + KS - 1) / KS + 15) / 16 * 16;
+    const int ks = (K + kc - 1) / kc;
+    enc_gemm_nt_splitk<<<dim3((unsigned)((M + 63) / 64), (N + 63) / 64, ks), 256, 0, st>>>(X, XS, Wt, WS, part, (int)M, N, K, kc);
+    const long MN = M * N;
+    enc_splitk_reduce<<<(unsigned)((MN + 255) / 256 > 4096 ? 4096 : (MN + 255) / 256), 256, 0, st>>>(part, ks, MN, N, Y, YS);
+}
+
 static void transpose_to(const float *src, long sld, float *dst, long dld, long R, int C, hipStream_t st)
 {
     enc_transpose<<<dim3((unsigned)((dld + 31) / 32), (C + 31) / 32, 1), 256, 0, st>>>(src, sld, dst, dld, (int)R, C);
@@ -2297,7 +2319,7 @@ static void transpose_to(const float *src, long sld, float *dst, long dld, long 
 
 static unsigned ew_grid(long n) { return (unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256); }
 
-struct EncSaved { size_t z_in, qkv, att, u1, st1, x1, hid, u2, st2, total; long Sp; };   // offsets in floats
+struct EncSaved { size_t z_in, qkv, att, astat, u1, st1, x1, hid, u2, st2, total; long Sp; };   // offsets in floats
 
 // The attention of the training step is evaluated in CHUNKS of Qc query rows (flash-style tiling at GEMM granularity): the
 // scores of a chunk [Qc][S] are computed, soft-maxed, used and dropped - in the forward AND again in the backward, which
@@ -2306,8 +2328,20 @@ struct EncSaved { size_t z_in, qkv, att, u1, st1, x1, hid, u2, st2, total; long 
 static long enc_chunk_rows(long S)
 {
     const long Sp = (S + 15) / 16 * 16;
-    long qc = (6L << 20) / Sp / 64 * 64;            // ~24 MB of fp32 per chunk buffer
-    if (qc < 64) qc = 64;
+    // 128-row blocks per chunk: up to ~48 MB of fp32 per chunk buffer, and among those sizes the one whose score GEMM
+    // (r x ceil(S / 128) tiles of 128 x 128) fills whole rounds of the 256 CUs best (S = 9600: 10 blocks = 750 tiles = 2.93
+    // rounds; 5 blocks = 375 tiles = 1.46 rounds would idle a quarter of the chip in every launch)
+    const long colt = (Sp + 127) / 128;
+    long rmax = (12L << 20) / Sp / 128;
+    if (rmax < 1) rmax = 1;
+    long best = rmax;
+    double beff = 0.0;
+    for (long r = rmax; r >= (rmax + 1) / 2; --r) {
+        const long tiles = r * colt, rounds = (tiles + 255) / 256;
+        const double eff = (double)tiles / (double)(rounds * 256);
+        if (eff > beff + 1e-9) { beff = eff; best = r; }
+    }
+    long qc = best * 128;
     const int forced = env_int("OPSEQ_ATTN_CHUNK", 0);          // tests: several chunks on a short sequence (a multiple of 16)
     if (forced > 0) qc = (forced + 15) / 16 * 16;
     return qc < S ? qc : S;
@@ -2319,7 +2353,7 @@ static EncSaved enc_saved_layout(long S, int E, int nhead, int ffn)
     L.Sp = (S + 15) / 16 * 16;
     size_t o = 0;
     auto take = [&](size_t n) { const size_t at = o; o += (n + 63) / 64 * 64; return at; };
-    L.z_in = take((size_t)S * E);  L.qkv = take((size_t)S * 3 * E);
+    L.z_in = take((size_t)S * E);  L.qkv = take((size_t)S * 3 * E);  L.astat = take((size_t)nhead * S * 2);   // softmax (max, 1/sum) per head and row
     L.att = take((size_t)S * E);   L.u1 = take((size_t)S * E);        L.st1 = take((size_t)S * 2);
     L.x1 = take((size_t)S * E);    L.hid = take((size_t)S * ffn);     L.u2 = take((size_t)S * E);
     L.st2 = take((size_t)S * 2);
@@ -2424,8 +2458,10 @@ extern "C" int opseq_encoder_layer_train_forward_f32(const float *z_in, float *z
             gemm_nt(qkv + q0 * 3 * E + h * hd, 3 * E, qkv + E + h * hd, 3 * E, nullptr, nullptr, P, Sp, qn, (int)S, hd, 0, st);
             float *Pd = D.thresh ? sc + SC.sq0 : nullptr;
             enc_softmax_rows<<<(unsigned)qn, 256, 0, st>>>(P, Pd, Sp, (int)S, scale, D.seed, 0u,
-                                                           (unsigned long long)h * S * S + (unsigned long long)q0 * S, D.thresh, D.inv_keep);
-            gemm_nt(Pd ? Pd : P, Sp, Vt, Sp, nullptr, nullptr, att + q0 * E + h * hd, E, qn, hd, (int)Sp, 0, st);
+                                                           (unsigned long long)h * S * S + (unsigned long long)q0 * S, D.thresh, D.inv_keep,
+                                                           (float2 *)(sv + SV.astat) + (size_t)h * S + q0);
+            if (S > QC) gemm_nt_splitk(Pd ? Pd : P, Sp, Vt, Sp, att + q0 * E + h * hd, E, qn, hd, (int)Sp, sc + SC.sq1, st);
+            else gemm_nt(Pd ? Pd : P, Sp, Vt, Sp, nullptr, nullptr, att + q0 * E + h * hd, E, qn, hd, (int)Sp, 0, st);
         }
     }
     float *e0 = sc + SC.e0;
@@ -2522,18 +2558,19 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
             const long qn = S - q0 < QC ? S - q0 : QC;
             const long qp = (qn + 15) / 16 * 16;                                              // the chunk as a K dimension
             const unsigned long long idx0 = (unsigned long long)h * S * S + (unsigned long long)q0 * S;
-            // the chunk's probabilities again (the same two kernels as the forward: the same bits)
+            // the chunk's probabilities again: the forward's score GEMM and the last pass of its softmax (the same bits)
             gemm_nt(qkv + q0 * 3 * E + h * hd, 3 * E, qkv + E + h * hd, 3 * E, nullptr, nullptr, pc, Sp, qn, (int)S, hd, 0, st);
             const float *Pu = pc;                                        // the matrix that multiplied V in the forward
-            enc_softmax_rows<<<(unsigned)qn, 256, 0, st>>>(pc, D.thresh ? sq2 : nullptr, Sp, (int)S, scale, D.seed, 0u, idx0,
-                                                           D.thresh, D.inv_keep);
+            enc_softmax_from_stats<<<(unsigned)qn, 256, 0, st>>>(pc, D.thresh ? sq2 : nullptr, Sp, (int)S, scale, D.seed, 0u, idx0,
+                                                                 D.thresh, D.inv_keep, (const float2 *)(sv + SV.astat) + (size_t)h * S + q0);
             if (D.thresh) Pu = sq2;
             const float *acc_v = q0 ? dV : nullptr, *acc_k = q0 ? dK : nullptr;               // later chunks accumulate
             transpose_to(Pu, Sp, sq1, qp, qn, (int)S, st);                                    // P^T [key][query of the chunk]
             gemm_nt(sq1, qp, dOt + q0, Sp, nullptr, acc_v, dV, 3 * E, S, hd, (int)qp, 0, st);             // dV += P^T dO
             gemm_nt(e2 + q0 * E + h * hd, E, qkv + 2 * E + h * hd, 3 * E, nullptr, nullptr, sq0, Sp, qn, (int)S, hd, 0, st);   // dP
             enc_softmax_bwd_rows<<<(unsigned)qn, 256, 0, st>>>(pc, sq0, Sp, (int)S, scale, D.seed, 0u, idx0, D.thresh, D.inv_keep);
-            gemm_nt(sq0, Sp, Kt, Sp, nullptr, nullptr, dQ + q0 * 3 * E, 3 * E, qn, hd, (int)Sp, 0, st);   // dQ rows of the chunk
+            if (S > QC) gemm_nt_splitk(sq0, Sp, Kt, Sp, dQ + q0 * 3 * E, 3 * E, qn, hd, (int)Sp, sq1, st);   // dQ rows of the chunk
+            else gemm_nt(sq0, Sp, Kt, Sp, nullptr, nullptr, dQ + q0 * 3 * E, 3 * E, qn, hd, (int)Sp, 0, st);
             transpose_to(sq0, Sp, sq1, qp, qn, (int)S, st);                                   // dS^T
             gemm_nt(sq1, qp, Qt + q0, Sp, nullptr, acc_k, dK, 3 * E, S, hd, (int)qp, 0, st);              // dK += dS^T Q
         }
