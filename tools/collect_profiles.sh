@@ -1,0 +1,32 @@
+#!/bin/bash
+# Run on the GPU box from the repo root: the rocprofv3 evidence of the round -> gpurun_out/r3p/ (copied into profiles/ by hand)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r3p
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+prof() { # name, cmd...
+  local name=$1; shift
+  (cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o p -- "$@" > $O/$name.log 2>&1)
+  cp $O/$name/*kernel_stats.csv $O/${name}_kernel_stats.csv 2>/dev/null || find $O/$name -name "*kernel_stats.csv" -exec cp {} $O/${name}_kernel_stats.csv \;
+}
+pmc() { # name, counters, cmd...
+  local name=$1; local ctr=$2; shift; shift
+  (cd $R && rocprofv3 --pmc $ctr --output-format csv -d $O/$name -o p -- "$@" > $O/$name.log 2>&1)
+}
+prof bench python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --repeats 5
+prof bench_transformer python bench.py --mode transformer --no-cpu-baseline --repeats 3
+prof train python bench.py --mode train --steps 20 --warmup 5 --loss l1 --no-cpu-baseline --repeats 3
+prof siblings python tools/stack_time.py --reps 5
+pmc pmc_fetch FETCH_SIZE python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --repeats 3
+pmc pmc_write WRITE_SIZE python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --repeats 3
+pmc pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --repeats 3
+pmc pmc_mfma_tr "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" python bench.py --mode transformer --no-cpu-baseline --repeats 3
+pmc pmc_mfma_train "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" python bench.py --mode train --steps 20 --warmup 5 --loss l1 --no-cpu-baseline --repeats 3
+cd $R
+python tools/pmc_reduce.py traffic $O/pmc_fetch $O/pmc_write "opnet_xcd_forward" > $O/pmc_xcd_traffic.json 2>&1
+python tools/pmc_reduce.py mfma $O/pmc_mfma > $O/mfma_util_bench.json 2>&1
+python tools/pmc_reduce.py mfma $O/pmc_mfma_tr > $O/mfma_util_transformer.json 2>&1
+python tools/pmc_reduce.py mfma $O/pmc_mfma_train > $O/mfma_util_train.json 2>&1
+# keep only the small artefacts
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +2M -delete
+ls -la $O | head -40
