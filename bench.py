@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py - OPNet inference throughput on MI355X (the BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--batch 32] [--engine xcd|chain]
+    python bench.py --gpus N --steps K --warmup W [--batch 32] [--engine xcd|chain] [--repeats 15]
+    python bench.py --mode train | transformer | detect      (configs 2 / 5, 3, 4 - their own lines)
+
+The timed region (exactly K steps between barrier + synchronize) is run --repeats times; `value` is the median.
 
 One "step" = one pass of the hot path (OPNet.forward through libopnet_hip.so) over one batch of `--batch` synthetic CATER
 clips (300 frames x 15 slots x 6 features, fp32) that is already resident in HBM, followed by the device-side
