@@ -292,9 +292,14 @@ extern "C" int opnet_forward_f32(const float *boxes, const float *packed, float 
 // forward, per-XCD persistent form (opnet_xcd_kernels.hip): ONE launch, weights resident in registers
 // ------------------------------------------------------------------------------------------------
 struct XcdWorkspaceLayout {  // offsets in bytes
-    size_t status, flags, xp, h1h, h2h, fbh, total;
-    int NGT;
+    size_t status, flags, xp, h1h, h2h, fbh, yp, total;
+    int NGT, ring;
 };
+
+// OPNET_XCD_RING (default 1): h1 / h2 / frames_boxes as rings of XCD_RING steps and the output head as per-CU partials
+// (8 KB per step and group) instead of full histories (48.25 KB per step and group) that a second kernel reads back:
+// 0.27 instead of 0.94 MB of workspace per clip, about half the HBM traffic; 0 = round 2's layout.
+static int xcd_ring_mode() { return env_int("OPNET_XCD_RING", 1) != 0; }
 
 static XcdWorkspaceLayout xcd_workspace_layout(int B, int T)
 {
@@ -302,12 +307,15 @@ static XcdWorkspaceLayout xcd_workspace_layout(int B, int T)
     const size_t NGT = (size_t)(B + 15) / 16;
     size_t o = 0;
     L.NGT = (int)NGT;
+    L.ring = xcd_ring_mode();
+    const size_t NS = L.ring ? (size_t)XCD_RING : (size_t)(T + 1);
     L.status = o; o += 2048;                                   // 8 control words + 256 XCC ids
     L.flags = o;  o += align_up(NGT * XCD_CUS * 4, 256);
     L.xp = o;     o += NGT * (size_t)(T + 2) * OPNET_KXQ * 256;
-    L.h1h = o;    o += NGT * (size_t)(T + 1) * (XCD_H1 / 4) * 256;
-    L.h2h = o;    o += NGT * (size_t)(T + 1) * (XCD_H2 / 4) * 256;
-    L.fbh = o;    o += NGT * (size_t)(T + 1) * 1024;
+    L.h1h = o;    o += NGT * NS * (XCD_H1 / 4) * 256;
+    L.h2h = o;    o += NGT * NS * (XCD_H2 / 4) * 256;
+    L.fbh = o;    o += NGT * NS * 1024;
+    L.yp = o;     if (L.ring) o += NGT * (size_t)T * XCD_CUS * 256;
     L.total = align_up(o, 256);
     return L;
 }
@@ -459,6 +467,7 @@ static int xcd_forward_impl(const XcdSources &src, const float *packed, float *y
     a.logits = logits;
     a.ws = w;
     a.xp_off = (unsigned)L.xp; a.h1_off = (unsigned)L.h1h; a.h2_off = (unsigned)L.h2h; a.fb_off = (unsigned)L.fbh; a.flags_off = (unsigned)L.flags;
+    a.ring = L.ring; a.yp_off = (unsigned)L.yp;
     a.trace = g_xcd_trace;
     a.force_safe = env_int("OPNET_XCD_SAFE", 0);
     a.debug = env_int("OPNET_XCD_DEBUG", 0);
@@ -481,7 +490,12 @@ static int xcd_forward_impl(const XcdSources &src, const float *packed, float *y
     else opnet_xcd_forward<false><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
     if (prof) prof_end(PROF_XCD, st, pe);
     HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
-    opnet_xcd_out_head<<<dim3(T, L.NGT), 256, 0, st>>>(a, y);
+    if (a.ring) {
+        const long ny = (long)L.NGT * T * 16;
+        opnet_xcd_y_reduce<<<(unsigned)((ny + 255) / 256 > 2048 ? 2048 : (ny + 255) / 256), 256, 0, st>>>(a, y);
+    } else {
+        opnet_xcd_out_head<<<dim3(T, L.NGT), 256, 0, st>>>(a, y);
+    }
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

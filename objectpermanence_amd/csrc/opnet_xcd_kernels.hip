@@ -50,6 +50,8 @@
 #define XCD_NGMAX 8            // 16-clip groups one XCD carries in one launch (8 x 16 x 8 XCDs = 1024 clips)
 #define XCD_H1 256
 #define XCD_H2 512
+#define XCD_RING 4             // slots of the h1 / h2 / frames_boxes rings (a.ring): a CU publishes step t only after it has gathered every
+                               // CU's step t - 1, i.e. after every CU has finished reading step t - 2 and older: 3 slots are enough
 #define XCD_SPIN_LIMIT 150000000ll    // wall_clock64 ticks (100 MHz: 1.5 s) before a poller gives up
 
 // LDS gather buffer of one phase, in float4 units: X0 = x[s] | H1 = h1[s-1] | H2 = h2[s-3] | FB = frames_boxes[s-2]
@@ -73,6 +75,10 @@ struct XcdArgs {
     float *logits;             // caller's [B][15][T]
     char *ws;                  // workspace base and the byte offsets of xp / h1h / h2h / flags in it (one buffer descriptor)
     unsigned xp_off, h1_off, h2_off, fb_off, flags_off;
+    int ring;                  // 0: h1h / h2h / fbh hold the full history ([T+1] slots per group) and opnet_xcd_out_head reads h2 back;
+                               // 1: they are rings of XCD_RING slots (slot = step & 3) and the output head leaves the launch as per-CU
+                               //    partials ypart [NGT][T][32 CUs][16 clips] float4 (opnet_xcd_y_reduce sums them)
+    unsigned yp_off;
     int force_safe;            // 1: always use the placement-independent write-through protocol (tests)
     int debug;                 // tools only (wrong results): bit 0 no poll/gather, 1 no head, 2 no cells, 3 no publish, 4 no x fetch
     unsigned long long *trace; // optional [phases][8] s_memtime stamps of block 0 (product wave 0: 0-1, finish wave 4: 2-7), or null
@@ -151,11 +157,12 @@ __global__ void __launch_bounds__(384) opnet_xcd_pack_input(const XcdSources src
         ((float4 *)a.xp)[(((long)gg * (T + 2) + slot) * OPNET_KXQ + kq) * 16 + clip] = v;
     }
     if (slot == 0) {
-        float4 *h1 = a.h1h + (long)gg * (T + 1) * (XCD_H1 * 4);
-        float4 *h2 = a.h2h + (long)gg * (T + 1) * (XCD_H2 * 4);
+        const long NS = a.ring ? XCD_RING : T + 1;             // slots per group
+        float4 *h1 = a.h1h + (long)gg * NS * (XCD_H1 * 4);
+        float4 *h2 = a.h2h + (long)gg * NS * (XCD_H2 * 4);
         for (int i = tid; i < XCD_H1 * 4; i += 384) h1[i] = z;
         for (int i = tid; i < XCD_H2 * 4; i += 384) h2[i] = z;
-        if (tid < 64) a.fbh[(long)gg * (T + 1) * 64 + tid] = z;
+        if (tid < 64) a.fbh[(long)gg * NS * 64 + tid] = z;
         if (tid < XCD_CUS) a.flags[gg * XCD_CUS + tid] = 0u;
         if (gg == 0 && tid < 8) a.status[tid] = 0u;
         if (gg == 0 && tid < XCD_COUNT * XCD_CUS) a.status[8 + tid] = 0xffffffffu;
@@ -316,6 +323,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
     __shared__ float sC1[XCD_NGMAX][2][64];
     __shared__ volatile int sAbort, sLocal, sH1done;
     __shared__ unsigned sArrive[2];
+    __shared__ __attribute__((aligned(16))) float4 sY[2][4][64];     // ring mode: W_out[0..3][unit] * h per (wave, lane = clip + 16 unit), by phase parity
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -477,6 +485,17 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
 #pragma unroll
         for (int q = 0; q < (HO ? 1 : 8); ++q) wx[q] = px[q];
     }
+    // history addressing: full history (slot = step) or rings of XCD_RING slots
+    const unsigned NS = a.ring ? (unsigned)XCD_RING : (unsigned)(T + 1);
+    const unsigned smask = a.ring ? (unsigned)(XCD_RING - 1) : 0xffffffffu;
+    // ring mode: W_out[o][unit of this lane] (prediction_layer, learned_models.py:33,47): the cell's h leaves as a partial of y
+    float wo[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.ring) {
+        const int k = 4 * t2 + u;
+        const float *pw = a.packed + P.woutp + (((k >> 4) * 64) + 16 * ((k & 15) >> 2)) * 4 + (k & 3);   // row o at lane offset o
+#pragma unroll
+        for (int o = 0; o < 4; ++o) wo[o] = pw[o * 4];
+    }
     const unsigned lds0 = (unsigned)(unsigned long long)(const void *)&sbuf[0][0];
     const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void *)a.ws, 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = lane * 16;
@@ -495,9 +514,9 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         // x[s] (slot s+1; past the end: the zero slot T+1), h1[s-1] (slot s), and HO: h2[s-3] (slot s-2), frames_boxes[s-2]
         // (slot s-1) / !HO: h2[s-2] (slot s-1)
         const unsigned ox0 = a.xp_off + ((gg * (T + 2) + (s < T ? s + 1 : T + 1)) * OPNET_KXQ) * 256 + w * 1024;
-        const unsigned oh1 = a.h1_off + ((gg * (T + 1) + (s <= T ? s : T)) * (XCD_H1 / 4)) * 256 + (w - 6) * 1024;
-        const unsigned oh2 = a.h2_off + ((gg * (T + 1) + (HO ? (s > 2 ? s - 2 : 0) : (s > 0 ? s - 1 : 0))) * (XCD_H2 / 4)) * 256 + (w - 22) * 1024;
-        const unsigned ofb = a.fb_off + (gg * (T + 1) + (s > 1 ? s - 1 : 0)) * 1024;
+        const unsigned oh1 = a.h1_off + ((gg * NS + ((unsigned)(s <= T ? s : T) & smask)) * (XCD_H1 / 4)) * 256 + (w - 6) * 1024;
+        const unsigned oh2 = a.h2_off + ((gg * NS + ((unsigned)(HO ? (s > 2 ? s - 2 : 0) : (s > 0 ? s - 1 : 0)) & smask)) * (XCD_H2 / 4)) * 256 + (w - 22) * 1024;
+        const unsigned ofb = a.fb_off + (gg * NS + ((unsigned)(s > 1 ? s - 1 : 0) & smask)) * 1024;
 #pragma unroll
         for (int j = 0; j < (XB_CHUNKS + 3) / 4; ++j) {
             // chunk 4j + w (wave-uniform): X0 = chunks 0..5, H1 = 6..21, H2 = 22..53, FB = 54
@@ -655,7 +674,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             // slot s (= frames_boxes[s-1]) as [feature][clip]
             const float f_lo = u == 0 ? fbv[0] : u == 1 ? fbv[1] : u == 2 ? fbv[2] : fbv[3];
             const float f_hi = u == 0 ? fbv[4] : u == 1 ? fbv[5] : 0.f;
-            const unsigned fo = a.fb_off + (gg * (T + 1) + s) * 1024;
+            const unsigned fo = a.fb_off + (gg * NS + ((unsigned)s & smask)) * 1024;
             xcd_store4(rws, (u * 16 + n) * 4, fo, f_lo, local);
             xcd_store4(rws, ((u + 4) * 16 + n) * 4, fo, f_hi, local);
           }
@@ -686,8 +705,11 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             XCD_WAVE_LDS_SYNC();
             if (lane < 16) {
                 const float4 hv = *(const float4 *)&sTR[w][0][lane * 4];
-                xcd_store16(rws, lane16, a.h2_off + (((gg * (T + 1) + (HO ? s - 1 : s)) * (XCD_H2 / 4) + t2) * 16) * 16, hv, local);
+                xcd_store16(rws, lane16, a.h2_off + (((gg * NS + ((unsigned)(HO ? s - 1 : s) & smask)) * (XCD_H2 / 4) + t2) * 16) * 16, hv, local);
             }
+            if (a.ring)     // this lane's terms of y = W_out h2: four products, summed by the CU's last-arriving wave (no shuffles here:
+                            // every VALU instruction of a finish wave is paid for by the MFMA stream of its SIMD)
+                sY[fp & 1][w][lane] = make_float4(wo[0] * h, wo[1] * h, wo[2] * h, wo[3] * h);
         }
         // ---- LSTM1 cell of step s (learned_models.py:39), by the upper-K wave of each pair ---------------------
         if (kh && s < T && alive && !(a.debug & 4)) {
@@ -699,17 +721,33 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             XCD_WAVE_LDS_SYNC();
             if (lane < 16) {
                 const float4 hv = *(const float4 *)&sTR[w][1][lane * 4];
-                xcd_store16(rws, lane16, a.h1_off + (((gg * (T + 1) + s + 1) * (XCD_H1 / 4) + t1) * 16) * 16, hv, local);
+                xcd_store16(rws, lane16, a.h1_off + (((gg * NS + ((unsigned)(s + 1) & smask)) * (XCD_H1 / 4) + t1) * 16) * 16, hv, local);
             }
         }
         if (tracer) a.trace[(long)fp * 8 + 5] = clock64();
         // ---- publish: every finish wave drains its stores (and DMA) and arrives at an LDS counter; the last one stores
         //      the CU's flag -------------------------------------------------------------------------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int last = 0;
         if (lane == 0 && alive && !(a.debug & 8)) {
             if (__hip_atomic_fetch_add(&sArrive[fp & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3u) {
                 __hip_atomic_store(&sArrive[fp & 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 xcd_store_flag(a.flags + gg * XCD_CUS + c, (unsigned)(s + 1), local);
+                last = 1;
+            }
+        }
+        if (a.ring && (HO ? s >= 2 : s >= 1) && !(a.debug & 4)) {
+            // the CU's last-arriving finish wave (the others' LDS writes precede their arrival in their own LDS queues): the CU's
+            // partial of y[t] = the four waves' parts in wave order -> ypart [group][t][CU][clip]; read after the launch, so it is
+            // a plain store behind the flag, off the hand-off's critical path
+            if (__builtin_amdgcn_readfirstlane(last)) {
+                // lane (clip n, output o = u): the CU's 16 units in (wave, unit) order, one sequential chain
+                const float *py = (const float *)&sY[fp & 1][0][0] + n * 4 + u;
+                float sum = py[0];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) sum += py[((k >> 2) * 64 + (k & 3) * 16) * 4];
+                const unsigned t_y = (unsigned)(HO ? s - 2 : s - 1);
+                xcd_store4(rws, (n * 4 + u) * 4, a.yp_off + ((gg * (unsigned)T + t_y) * XCD_CUS + c) * 256, sum, true);
             }
         }
         if (tracer) a.trace[(long)fp * 8 + 6] = clock64();
@@ -768,5 +806,29 @@ __global__ void __launch_bounds__(256) opnet_xcd_out_head(const XcdArgs a, float
         const long b = (long)gg * 16 + tid;
         if (a.status[0] != 0u) sum = make_float4(NAN, NAN, NAN, NAN);
         if (b < a.B) ((float4 *)y)[b * T + t] = sum;
+    }
+}
+
+
+// ring mode: y[b][t][0..3] = the 32 CUs' partials of W_out h2[t] in CU order (each one sequential chain over the CU's 16 units in
+// (wave, unit) order); one thread per (group, t, clip).  An aborted launch poisons y with NaN.
+__global__ void __launch_bounds__(256) opnet_xcd_y_reduce(const XcdArgs a, float *__restrict__ y)
+{
+    const long total = (long)a.NGT * a.T * 16;
+    const float4 *yp = (const float4 *)(a.ws + a.yp_off);
+    const bool bad = a.status[0] != 0u;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i & 15);
+        const long gt = i >> 4;                                  // gg * T + t
+        const float4 *p = yp + gt * (XCD_CUS * 16) + n;
+        float4 sum = p[0];
+        for (int cu = 1; cu < XCD_CUS; ++cu) {
+            const float4 v = p[cu * 16];
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        if (bad) sum = make_float4(NAN, NAN, NAN, NAN);
+        const long gg = gt / a.T, t = gt - gg * a.T;
+        const long b = gg * 16 + n;
+        if (b < a.B) ((float4 *)y)[b * a.T + t] = sum;
     }
 }

@@ -30,6 +30,16 @@ def test_header_symbols_are_exported():
         assert hasattr(lib, name), f"{name} declared in include/opnet_hip.h but not exported"
 
 
+def test_persistent_forward_workspace_is_rings_not_histories(monkeypatch):
+    """the per-XCD persistent forward keeps h1 / h2 / frames_boxes in 4-slot rings: 0.27 MB of workspace per clip at T = 300
+    (packed input + per-CU partials of the output head) against 0.94 MB with the full histories of round 2"""
+    lib = _lib()
+    ring = lib.opnet_xcd_workspace_bytes(1024, 300, 256, 512)
+    monkeypatch.setenv("OPNET_XCD_RING", "0")
+    full = lib.opnet_xcd_workspace_bytes(1024, 300, 256, 512)
+    assert 0 < ring < 300e6 < 900e6 < full
+
+
 def test_size_queries_and_validation_without_gpu():
     lib = _lib()
     assert lib.opnet_hip_abi_version() == 1

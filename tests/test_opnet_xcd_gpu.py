@@ -114,6 +114,24 @@ def test_bench_shape_matches_c_oracle_on_every_clip():
     assert (px != px_ref).mean() < 1e-3 and np.abs(px - px_ref).max() <= 1
 
 
+@pytest.mark.parametrize("B,T", [(40, 9), (150, 7), (300, 12), (640, 5)])
+def test_ring_layout_and_full_history_layout_agree(monkeypatch, B, T):
+    """OPNET_XCD_RING=1 (default): h1 / h2 / frames_boxes live in 4-slot rings and y leaves the launch as per-CU partials;
+    =0: round 2's full histories + the output-head kernel.  The recurrences are the same instructions (logits bit-identical);
+    y differs only in the summation order of its 512-term dot product; both match the oracle."""
+    boxes, _ = synth.make_batch(321, B, T)
+    outs = {}
+    for ring in ("1", "0"):
+        monkeypatch.setenv("OPNET_XCD_RING", ring)
+        m, params = _model(True)
+        outs[ring] = _run(m, boxes)
+    y_ref, lg_ref = oo.opnet_forward(boxes, params, dtype=np.float64)
+    for ring in ("1", "0"):
+        assert np.abs(outs[ring][0] - y_ref).max() < TOL_Y and np.abs(outs[ring][1] - lg_ref).max() < TOL_LOGITS
+    assert np.array_equal(outs["1"][1], outs["0"][1])
+    assert np.abs(outs["1"][0] - outs["0"][0]).max() < 2e-6
+
+
 def test_persistent_forward_chunks_large_batches():
     """more clips than one launch carries (opnet_xcd_max_batch) are run as several chained launches"""
     from objectpermanence_amd import _lib
