@@ -93,6 +93,11 @@ struct SeqXArgs {
 };
 
 typedef float sx_f32x4 __attribute__((ext_vector_type(4)));
+// wave-private LDS written by the lanes of a wave and read back by other lanes of the SAME wave: a wave's LDS instructions are
+// executed in order, so no s_waitcnt is needed between the write and the read - only the compiler must not reorder them
+#ifndef SX_LDS_SYNC
+#define SX_LDS_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 #ifndef SX_RING
 #define SX_RING 8
 #endif
@@ -394,7 +399,7 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
 #pragma unroll
             for (int r = 0; r < NLD; ++r)
                 if (64 * r + lane < 4 * NXWMAX) SX[64 * r + lane] = x4_as_float4(xr[r]);      // (zeros beyond the wave's share)
-            XCD_WAVE_LDS_SYNC();
+            SX_LDS_SYNC();
             if (upper) sx_products<NXW1, true, (2 * NXW1) / 3>(acc, ax, SX + j, ask_h);
             else sx_products<NXW0, true, (2 * NXW0) / 3>(acc, ax, SX + j, ask_h);
         } else {
@@ -412,7 +417,7 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
                 if (gn == ng) { gn = 0; ++tn; }
                 if (tn < T) ask_x(gn, tn);
             }
-            XCD_WAVE_LDS_SYNC();
+            SX_LDS_SYNC();
             sx_products<32, false, 99>(acc, ah, &sH[w][0] + j, []() {});
         }
         {
