@@ -293,13 +293,19 @@ extern "C" int opnet_forward_f32(const float *boxes, const float *packed, float 
 // ------------------------------------------------------------------------------------------------
 struct XcdWorkspaceLayout {  // offsets in bytes
     size_t status, flags, xp, h1h, h2h, fbh, yp, total;
-    int NGT, ring;
+    int NGT, ring, ho;
 };
 
-// OPNET_XCD_RING (default 1): h1 / h2 / frames_boxes as rings of XCD_RING steps and the output head as per-CU partials
-// (8 KB per step and group) instead of full histories (48.25 KB per step and group) that a second kernel reads back:
-// 0.27 instead of 0.94 MB of workspace per clip, about half the HBM traffic; 0 = round 2's layout.
+// OPNET_XCD_RING (default 1): h1 / h2 / frames_boxes as rings of XCD_RING steps and the output head inside the launch (head-once
+// form: 32 more MFMAs per product wave of one CU per phase; otherwise per-CU partials, 8 KB per step and group, summed by
+// opnet_xcd_y_reduce) instead of full histories (48.25 KB per step and group) that a second kernel reads back (DESIGN.md
+// section 5a); 0 = round 2's layout.
 static int xcd_ring_mode() { return env_int("OPNET_XCD_RING", 1) != 0; }
+// three or more groups on the fullest XCD (they set the launch's duration): the "head once" form (the selection head on
+// one wave per XCD and phase, LSTM2 one more step behind); fewer: every CU computes the head (the exchange is on the
+// critical path there and a lone head wave lengthens it: 88 k against 106 k clips/s at 256 clips, 68 k against 75 k at
+// 128; at 320 clips - XCDs with 3 and with 2 groups - 106 k against 93 k the other way).  OPNET_XCD_HO = 0 / 1 overrides.
+static int xcd_head_once(int NGT) { return env_int("OPNET_XCD_HO", (NGT + XCD_COUNT - 1) / XCD_COUNT >= 3 ? 1 : 0) != 0; }
 
 static XcdWorkspaceLayout xcd_workspace_layout(int B, int T)
 {
@@ -308,6 +314,7 @@ static XcdWorkspaceLayout xcd_workspace_layout(int B, int T)
     size_t o = 0;
     L.NGT = (int)NGT;
     L.ring = xcd_ring_mode();
+    L.ho = xcd_head_once(L.NGT);
     const size_t NS = L.ring ? (size_t)XCD_RING : (size_t)(T + 1);
     L.status = o; o += 2048;                                   // 8 control words + 256 XCC ids
     L.flags = o;  o += align_up(NGT * XCD_CUS * 4, 256);
@@ -315,7 +322,7 @@ static XcdWorkspaceLayout xcd_workspace_layout(int B, int T)
     L.h1h = o;    o += NGT * NS * (XCD_H1 / 4) * 256;
     L.h2h = o;    o += NGT * NS * (XCD_H2 / 4) * 256;
     L.fbh = o;    o += NGT * NS * 1024;
-    L.yp = o;     if (L.ring) o += NGT * (size_t)T * XCD_CUS * 256;
+    L.yp = o;     if (L.ring && !L.ho) o += NGT * (size_t)T * XCD_CUS * 256;
     L.total = align_up(o, 256);
     return L;
 }
@@ -466,8 +473,8 @@ static int xcd_forward_impl(const XcdSources &src, const float *packed, float *y
     a.status = (unsigned *)(w + L.status);
     a.logits = logits;
     a.ws = w;
-    a.xp_off = (unsigned)L.xp; a.h1_off = (unsigned)L.h1h; a.h2_off = (unsigned)L.h2h; a.fb_off = (unsigned)L.fbh; a.flags_off = (unsigned)L.flags;
-    a.ring = L.ring; a.yp_off = (unsigned)L.yp;
+    a.xp_off = (unsigned)L.xp; a.h1_off = (unsigned)L.h1h; a.h2_off = (unsigned)L.h2h; a.fb_off = (unsigned)L.fbh; a.flags_off = (unsigned)L.flags; a.status_off = (unsigned)L.status;
+    a.ring = L.ring; a.yp_off = (unsigned)L.yp; a.y = y;
     a.trace = g_xcd_trace;
     a.force_safe = env_int("OPNET_XCD_SAFE", 0);
     a.debug = env_int("OPNET_XCD_DEBUG", 0);
@@ -481,16 +488,14 @@ static int xcd_forward_impl(const XcdSources &src, const float *packed, float *y
     else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
     ProfPair pe{};
     const bool prof = prof_begin(st, &pe);
-    // three or more groups on the fullest XCD (they set the launch's duration): the "head once" form (the selection head on
-    // one wave per XCD and phase, LSTM2 one more step behind); fewer: every CU computes the head (the exchange is on the
-    // critical path there and a lone head wave lengthens it: 88 k against 106 k clips/s at 256 clips, 68 k against 75 k at
-    // 128; at 320 clips - XCDs with 3 and with 2 groups - 106 k against 93 k the other way).  OPNET_XCD_HO = 0 / 1 overrides.
-    const int ho = env_int("OPNET_XCD_HO", (L.NGT + XCD_COUNT - 1) / XCD_COUNT >= 3 ? 1 : 0);
+    const int ho = L.ho;                    // xcd_head_once
     if (ho) opnet_xcd_forward<true><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
     else opnet_xcd_forward<false><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
     if (prof) prof_end(PROF_XCD, st, pe);
     HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
-    if (a.ring) {
+    if (a.ring && ho) {
+        opnet_xcd_y_poison<<<64, 256, 0, st>>>(a, y);      // y left the launch complete; NaN only if the launch gave up
+    } else if (a.ring) {
         const long ny = (long)L.NGT * T * 16;
         opnet_xcd_y_reduce<<<(unsigned)((ny + 255) / 256 > 2048 ? 2048 : (ny + 255) / 256), 256, 0, st>>>(a, y);
     } else {

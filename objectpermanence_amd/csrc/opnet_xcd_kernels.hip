@@ -74,11 +74,15 @@ struct XcdArgs {
                                // [8 + b] XCC_ID of block b
     float *logits;             // caller's [B][15][T]
     char *ws;                  // workspace base and the byte offsets of xp / h1h / h2h / flags in it (one buffer descriptor)
-    unsigned xp_off, h1_off, h2_off, fb_off, flags_off;
+    unsigned xp_off, h1_off, h2_off, fb_off, flags_off, status_off;
     int ring;                  // 0: h1h / h2h / fbh hold the full history ([T+1] slots per group) and opnet_xcd_out_head reads h2 back;
-                               // 1: they are rings of XCD_RING slots (slot = step & 3) and the output head leaves the launch as per-CU
-                               //    partials ypart [NGT][T][32 CUs][16 clips] float4 (opnet_xcd_y_reduce sums them)
+                               // 1: they are rings of XCD_RING slots (slot = step & 3) and the output head is computed in the launch:
+                               //    head-once form: y[s-3] = W_out h2[s-3] as 32 more MFMAs per product wave of ONE CU of the XCD per
+                               //    phase, on the B fragments its LSTM2 products stream anyway, stored to y by that CU (one more phase
+                               //    per group: s = T+2);  otherwise per-CU partials ypart [NGT][T][32 CUs][16 clips] float4, summed by
+                               //    opnet_xcd_y_reduce
     unsigned yp_off;
+    float *y;                  // caller's [B][T][4] (ring mode, head-once form)
     int force_safe;            // 1: always use the placement-independent write-through protocol (tests)
     int debug;                 // tools only (wrong results): bit 0 no poll/gather, 1 no head, 2 no cells, 3 no publish, 4 no x fetch
     unsigned long long *trace; // optional [phases][8] s_memtime stamps of block 0 (product wave 0: 0-1, finish wave 4: 2-7), or null
@@ -202,6 +206,44 @@ __device__ __forceinline__ bool xcd_wait_flags(const unsigned *flags, unsigned n
     }
 }
 
+// The same through the workspace's buffer descriptor (wave-uniform byte offsets of the group's flags and of the status words): the
+// finish waves' loop keeps no 64-bit pointer alive for it.  Every SGPR the loop does not hold is one the compiler does not spill into
+// VGPR lanes - and a v_readlane in that loop is a VALU instruction the SIMD's MFMA stream pays for (section 3a of DESIGN.md).
+__device__ __forceinline__ bool xcd_wait_flags_ws(__amdgpu_buffer_rsrc_t rws, unsigned flags_soff, unsigned need, unsigned status_soff, int phase)
+{
+    const unsigned lane = threadIdx.x & 63, fv = (lane & 31) * 4;
+    if (__all(__builtin_amdgcn_raw_buffer_load_b32(rws, fv, flags_soff, 16) >= need)) return true;
+    long long t0 = 0;
+    for (unsigned spins = 1;; ++spins) {
+        __builtin_amdgcn_s_sleep(4);
+        if (__all(__builtin_amdgcn_raw_buffer_load_b32(rws, fv, flags_soff, 16) >= need)) return true;
+        if ((spins & 63u) == 0) {
+            if (__builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(rws, 0, status_soff, 16)) != 0u) return false;
+            const long long now = (long long)wall_clock64();
+            if (spins == 64u) t0 = now;
+            if (now - t0 > XCD_SPIN_LIMIT) {
+                if (lane == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)blockIdx.x, rws, 4, status_soff, 16);
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)phase, rws, 8, status_soff, 16);
+                    __builtin_amdgcn_raw_buffer_store_b32(1u, rws, 0, status_soff, 16);
+                }
+                return false;
+            }
+        }
+    }
+}
+
+// A kernel argument fetched where it is used (one s_load from the kernarg segment; the struct is the kernel's only argument, at
+// offset 0) instead of living in SGPRs across the finish waves' loop: for pointers only one wave in 128 needs per phase.
+template <unsigned OFF>
+__device__ __forceinline__ unsigned long long xcd_karg_u64()
+{
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFF) : "memory");
+    return v;
+}
+#define XCD_KARG(type, field) ((type)xcd_karg_u64<(unsigned)__builtin_offsetof(XcdArgs, field)>())
+
 // Do the 32 workgroups of group x (blocks x, x + 8, ...) sit on one XCD?  Every block publishes its XCC_ID (write-through)
 // and reads the 32 ids of its group (sc1 loads), so all of them reach the same verdict.  -1 = gave up (abort raised).
 __device__ __forceinline__ int xcd_group_is_local(unsigned *status, int x)
@@ -310,6 +352,20 @@ __device__ __forceinline__ int xcd_group_is_local(unsigned *status, int x)
 // which CU of the XCD computes the selection head of (step s's phase, group gi): rotates so that the extra work (16 MFMAs a
 // wave + softmax / einsum in one finish wave) lands on every CU once in 32 phases
 __host__ __device__ inline int xcd_head_cu(int s, int gi) { return (s + 11 * gi) & (XCD_CUS - 1); }
+// ... and which one the output head y[s-3] (ring mode): half an XCD away from the selection head's
+__host__ __device__ inline int xcd_y_cu(int s, int gi) { return (s + 11 * gi + 16) & (XCD_CUS - 1); }
+
+// wave-uniform condition bits of the finish waves' loop (see XCD_CF there)
+#define XCD_CF_NG4 1u
+#define XCD_CF_NG2 2u
+#define XCD_CF_NG1 4u
+#define XCD_CF_DBG1 8u
+#define XCD_CF_DBG2 16u
+#define XCD_CF_DBG4 32u
+#define XCD_CF_DBG8 64u
+#define XCD_CF_RING 128u
+#define XCD_CF_LOCAL 256u
+#define XCD_CF_TRACE 512u
 
 #define XH_F4 (3 * 64)         // sHAND per product wave: LSTM2 gates | LSTM1 partial | head partial
 
@@ -339,7 +395,9 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
     const int t1 = 2 * c + (w >> 1), kh = w & 1;
     // HO ("head once"): steps 0 .. T+1 = LSTM1 step s | head step s-1 on ONE wave of the XCD | LSTM2 step s-2;
     // otherwise steps 0 .. T = LSTM1 step s | head + LSTM2 step s-1 on every CU
-    const int nph = (HO ? T + 2 : T + 1) * ng;
+    // (ring mode, HO: one more step, in which only the output head's CU computes: y[T-1] needs h2[T-1] in a gather buffer)
+    const bool YH = HO && a.ring != 0;
+    const int nph = (HO ? (YH ? T + 3 : T + 2) : T + 1) * ng;
     const PackedLayout P = packed_layout(XCD_H1, XCD_H2);
     if (wv == XCD_FW0) {
         // placement check by the first finish wave (groups with no work still publish their id and leave)
@@ -384,9 +442,20 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             ax[1] = px[4];
         }
         const bool mtracer = a.trace && blockIdx.x == 0 && tid == (4 - XCD_FW0) * 64;
+        // output head (YH): A fragments of W_out (rows 0..3 of a 16-row tile, the rest zero) - not resident: the CU needs them
+        // once in 32 phases, two at a time straight from the packed image (L2-resident)
+        // (a buffer descriptor + one lane offset: with pointers the compiler keeps 32 per-lane addresses and spills them)
+        const __amdgpu_buffer_rsrc_t rwy = __builtin_amdgcn_make_buffer_rsrc((void *)(a.packed + P.woutp), 0, (XCD_H2 / 16) * 1024, 0x00020000);
+        const unsigned ylane = lane * 16;
+        auto yfrag = [&](int q) -> float4 {     // fragment of hexadecet q (wave-uniform)
+            const xcd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rwy, ylane, (unsigned)q * 1024u, 0);
+            return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        };
         __syncthreads();                        // phase 0's gather has landed
         if (sAbort) return;
+        int pgi = 0, ps = 0;                    // phase p = ps * ng + pgi
         for (int p = 0; p < nph; ++p) {
+            const bool ycu = YH && ps >= 3 && xcd_y_cu(ps, pgi) == c;
             const float4 *F = &sbuf[p & 1][0] + lane;
             const float *FBp = (const float *)(&sbuf[p & 1][XB_FB]) + u * 16 + n;   // frames_boxes[s-2][4 j + u][clip n]
             // B fragment of LSTM1 hexadecet 11 kh + j of [x 0..5 | h1 6..21]: the buffer is X0 | H1 | H2, so the lower-K
@@ -399,9 +468,13 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             // of one hexadecet on the same accumulator (40-cycle dependent latency against a 32-cycle issue) and keeps
             // only one or two B fragments in flight.  Fragments are fetched one j-step (12 MFMAs ~ 400 cycles) ahead.
             f32x4 accH = {0.f, 0.f, 0.f, 0.f}, acc1, acc2a, acc2b;   // accH: !HO only
-            auto products = [&](auto ym) {
+            auto products = [&](auto ym, auto yk) {
                 constexpr int YM = decltype(ym)::value;
+                constexpr bool YK = decltype(yk)::value;    // this CU computes the output head in this phase
                 float4 fa[2], fb[2], fl[2];
+                float4 ay0, ay1;
+                f32x4 accYa, accYb;             // (local to this variant: no copies on the other CUs' path)
+                if (YK) { ay0 = yfrag(2 * w); ay1 = yfrag(2 * w + 1); }
                 fa[0] = F[XB_H2]; fb[0] = F[XB_H2 + 64]; fl[0] = FL[0];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -440,6 +513,20 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
                     if (l1) XCD_MFMA(acc1, a1[j].w, fl[cur].w);
                     if (hd && !HO) XCD_MFMA(accH, as_[HO ? 0 : j - 11].w, fl[cur].w);
                     __builtin_amdgcn_sched_barrier(0);
+                    // output head: K is split over the four product waves - wave w takes the hexadecet pairs j = w, w+4, w+8,
+                    // w+12 (the B fragments this iteration holds), two chains, every other MFMA with the yielding gap
+                    if (YK && (j & 3) == w) {
+                        if (j < 4) {
+                            XCD_MFMA0_G(accYa, ay0.x, fa[cur].x, XCD_GAP); XCD_MFMA0_G(accYb, ay1.x, fb[cur].x, 0);
+                        } else {
+                            XCD_MFMA_G(accYa, ay0.x, fa[cur].x, XCD_GAP); XCD_MFMA_G(accYb, ay1.x, fb[cur].x, 0);
+                        }
+                        XCD_MFMA_G(accYa, ay0.y, fa[cur].y, XCD_GAP); XCD_MFMA_G(accYb, ay1.y, fb[cur].y, 0);
+                        XCD_MFMA_G(accYa, ay0.z, fa[cur].z, XCD_GAP); XCD_MFMA_G(accYb, ay1.z, fb[cur].z, 0);
+                        XCD_MFMA_G(accYa, ay0.w, fa[cur].w, XCD_GAP); XCD_MFMA_G(accYb, ay1.w, fb[cur].w, 0);
+                        if (j + 4 < 16) { ay0 = yfrag(2 * j + 8); ay1 = yfrag(2 * j + 9); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 // HO: LSTM2's input part W_ih2 . frames_boxes[s-2] (K = 6 -> 8): two more MFMAs on the two LSTM2 chains
                 if (HO) {
@@ -449,11 +536,20 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
                     XCD_MFMA(acc2b, ax[1], b1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (YK) {                       // this wave's K quarter of the output head -> the (otherwise unused) head slot
+                    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(accYa), "+v"(accYb));
+                    (&sHAND[p & 1][w][0] + lane)[128] = make_float4(accYa[0] + accYb[0], accYa[1] + accYb[1], accYa[2] + accYb[2], accYa[3] + accYb[3]);
+                }
             };
-            if (ng == 1) products(std::integral_constant<int, -1>{});
-            else if (ng == 2) products(std::integral_constant<int, XCD_NY2>{});
-            else if (ng == 3) products(std::integral_constant<int, HO ? 0 : XCD_NY3>{});
-            else products(std::integral_constant<int, XCD_NY4>{});
+            const std::false_type y0{};
+            const std::integral_constant<bool, HO> y1{};
+            if (ycu) {                          // (the gap pattern of three or more groups: the phase is longer anyway)
+                products(std::integral_constant<int, HO ? 0 : XCD_NY3>{}, y1);
+            } else if (YH && ps == T + 2) {     // the extra step of the output head: nothing to do on the other CUs
+            } else if (ng == 1) products(std::integral_constant<int, -1>{}, y0);
+            else if (ng == 2) products(std::integral_constant<int, XCD_NY2>{}, y0);
+            else if (ng == 3) products(std::integral_constant<int, HO ? 0 : XCD_NY3>{}, y0);
+            else products(std::integral_constant<int, XCD_NY4>{}, y0);
             XCD_MFMA_DRAIN(acc2a, acc2b, acc1, accH);
             if (mtracer) a.trace[(long)p * 8 + 1] = clock64();
             float4 *hd_ = &sHAND[p & 1][w][0] + lane;
@@ -470,6 +566,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
+            if (++pgi == ng) { pgi = 0; ++ps; }
         }
         return;
     }
@@ -490,7 +587,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
     const unsigned smask = a.ring ? (unsigned)(XCD_RING - 1) : 0xffffffffu;
     // ring mode: W_out[o][unit of this lane] (prediction_layer, learned_models.py:33,47): the cell's h leaves as a partial of y
     float wo[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.ring) {
+    if (a.ring && !HO) {
         const int k = 4 * t2 + u;
         const float *pw = a.packed + P.woutp + (((k >> 4) * 64) + 16 * ((k & 15) >> 2)) * 4 + (k & 3);   // row o at lane offset o
 #pragma unroll
@@ -508,7 +605,8 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
     bool alive = true;
 
     // this wave's share (chunks w, w+4, ...) of the gather of phase (group gi, step s) into LDS buffer `buf`
-    auto gather = [&](int gi, int s, int buf) {
+    // (w arrives as a parameter: the loop hands in a copy the compiler cannot see through, see XCD_CF below)
+    auto gather = [&](int gi, int s, int buf, int w) {
         const unsigned gg = g0 + gi;
         const unsigned dst = lds0 + (unsigned)buf * (XB_F4 * 16) + w * 1024;
         // x[s] (slot s+1; past the end: the zero slot T+1), h1[s-1] (slot s), and HO: h2[s-3] (slot s-2), frames_boxes[s-2]
@@ -534,27 +632,39 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         return __all(v >= need);
     };
     // wait until every CU of the group's XCD has published step sn - 1, then gather phase (gn, sn)
-    auto poll_gather = [&](int gn, int sn, int buf, int phase) {
-        if (!alive || (a.debug & 1)) return;
+    auto poll_gather = [&](int gn, int sn, int buf, int phase, int w, unsigned cf) {
+        if (!alive || (cf & XCD_CF_DBG1)) return;
         if (sn > 0 && !flags_ready(gn, (unsigned)sn))
-            alive = xcd_wait_flags(a.flags + (g0 + gn) * XCD_CUS, (unsigned)sn, a.status, phase);
-        if (alive) gather(gn, sn, buf);
+            alive = xcd_wait_flags_ws(rws, a.flags_off + (g0 + gn) * (XCD_CUS * 4), (unsigned)sn, a.status_off, phase);
+        if (alive) gather(gn, sn, buf, w);
         else sAbort = 1;
     };
 
-    gather(0, 0, 0);                            // phase 0 reads only zero slots and x[0]: nothing to wait for
-    if (ng >= 2 && nph > 1) gather(1, 0, 1);    // phase 1 = group 1, step 0
+    gather(0, 0, 0, w);                         // phase 0 reads only zero slots and x[0]: nothing to wait for
+    if (ng >= 2 && nph > 1) gather(1, 0, 1, w); // phase 1 = group 1, step 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (sAbort) return;
-    const bool local = __builtin_amdgcn_readfirstlane(sLocal) != 0;
-    const bool tracer = a.trace && blockIdx.x == 0 && tid == XCD_FW0 * 64;
+    // XCD_CF: the loop's wave-uniform, loop-invariant conditions as bits of ONE scalar that is made opaque at the top of every phase
+    // (and w with it).  Left to itself the compiler hoists each such condition out of the loop as a 64-bit lane mask - 15 of them
+    // here, 30 SGPRs - runs out of SGPRs, spills them into VGPR lanes, and every v_readlane that fetches one back inside the loop is a
+    // VALU instruction taken from the MFMA stream of this SIMD (a dozen per phase, measured: ~200 cycles of a 7 300-cycle phase).
+    // Tested at the point of use, a bit costs one scalar instruction and no register.
+    const unsigned cfbits = (ng >= 4 ? XCD_CF_NG4 : 0u) | (ng >= 2 ? XCD_CF_NG2 : 0u) | (ng == 1 ? XCD_CF_NG1 : 0u)
+                            | ((a.debug & 1) ? XCD_CF_DBG1 : 0u) | ((a.debug & 2) ? XCD_CF_DBG2 : 0u) | ((a.debug & 4) ? XCD_CF_DBG4 : 0u)
+                            | ((a.debug & 8) ? XCD_CF_DBG8 : 0u) | (a.ring ? XCD_CF_RING : 0u)
+                            | (__builtin_amdgcn_readfirstlane(sLocal) != 0 ? XCD_CF_LOCAL : 0u)
+                            | ((a.trace && blockIdx.x == 0 && wv == XCD_FW0) ? XCD_CF_TRACE : 0u);
 
     int gi = 0, s = 0;                          // phase fp = s * ng + gi
     for (int fp = 0; fp < nph; ++fp) {
+        unsigned cf = __builtin_amdgcn_readfirstlane(cfbits);
+        int wq = w;
+        asm volatile("" : "+s"(cf), "+s"(wq));
+        const bool local = (cf & XCD_CF_LOCAL) != 0, tracer = (cf & XCD_CF_TRACE) != 0 && lane == 0;
         const unsigned gg = g0 + gi;
         // the phase after next (two or more groups) / the next phase (one group)
-        const int ahead = ng >= 2 ? 2 : 1;
+        const int ahead = (cf & XCD_CF_NG2) ? 2 : 1;
         int gn = gi + ahead, sn = s;
         while (gn >= ng) { gn -= ng; ++sn; }
         // Who computes the selection head of step s-1: !HO every finish wave (every CU needs frames_boxes at once); HO wave 0
@@ -564,7 +674,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         // all issued before the barrier - which must therefore not drain vmcnt - so that the round trips are over when the
         // phase's sums arrive
         const bool head_cu = HO && xcd_head_cu(s, gi) == c && s >= 1 && s <= T;
-        const bool head_wave = HO ? (head_cu && w == 0) : (s >= 1);
+        const bool head_wave = HO ? (head_cu && wq == 0) : (s >= 1);
         xcd_u32x4 xq[6];
         float4 wsel[HO ? 16 : 1];
         if (head_wave) {
@@ -572,7 +682,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
 #pragma unroll
             for (int j = 0; j < 6; ++j) xq[j] = __builtin_amdgcn_raw_buffer_load_b128(rws, xq_voff + j * 256, xs, 0);
             if (HO) {
-                const float4 *ps = (const float4 *)(a.packed + P.wselp) + lane;
+                const float4 *ps = (const float4 *)(XCD_KARG(const float *, packed) + P.wselp) + lane;
 #pragma unroll
                 for (int q = 0; q < (HO ? 16 : 1); ++q) wsel[q] = ps[q * 64];
             }
@@ -580,26 +690,26 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // barrier fp: the phase's accumulators are in sHAND[fp & 1]
         asm volatile("" ::: "memory");
-        if (tracer) a.trace[(long)fp * 8 + 2] = clock64();
+        if (tracer) XCD_KARG(unsigned long long *, trace)[(long)fp * 8 + 2] = clock64();
         if (sAbort) return;
         // If the phase after next already has its inputs published (four or more groups per XCD: its group finished its
         // previous step more than a window ago) the gather goes first and lands under the finish; otherwise the finish
         // goes first and the gather follows it (three groups: published by then; two: it is THIS finish - the product
         // waves wait for the exchange)
         bool early = false;
-        if (ng >= 4 && !head_cu && fp + 2 < nph && alive && !(a.debug & 1) && (sn == 0 || flags_ready(gn, (unsigned)sn))) {
-            gather(gn, sn, fp & 1);
+        if ((cf & XCD_CF_NG4) && !head_cu && fp + 2 < nph && alive && !(cf & XCD_CF_DBG1) && (sn == 0 || flags_ready(gn, (unsigned)sn))) {
+            gather(gn, sn, fp & 1, wq);
             early = true;
         }
-        if (tracer) a.trace[(long)fp * 8 + 3] = clock64();
+        if (tracer) XCD_KARG(unsigned long long *, trace)[(long)fp * 8 + 3] = clock64();
 
         const float4 *H = &sHAND[fp & 1][0][0] + lane;
         // ---- selection head of step s-1 (learned_models.py:40-43,50): logits, softmax, einsum -> frames_boxes[s-1].  !HO: it
         //      feeds this wave's LSTM2 cell right away; HO: it travels to every CU with this phase's publish and enters LSTM2
         //      as two MFMAs one step later -----------------------------------------------------------------------------
         float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
-        if (HO && head_wave && !(alive && !(a.debug & 2)) && lane == 0) sH1done = fp + 1;   // skipped head: still release the buffer
-        if (head_wave && alive && !(a.debug & 2)) {
+        if (HO && head_wave && !(alive && !(cf & XCD_CF_DBG2)) && lane == 0) sH1done = fp + 1;   // skipped head: still release the buffer
+        if (head_wave && alive && !(cf & XCD_CF_DBG2)) {
             float v[4];
             if (HO) {
                 // the whole 16 x 256 x 16-clip product on this one wave: B fragments = h1[s-1] out of the phase's gather buffer
@@ -629,7 +739,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
                 v[2] = ((h0.z + h1.z) + h2.z) + h3.z; v[3] = ((h0.w + h1.w) + h2.w) + h3.w;
             }
             if (HO || (c == ((s - 1) & (XCD_CUS - 1)) && w == 0)) {   // wave-uniform: this wave writes the step's logits
-                float *lg = a.logits + ((long)gg * 16 * OPNET_SLOTS_) * T + (s - 1);
+                float *lg = XCD_KARG(float *, logits) + ((long)gg * 16 * OPNET_SLOTS_) * T + (s - 1);
                 const bool clip_ok = (int)(gg * 16 + n) < a.B;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -679,10 +789,10 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             xcd_store4(rws, ((u + 4) * 16 + n) * 4, fo, f_hi, local);
           }
         }
-        if (tracer) a.trace[(long)fp * 8 + 4] = clock64();
+        if (tracer) XCD_KARG(unsigned long long *, trace)[(long)fp * 8 + 4] = clock64();
         // ---- LSTM2 cell (learned_models.py:46): lane (clip n, unit 4 t2 + u).  HO: step s-2, the gates arrive complete (the
         //      input part W_ih2 . frames_boxes[s-2] rode the MFMA stream); !HO: step s-1, the input part is added here -------
-        if ((HO ? s >= 2 : s >= 1) && alive && !(a.debug & 4)) {
+        if ((HO ? s >= 2 && s <= T + 1 : s >= 1) && alive && !(cf & XCD_CF_DBG4)) {
             const float4 g2 = H[w * XH_F4];
             float g[4] = {g2.x, g2.y, g2.z, g2.w};
             if (!HO) {
@@ -707,12 +817,12 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
                 const float4 hv = *(const float4 *)&sTR[w][0][lane * 4];
                 xcd_store16(rws, lane16, a.h2_off + (((gg * NS + ((unsigned)(HO ? s - 1 : s) & smask)) * (XCD_H2 / 4) + t2) * 16) * 16, hv, local);
             }
-            if (a.ring)     // this lane's terms of y = W_out h2: four products, summed by the CU's last-arriving wave (no shuffles here:
-                            // every VALU instruction of a finish wave is paid for by the MFMA stream of its SIMD)
+            if ((cf & XCD_CF_RING) && !HO)   // this lane's terms of y = W_out h2: four products, summed by the CU's last-arriving wave (no shuffles
+                                 // here: every VALU instruction of a finish wave is paid for by the MFMA stream of its SIMD)
                 sY[fp & 1][w][lane] = make_float4(wo[0] * h, wo[1] * h, wo[2] * h, wo[3] * h);
         }
         // ---- LSTM1 cell of step s (learned_models.py:39), by the upper-K wave of each pair ---------------------
-        if (kh && s < T && alive && !(a.debug & 4)) {
+        if ((wq & 1) && s < T && alive && !(cf & XCD_CF_DBG4)) {
             const float4 lo = H[(w - 1) * XH_F4 + 64], hi = H[w * XH_F4 + 64];
             float cc = sC1[gi][w >> 1][lane];
             const float h = lstm_cell(lo.x + hi.x, lo.y + hi.y, lo.z + hi.z, lo.w + hi.w, &cc);
@@ -724,19 +834,21 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
                 xcd_store16(rws, lane16, a.h1_off + (((gg * NS + ((unsigned)(s + 1) & smask)) * (XCD_H1 / 4) + t1) * 16) * 16, hv, local);
             }
         }
-        if (tracer) a.trace[(long)fp * 8 + 5] = clock64();
+        if (tracer) XCD_KARG(unsigned long long *, trace)[(long)fp * 8 + 5] = clock64();
         // ---- publish: every finish wave drains its stores (and DMA) and arrives at an LDS counter; the last one stores
         //      the CU's flag -------------------------------------------------------------------------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int last = 0;
-        if (lane == 0 && alive && !(a.debug & 8)) {
+        if (lane == 0 && alive && !(cf & XCD_CF_DBG8)) {
             if (__hip_atomic_fetch_add(&sArrive[fp & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3u) {
                 __hip_atomic_store(&sArrive[fp & 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                xcd_store_flag(a.flags + gg * XCD_CUS + c, (unsigned)(s + 1), local);
+                // (plain store: the line stays in this XCD's L2; otherwise write-through, as xcd_store_flag)
+                if (local) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(s + 1), rws, 0, a.flags_off + (gg * XCD_CUS + c) * 4, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32((unsigned)(s + 1), rws, 0, a.flags_off + (gg * XCD_CUS + c) * 4, 16);
                 last = 1;
             }
         }
-        if (a.ring && (HO ? s >= 2 : s >= 1) && !(a.debug & 4)) {
+        if ((cf & XCD_CF_RING) && !HO && s >= 1 && !(cf & XCD_CF_DBG4)) {
             // the CU's last-arriving finish wave (the others' LDS writes precede their arrival in their own LDS queues): the CU's
             // partial of y[t] = the four waves' parts in wave order -> ypart [group][t][CU][clip]; read after the launch, so it is
             // a plain store behind the flag, off the hand-off's critical path
@@ -746,20 +858,29 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
                 float sum = py[0];
 #pragma unroll
                 for (int k = 1; k < 16; ++k) sum += py[((k >> 2) * 64 + (k & 3) * 16) * 4];
-                const unsigned t_y = (unsigned)(HO ? s - 2 : s - 1);
+                const unsigned t_y = (unsigned)(s - 1);
                 xcd_store4(rws, (n * 4 + u) * 4, a.yp_off + ((gg * (unsigned)T + t_y) * XCD_CUS + c) * 256, sum, true);
             }
         }
-        if (tracer) a.trace[(long)fp * 8 + 6] = clock64();
+        if (HO && (cf & XCD_CF_RING) && wq == 2 && s >= 3 && xcd_y_cu(s, gi) == c && alive && !(cf & XCD_CF_DBG4)) {
+            // output head of step s-3 (prediction_layer, learned_models.py:33,47): the four product waves' K quarters in wave order;
+            // rows 0..3 of the tile = the registers of lanes 0..15 (clip = lane).  Behind the publish: nothing in the launch reads y
+            const float4 p0 = H[0 * XH_F4 + 128], p1 = H[1 * XH_F4 + 128], p2 = H[2 * XH_F4 + 128], p3 = H[3 * XH_F4 + 128];
+            const long b = (long)gg * 16 + lane;
+            if (lane < 16 && b < a.B)
+                XCD_KARG(float4 *, y)[b * T + (s - 3)] = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                                                               ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        }
+        if (tracer) XCD_KARG(unsigned long long *, trace)[(long)fp * 8 + 6] = clock64();
         if (!early && fp + ahead < nph) {
-            if (head_cu && ng >= 2) {           // the gather fills the buffer this CU's head wave read h1 from
+            if (head_cu && (cf & XCD_CF_NG2)) {           // the gather fills the buffer this CU's head wave read h1 from
                 while (sH1done < fp + 1 && !sAbort) __builtin_amdgcn_s_sleep(1);
             }
-            poll_gather(gn, sn, (fp + ahead) & 1, fp);
+            poll_gather(gn, sn, (fp + ahead) & 1, fp, wq, cf);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (tracer) a.trace[(long)fp * 8 + 7] = clock64();
-        if (ng == 1) {
+        if (tracer) XCD_KARG(unsigned long long *, trace)[(long)fp * 8 + 7] = clock64();
+        if (cf & XCD_CF_NG1) {
             __syncthreads();
             if (sAbort) return;
         }
@@ -831,4 +952,14 @@ __global__ void __launch_bounds__(256) opnet_xcd_y_reduce(const XcdArgs a, float
         const long b = gg * 16 + n;
         if (b < a.B) ((float4 *)y)[b * a.T + t] = sum;
     }
+}
+
+
+// ring mode, head-once form: y was written inside the launch; an aborted launch poisons it with NaN like the other tails do
+__global__ void __launch_bounds__(256) opnet_xcd_y_poison(const XcdArgs a, float *__restrict__ y)
+{
+    if (a.status[0] == 0u) return;
+    const long total = (long)a.B * a.T;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+        ((float4 *)y)[i] = make_float4(NAN, NAN, NAN, NAN);
 }

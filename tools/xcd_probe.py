@@ -63,9 +63,9 @@ def main():
                  if "chain" in res else "") + f" | status {list(st.values())[-1]}", flush=True)
     if args.trace:
         lib = _lib.load()
-        for B in (128, 256, 384, 512):
+        for B in (128, 256, 384, 512, 640):
             ng = (B + 127) // 128
-            tr = torch.zeros((T + 1) * ng * 8, dtype=torch.int64, device=dev)
+            tr = torch.zeros((T + 3) * ng * 8, dtype=torch.int64, device=dev)
             lib.opnet_xcd_set_trace(tr.data_ptr())
             boxes, _ = synth.make_batch(0, 64, T)
             x = torch.from_numpy(np.tile(boxes, ((B + 63) // 64, 1, 1, 1))[:B]).to(dev)
@@ -83,6 +83,14 @@ def main():
                       B, ng, med(np.diff(ph[:, 0])), med(ph[:, 1] - ph[:, 0]), med(ph[1:, 0] - ph[:-1, 1]),
                       med(ph[:, 3] - ph[:, 2]), med(ph[:, 4] - ph[:, 3]), med(ph[:, 5] - ph[:, 4]), med(ph[:, 6] - ph[:, 5]),
                       med(ph[:, 7] - ph[:, 6]), med(ph[1:, 2] - ph[:-1, 7])))
+            # block 0 = CU 0 of XCD 0: its phases by role (selection head / output head of the phase's step on this CU / neither)
+            fp = np.arange(len(t))[len(t) // 3: 2 * len(t) // 3 - 1]
+            gi, st_ = fp % ng, fp // ng
+            role = np.where(((st_ + 11 * gi) & 31) == 0, 1, np.where(((st_ + 11 * gi + 16) & 31) == 0, 2, 0))
+            per, prod = t[fp + 1, 0] - t[fp, 0], t[fp, 1] - t[fp, 0]
+            print("   mean period %.0f; by role (plain / sel head / out head): period %s, products %s" % (
+                per.mean(), [round(float(per[role == r].mean())) for r in (0, 1, 2)],
+                [round(float(prod[role == r].mean())) for r in (0, 1, 2)]))
 
 
 if __name__ == "__main__":
