@@ -233,6 +233,21 @@ __device__ __forceinline__ bool xcd_wait_flags_ws(__amdgpu_buffer_rsrc_t rws, un
     }
 }
 
+#define XCD_LDS_LD(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define XCD_LDS_ST(x, v) __hip_atomic_store(&(x), (int)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+// One LDS add by lane 0 alone (exec = 1 for the one instruction), the old value to the whole wave.  What the compiler makes of
+// `if (lane == 0) atomic_add(...)` is a dozen VALU instructions (mbcnt, compares, moves) - in the finish waves' loop every one of
+// them is taken from the MFMA stream.
+__device__ __forceinline__ unsigned xcd_lds_add_lane0(unsigned lds_addr, unsigned val)
+{
+    unsigned old;
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(old), "=&s"(keep) : "v"(lds_addr), "v"(val) : "memory");
+    return __builtin_amdgcn_readfirstlane(old);
+}
+
 // A kernel argument fetched where it is used (one s_load from the kernarg segment; the struct is the kernel's only argument, at
 // offset 0) instead of living in SGPRs across the finish waves' loop: for pointers only one wave in 128 needs per phase.
 template <unsigned OFF>
@@ -302,7 +317,10 @@ __device__ __forceinline__ int xcd_group_is_local(unsigned *status, int x)
 #define XCD_TAIL 1
 #endif
 #ifndef XCD_TAIL_HO
-#define XCD_TAIL_HO 1          // head-once form: measured 124 / 126 / 129 k clips/s at 384 / 512 / 1024 clips; every 2nd row 117 / 126 / 129, 3rd 105 / 123 / 125
+#define XCD_TAIL_HO 2          // head-once form, every 2nd row: 131 / 133.5 / 134.8 / 136.6 k clips/s at 384 / 512 / 640 / 1024 clips (every row: 128 / 131 /
+                               // 131 / 132, every 3rd: 130 / 133.4 / 135.9 / -, every 4th: 128.7 at 640).  Round 2 measured the opposite (every row 124 / 126 / 129,
+                               // every 2nd 117 / 126 / 129): the finish waves then executed ~25 more VALU instructions per phase (SGPR spill reloads,
+                               // the compiler's lane-0 atomic) and needed every gap to get through them
 #endif
 #define XCD_TAILV (HO ? XCD_TAIL_HO : XCD_TAIL)
 #define XCD_MFMA_LEAD(acc, av, bv) do { if (ROW < YM || (XCD_TAILV > 0 && YM >= 0 && (ROW % (XCD_TAILV > 0 ? XCD_TAILV : 1)) == 0)) XCD_MFMA_G(acc, av, bv, XCD_GAP); else XCD_MFMA_G(acc, av, bv, 0); } while (0)
@@ -377,7 +395,8 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
     __shared__ __attribute__((aligned(16))) float sTR[4][2][64];     // (clip, unit) -> float4-per-clip transposes
     __shared__ float sC2[XCD_NGMAX][4][64];
     __shared__ float sC1[XCD_NGMAX][2][64];
-    __shared__ volatile int sAbort, sLocal, sH1done;
+    __shared__ int sAbort, sLocal, sH1done;      // read / written through XCD_LDS_LD / XCD_LDS_ST (a `volatile` LDS word is accessed with
+                                                 // FLAT instructions and a vmcnt wait; these are plain ds_read / ds_write)
     __shared__ unsigned sArrive[2];
     __shared__ __attribute__((aligned(16))) float4 sY[2][4][64];     // ring mode: W_out[0..3][unit] * h per (wave, lane = clip + 16 unit), by phase parity
 
@@ -406,10 +425,10 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             if (lane == 0) __hip_atomic_store(a.status + 8 + blockIdx.x, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf,
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (lane == 0) {
-            sLocal = loc > 0 && a.force_safe == 0;
-            sAbort = loc < 0;
+            XCD_LDS_ST(sLocal, loc > 0 && a.force_safe == 0);
+            XCD_LDS_ST(sAbort, loc < 0);
             sArrive[0] = 0u; sArrive[1] = 0u;
-            sH1done = 0;
+            XCD_LDS_ST(sH1done, 0);
             if (loc == 0 && c == 0) atomicAdd(a.status + 3, 1u);
         }
     }
@@ -452,7 +471,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         };
         __syncthreads();                        // phase 0's gather has landed
-        if (sAbort) return;
+        if (XCD_LDS_LD(sAbort)) return;
         int pgi = 0, ps = 0;                    // phase p = ps * ng + pgi
         for (int p = 0; p < nph; ++p) {
             const bool ycu = YH && ps >= 3 && xcd_y_cu(ps, pgi) == c;
@@ -637,14 +656,14 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         if (sn > 0 && !flags_ready(gn, (unsigned)sn))
             alive = xcd_wait_flags_ws(rws, a.flags_off + (g0 + gn) * (XCD_CUS * 4), (unsigned)sn, a.status_off, phase);
         if (alive) gather(gn, sn, buf, w);
-        else sAbort = 1;
+        else XCD_LDS_ST(sAbort, 1);
     };
 
     gather(0, 0, 0, w);                         // phase 0 reads only zero slots and x[0]: nothing to wait for
     if (ng >= 2 && nph > 1) gather(1, 0, 1, w); // phase 1 = group 1, step 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (sAbort) return;
+    if (XCD_LDS_LD(sAbort)) return;
     // XCD_CF: the loop's wave-uniform, loop-invariant conditions as bits of ONE scalar that is made opaque at the top of every phase
     // (and w with it).  Left to itself the compiler hoists each such condition out of the loop as a 64-bit lane mask - 15 of them
     // here, 30 SGPRs - runs out of SGPRs, spills them into VGPR lanes, and every v_readlane that fetches one back inside the loop is a
@@ -653,7 +672,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
     const unsigned cfbits = (ng >= 4 ? XCD_CF_NG4 : 0u) | (ng >= 2 ? XCD_CF_NG2 : 0u) | (ng == 1 ? XCD_CF_NG1 : 0u)
                             | ((a.debug & 1) ? XCD_CF_DBG1 : 0u) | ((a.debug & 2) ? XCD_CF_DBG2 : 0u) | ((a.debug & 4) ? XCD_CF_DBG4 : 0u)
                             | ((a.debug & 8) ? XCD_CF_DBG8 : 0u) | (a.ring ? XCD_CF_RING : 0u)
-                            | (__builtin_amdgcn_readfirstlane(sLocal) != 0 ? XCD_CF_LOCAL : 0u)
+                            | (__builtin_amdgcn_readfirstlane(XCD_LDS_LD(sLocal)) != 0 ? XCD_CF_LOCAL : 0u)
                             | ((a.trace && blockIdx.x == 0 && wv == XCD_FW0) ? XCD_CF_TRACE : 0u);
 
     int gi = 0, s = 0;                          // phase fp = s * ng + gi
@@ -691,7 +710,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         __builtin_amdgcn_s_barrier();           // barrier fp: the phase's accumulators are in sHAND[fp & 1]
         asm volatile("" ::: "memory");
         if (tracer) XCD_KARG(unsigned long long *, trace)[(long)fp * 8 + 2] = clock64();
-        if (sAbort) return;
+        if (XCD_LDS_LD(sAbort)) return;
         // If the phase after next already has its inputs published (four or more groups per XCD: its group finished its
         // previous step more than a window ago) the gather goes first and lands under the finish; otherwise the finish
         // goes first and the gather follows it (three groups: published by then; two: it is THIS finish - the product
@@ -708,7 +727,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         //      feeds this wave's LSTM2 cell right away; HO: it travels to every CU with this phase's publish and enters LSTM2
         //      as two MFMAs one step later -----------------------------------------------------------------------------
         float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
-        if (HO && head_wave && !(alive && !(cf & XCD_CF_DBG2)) && lane == 0) sH1done = fp + 1;   // skipped head: still release the buffer
+        if (HO && head_wave && !(alive && !(cf & XCD_CF_DBG2)) && lane == 0) XCD_LDS_ST(sH1done, fp + 1);   // skipped head: still release the buffer
         if (head_wave && alive && !(cf & XCD_CF_DBG2)) {
             float v[4];
             if (HO) {
@@ -719,7 +738,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) bh[q] = Fh[q * 64];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) sH1done = fp + 1;
+                if (lane == 0) XCD_LDS_ST(sH1done, fp + 1);
                 f32x4 ha = {0.f, 0.f, 0.f, 0.f}, hb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < 16; q += 2) {
@@ -838,21 +857,21 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         // ---- publish: every finish wave drains its stores (and DMA) and arrives at an LDS counter; the last one stores
         //      the CU's flag -------------------------------------------------------------------------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int last = 0;
-        if (lane == 0 && alive && !(cf & XCD_CF_DBG8)) {
-            if (__hip_atomic_fetch_add(&sArrive[fp & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3u) {
-                __hip_atomic_store(&sArrive[fp & 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (the counter only grows - four arrivals per use, two phases apart behind a barrier: the fourth arriver sees 3 mod 4)
+        bool last = false;
+        if (alive && !(cf & XCD_CF_DBG8)) {
+            last = (xcd_lds_add_lane0((unsigned)(unsigned long long)(const void *)&sArrive[fp & 1], 1u) & 3u) == 3u;
+            if (last && lane == 0) {
                 // (plain store: the line stays in this XCD's L2; otherwise write-through, as xcd_store_flag)
                 if (local) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(s + 1), rws, 0, a.flags_off + (gg * XCD_CUS + c) * 4, 0);
                 else __builtin_amdgcn_raw_buffer_store_b32((unsigned)(s + 1), rws, 0, a.flags_off + (gg * XCD_CUS + c) * 4, 16);
-                last = 1;
             }
         }
         if ((cf & XCD_CF_RING) && !HO && s >= 1 && !(cf & XCD_CF_DBG4)) {
             // the CU's last-arriving finish wave (the others' LDS writes precede their arrival in their own LDS queues): the CU's
             // partial of y[t] = the four waves' parts in wave order -> ypart [group][t][CU][clip]; read after the launch, so it is
             // a plain store behind the flag, off the hand-off's critical path
-            if (__builtin_amdgcn_readfirstlane(last)) {
+            if (last) {
                 // lane (clip n, output o = u): the CU's 16 units in (wave, unit) order, one sequential chain
                 const float *py = (const float *)&sY[fp & 1][0][0] + n * 4 + u;
                 float sum = py[0];
@@ -874,7 +893,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         if (tracer) XCD_KARG(unsigned long long *, trace)[(long)fp * 8 + 6] = clock64();
         if (!early && fp + ahead < nph) {
             if (head_cu && (cf & XCD_CF_NG2)) {           // the gather fills the buffer this CU's head wave read h1 from
-                while (sH1done < fp + 1 && !sAbort) __builtin_amdgcn_s_sleep(1);
+                while (XCD_LDS_LD(sH1done) < fp + 1 && !XCD_LDS_LD(sAbort)) __builtin_amdgcn_s_sleep(1);
             }
             poll_gather(gn, sn, (fp + ahead) & 1, fp, wq, cf);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -882,7 +901,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         if (tracer) XCD_KARG(unsigned long long *, trace)[(long)fp * 8 + 7] = clock64();
         if (cf & XCD_CF_NG1) {
             __syncthreads();
-            if (sAbort) return;
+            if (XCD_LDS_LD(sAbort)) return;
         }
         if (++gi == ng) { gi = 0; ++s; }
     }
