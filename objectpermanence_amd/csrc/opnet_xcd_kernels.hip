@@ -314,7 +314,8 @@ __device__ __forceinline__ int xcd_group_is_local(unsigned *status, int x)
 // instructions the finish wave has left (flag compare of the poll, address moves of the gather) are not frozen until the
 // product phase ends
 #ifndef XCD_TAIL
-#define XCD_TAIL 1
+#define XCD_TAIL 2             // every-CU-head form, round 3 (lighter finish loop): every 2nd row 2.24 ms at 256 clips / 2.16 at 192 against 2.31 / 2.22 with
+                               // every row; with XCD_NY2 = 8 on top 2.55 / 2.50
 #endif
 #ifndef XCD_TAIL_HO
 #define XCD_TAIL_HO 2          // head-once form, every 2nd row: 131 / 133.5 / 134.8 / 136.6 k clips/s at 384 / 512 / 640 / 1024 clips (every row: 128 / 131 /
