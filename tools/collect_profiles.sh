@@ -23,10 +23,20 @@ pmc pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" python
 pmc pmc_mfma_tr "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" python bench.py --mode transformer --no-cpu-baseline --repeats 3
 pmc pmc_mfma_train "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" python bench.py --mode train --steps 20 --warmup 5 --loss l1 --no-cpu-baseline --repeats 3
 cd $R
-python tools/pmc_reduce.py traffic $O/pmc_fetch $O/pmc_write "opnet_xcd_forward" > $O/pmc_xcd_traffic.json 2>&1
+python tools/pmc_reduce.py shapes $O/pmc_fetch $O/pmc_write 160,400,640 profiles/r3_pmc_traffic.json > $O/pmc_xcd_traffic.json 2>&1
 python tools/pmc_reduce.py mfma $O/pmc_mfma > $O/mfma_util_bench.json 2>&1
 python tools/pmc_reduce.py mfma $O/pmc_mfma_tr > $O/mfma_util_transformer.json 2>&1
 python tools/pmc_reduce.py mfma $O/pmc_mfma_train > $O/mfma_util_train.json 2>&1
+# per-launch durations of the persistent forward out of the kernel trace (the stats CSV only has the mean over all launch shapes)
+python - <<'PY' > $O/bench_xcd_forward_launches.csv 2>&1
+import csv, glob, os
+O = os.environ.get("GRAFT_REPO_ROOT", os.getcwd()) + "/gpurun_out/r3p"
+for path in glob.glob(O + "/bench/**/*kernel_trace.csv", recursive=True):
+    print("dispatch,kernel,duration_ns")
+    for r in csv.DictReader(open(path)):
+        if "opnet_xcd_forward" in r["Kernel_Name"]:
+            print(f'{r["Dispatch_Id"]},{r["Kernel_Name"].split("(")[0].replace("void ", "")},{int(r["End_Timestamp"]) - int(r["Start_Timestamp"])}')
+PY
 # keep only the small artefacts
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +2M -delete
 ls -la $O | head -40
