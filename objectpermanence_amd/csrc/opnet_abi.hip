@@ -727,8 +727,9 @@ static TrainPackedLayout train_packed_layout(int H1, int H2)
 
 struct TrainWorkspaceLayout {  // offsets in bytes
     size_t io, xp, state, h1all, c1all, h2all, c2all, state_end, x2all, g1, g2, psave, ystage, lgstage,
-        dyp, dlall, dhpart2, dhpart1, dx2part, dcz, dc2, dc1, dcz_end, l1part, x4h1x, x4h2x, x4status, x4da1x, x4da2x, x4dfx, total;
+        dyp, dlall, dhpart2, dhpart1, dx2part, dcz, dc2, dc1, dcz_end, l1part, x4h1x, x4h2x, x4status, x4da1x, x4da2x, x4dfx, wgpart, total;
 };
+#define WG2_MAX_WAVES 1024      // one round of the chip's SIMDs (opnet_wgrad_tiles)
 
 // the 4-clip persistent step carries up to X4_NGMAX row blocks; its exchange buffers exist only for such batches
 static bool x4_batch(int B, int H1, int H2) { return x4_dims(H1, H2) && (B + 31) / 32 <= X4_NGMAX; }
@@ -770,6 +771,8 @@ static TrainWorkspaceLayout train_workspace_layout(int B, int T, int H1, int H2)
     L.x4da1x = o;  o += NG * X4_SLOTS * 131072;   // partial dh1: [32 owners][32 producers][128 B]
     L.x4da2x = o;  o += NG * X4_SLOTS * 262144;   // partial dh2: [32 owners][32 producers][256 B]
     L.x4dfx = o;   o += NG * X4_SLOTS * 4096;
+    o = align_up(o, 4096);
+    L.wgpart = o;  o += (size_t)WG2_MAX_WAVES * WG2_PART_F * 4;     // partial tiles of the weight-gradient waves (64 MB)
     L.total = align_up(o, 256);
     return L;
 }
@@ -1285,6 +1288,57 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
     }
     // a forward or reverse recurrence that gave up (4-clip persistent kernels) left partial histories: every dW becomes NaN
     wb.abort = x4_batch(B, H1, H2) ? (const unsigned *)(w + W.x4status) : nullptr;
+    if (env_int("OPNET_WGRAD2", 1) != 0) {
+        // one wave per (tile, time slice): 128 x 128 tiles for the products with both dimensions large, 64 x 64 for the rest; the
+        // slices sized so that every wave job fits ONE round of the SIMDs and big (4 units of work per step) and small (1) end together
+        Wg2Batch tb;
+        memset(&tb, 0, sizeof(tb));
+        int order[OPNET_WGRAD_JOBS], nb = 0, ns = 0, k = 0;
+        for (int pass = 1; pass >= 0; --pass)
+            for (int j = 0; j < njobs; ++j) {
+                const int big = wb.job[j].MQ >= 32 && wb.job[j].NQ >= 17;
+                if (big == pass) order[k++] = j;
+            }
+        for (int q = 0; q < njobs; ++q) {
+            Wg2Job &J = tb.job[q];
+            J.g = wb.job[order[q]];
+            J.big = J.g.MQ >= 32 && J.g.NQ >= 17;
+            const int tq = J.big ? 32 : 16;
+            J.tiles_m = (J.g.MQ + tq - 1) / tq;
+            J.tiles_n = (J.g.NQ + tq - 1) / tq;
+            (J.big ? nb : ns) += J.tiles_m * J.tiles_n;
+        }
+        const long nit = (long)T * RB;
+        long best = -1;
+        int sb_best = 1, ss_best = 1;
+        for (int ss = 1; ss <= 32; ++ss) {
+            const long left = WG2_MAX_WAVES - (long)ns * ss;
+            if (ns && left < (nb ? nb : 0)) break;
+            long sb = nb ? left / nb : 1;
+            if (sb > nit) sb = nit;
+            if (sb < 1) break;
+            const long cost_b = nb ? (nit + sb - 1) / sb * 4 : 0, cost_s = ns ? (nit + ss - 1) / ss : 0;
+            const long cost = cost_b > cost_s ? cost_b : cost_s;
+            if (best < 0 || cost < best) { best = cost; sb_best = (int)sb; ss_best = ss; }
+            if (!ns) break;
+        }
+        if (best >= 0) {
+            int nw = 0;
+            for (int q = 0; q < njobs; ++q) {
+                Wg2Job &J = tb.job[q];
+                J.slices = J.big ? sb_best : ss_best;
+                J.wave_begin = nw;
+                nw += J.slices * J.tiles_m * J.tiles_n;
+            }
+            tb.njobs = njobs; tb.nwaves = nw;
+            tb.partial = (float *)(w + W.wgpart);
+            tb.abort = wb.abort;
+            opnet_wgrad_tiles<<<(nw + 3) / 4, 256, 0, st>>>(tb);
+            opnet_wgrad_reduce<<<1024, 256, 0, st>>>(tb);
+            HIP_TRY(hipGetLastError());
+            return OPNET_OK;
+        }
+    }
     opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;

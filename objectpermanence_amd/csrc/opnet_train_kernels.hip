@@ -666,6 +666,173 @@ __global__ void __launch_bounds__(256) opnet_wgrad(const WgradBatch batch)
 }
 
 // ------------------------------------------------------------------------------------------------
+// weight gradients, second form (round 3): one WAVE per (output tile, time slice), 128 x 128 tiles for the big products
+// ------------------------------------------------------------------------------------------------
+// opnet_wgrad above gives a workgroup a 64 x 64 tile and lets its four waves split the time range: every wave then loads 16 float4 per
+// 128 MFMAs, nothing is shared between waves, 1.9 GB come out of the L2 / Infinity Cache per launch and the matrix pipe is 52 % busy
+// (profiles/r3_mfma_util_train.json).  Here a wave owns a 128 x 128 tile (32 m-quads x 32 n-quads: 64 accumulator quads = 256
+// registers, in AGPRs - one wave per SIMD has 512) for ONE slice of the time range: 4 float4 per 64 MFMAs, half the operand
+// traffic per flop, fetched three clip groups ahead through a ring of four.  The products whose N or M is tiny (W_ih2: N = 6,
+// the two heads: M = 15 / 4) keep 64 x 64 tiles.  Every wave writes its partial tile in accumulator order (1 KB per store
+// instruction) to the workspace; opnet_wgrad_reduce sums the slices of a tile in slice order (deterministic), maps (m, n) to the
+// torch layout and writes the gradient.  The host sizes the slices so that all wave jobs run in ONE round of the 1 024 SIMDs and
+// big (512 MFMAs per step) and small (128) jobs end together.
+struct Wg2Job {
+    WgradArgs g;               // operands and output as in opnet_wgrad (tiles_m / tile_begin unused)
+    int big;                   // 1: 128 x 128 tiles, 0: 64 x 64
+    int tiles_m, tiles_n;      // tile grid
+    int slices;                // time slices per tile
+    int wave_begin;            // first wave job of this product: wave job = wave_begin + (slice * tiles_m + tile_m) * tiles_n + tile_n
+};
+struct Wg2Batch {
+    Wg2Job job[OPNET_WGRAD_JOBS];
+    int njobs, nwaves;
+    float *partial;            // [wave job][16 384 floats] (small jobs use the first 4 096)
+    const unsigned *abort;
+};
+#define WG2_PART_F 16384
+
+template <int GA, int GB>
+__device__ __forceinline__ void wg2_tile(const float4 *P, long p_stride, int MQ, const float4 *Q, long q_stride, int NQ, int mq0, int nq0,
+                                         long it0, long it1, float *__restrict__ part)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kc = lane >> 4;
+    // operands through buffer descriptors based at the slice's first step: a wave-uniform byte offset per (step, clip group), one lane
+    // offset per fragment row - and a lane whose row does not exist gets an offset past the end, which reads as zero: no branches, no
+    // 64-bit address arithmetic in the loop
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)(P + it0 * p_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(Q + it0 * q_stride), 0, 0x7fffffff, 0x00020000);
+    unsigned va[GA], vb[GB];
+#pragma unroll
+    for (int a = 0; a < GA; ++a) va[a] = (mq0 + 16 * a + i) < MQ ? (unsigned)(((mq0 + 16 * a + i) * 32 + kc) * 16) : 0x80000000u;
+#pragma unroll
+    for (int b = 0; b < GB; ++b) vb[b] = (nq0 + 16 * b + i) < NQ ? (unsigned)(((nq0 + 16 * b + i) * 32 + kc) * 16) : 0x80000000u;
+    const unsigned ps = (unsigned)(p_stride * 16), qs = (unsigned)(q_stride * 16);
+    const int nst = (int)(it1 - it0);
+    // the accumulators are pinned to AGPRs (constraint "a"): left to the register allocator, a part of the 256 lives in VGPRs and is
+    // copied in and out around the loop body - 1.5 v_accvgpr moves per MFMA
+    f32x4 acc[GA][GB][4][4];
+#pragma unroll
+    for (int a = 0; a < GA; ++a)
+#pragma unroll
+        for (int b = 0; b < GB; ++b)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    acc[a][b][x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    asm volatile("" : "+a"(acc[a][b][x][y]));
+                }
+    // ring of four clip groups, three ahead: slot = clip group & 3 (eight clip groups per step: static indices).  Past the slice's
+    // last step the ring re-reads that step (never used).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[4][GA], rb[4][GB];
+    auto fetch = [&](int st, int cg, int slot) {
+        const unsigned so = (unsigned)(st < nst ? st : nst - 1);
+#pragma unroll
+        for (int a = 0; a < GA; ++a) ra[slot][a] = __builtin_amdgcn_raw_buffer_load_b128(rp, va[a], so * ps + cg * 64, 0);
+#pragma unroll
+        for (int b = 0; b < GB; ++b) rb[slot][b] = __builtin_amdgcn_raw_buffer_load_b128(rq, vb[b], so * qs + cg * 64, 0);
+    };
+    if (nst > 0) { fetch(0, 0, 0); fetch(0, 1, 1); fetch(0, 2, 2); }
+    for (int st = 0; st < nst; ++st) {
+#pragma unroll
+        for (int cg = 0; cg < 8; ++cg) {
+            fetch(st + ((cg + 3) >> 3), (cg + 3) & 7, (cg + 3) & 3);
+            const int sl = cg & 3;
+#pragma unroll
+            for (int a = 0; a < GA; ++a) {
+                const float ae[4] = {__uint_as_float(ra[sl][a][0]), __uint_as_float(ra[sl][a][1]), __uint_as_float(ra[sl][a][2]), __uint_as_float(ra[sl][a][3])};
+#pragma unroll
+                for (int b = 0; b < GB; ++b) {
+                    const float be[4] = {__uint_as_float(rb[sl][b][0]), __uint_as_float(rb[sl][b][1]), __uint_as_float(rb[sl][b][2]), __uint_as_float(rb[sl][b][3])};
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int y = 0; y < 4; ++y)
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[a][b][x][y]) : "v"(ae[x]), "v"(be[y]));
+                }
+            }
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // the last MFMAs' results (8 passes: 11 wait states) before they are read
+    float4 *out = (float4 *)part + lane;
+#pragma unroll
+    for (int a = 0; a < GA; ++a)
+#pragma unroll
+        for (int b = 0; b < GB; ++b)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    const f32x4 v = acc[a][b][x][y];
+                    out[(((a * GB + b) * 4 + x) * 4 + y) * 64] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+}
+
+__global__ void __launch_bounds__(256, 1) opnet_wgrad_tiles(const Wg2Batch batch)
+{
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wj = blockIdx.x * 4 + w;
+    if (wj >= batch.nwaves) return;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < OPNET_WGRAD_JOBS; ++k)
+        if (k < batch.njobs && wj >= batch.job[k].wave_begin) j = k;
+    const Wg2Job &J = batch.job[j];
+    const int r = wj - J.wave_begin;
+    const int tn = r % J.tiles_n, tm = (r / J.tiles_n) % J.tiles_m, sl = r / (J.tiles_n * J.tiles_m);
+    const long nit = (long)J.g.T * J.g.RB;
+    const long it0 = (sl * nit) / J.slices, it1 = ((sl + 1) * nit) / J.slices;
+    float *part = batch.partial + (long)wj * WG2_PART_F;
+    // (the job's fields by value: through the reference every use is a scalar load from the kernarg segment and a wait)
+    const float4 *P = J.g.P, *Q = J.g.Q;
+    const long p_stride = J.g.p_stride, q_stride = J.g.q_stride;
+    const int MQ = J.g.MQ, NQ = J.g.NQ;
+    if (J.big) wg2_tile<2, 2>(P, p_stride, MQ, Q, q_stride, NQ, tm * 32, tn * 32, it0, it1, part);
+    else wg2_tile<1, 1>(P, p_stride, MQ, Q, q_stride, NQ, tm * 16, tn * 16, it0, it1, part);
+}
+
+// one thread per accumulator quad (tile, a, b, x, y, lane): the slices of the tile in slice order, then the four rows of the quad
+__global__ void __launch_bounds__(256) opnet_wgrad_reduce(const Wg2Batch batch)
+{
+    const bool bad = batch.abort && *batch.abort != 0u;
+    for (int j = 0; j < batch.njobs; ++j) {
+        const Wg2Job &J = batch.job[j];
+        const WgradArgs &g = J.g;
+        const int G = J.big ? 2 : 1;
+        const long quads = (long)G * G * 16 * 64;                  // float4 per tile
+        const long ntile = (long)J.tiles_m * J.tiles_n;
+        for (long idx = blockIdx.x * 256L + threadIdx.x; idx < ntile * quads; idx += (long)gridDim.x * 256) {
+            const long tile = idx / quads;
+            const int q = (int)(idx - tile * quads);
+            const int l = q & 63, y = (q >> 6) & 3, x = (q >> 8) & 3, ab = q >> 10;
+            const int b = ab % G, a = ab / G;
+            const int tn = (int)(tile % J.tiles_n), tm = (int)(tile / J.tiles_n);
+            const float4 *p = (const float4 *)(batch.partial + (long)(J.wave_begin + tile) * WG2_PART_F) + q;
+            float4 sum = p[0];
+            for (int s = 1; s < J.slices; ++s) {
+                const float4 v = p[(long)s * ntile * (WG2_PART_F / 4)];
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            if (bad) sum = make_float4(NAN, NAN, NAN, NAN);
+            // D layout of 16x16x4: lane l holds column j = l & 15, rows 4 (l >> 4) + r
+            const int nn = 4 * (tn * 16 * G + 16 * b + (l & 15)) + y;
+            const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 4 * (tm * 16 * G + 16 * a + 4 * (l >> 4) + r) + x;
+                if (m < g.mvalid && nn < g.nvalid) {
+                    const int row = g.rowmode == 1 ? (m & 3) * g.H + (m >> 2) : m;
+                    g.out[(long)row * g.ld + nn] = sv[r];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // loss and optimiser
 // ------------------------------------------------------------------------------------------------
 // mean(|y - label|) (nn.L1Loss(reduction="none") then torch.mean, training_main.py:152,192,204) and
