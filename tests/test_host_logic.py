@@ -475,4 +475,5 @@ def test_small_batch_persistent_form_sizes_and_limits():
     assert lib.opnet_xcd4_workspace_bytes(32, 300, 256, 256) == 0
     # the training workspace carries the exchange rings of the persistent step for batches it can serve
     t32, t256 = lib.opnet_train_workspace_bytes(32, 300, 256, 512), lib.opnet_train_workspace_bytes(256, 300, 256, 512)
-    assert t32 > 32 * 5_000_000 and t256 > 7 * t32 * 0.9
+    fixed = 1024 * 16384 * 4                              # partial tiles of the weight-gradient waves: one round of the SIMDs, any batch
+    assert t32 - fixed > 32 * 5_000_000 and t256 - fixed > 7 * (t32 - fixed) * 0.9
