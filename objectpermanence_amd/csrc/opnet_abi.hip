@@ -1322,7 +1322,14 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
             if (best < 0 || cost < best) { best = cost; sb_best = (int)sb; ss_best = ss; }
             if (!ns) break;
         }
-        if (best >= 0) {
+        // (a wave addresses its slice through a buffer descriptor: 2 GiB from the slice's first step)
+        long span = 0;
+        for (int q = 0; q < njobs && best >= 0; ++q) {
+            const long steps = nit / (tb.job[q].big ? sb_best : ss_best) + 2;
+            const long ps = tb.job[q].g.p_stride > tb.job[q].g.q_stride ? tb.job[q].g.p_stride : tb.job[q].g.q_stride;
+            if (steps * ps * 16 > span) span = steps * ps * 16;
+        }
+        if (best >= 0 && span < (1L << 31)) {
             int nw = 0;
             for (int q = 0; q < njobs; ++q) {
                 Wg2Job &J = tb.job[q];
