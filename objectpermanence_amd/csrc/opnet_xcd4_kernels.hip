@@ -91,6 +91,23 @@ struct Xcd4Args {
 
 typedef float x4_f32x4 __attribute__((ext_vector_type(4)));
 #define X4_MFMA(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc, 0, 0, 0)
+// The forward's product loop as asm statements, LSTM2's weights (128 of the wave's registers) as AccVGPR A operands: with all the
+// weights in VGPRs the kernel needs ~310 registers, the allocator parks 54 of them in AGPRs and moves them back and forth around the
+// products - ~80 v_accvgpr moves per phase, VALU instructions on the step's critical path.  An MFMA reads an A operand out of an
+// AGPR at the same rate (measured in the stacked-LSTM launch), so the weights can LIVE there.  What the compiler no longer does for
+// asm MFMAs: chains accumulate in place (D = C: forwarded, no wait states), B operands come from counted ds_reads, the A operands
+// were written at kernel start, X4_MFMA_DRAIN pads the last results (2 passes: 5 wait states) before the compiler's code reads them.
+#ifndef X4_AG
+#define X4_AG 1
+#endif
+#if X4_AG
+#define X4_MFMA_W(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(av), "v"(bv))
+#else
+#define X4_MFMA_W(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
+#endif
+#define X4_MFMA_V(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
+#define X4_MFMA_DRAIN8(c0, c1, c2, c3, c4, c5, c6, c7) \
+    asm volatile("s_nop 7" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7))
 
 __device__ __forceinline__ float4 x4_as_float4(xcd_u32x4 r)
 {
@@ -332,10 +349,11 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
             const float4 *F2 = S + X4B_H2 + (32 * w) * 4 + j;
             const float4 *F1 = S + X4B_X0 + (22 * w + (b >> 3)) * 4 + j;
             const float4 *FH = S + X4B_H1 + (16 * w + (b >> 2)) * 4 + j;
-            x4_f32x4 c2[4], c1[2], cH[2];
+            // (four chains per product: with two, LSTM1's 44 and the head's 16 MFMAs wait for each other's results - a dependent
+            // v_mfma_f32_4x4x1 issues every ~30 cycles, the pipe takes one every 9.5)
+            x4_f32x4 c2[4], c1[4], cH[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) c2[q] = (x4_f32x4){0.f, 0.f, 0.f, 0.f};
-            c1[0] = c1[1] = cH[0] = cH[1] = (x4_f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < 4; ++q) c2[q] = c1[q] = cH[q] = (x4_f32x4){0.f, 0.f, 0.f, 0.f};
             // 47 B fragments (32 LSTM2 | 11 LSTM1 | 4 head) through a ring of X4_RING registers quads, fetched X4_AHEAD
             // fragments (~40 cycles of MFMA each) ahead: with one ds_read in flight per 4 MFMAs (what the compiler schedules
             // when left alone) every fragment's LDS latency is exposed (measured 2 750 cycles for the 194 MFMAs instead of
@@ -354,38 +372,41 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
                 __builtin_amdgcn_sched_barrier(0);
                 const float4 bq = bf[idx % X4_RING];
                 if (idx < 32) {
-                    X4_MFMA(c2[0], a2[idx < 32 ? idx : 0].x, bq.x);
-                    X4_MFMA(c2[1], a2[idx < 32 ? idx : 0].y, bq.y);
-                    X4_MFMA(c2[2], a2[idx < 32 ? idx : 0].z, bq.z);
-                    X4_MFMA(c2[3], a2[idx < 32 ? idx : 0].w, bq.w);
+                    X4_MFMA_W(c2[0], a2[idx < 32 ? idx : 0].x, bq.x);
+                    X4_MFMA_W(c2[1], a2[idx < 32 ? idx : 0].y, bq.y);
+                    X4_MFMA_W(c2[2], a2[idx < 32 ? idx : 0].z, bq.z);
+                    X4_MFMA_W(c2[3], a2[idx < 32 ? idx : 0].w, bq.w);
                 } else if (idx < 43) {
                     const int m = idx < 43 ? idx - 32 : 0;
-                    X4_MFMA(c1[0], a1[m].x, bq.x);
-                    X4_MFMA(c1[1], a1[m].y, bq.y);
-                    X4_MFMA(c1[0], a1[m].z, bq.z);
-                    X4_MFMA(c1[1], a1[m].w, bq.w);
+                    X4_MFMA_V(c1[0], a1[m].x, bq.x);
+                    X4_MFMA_V(c1[1], a1[m].y, bq.y);
+                    X4_MFMA_V(c1[2], a1[m].z, bq.z);
+                    X4_MFMA_V(c1[3], a1[m].w, bq.w);
                 } else {
                     const int m = idx - 43;
-                    X4_MFMA(cH[0], as_[m].x, bq.x);
-                    X4_MFMA(cH[1], as_[m].y, bq.y);
-                    X4_MFMA(cH[0], as_[m].z, bq.z);
-                    X4_MFMA(cH[1], as_[m].w, bq.w);
+                    X4_MFMA_V(cH[0], as_[m].x, bq.x);
+                    X4_MFMA_V(cH[1], as_[m].y, bq.y);
+                    X4_MFMA_V(cH[2], as_[m].z, bq.z);
+                    X4_MFMA_V(cH[3], as_[m].w, bq.w);
                 }
                 if (idx == 31 && w == 0) {      // LSTM2's input part: W_ih2 . frames_boxes[s-2] (K = 6)
-                    X4_MFMA(c2[0], ax[0].x, f0.x);
-                    X4_MFMA(c2[1], ax[0].y, f0.y);
-                    X4_MFMA(c2[2], ax[0].z, f0.z);
-                    X4_MFMA(c2[3], ax[0].w, f0.w);
-                    X4_MFMA(c2[0], ax[1].x, f1.x);
-                    X4_MFMA(c2[1], ax[1].y, f1.y);
+                    X4_MFMA_V(c2[0], ax[0].x, f0.x);
+                    X4_MFMA_V(c2[1], ax[0].y, f0.y);
+                    X4_MFMA_V(c2[2], ax[0].z, f0.z);
+                    X4_MFMA_V(c2[3], ax[0].w, f0.w);
+                    X4_MFMA_V(c2[0], ax[1].x, f1.x);
+                    X4_MFMA_V(c2[1], ax[1].y, f1.y);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            X4_MFMA_DRAIN8(c2[0], c2[1], c2[2], c2[3], c1[0], c1[1], c1[2], c1[3]);
+            asm volatile("" : "+v"(cH[0]), "+v"(cH[1]), "+v"(cH[2]), "+v"(cH[3]));
             float4 *pp = &sP[w][0][lane];
             pp[0] = make_float4((c2[0][0] + c2[1][0]) + (c2[2][0] + c2[3][0]), (c2[0][1] + c2[1][1]) + (c2[2][1] + c2[3][1]),
                                 (c2[0][2] + c2[1][2]) + (c2[2][2] + c2[3][2]), (c2[0][3] + c2[1][3]) + (c2[2][3] + c2[3][3]));
-            pp[64] = make_float4(c1[0][0] + c1[1][0], c1[0][1] + c1[1][1], c1[0][2] + c1[1][2], c1[0][3] + c1[1][3]);
-            pp[128] = make_float4(cH[0][0] + cH[1][0], cH[0][1] + cH[1][1], cH[0][2] + cH[1][2], cH[0][3] + cH[1][3]);
+            const x4_f32x4 s1 = (c1[0] + c1[1]) + (c1[2] + c1[3]), sH = (cH[0] + cH[1]) + (cH[2] + cH[3]);
+            pp[64] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+            pp[128] = make_float4(sH[0], sH[1], sH[2], sH[3]);
         }
         if (tracer) a.trace[(long)p * 8 + 1] = clock64();
         __syncthreads();                        // barrier 1: the phase's partials are in sP
@@ -970,7 +991,11 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         // ================================ products: the CU's gate columns x its da -> partial dh rows of every unit ==========
         if (!(a.debug & 16)) {
             const float4 *F2 = &sDA2[buf][0][0] + j, *F1 = &sDA1[0][0] + j;
-            x4_f32x4 d2a = {0.f, 0.f, 0.f, 0.f}, d2b = d2a, d1 = d2a;
+            // one accumulator chain per (row set, fragment element): a dependent v_mfma_f32_4x4x1 can issue every ~30 cycles, so with the
+            // three chains of the first version (d2a / d2b alternating, d1 alone) the 160 MFMAs took ~2 900 cycles instead of the
+            // pipe's 1 500.  (W_hh2's columns are AccVGPR operands, as in the forward.)
+            const x4_f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            x4_f32x4 e2a[4] = {z4, z4, z4, z4}, e2b[4] = {z4, z4, z4, z4}, e1[4] = {z4, z4, z4, z4};
             float4 bf[X4_RING];
             // 24 B fragments: 16 of da2 (each feeds set 0 and set 1: 8 MFMAs) | 8 of da1 (4 MFMAs), X4_AHEAD ahead
             auto frag = [&](int idx) -> const float4 * { return idx < 16 ? F2 + idx * 4 : F1 + (idx - 16) * 4; };
@@ -983,19 +1008,23 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                 const float4 bq = bf[idx % X4_RING];
                 if (idx < 16) {
                     const float4 wa = b2[idx < 16 ? idx : 0], wb = b2[idx < 16 ? 16 + idx : 16];
-                    X4_MFMA(d2a, wa.x, bq.x); X4_MFMA(d2b, wb.x, bq.x);
-                    X4_MFMA(d2a, wa.y, bq.y); X4_MFMA(d2b, wb.y, bq.y);
-                    X4_MFMA(d2a, wa.z, bq.z); X4_MFMA(d2b, wb.z, bq.z);
-                    X4_MFMA(d2a, wa.w, bq.w); X4_MFMA(d2b, wb.w, bq.w);
+                    X4_MFMA_W(e2a[0], wa.x, bq.x); X4_MFMA_W(e2b[0], wb.x, bq.x);
+                    X4_MFMA_W(e2a[1], wa.y, bq.y); X4_MFMA_W(e2b[1], wb.y, bq.y);
+                    X4_MFMA_W(e2a[2], wa.z, bq.z); X4_MFMA_W(e2b[2], wb.z, bq.z);
+                    X4_MFMA_W(e2a[3], wa.w, bq.w); X4_MFMA_W(e2b[3], wb.w, bq.w);
                 } else {
                     const float4 wc = b1[idx - 16];
-                    X4_MFMA(d1, wc.x, bq.x);
-                    X4_MFMA(d1, wc.y, bq.y);
-                    X4_MFMA(d1, wc.z, bq.z);
-                    X4_MFMA(d1, wc.w, bq.w);
+                    X4_MFMA_V(e1[0], wc.x, bq.x);
+                    X4_MFMA_V(e1[1], wc.y, bq.y);
+                    X4_MFMA_V(e1[2], wc.z, bq.z);
+                    X4_MFMA_V(e1[3], wc.w, bq.w);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            X4_MFMA_DRAIN8(e2a[0], e2a[1], e2a[2], e2a[3], e2b[0], e2b[1], e2b[2], e2b[3]);
+            asm volatile("" : "+v"(e1[0]), "+v"(e1[1]), "+v"(e1[2]), "+v"(e1[3]));
+            const x4_f32x4 d2a = (e2a[0] + e2a[1]) + (e2a[2] + e2a[3]), d2b = (e2b[0] + e2b[1]) + (e2b[2] + e2b[3]),
+                           d1 = (e1[0] + e1[1]) + (e1[2] + e1[3]);
             // lane (block bb, clip j) holds rows 4 bb .. 4 bb + 3 of its row set = one float4 of the owner's chunk:
             //   dh2 row 128 w + 64 set + 4 bb + i -> owner 8 w + 4 set + (bb >> 2), unit quad bb & 3
             //   dh1 row  64 w + 4 bb + i          -> owner 8 w + (bb >> 1),         unit quad bb & 1
