@@ -2125,6 +2125,13 @@ extern "C" int opseq_lstm_stack_train_forward_f32(const float *x, const float *p
             sx.gsave[l] = (float4 *)(w + W.g[l]);
         }
         seqx_init<<<512, 256, 0, st>>>(sx);
+        // The launch works on groups of 4 clips; the backward and the weight-gradient GEMM on whole row blocks of 32.  Clips of the
+        // last row block that no group covers keep whatever the caller's workspace held in the gate histories - and a NaN there turns
+        // 0 x NaN into a NaN gradient (seen with a workspace that an aborted launch's poisoned tensors had occupied before).  Zeros
+        // there (their h / c histories are zeroed with the state above): only for ragged batches, ~25 us per 64 MB.
+        if (sx.NGT * 4 < a.RB * 32)
+            for (int l = 0; l < L; ++l)
+                HIP_TRY(hipMemsetAsync(w + W.g[l], 0, (size_t)T * a.RB * (size_t)H * 32 * 16, st));
         {
             std::lock_guard<std::mutex> lock(g_xcd_mu);
             if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));

@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
     __shared__ __attribute__((aligned(16))) float sFB[X4_NGMAX][4][8]; // frames_boxes of the group's previous head step
     __shared__ float sC2[X4_NGMAX][64];
     __shared__ float sC1[X4_NGMAX][32];
-    __shared__ volatile int sAbort, sLocal;
+    __shared__ int sAbort, sLocal;          // through XCD_LDS_LD / XCD_LDS_ST: ds_read / ds_write (a volatile LDS word is a FLAT access + vmcnt wait)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -269,8 +269,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
     if (w == 0) {
         const int loc = xcd_group_is_local(a.status, x);
         if (lane == 0) {
-            sLocal = loc > 0 && a.force_safe == 0;
-            sAbort = loc < 0;
+            XCD_LDS_ST(sLocal, loc > 0 && a.force_safe == 0);
+            XCD_LDS_ST(sAbort, loc < 0);
             if (loc == 0 && c == 0) atomicAdd(a.status + 3, 1u);
         }
     }
@@ -332,10 +332,11 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
                             S + X4B_H2 + w * 256, a.status, phase);
     };
 
-    if (!gather(0, 0, 0, 0)) sAbort = 1;
+    if (!gather(0, 0, 0, 0)) XCD_LDS_ST(sAbort, 1);
     __syncthreads();
-    if (sAbort) return;
-    const bool local = __builtin_amdgcn_readfirstlane(sLocal) != 0;
+    if (XCD_LDS_LD(sAbort)) return;
+    int abort_seen = 0;                         // the abort word as read behind the PREVIOUS phase's last barrier (see the loop's end)
+    const bool local = __builtin_amdgcn_readfirstlane(XCD_LDS_LD(sLocal)) != 0;
     const bool tracer = a.trace && blockIdx.x == 0 && tid == 0;
     const int nph = (T + 2) * ng;
 
@@ -549,14 +550,17 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
         // ================================ the next phase's inputs ==========================================================
         if (more && alive && !(a.debug & 1)) {
             alive = gather(gn, sn, buf ^ 1, p);
-            if (!alive) sAbort = 1;
+            if (!alive) XCD_LDS_ST(sAbort, 1);
         }
         if (tracer) a.trace[(long)p * 8 + 5] = clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // orders this phase's re-arm stores before the next publish
         if (tracer) a.trace[(long)p * 8 + 6] = clock64();
         __syncthreads();                        // barrier 2: the next phase's inputs have landed
         if (tracer) a.trace[(long)p * 8 + 7] = clock64();
-        if (sAbort) return;
+        // the abort word is looked at one phase late: read here, behind the barrier, but only tested a phase on, so that the LDS round
+        // trip stays off the step's critical chain (an aborted launch's outputs are NaN whatever this block still stores)
+        if (abort_seen) return;
+        abort_seen = XCD_LDS_LD(sAbort);
         gi = gn;
         s = sn;
     }
@@ -731,7 +735,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     __shared__ __attribute__((aligned(16))) float sDL[X4_NGMAX][2][4][16];   // dl of the group's head steps, by phase parity: [clip][slot]
     __shared__ float sDFB[2][32];
     __shared__ __attribute__((aligned(16))) float4 sHX[X4_NGMAX][2][28][4];   // the head step's boxes (24 k-quads) and p (4 slot quads) x 4 clips, by step parity
-    __shared__ volatile int sAbort, sLocal;
+    __shared__ int sAbort, sLocal;          // through XCD_LDS_LD / XCD_LDS_ST: ds_read / ds_write (a volatile LDS word is a FLAT access + vmcnt wait)
 
     // the forward of this step gave up (sticky abort word, see opnet_xcd4_init_bwd): its histories are partial - leave
     if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
@@ -743,8 +747,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     if (w == 0) {
         const int loc = xcd_group_is_local(a.status, x);
         if (lane == 0) {
-            sLocal = loc > 0 && a.force_safe == 0;
-            sAbort = loc < 0;
+            XCD_LDS_ST(sLocal, loc > 0 && a.force_safe == 0);
+            XCD_LDS_ST(sAbort, loc < 0);
             if (loc == 0 && c == 0) atomicAdd(a.status + 3, 1u);
         }
     }
@@ -819,11 +823,12 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         }
     };
 
-    if (!gather(0, 0, 0, 0)) sAbort = 1;
+    if (!gather(0, 0, 0, 0)) XCD_LDS_ST(sAbort, 1);
     fetch(0, 0, cg, cdy, cct, ccp);
     __syncthreads();
-    if (sAbort) return;
-    const bool local = __builtin_amdgcn_readfirstlane(sLocal) != 0;
+    if (XCD_LDS_LD(sAbort)) return;
+    int abort_seen = 0;                         // the abort word as read behind the PREVIOUS phase's last barrier (see the loop's end)
+    const bool local = __builtin_amdgcn_readfirstlane(XCD_LDS_LD(sLocal)) != 0;
     const bool tracer = a.trace && blockIdx.x == 0 && tid == 0;
     const int nph = (T + 3) * ng;
 
@@ -1066,14 +1071,14 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) { bad |= v[q] == X4_SENT; hsum += __uint_as_float(v[q]); }
                     if (!__any(bad)) break;
-                    if (!x4_keep_polling(spins, t0, a.status, p)) { alive = false; sAbort = 1; break; }
+                    if (!x4_keep_polling(spins, t0, a.status, p)) { alive = false; XCD_LDS_ST(sAbort, 1); break; }
                 }
             }
         }
         // ================================ the next phase's inputs ==========================================================
         if (more && alive && !(a.debug & 1)) {
             alive = gather(gn, nn, buf ^ 1, p);
-            if (!alive) sAbort = 1;
+            if (!alive) XCD_LDS_ST(sAbort, 1);
         }
         if (tracer) a.trace[(long)p * 8 + 4] = clock64();
         if (hfetch) {
@@ -1084,7 +1089,10 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         if (tracer) a.trace[(long)p * 8 + 5] = clock64();
         __syncthreads();                        // barrier 2: the next phase's chunks have landed
         if (tracer) a.trace[(long)p * 8 + 6] = clock64();
-        if (sAbort) return;
+        // the abort word is looked at one phase late: read here, behind the barrier, but only tested a phase on, so that the LDS round
+        // trip stays off the step's critical chain (an aborted launch's outputs are NaN whatever this block still stores)
+        if (abort_seen) return;
+        abort_seen = XCD_LDS_LD(sAbort);
         gprev = gi;
         nprev = n;
         gi = gn;

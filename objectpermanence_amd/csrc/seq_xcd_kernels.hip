@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
     __shared__ float4 sPad[4096];          // 64 KB never used: > 80 KB of LDS in total keep a second workgroup off the CU (every
                                            // CU must host exactly one of the 256 workgroups, or the exchange waits for a block
                                            // that is not resident)
-    __shared__ volatile int sAbort, sLocal;
+    __shared__ int sAbort, sLocal;          // through XCD_LDS_LD / XCD_LDS_ST: ds_read / ds_write (a volatile LDS word is a FLAT access + vmcnt wait)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,8 +244,8 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
     if (w == 0) {
         const int loc = xcd_group_is_local(a.status, x);
         if (lane == 0) {
-            sLocal = loc > 0 && a.force_safe == 0;
-            sAbort = loc < 0;
+            XCD_LDS_ST(sLocal, loc > 0 && a.force_safe == 0);
+            XCD_LDS_ST(sAbort, loc < 0);
             if (loc == 0 && c == 0) atomicAdd(a.status + 3, 1u);
         }
     }
@@ -293,8 +293,9 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
     const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void *)a.ws, 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = lane * 16;
     __syncthreads();
-    if (sAbort) return;
-    const bool local = __builtin_amdgcn_readfirstlane(sLocal) != 0;
+    if (XCD_LDS_LD(sAbort)) return;
+    int abort_seen = 0;                         // the abort word as read behind the PREVIOUS phase's last barrier (see the loop's end)
+    const bool local = __builtin_amdgcn_readfirstlane(XCD_LDS_LD(sLocal)) != 0;
     const bool top = l == L - 1;
     const int nph = T * ng;
     constexpr int NLD = (NXWMAX + 15) / 16;                      // 1-KB pieces (16 k-quads x 4 clips) an x wave loads per phase
@@ -427,11 +428,14 @@ __global__ void __launch_bounds__(256) seqx_forward(const SeqXArgs a)
                 s4[r] = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + ((acc[4][r] + acc[5][r]) + (acc[6][r] + acc[7][r]));
             sP[p & 1][w][lane] = make_float4(s4[0], s4[1], s4[2], s4[3]);
         }
-        if (!ok) sAbort = 1;
+        if (!ok) XCD_LDS_ST(sAbort, 1);
         SX_STAMP(4);                            // products done
         __syncthreads();                        // the phase's partials are in sP
         SX_STAMP(5);
-        if (sAbort) return;
+        // the abort word is looked at one phase late: read here, behind the barrier, but only tested a phase on, so that the LDS round
+        // trip stays off the step's critical chain (an aborted launch's outputs are NaN whatever this block still stores)
+        if (abort_seen) return;
+        abort_seen = XCD_LDS_LD(sAbort);
         gp = gi; tp = t;
         if (++gi == ng) { gi = 0; ++t; }
     }
