@@ -677,7 +677,6 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
                             | ((a.trace && blockIdx.x == 0 && wv == XCD_FW0) ? XCD_CF_TRACE : 0u);
 
     int gi = 0, s = 0;                          // phase fp = s * ng + gi
-    int abort_seen = 0;
     for (int fp = 0; fp < nph; ++fp) {
         unsigned cf = __builtin_amdgcn_readfirstlane(cfbits);
         int wq = w;
@@ -712,10 +711,7 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         __builtin_amdgcn_s_barrier();           // barrier fp: the phase's accumulators are in sHAND[fp & 1]
         asm volatile("" ::: "memory");
         if (tracer) XCD_KARG(unsigned long long *, trace)[(long)fp * 8 + 2] = clock64();
-        // the abort word is read here, behind the barrier, and tested one phase later: its LDS round trip stays off the finish waves'
-        // chain (which IS the critical path with one or two groups per XCD); an aborted launch's outputs are NaN anyway
-        if (abort_seen) return;
-        abort_seen = XCD_LDS_LD(sAbort);
+        if (XCD_LDS_LD(sAbort)) return;
         // If the phase after next already has its inputs published (four or more groups per XCD: its group finished its
         // previous step more than a window ago) the gather goes first and lands under the finish; otherwise the finish
         // goes first and the gather follows it (three groups: published by then; two: it is THIS finish - the product
@@ -904,7 +900,10 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (tracer) XCD_KARG(unsigned long long *, trace)[(long)fp * 8 + 7] = clock64();
-        if (cf & XCD_CF_NG1) __syncthreads();    // (an abort is seen at the top of the next phase)
+        if (cf & XCD_CF_NG1) {
+            __syncthreads();
+            if (XCD_LDS_LD(sAbort)) return;
+        }
         if (++gi == ng) { gi = 0; ++s; }
     }
 }
