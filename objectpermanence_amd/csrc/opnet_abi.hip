@@ -859,8 +859,7 @@ extern "C" int opnet_train_pack_weights_f32(const float *w_ih1, const float *w_h
             packed + P.woutp, nullptr, w_out, 0, 0, H2, 0, 4, 1, 1);                // the output head's tiles (opnet_xcd4_out_head)
     }
     if (x4_dims(H1, H2)) {
-        opnet_xcd4_pack_fwd<<<1024, 256, 0, st>>>(packed + L.x4fwd, w_ih1, w_hh1, w_sel, w_ih2, w_hh2);
-        opnet_xcd4_pack_bwd<<<1024, 256, 0, st>>>(packed + L.x4bwd, w_hh1, w_sel, w_ih2, w_hh2, w_out);
+        opnet_xcd4_pack_both<<<2048, 256, 0, st>>>(packed + L.x4fwd, packed + L.x4bwd, w_ih1, w_hh1, w_sel, w_ih2, w_hh2, w_out);
     }
     HIP_TRY(hipGetLastError());
     {
@@ -1078,7 +1077,7 @@ extern "C" int opnet_xcd4_forward_f32(const float *boxes, const float *packed, f
     else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
     opnet_xcd4_forward<false><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(x);
     HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
-    opnet_xcd4_out_head<<<dim3(T, RB), 256, 0, st>>>(x);
+    opnet_xcd4_out_head<<<dim3(T, RB), 256, 0, st>>>(x, nullptr, nullptr);
     opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
@@ -1154,25 +1153,25 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
     const TrainWorkspaceLayout W = train_workspace_layout(B, T, H1, H2);
     hipStream_t st = (hipStream_t)stream;
     OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
-    opnet_set_io<<<1, 1, 0, st>>>(dio, io);
-    opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     if (x4_use(B, T, H1, H2)) {
-        // small batch on a whole device: the 4-clip persistent step (opnet_xcd4_kernels.hip) writes the same histories
+        // small batch on a whole device: the 4-clip persistent step (opnet_xcd4_kernels.hip) writes the same histories.  Three
+        // launches per forward: prologue (device-side io, input pack, rings), the recurrence, output head + copies to the caller
         Xcd4Args x;
         if (int rc = make_x4_args(&x, packed, workspace, B, T, H1, H2)) return rc;
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
-        opnet_xcd4_init<<<8, 256, 0, st>>>(x);
+        opnet_x4_train_prologue<<<dim3(T, a.RB + 1), 256, 0, st>>>(dio, io, x);
         std::lock_guard<std::mutex> lock(g_xcd_mu);
         if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
         else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
         opnet_xcd4_forward<true><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(x);
         HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
-        opnet_xcd4_out_head<<<dim3(T, a.RB), 256, 0, st>>>(x);
-        opnet_copy_out<<<copy_grid(B, T), 256, 0, st>>>(dio);
+        opnet_xcd4_out_head<<<dim3(T, a.RB + 1), 256, 0, st>>>(x, (float4 *)y, logits);
         HIP_TRY(hipGetLastError());
         return OPNET_OK;
     }
+    opnet_set_io<<<1, 1, 0, st>>>(dio, io);
+    opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     if (int rc = train_chain_layouts(packed, st)) return rc;
     // the status words of the 4-clip kernels are sticky from the forward to the weight-gradient launch and the optimiser's
     // guard: a forward on the launch chain has to say "nothing aborted" itself
@@ -1222,8 +1221,10 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
     hipStream_t st = (hipStream_t)stream;
     const int RB = a.RB;
     char *w = (char *)workspace;
-    opnet_pack_dy<<<256, 256, 0, st>>>((const float4 *)dy, (float4 *)(w + W.dyp), (float *)(w + W.dcz),
-                                        (long)((W.dcz_end - W.dcz) / 4), B, T, RB);
+    const bool x4_bwd = !mlp && x4_use(B, T, H1, H2) && env_int("OPNET_XCD4_BWD", 1) != 0;
+    if (!x4_bwd)        // (the 4-clip persistent form packs dy in its own initialisation launch)
+        opnet_pack_dy<<<256, 256, 0, st>>>((const float4 *)dy, (float4 *)(w + W.dyp), (float *)(w + W.dcz),
+                                            (long)((W.dcz_end - W.dcz) / 4), B, T, RB);
     bw.mlp = mlp;
     if (mlp) opnet_mlp_dhid<<<4096, 256, 0, st>>>(bw);
     // Reverse recurrence.  Up to four row blocks: ONE fused launch per step - a workgroup owns complete dh rows, so the
@@ -1232,13 +1233,14 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
     // leave most of the chip idle (measured per step, fused / split: B=96 6.72 / 7.17 ms, B=128 7.79 / 7.92, B=256 12.97 / 12.38).
     const char *mode = getenv("OPNET_BWD_MODE");          // "fused" / "split": measurement override
     const bool fused = mode ? strcmp(mode, "fused") == 0 : RB <= 4;
-    if (!mlp && x4_use(B, T, H1, H2) && env_int("OPNET_XCD4_BWD", 1) != 0) {
+    if (x4_bwd) {
         // small batch on a whole device: the 4-clip persistent reverse recurrence (opnet_xcd4_kernels.hip)
         Xcd4BArgs x;
         make_x4b_args(&x, packed, workspace, B, T, H1, H2);
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
-        opnet_xcd4_init_bwd<<<256, 256, 0, st>>>(x);
+        opnet_xcd4_init_bwd<<<256, 256, 0, st>>>(x, (const float4 *)dy, (float4 *)(w + W.dyp), (float *)(w + W.dcz),
+                                                 (long)((W.dcz_end - W.dcz) / 4), B);
         std::lock_guard<std::mutex> lock(g_xcd_mu);
         if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
         else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));

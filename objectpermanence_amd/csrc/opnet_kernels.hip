@@ -121,16 +121,15 @@ __global__ void opnet_set_io(OpnetIO *dst, OpnetIO src) { *dst = src; }
 // 0, learned_models.py:39,46 pass no initial state): it is the first kernel node of the forward, so
 // the zeroing is ordered like every other kernel of the chain (a hipGraph memset root node is not
 // ordered against the tail of a previous replay of the same graph on ROCm 7.2 - measured).
-__global__ void __launch_bounds__(256) opnet_pack_input(const OpnetIO *__restrict__ io)
+// (the body, for the workgroup (t, rb) of a T x nrb grid; also part of opnet_x4_train_prologue)
+__device__ __forceinline__ void pack_input_body(const OpnetIO *__restrict__ io, int t, int rb, int nrb)
 {
-    const int t = blockIdx.x;
-    const int rb = blockIdx.y;
     const int B = io->B, T = io->T, RB = io->RB;
     {
         float4 *__restrict__ st = io->state;
         const long n = io->state_f4;
-        const long nthreads = (long)gridDim.x * gridDim.y * 256;
-        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < n; i += nthreads)
+        const long nthreads = (long)T * nrb * 256;
+        for (long i = ((long)rb * T + t) * 256 + threadIdx.x; i < n; i += nthreads)
             st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float *__restrict__ boxes = io->boxes;
@@ -150,6 +149,11 @@ __global__ void __launch_bounds__(256) opnet_pack_input(const OpnetIO *__restric
         }
         xp[kq * 32 + clip] = v;
     }
+}
+
+__global__ void __launch_bounds__(256) opnet_pack_input(const OpnetIO *__restrict__ io)
+{
+    pack_input_body(io, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // staging -> caller's y [B][T][4] and logits [B][15][T] (both staging buffers use the same layouts

@@ -182,12 +182,12 @@ __device__ __forceinline__ bool x4_gather_sum4(__amdgpu_buffer_rsrc_t rws, unsig
 }
 
 // fp32 weights -> the register images of opnet_xcd4_forward (see the layout notes above)
-__global__ void __launch_bounds__(256) opnet_xcd4_pack_fwd(float *__restrict__ out, const float *__restrict__ w_ih1,
-                                                           const float *__restrict__ w_hh1, const float *__restrict__ w_sel,
-                                                           const float *__restrict__ w_ih2, const float *__restrict__ w_hh2)
+__device__ __forceinline__ void x4_pack_fwd_body(float *__restrict__ out, const float *__restrict__ w_ih1,
+                                                 const float *__restrict__ w_hh1, const float *__restrict__ w_sel,
+                                                 const float *__restrict__ w_ih2, const float *__restrict__ w_hh2, unsigned bid, unsigned nblk)
 {
     const X4Packed P = x4_packed_layout();
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < P.total; idx += (size_t)gridDim.x * blockDim.x) {
+    for (size_t idx = bid * (size_t)blockDim.x + threadIdx.x; idx < P.total; idx += (size_t)nblk * blockDim.x) {
         const int e = idx & 3, lane = (idx >> 2) & 63, b = lane >> 2, i = lane & 3;
         float v = 0.f;
         if (idx < P.a1) {
@@ -218,9 +218,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_pack_fwd(float *__restrict__ o
 }
 
 // status words and the XCC sentinels; the exchange rings: slot 0 = the zero initial state, the others unpublished
-__global__ void __launch_bounds__(256) opnet_xcd4_init(Xcd4Args a)
+__device__ __forceinline__ void x4_init_body(const Xcd4Args &a, int tid, int n)
 {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
     const int NG = a.RB * 8;
     if (tid < 8) a.status[tid] = 0u;
     for (int i = tid; i < 256; i += n) a.status[8 + i] = 0xffffffffu;
@@ -228,6 +227,22 @@ __global__ void __launch_bounds__(256) opnet_xcd4_init(Xcd4Args a)
     xcd_u32x4 *h1x = (xcd_u32x4 *)(a.ws + a.h1x_off), *h2x = (xcd_u32x4 *)(a.ws + a.h2x_off);
     for (int i = tid; i < NG * X4_SLOTS * 256; i += n) h1x[i] = ((i >> 8) & (X4_SLOTS - 1)) == 0 ? z : sent;
     for (int i = tid; i < NG * X4_SLOTS * 512; i += n) h2x[i] = ((i >> 9) & (X4_SLOTS - 1)) == 0 ? z : sent;
+}
+
+__global__ void __launch_bounds__(256) opnet_xcd4_init(Xcd4Args a)
+{
+    x4_init_body(a, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// The three launches in front of the training forward as one (each of them is a few microseconds of work behind ~4 us of launch):
+// the caller's pointers into the device-side OpnetIO (opnet_copy_out reads it), boxes -> xp + zeroed state (opnet_pack_input),
+// status words and exchange rings (opnet_xcd4_init).  Grid (T, RB + 1): row RB initialises, the rest pack; the pack reads the
+// pointers out of the kernarg copy, not out of the struct this launch is writing.
+__global__ void __launch_bounds__(256) opnet_x4_train_prologue(OpnetIO *dio, const OpnetIO io, const Xcd4Args a)
+{
+    if ((int)blockIdx.y < io.RB) { pack_input_body(&io, blockIdx.x, blockIdx.y, io.RB); return; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *dio = io;
+    x4_init_body(a, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // lane i of every row of 16 lanes receives lane i + N of its row
@@ -569,11 +584,19 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
 // y staging [RB*32][T] float4 = W_out h2[t] (prediction_layer, learned_models.py:33,47) from the h2 history; one workgroup per
 // (t, row block): thread (r, clip) walks k-quads r, r + 8, ...; the 8 partials are summed in fixed order.  An aborted persistent
 // launch (status[0] != 0) poisons y with NaN.
-__global__ void __launch_bounds__(256) opnet_xcd4_out_head(const Xcd4Args a)
+// y_out / lg_out (training forward; null otherwise): the caller's y [B][T][4] is written here as well, and one more row of
+// workgroups (blockIdx.y == RB) copies the staged logits to the caller's [B][15][T] - what opnet_copy_out did in a launch of its own
+__global__ void __launch_bounds__(256) opnet_xcd4_out_head(const Xcd4Args a, float4 *__restrict__ y_out, float *__restrict__ lg_out)
 {
     __shared__ float sw[4][512];
     __shared__ __attribute__((aligned(16))) float4 red[8][32];
     const int t = blockIdx.x, rb = blockIdx.y, tid = threadIdx.x, T = a.T;
+    if (rb == a.RB) {
+        const float *__restrict__ ls = (const float *)(a.ws + a.lg_off);
+        const long nl = (long)a.B * OPNET_SLOTS_ * T;
+        for (long i = (long)t * 256 + tid; i < nl; i += (long)gridDim.x * 256) lg_out[i] = ls[i];
+        return;
+    }
     const float *wo = a.woutp;                 // [H2/16][64][4]: lane l = row l & 15, k = 16 q + 4 (l >> 4) + e
     for (int i = tid; i < 4 * 512; i += 256) {
         const int o = i / 512, k = i % 512;
@@ -603,6 +626,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_out_head(const Xcd4Args a)
         }
         if (a.status[0] != 0u) sum = make_float4(NAN, NAN, NAN, NAN);
         ((float4 *)(a.ws + a.ys_off))[((size_t)rb * 32 + tid) * T + t] = sum;
+        if (y_out && rb * 32 + tid < a.B) y_out[((size_t)rb * 32 + tid) * T + t] = sum;
     }
 }
 
@@ -671,12 +695,12 @@ struct Xcd4BArgs {
     unsigned long long *trace;
 };
 
-__global__ void __launch_bounds__(256) opnet_xcd4_pack_bwd(float *__restrict__ out, const float *__restrict__ w_hh1,
-                                                           const float *__restrict__ w_sel, const float *__restrict__ w_ih2,
-                                                           const float *__restrict__ w_hh2, const float *__restrict__ w_out)
+__device__ __forceinline__ void x4_pack_bwd_body(float *__restrict__ out, const float *__restrict__ w_hh1,
+                                                 const float *__restrict__ w_sel, const float *__restrict__ w_ih2,
+                                                 const float *__restrict__ w_hh2, const float *__restrict__ w_out, unsigned bid, unsigned nblk)
 {
     const X4BPacked P = x4b_packed_layout();
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < P.total; idx += (size_t)gridDim.x * blockDim.x) {
+    for (size_t idx = bid * (size_t)blockDim.x + threadIdx.x; idx < P.total; idx += (size_t)nblk * blockDim.x) {
         const int e = idx & 3, lane = (idx >> 2) & 63, b = lane >> 2, i = lane & 3;
         float v = 0.f;
         if (idx < P.b1) {
@@ -707,10 +731,43 @@ __global__ void __launch_bounds__(256) opnet_xcd4_pack_bwd(float *__restrict__ o
 }
 
 // status, the exchange rings: slot T & 3 of the partials = zeros (da_T = 0), everything else unpublished
-__global__ void __launch_bounds__(256) opnet_xcd4_init_bwd(Xcd4BArgs a)
+__global__ void __launch_bounds__(256) opnet_xcd4_pack_fwd(float *__restrict__ out, const float *__restrict__ w_ih1,
+                                                           const float *__restrict__ w_hh1, const float *__restrict__ w_sel,
+                                                           const float *__restrict__ w_ih2, const float *__restrict__ w_hh2)
+{
+    x4_pack_fwd_body(out, w_ih1, w_hh1, w_sel, w_ih2, w_hh2, blockIdx.x, gridDim.x);
+}
+// both register images of a training step's weights in one launch (they are re-packed after every optimiser step): the first half of
+// the grid writes the forward's, the second the backward's
+__global__ void __launch_bounds__(256) opnet_xcd4_pack_both(float *__restrict__ out_f, float *__restrict__ out_b, const float *__restrict__ w_ih1,
+                                                            const float *__restrict__ w_hh1, const float *__restrict__ w_sel,
+                                                            const float *__restrict__ w_ih2, const float *__restrict__ w_hh2,
+                                                            const float *__restrict__ w_out)
+{
+    const unsigned half = gridDim.x / 2;
+    if (blockIdx.x < half) x4_pack_fwd_body(out_f, w_ih1, w_hh1, w_sel, w_ih2, w_hh2, blockIdx.x, half);
+    else x4_pack_bwd_body(out_b, w_hh1, w_sel, w_ih2, w_hh2, w_out, blockIdx.x - half, half);
+}
+
+// (+ opnet_pack_dy's work when dy is given: the caller's dy [B][T][4] -> dyp [t][rb][clip], zeroed cell-gradient carry - one launch
+// in front of the reverse recurrence instead of two)
+__global__ void __launch_bounds__(256) opnet_xcd4_init_bwd(Xcd4BArgs a, const float4 *__restrict__ dy, float4 *__restrict__ dyp,
+                                                           float *__restrict__ dc_zero, long n_dc, int B)
 {
     const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, n = (long)gridDim.x * blockDim.x;
     const long NG = a.RB * 8;
+    if (dy) {
+        const long nd = (long)a.T * a.RB * 32;
+        for (long idx = tid; idx < nd; idx += n) {
+            const int clip = idx & 31;
+            const long trb = idx >> 5;
+            const int rb = trb % a.RB;
+            const int t = trb / a.RB;
+            const int b = rb * 32 + clip;
+            dyp[idx] = b < B ? dy[(long)b * a.T + t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (long idx = tid; idx < n_dc; idx += n) dc_zero[idx] = 0.f;
+    }
     // status[0..2] (abort code, block, phase) are STICKY from the forward of this step: an aborted forward makes the
     // reverse recurrence leave at once, and the weight-gradient launch and the optimiser's guard still see the abort word
     if (tid >= 3 && tid < 8) a.status[tid] = 0u;

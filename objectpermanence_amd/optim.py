@@ -45,6 +45,30 @@ class _L1Mean(torch.autograd.Function):
         return dy * grad_out, None, None
 
 
+def loss_and_grad(y: torch.Tensor, labels: torch.Tensor, beta: float = 0.0):
+    """(loss, dloss/dy) of the supervised loss WITHOUT an autograd node: a training step that calls `y.backward(dy)` itself
+    saves the two launches `loss.backward()` spends on the implicit gradient 1.0 (a fill) and on `dy * 1.0`."""
+    if not y.is_cuda:
+        raise RuntimeError("loss_and_grad runs on the GPU only (no CPU fallback)")
+    lib = _lib.load()
+    yd = y.detach().contiguous().float()
+    labels = labels.to(yd.device).contiguous().float()
+    n = yd.numel()
+    loss = torch.empty((), dtype=torch.float32, device=yd.device)
+    dy = torch.empty_like(yd)
+    scratch = torch.empty(4096, dtype=torch.uint8, device=yd.device)
+    with torch.cuda.device(yd.device):
+        st = torch.cuda.current_stream(yd.device).cuda_stream
+        if beta > 0:
+            rc = lib.opnet_smooth_l1_loss_f32(yd.data_ptr(), labels.data_ptr(), loss.data_ptr(), dy.data_ptr(), n, float(beta),
+                                              scratch.data_ptr(), scratch.numel(), st)
+        else:
+            rc = lib.opnet_l1_loss_f32(yd.data_ptr(), labels.data_ptr(), loss.data_ptr(), dy.data_ptr(), n, scratch.data_ptr(),
+                                       scratch.numel(), st)
+    _lib.check(rc, "opnet_l1_loss_f32")
+    return loss, dy
+
+
 def l1_mean(y: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     return _L1Mean.apply(y, labels, 0.0)
 

@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from . import parallel
-from .optim import l1_mean, smooth_l1_mean
+from .optim import l1_mean, loss_and_grad, smooth_l1_mean
 from .supported_models import DOUBLE_OUTPUT_MODELS, NO_LABELS_MODELS
 
 
@@ -63,9 +63,14 @@ def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.O
     if n_local > 0:
         out = model(boxes)
         output = out[0] if model_name in DOUBLE_OUTPUT_MODELS else out
-        loss, _, _ = compute_loss(model_name, output, labels, mask, loss_kind, with_consistency=False)
-        loss.backward()
-        loss = loss.detach()
+        if model_name not in NO_LABELS_MODELS and output.is_cuda:
+            # supervised loss: value and gradient from one call, the backward started from dy (no autograd node for the loss)
+            loss, dy = loss_and_grad(output, labels, 1.0 if loss_kind == "smooth_l1" else 0.0)
+            output.backward(dy)
+        else:
+            loss, _, _ = compute_loss(model_name, output, labels, mask, loss_kind, with_consistency=False)
+            loss.backward()
+            loss = loss.detach()
         guard_word = model.launch_guard() if hasattr(model, "launch_guard") else None
     else:
         loss = bucket.flat.new_zeros(())
