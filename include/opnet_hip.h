@@ -139,7 +139,8 @@ int opnet_xcd4_enabled(void);
 /* ---- training (replaces torch autograd through OPNet.forward, nn.L1Loss and torch.optim.Adam as used
  *      at training_main.py:150-152,183-217) ---------------------------------------------------------
  * opnet_train_forward_f32 is opnet_forward_f32 that additionally keeps every step's h, c, gates,
- * slot probabilities and frames_boxes in `workspace` (5.7 MB/clip at T=300).
+ * slot probabilities and frames_boxes in `workspace` (5.7 MB/clip at T=300, plus 64 MB whatever the batch: the partial
+ * tiles of the weight-gradient waves).
  * opnet_train_backward_f32 consumes that history and dy = dLoss/dy_boxes [B,T,4] and writes the six
  * weight gradients in the state_dict layouts (`boxes` never requires grad; the logits output is not
  * differentiated - no reference loss uses it, training_main.py:186-210).  `packed` must come from
