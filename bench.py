@@ -772,11 +772,16 @@ def bench_infer_xcd(args, model, boxes, world, rank, dev, dist):
     exchange = dist is not None
     state = {"y": None, "pred": None, "seen": 0, "gathered": []}
     comm = torch.cuda.Stream(device=dev) if exchange else None
+    if exchange:
+        # the next launch's input concatenation overlaps the collective, the persistent launch itself waits for it: it needs
+        # every CU of the device, and an RCCL kernel that holds some while a slower rank's collective sits behind ITS 5-ms
+        # launch would stall this rank's launch for as long (ranks would take turns waiting for each other)
+        server.before_launch = lambda: torch.cuda.current_stream(dev).wait_stream(comm)
 
     def after_flush():
         # one post-process per launch on the stream the forward was enqueued on; the all-gather of its int32 predictions
-        # (3 MB for 640 clips) runs on a SIDE stream behind an event, so the next launch's input concatenation and
-        # recurrence do not wait for the collective (north_star: "overlapped ... on a side HIP stream")
+        # (3 MB for 640 clips) runs on a SIDE stream behind an event, so the host side of the next launch (request queue,
+        # input concatenation) does not wait for the collective (north_star: "overlapped ... on a side HIP stream")
         if server.forwards == state["seen"]:
             return
         state["seen"] = server.forwards

@@ -52,6 +52,10 @@ class ReasonerServer:
         self.concat = bool(concat)
         self._queue: List[Tuple[torch.Tensor, PendingResult]] = []
         self._pending = 0
+        # optional callable run on the host right before the forward is enqueued (after the requests were concatenated): a
+        # data-parallel caller makes the launch wait for its previous collective here - a persistent launch needs every CU of
+        # the device, and an RCCL kernel that holds a few of them while it waits for a slower rank would stall it
+        self.before_launch = None
         self.last_output = None      # the whole output of the last forward (callers that post-process per launch)
         self.forwards = 0            # statistics: forwards issued / clips served
         self.clips = 0
@@ -80,9 +84,14 @@ class ReasonerServer:
         queue, self._queue, self._pending = self._queue, [], 0
         try:
             if len(queue) > 1 and not self.concat and hasattr(self.model, "forward_requests"):
+                if self.before_launch is not None:
+                    self.before_launch()
                 out = self.model.forward_requests([q[0] for q in queue])     # OPNet: one launch over the requests where they lie
             else:
-                out = self.model(queue[0][0] if len(queue) == 1 else torch.cat([q[0] for q in queue], dim=0))
+                x = queue[0][0] if len(queue) == 1 else torch.cat([q[0] for q in queue], dim=0)
+                if self.before_launch is not None:
+                    self.before_launch()
+                out = self.model(x)
         except Exception as e:
             # a bad shape, an out-of-memory concatenation, an ABI error: the requests of this forward are not silently lost -
             # each handle re-raises from result() (and done() turns true), the server stays usable
