@@ -347,8 +347,11 @@ __device__ __forceinline__ int xcd_group_is_local(unsigned *status, int x)
 #ifndef XCD_NY4
 #define XCD_NY4 0              // four or more: a window of slack - the tail gap alone is enough
 #endif
-// an 8-pass MFMA's result may be read by other instructions 11 wait states after it issued (16-pass: 19): 20 here
-#define XCD_MFMA_DRAIN(a0, a1, a2, a3) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
+// an 8-pass MFMA's result may be read by other instructions 11 wait states after it issued (16-pass: 19)
+#ifndef XCD_DRAIN_NOP
+#define XCD_DRAIN_NOP "s_nop 13"      // 14 wait states (11 required; the 20 of round 2 cost ~25 cycles per phase)
+#endif
+#define XCD_MFMA_DRAIN(a0, a1, a2, a3) asm volatile(XCD_DRAIN_NOP : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
 
 // ------------------------------------------------------------------------------------------------------------------
 // the persistent kernel: 8 waves per CU, two roles
