@@ -811,10 +811,16 @@ __global__ void __launch_bounds__(256) opnet_wgrad_reduce(const Wg2Batch batch)
             const int b = ab % G, a = ab / G;
             const int tn = (int)(tile % J.tiles_n), tm = (int)(tile / J.tiles_n);
             const float4 *p = (const float4 *)(batch.partial + (long)(J.wave_begin + tile) * WG2_PART_F) + q;
-            float4 sum = p[0];
-            for (int s = 1; s < J.slices; ++s) {
-                const float4 v = p[(long)s * ntile * (WG2_PART_F / 4)];
-                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            // slices in slice order, eight loads in flight at a time (one after the other each costs a full memory round trip)
+            const long sstride = ntile * (WG2_PART_F / 4);
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s0 = 0; s0 < J.slices; s0 += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = s0 + k < J.slices ? p[(long)(s0 + k) * sstride] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (s0 + k < J.slices) { sum.x += v[k].x; sum.y += v[k].y; sum.z += v[k].z; sum.w += v[k].w; }
             }
             if (bad) sum = make_float4(NAN, NAN, NAN, NAN);
             // D layout of 16x16x4: lane l holds column j = l & 15, rows 4 (l >> 4) + r
