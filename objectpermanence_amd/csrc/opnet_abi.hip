@@ -853,13 +853,12 @@ extern "C" int opnet_train_pack_weights_f32(const float *w_ih1, const float *w_h
     const bool lazy = x4_dims(H1, H2) && x4_on() && x4_device();
     if (!lazy) {
         if (int rc = pack_chain_train_layouts(w_ih1, w_hh1, w_sel, w_ih2, w_hh2, w_out, packed, H1, H2, st)) return rc;
-    } else {
-        const PackedLayout P = packed_layout(H1, H2);
-        opnet_pack_tiles<<<(unsigned)(((size_t)(H2 / 16) * 256 + 255) / 256), 256, 0, st>>>(
-            packed + P.woutp, nullptr, w_out, 0, 0, H2, 0, 4, 1, 1);                // the output head's tiles (opnet_xcd4_out_head)
     }
     if (x4_dims(H1, H2)) {
-        opnet_xcd4_pack_both<<<2048, 256, 0, st>>>(packed + L.x4fwd, packed + L.x4bwd, w_ih1, w_hh1, w_sel, w_ih2, w_hh2, w_out);
+        // (lazy: the output head's tiles - all opnet_xcd4_out_head reads of the chain's layouts - ride in the same launch)
+        const PackedLayout P = packed_layout(H1, H2);
+        opnet_xcd4_pack_both<<<2048, 256, 0, st>>>(packed + L.x4fwd, packed + L.x4bwd, w_ih1, w_hh1, w_sel, w_ih2, w_hh2, w_out,
+                                                   lazy ? packed + P.woutp : nullptr);
     }
     HIP_TRY(hipGetLastError());
     {
@@ -1160,7 +1159,9 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
         if (int rc = make_x4_args(&x, packed, workspace, B, T, H1, H2)) return rc;
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
-        opnet_x4_train_prologue<<<dim3(T, a.RB + 1), 256, 0, st>>>(dio, io, x);
+        OpnetIO io_nz = io;
+        io_nz.state_f4 = 0;                     // (the prologue zeroes slot 0 of the histories itself)
+        opnet_x4_train_prologue<<<dim3(T, a.RB + 1), 256, 0, st>>>(dio, io_nz, x);
         std::lock_guard<std::mutex> lock(g_xcd_mu);
         if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
         else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));

@@ -242,7 +242,15 @@ __global__ void __launch_bounds__(256) opnet_x4_train_prologue(OpnetIO *dio, con
 {
     if ((int)blockIdx.y < io.RB) { pack_input_body(&io, blockIdx.x, blockIdx.y, io.RB); return; }
     if (blockIdx.x == 0 && threadIdx.x == 0) *dio = io;
-    x4_init_body(a, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+    const int tid = blockIdx.x * 256 + threadIdx.x, n = gridDim.x * 256;
+    x4_init_body(a, tid, n);
+    // slot 0 of the four state histories (h1, c1, h2, c2 of "step -1": the backward and the weight gradients read them); the
+    // launch chain zeroes its whole state region (59 MB at 32 x 300) because its step kernels read what they have not written yet
+    // - here every other slot is written by the recurrence before anything reads it (the host passes io.state_f4 = 0)
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 *h1 = (float4 *)(a.ws + a.h1_off), *c1 = (float4 *)(a.ws + a.c1_off), *h2 = (float4 *)(a.ws + a.h2_off), *c2 = (float4 *)(a.ws + a.c2_off);
+    for (int i = tid; i < a.RB * 2048; i += n) { h1[i] = z; c1[i] = z; }
+    for (int i = tid; i < a.RB * 4096; i += n) { h2[i] = z; c2[i] = z; }
 }
 
 // lane i of every row of 16 lanes receives lane i + N of its row
@@ -742,9 +750,16 @@ __global__ void __launch_bounds__(256) opnet_xcd4_pack_fwd(float *__restrict__ o
 __global__ void __launch_bounds__(256) opnet_xcd4_pack_both(float *__restrict__ out_f, float *__restrict__ out_b, const float *__restrict__ w_ih1,
                                                             const float *__restrict__ w_hh1, const float *__restrict__ w_sel,
                                                             const float *__restrict__ w_ih2, const float *__restrict__ w_hh2,
-                                                            const float *__restrict__ w_out)
+                                                            const float *__restrict__ w_out, float *__restrict__ out_head)
 {
     const unsigned half = gridDim.x / 2;
+    if (blockIdx.x < 32 && out_head) {
+        // the output head's A-fragment tile (opnet_pack_tiles, mode 1: 4 rows of a 16-row tile, K = 512): 8 192 floats
+        const int idx = blockIdx.x * 256 + threadIdx.x;
+        const int e = idx & 3, lane = (idx >> 2) & 63, q = idx >> 8, i = lane & 15;
+        const int k = 16 * q + 4 * (lane >> 4) + e;
+        out_head[idx] = i < 4 ? w_out[i * 512 + k] : 0.f;
+    }
     if (blockIdx.x < half) x4_pack_fwd_body(out_f, w_ih1, w_hh1, w_sel, w_ih2, w_hh2, blockIdx.x, half);
     else x4_pack_bwd_body(out_b, w_hh1, w_sel, w_ih2, w_hh2, w_out, blockIdx.x - half, half);
 }
