@@ -801,6 +801,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     __shared__ __attribute__((aligned(16))) float4 sDA2[2][16][4];     // the CU's da2 of the phase (by phase parity: wave 3 turns the previous
                                                                        // phase's into its dfb part): [unit'][clip] -> (i, f, g, o)
     __shared__ __attribute__((aligned(16))) float4 sDA1[8][4];
+    __shared__ long long sArrT[4];                                     // tools (trace): arrival of each wave at barrier 2
     __shared__ __attribute__((aligned(16))) float4 sX[2][64];          // per-unit parts of dfb: features 0..3 | 4..7
     __shared__ float sDC2[X4_NGMAX][64];
     __shared__ float sDC1[X4_NGMAX][32];
@@ -1159,8 +1160,14 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // orders this phase's re-arm stores before the next publish
         if (tracer) a.trace[(long)p * 8 + 5] = clock64();
+        if (a.trace && blockIdx.x == 0 && lane == 0) sArrT[w] = clock64();      // tools: when each wave reaches barrier 2
         __syncthreads();                        // barrier 2: the next phase's chunks have landed
-        if (tracer) a.trace[(long)p * 8 + 6] = clock64();
+        if (tracer) {
+            a.trace[(long)p * 8 + 6] = clock64();
+            const long long t0 = sArrT[0];      // waves 1..3 relative to wave 0, 16 bits each
+            a.trace[(long)p * 8 + 7] = (unsigned long long)(((sArrT[1] - t0) & 0xffff) | (((sArrT[2] - t0) & 0xffff) << 16)
+                                                            | (((sArrT[3] - t0) & 0xffff) << 32));
+        }
         // the abort word is looked at one phase late: read here, behind the barrier, but only tested a phase on, so that the LDS round
         // trip stays off the step's critical chain (an aborted launch's outputs are NaN whatever this block still stores)
         if (abort_seen) return;

@@ -307,6 +307,13 @@ def test_reasoner_server_batches_requests_and_slices_outputs():
     assert a.done() and not b.done()
     srv.flush()
     assert b.done() and calls[-2:] == [4, 4]
+    # before_launch (a data-parallel caller makes the launch wait for its previous collective there): once per forward, after the
+    # requests were concatenated and before the model is called
+    order = []
+    srv.before_launch = lambda: order.append(("hook", len(calls)))
+    srv.submit(torch.randn(8, 5, 15, 6)); srv.submit(torch.randn(8, 5, 15, 6))
+    srv.flush()
+    assert order == [("hook", len(calls) - 1)] and calls[-1] == 16
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -227,3 +227,29 @@ def test_fused_and_split_backward_agree(monkeypatch):
             scale = max(1e-3, np.abs(gs[k]).max())
             assert np.abs(gf[k] - gs[k]).max() <= 2e-5 * scale, (B, k)
             assert np.array_equal(ga[k], gf[k] if B <= 128 else gs[k]), (B, k)       # the automatic choice
+
+
+@pytest.mark.parametrize("B,T", [(32, 40), (7, 13), (70, 9)])
+def test_wave_tile_weight_gradients_agree_with_the_workgroup_tile_kernel(monkeypatch, B, T):
+    """opnet_wgrad_tiles + opnet_wgrad_reduce (one wave per 128 x 128 / 64 x 64 tile and time slice) against
+    opnet_wgrad (OPNET_WGRAD2=0) on the same histories: the reference hidden sizes (both tile forms, ragged row blocks), same
+    gradients up to the order of the sum over time; and the wave-tile form reproduces itself bit for bit"""
+    from objectpermanence_amd import ModelsFactory, l1_mean
+    cfg = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
+    p = synth.opnet_synth_params(cfg)
+    boxes, labels = synth.make_batch(5, B, T)
+
+    def grads(flag):
+        monkeypatch.setenv("OPNET_WGRAD2", flag)
+        m = ModelsFactory.get_model("opnet", cfg)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in p.items()})
+        m.to("cuda:0").train(True)
+        l1_mean(m(torch.from_numpy(boxes).cuda())[0], torch.from_numpy(labels).cuda()).backward()
+        torch.cuda.synchronize()
+        return {k: v.grad.cpu().numpy() for k, v in m.named_parameters()}
+
+    new, old, again = grads("1"), grads("0"), grads("1")
+    for k in new:
+        scale = max(1e-6, np.abs(old[k]).max())
+        assert np.isfinite(new[k]).all() and np.abs(new[k] - old[k]).max() <= 2e-5 * scale, k
+        assert np.array_equal(new[k], again[k]), k

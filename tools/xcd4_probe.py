@@ -91,5 +91,10 @@ def main():
         print(f"  backward, block 0 wave 0, cycles (median; each stamp costs ~200): period {med(np.diff(ph[:, 0])):.0f} | "
               + ", ".join(f"{n} {v:.0f}" for n, v in zip(BN + ["loop"], parts)), flush=True)
 
+        sx = lambda v: ((v.astype(np.int64) & 0xffff) ^ 0x8000) - 0x8000
+        d = ph[:, 7].astype(np.int64)
+        print("  backward: arrival at barrier 2 relative to wave 0, cycles (median): wave 1 %+.0f, wave 2 %+.0f, wave 3 %+.0f" % (
+            med(sx(d)), med(sx(d >> 16)), med(sx(d >> 32))), flush=True)
+
 if __name__ == "__main__":
     main()
