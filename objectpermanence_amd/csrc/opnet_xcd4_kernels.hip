@@ -901,12 +901,19 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     __syncthreads();
     if (XCD_LDS_LD(sAbort)) return;
     int abort_seen = 0;                         // the abort word as read behind the PREVIOUS phase's last barrier (see the loop's end)
-    const bool local = __builtin_amdgcn_readfirstlane(XCD_LDS_LD(sLocal)) != 0;
-    const bool tracer = a.trace && blockIdx.x == 0 && tid == 0;
+    // the loop's wave-uniform, loop-invariant conditions (debug switches, placement, tracing, the wave's role) as bits of one scalar that
+    // is made opaque at the top of every phase, w likewise: hoisted out of the loop as 64-bit lane masks they - and the workspace's
+    // buffer descriptor with them - were spilled into VGPR lanes and fetched back with ~35 v_readlane per phase (opnet_xcd_kernels.hip)
+    const unsigned cfbits = ((unsigned)a.debug & 0xffffu) | (__builtin_amdgcn_readfirstlane(XCD_LDS_LD(sLocal)) != 0 ? 0x10000u : 0u)
+                            | ((a.trace && blockIdx.x == 0) ? 0x20000u : 0u);
     const int nph = (T + 3) * ng;
 
     int gi = 0, n = 0, gprev = 0, nprev = -1;      // (gprev, nprev): the previous phase
     for (int p = 0; p < nph; ++p) {
+        unsigned cfq = __builtin_amdgcn_readfirstlane(cfbits);
+        int wq = w;
+        asm volatile("" : "+s"(cfq), "+s"(wq));
+        const bool local = (cfq & 0x10000u) != 0, tracer = (cfq & 0x20000u) != 0 && tid == 0;
         const int buf = p & 1;
         int gn = gi + 1, nn = n;
         if (gn == ng) { gn = 0; ++nn; }
@@ -917,12 +924,12 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         if (more) fetch(gn, nn, ng_, ndy, nct, ncp);
         // ================================ the cells (and the head backward), by wave ========================================
         const float *PF = (const float *)&sbuf[buf][0];
-        if (w == 0) {
+        if (wq == 0) {
             // ---- LSTM2 cell backward at t = T-1-n: lane = (unit 16 c + b, clip j): component b & 3 of the float4 (unit quad b >> 2,
             //      clip j) of every producer's chunk ---------------------------------------------------------------------------
             const int t = T - 1 - n;
             float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < T && !(a.debug & 4)) {
+            if (t >= 0 && t < T && !(cfq & 4)) {
                 // the 32 producers' partials: the gathering waves have added them four by four - 2 waves x 4 lane groups are left
                 float r0 = 0.f, r1 = 0.f;
                 const float *pr = PF + X4D_P2 * 4 + ((b >> 2) * 4 + j) * 4 + (b & 3);
@@ -939,14 +946,14 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                 sDC2[gi][lane] = dco;
                 sDA2[buf][b][j] = da;
                 // da replaces the saved gates (the weight-gradient GEMMs read it there)
-                if (!(a.debug & 2))
+                if (!(cfq & 2))
                 ((float4 *)(a.ws + a.g2_off))[(((size_t)t * RB + rb) * 512 + 16 * c + b) * 32 + cb + j] = da;
             } else sDA2[buf][b][j] = da;
-        } else if (w == 1) {
+        } else if (wq == 1) {
             // ---- LSTM1 cell backward at t = T+2-n: lanes 0..31 = (unit 8 c + b, clip j) ------------------------------------------
             const int t = T + 2 - n;
             float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < T && !(a.debug & 4)) {
+            if (t >= 0 && t < T && !(cfq & 4)) {
                 float rec = 0.f;
                 const int lb = (lane & 31) >> 2;
                 const float *pr = PF + X4D_P1 * 4 + ((lb >> 2) * 4 + j) * 4 + (lb & 3);       // 8 lane groups of the summed piece
@@ -968,16 +975,16 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                     float dco;
                     da = cell_backward(dh, sDC1[gi][lane], cg, cct, ccp, &dco);
                     sDC1[gi][lane] = dco;
-                    if (!(a.debug & 2))
+                    if (!(cfq & 2))
                     ((float4 *)(a.ws + a.g1_off))[(((size_t)t * RB + rb) * 256 + 8 * c + b) * 32 + cb + j] = da;
                 }
             }
             if (lane < 32) sDA1[b][j] = da;
         }
-        if (w == 2) {
+        if (wq == 2) {
             // ---- head backward at t = T+1-n (dfb_t was summed at the end of the previous phase): dp, dl_t -> LDS for wave 1 one phase on --
             const int t = T + 1 - n;
-            if (t >= 0 && t < T && !(a.debug & 8)) {
+            if (t >= 0 && t < T && !(cfq & 8)) {
                 const float sum = hsum;
                     // this step's slot probabilities and boxes (lanes 0..15 = (slot quad rg, clip j)): left in LDS by wave 3 one
                     // phase ago (they come from HBM)
@@ -1024,13 +1031,13 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                     }
             }
         }
-        if (w == 3 && nprev >= 0) {
+        if (wq == 3 && nprev >= 0) {
             // ---- the CU's part of dfb_t = W_ih2^T da2_t of the PREVIOUS phase's LSTM2 step (its da2 is still in LDS): MFMA block = unit,
             //      k = gate, B = da2; D[unit b][feature][clip j], then the sum over the 16 units through LDS.  Kept off wave 0's
             //      path to the barrier (-700 cycles there), which is why the head runs two steps behind LSTM2.  Re-armed THREE steps
             //      on (its reader, wave 2, runs beside the publishing waves of its phase).
             const int t = T - 1 - nprev;
-            if (t >= 0 && t < T && !(a.debug & 4)) {
+            if (t >= 0 && t < T && !(cfq & 4)) {
                 const unsigned gp = gprev * 8 + x;
                 const float4 da = sDA2[buf ^ 1][b][j];
                 x4_f32x4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f};
@@ -1054,7 +1061,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         // wave 3: the next head step's boxes and p, from HBM into registers now, into LDS at the end of the phase
         float4 hxa = make_float4(0.f, 0.f, 0.f, 0.f), hxb = hxa;
         const int tn = T + 1 - nn;
-        const bool hfetch = w == 3 && more && tn >= 0 && tn < T;
+        const bool hfetch = wq == 3 && more && tn >= 0 && tn < T;
         if (hfetch) {
             // lane = (k-quad or slot quad q, clip j): boxes k-quads 0..15 | boxes k-quads 16..23 and p
             const float4 *xs = (const float4 *)(a.ws + a.xp_off) + ((size_t)tn * RB + gn) * (OPNET_KXQ * 32) + cb + j;
@@ -1067,7 +1074,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         if (tracer) a.trace[(long)p * 8 + 2] = clock64();
         // (an abort can only be raised in the second half of a phase: it is looked at after barrier 2)
         // ================================ products: the CU's gate columns x its da -> partial dh rows of every unit ==========
-        if (!(a.debug & 16)) {
+        if (!(cfq & 16)) {
             const float4 *F2 = &sDA2[buf][0][0] + j, *F1 = &sDA1[0][0] + j;
             // one accumulator chain per (row set, fragment element): a dependent v_mfma_f32_4x4x1 can issue every ~30 cycles, so with the
             // three chains of the first version (d2a / d2b alternating, d1 alone) the 160 MFMAs took ~2 900 cycles instead of the
@@ -1127,7 +1134,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
         if (tracer) a.trace[(long)p * 8 + 3] = clock64();
         // ================================ wave 2: the next head step's dfb = sum of the 32 CUs' parts (published in this phase's
         //                                  first half, i.e. long ago), fetched now so that the head backward is pure arithmetic ====
-        if (w == 2 && more && alive && !(a.debug & 8)) {
+        if (wq == 2 && more && alive && !(cfq & 8)) {
             const int t = T + 1 - nn;
             hsum = 0.f;
             if (t >= 0 && t < T) {
@@ -1149,7 +1156,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
             }
         }
         // ================================ the next phase's inputs ==========================================================
-        if (more && alive && !(a.debug & 1)) {
+        if (more && alive && !(cfq & 1)) {
             alive = gather(gn, nn, buf ^ 1, p);
             if (!alive) XCD_LDS_ST(sAbort, 1);
         }
