@@ -74,7 +74,7 @@ def main():
         lib = _lib.load()
         for B in (128, 256, 384, 512, 640):
             ng = (B + 127) // 128
-            tr = torch.zeros((T + 3) * ng * 8, dtype=torch.int64, device=dev)
+            tr = torch.zeros((T + 4) * ng * 8, dtype=torch.int64, device=dev)
             lib.opnet_xcd_set_trace(tr.data_ptr())
             boxes, _ = synth.make_batch(0, 64, T)
             x = torch.from_numpy(np.tile(boxes, ((B + 63) // 64, 1, 1, 1))[:B]).to(dev)
