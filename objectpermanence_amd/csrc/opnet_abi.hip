@@ -1185,6 +1185,70 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
     return OPNET_OK;
 }
 
+// The weight gradients of up to OPNET_WGRAD_JOBS products as one wave per (tile, time slice) (opnet_wgrad_tiles + opnet_wgrad_reduce,
+// DESIGN.md 9c): 128 x 128 tiles for the products with both dimensions large, 64 x 64 for the rest; the slices sized so that every
+// wave job fits ONE round of the SIMDs and big (4 units of work per step) and small (1) end together.  `partial`: WG2_MAX_WAVES x
+// WG2_PART_F floats of workspace.  false = not applicable (OPNET_WGRAD2=0, or a slice beyond a buffer descriptor's 2 GiB): the caller
+// runs opnet_wgrad.
+static bool wgrad_wave_tiles(const WgradArgs *jobs, int njobs, int T, int RB, float *partial, const unsigned *abort, hipStream_t st)
+{
+    if (env_int("OPNET_WGRAD2", 1) == 0 || njobs < 1 || njobs > OPNET_WGRAD_JOBS || !partial) return false;
+    Wg2Batch tb;
+    memset(&tb, 0, sizeof(tb));
+    int order[OPNET_WGRAD_JOBS], nb = 0, ns = 0, k = 0;
+    for (int pass = 1; pass >= 0; --pass)
+        for (int j = 0; j < njobs; ++j) {
+            const int big = jobs[j].MQ >= 32 && jobs[j].NQ >= 17;
+            if (big == pass) order[k++] = j;
+        }
+    for (int q = 0; q < njobs; ++q) {
+        Wg2Job &J = tb.job[q];
+        J.g = jobs[order[q]];
+        J.big = J.g.MQ >= 32 && J.g.NQ >= 17;
+        const int tq = J.big ? 32 : 16;
+        J.tiles_m = (J.g.MQ + tq - 1) / tq;
+        J.tiles_n = (J.g.NQ + tq - 1) / tq;
+        (J.big ? nb : ns) += J.tiles_m * J.tiles_n;
+    }
+    const long nit = (long)T * RB;
+    long best = -1;
+    int sb_best = 1, ss_best = 1;
+    for (int ss = 1; ss <= 32; ++ss) {
+        const long left = WG2_MAX_WAVES - (long)ns * ss;
+        if (left < (nb ? nb : 0) || (!nb && left < 0)) break;
+        long sb = nb ? left / nb : 1;
+        if (sb > nit) sb = nit;
+        if (sb < 1) break;
+        const long cost_b = nb ? (nit + sb - 1) / sb * 4 : 0, cost_s = ns ? (nit + ss - 1) / ss : 0;
+        const long cost = cost_b > cost_s ? cost_b : cost_s;
+        if (best < 0 || cost < best) { best = cost; sb_best = (int)sb; ss_best = ss; }
+        if (!ns) break;
+    }
+    if (best < 0) return false;
+    // (a wave addresses its slice through a buffer descriptor: 2 GiB from the slice's first step)
+    long span = 0;
+    for (int q = 0; q < njobs; ++q) {
+        const long steps = nit / (tb.job[q].big ? sb_best : ss_best) + 2;
+        const long ps = tb.job[q].g.p_stride > tb.job[q].g.q_stride ? tb.job[q].g.p_stride : tb.job[q].g.q_stride;
+        if (steps * ps * 16 > span) span = steps * ps * 16;
+    }
+    if (span >= (1L << 31)) return false;
+    int nw = 0;
+    for (int q = 0; q < njobs; ++q) {
+        Wg2Job &J = tb.job[q];
+        J.slices = J.big ? sb_best : ss_best;
+        J.wave_begin = nw;
+        nw += J.slices * J.tiles_m * J.tiles_n;
+    }
+    if (nw > WG2_MAX_WAVES) return false;
+    tb.njobs = njobs; tb.nwaves = nw;
+    tb.partial = partial;
+    tb.abort = abort;
+    opnet_wgrad_tiles<<<(nw + 3) / 4, 256, 0, st>>>(tb);
+    opnet_wgrad_reduce<<<1024, 256, 0, st>>>(tb);
+    return true;
+}
+
 static int train_backward_impl(const float *dy, const float *packed, void *workspace, size_t workspace_bytes,
                                float *g_ih1, float *g_hh1, float *g_sel, float *g_ih2, float *g_hh2, float *g_out,
                                int B, int T, int H1, int H2, void *stream, int mlp);
@@ -1291,63 +1355,9 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
     }
     // a forward or reverse recurrence that gave up (4-clip persistent kernels) left partial histories: every dW becomes NaN
     wb.abort = x4_batch(B, H1, H2) ? (const unsigned *)(w + W.x4status) : nullptr;
-    if (env_int("OPNET_WGRAD2", 1) != 0) {
-        // one wave per (tile, time slice): 128 x 128 tiles for the products with both dimensions large, 64 x 64 for the rest; the
-        // slices sized so that every wave job fits ONE round of the SIMDs and big (4 units of work per step) and small (1) end together
-        Wg2Batch tb;
-        memset(&tb, 0, sizeof(tb));
-        int order[OPNET_WGRAD_JOBS], nb = 0, ns = 0, k = 0;
-        for (int pass = 1; pass >= 0; --pass)
-            for (int j = 0; j < njobs; ++j) {
-                const int big = wb.job[j].MQ >= 32 && wb.job[j].NQ >= 17;
-                if (big == pass) order[k++] = j;
-            }
-        for (int q = 0; q < njobs; ++q) {
-            Wg2Job &J = tb.job[q];
-            J.g = wb.job[order[q]];
-            J.big = J.g.MQ >= 32 && J.g.NQ >= 17;
-            const int tq = J.big ? 32 : 16;
-            J.tiles_m = (J.g.MQ + tq - 1) / tq;
-            J.tiles_n = (J.g.NQ + tq - 1) / tq;
-            (J.big ? nb : ns) += J.tiles_m * J.tiles_n;
-        }
-        const long nit = (long)T * RB;
-        long best = -1;
-        int sb_best = 1, ss_best = 1;
-        for (int ss = 1; ss <= 32; ++ss) {
-            const long left = WG2_MAX_WAVES - (long)ns * ss;
-            if (ns && left < (nb ? nb : 0)) break;
-            long sb = nb ? left / nb : 1;
-            if (sb > nit) sb = nit;
-            if (sb < 1) break;
-            const long cost_b = nb ? (nit + sb - 1) / sb * 4 : 0, cost_s = ns ? (nit + ss - 1) / ss : 0;
-            const long cost = cost_b > cost_s ? cost_b : cost_s;
-            if (best < 0 || cost < best) { best = cost; sb_best = (int)sb; ss_best = ss; }
-            if (!ns) break;
-        }
-        // (a wave addresses its slice through a buffer descriptor: 2 GiB from the slice's first step)
-        long span = 0;
-        for (int q = 0; q < njobs && best >= 0; ++q) {
-            const long steps = nit / (tb.job[q].big ? sb_best : ss_best) + 2;
-            const long ps = tb.job[q].g.p_stride > tb.job[q].g.q_stride ? tb.job[q].g.p_stride : tb.job[q].g.q_stride;
-            if (steps * ps * 16 > span) span = steps * ps * 16;
-        }
-        if (best >= 0 && span < (1L << 31)) {
-            int nw = 0;
-            for (int q = 0; q < njobs; ++q) {
-                Wg2Job &J = tb.job[q];
-                J.slices = J.big ? sb_best : ss_best;
-                J.wave_begin = nw;
-                nw += J.slices * J.tiles_m * J.tiles_n;
-            }
-            tb.njobs = njobs; tb.nwaves = nw;
-            tb.partial = (float *)(w + W.wgpart);
-            tb.abort = wb.abort;
-            opnet_wgrad_tiles<<<(nw + 3) / 4, 256, 0, st>>>(tb);
-            opnet_wgrad_reduce<<<1024, 256, 0, st>>>(tb);
-            HIP_TRY(hipGetLastError());
-            return OPNET_OK;
-        }
+    if (wgrad_wave_tiles(wb.job, njobs, T, RB, (float *)(w + W.wgpart), wb.abort, st)) {
+        HIP_TRY(hipGetLastError());
+        return OPNET_OK;
     }
     opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
     HIP_TRY(hipGetLastError());
@@ -1926,7 +1936,7 @@ static StackTrainPacked stack_train_packed_layout(int L, int KX, int H)
 
 struct StackTrainWs {
     size_t xp, state, hall[SEQ_MAX_LAYERS], call[SEQ_MAX_LAYERS], state_end, g[SEQ_MAX_LAYERS], ystage, dyp,
-        rpart[SEQ_MAX_LAYERS], dxpart[SEQ_MAX_LAYERS], dcz, dc[SEQ_MAX_LAYERS], dcz_end, darows,
+        rpart[SEQ_MAX_LAYERS], dxpart[SEQ_MAX_LAYERS], dcz, dc[SEQ_MAX_LAYERS], dcz_end, darows, wgpart,
         sx_status, sx_hl[2], sx_hc[2], total;      // sx_*: exchange histories + status words of the persistent forward
 };
 static bool seqx_train_shape(int B, int L, int KX, int H) { return seqx_dims(L, KX, H) && B <= opseq_xcd_max_batch(L); }
@@ -1955,6 +1965,7 @@ static StackTrainWs stack_train_ws_layout(int B, int T, int L, int KX, int H)
     W.dcz_end = o;
     W.darows = o; o += (size_t)B * TT * 4 * H * 4;      // da0 as rows, for the input-gradient GEMM
     o = align_up(o, 4096);
+    W.wgpart = o; o += (size_t)WG2_MAX_WAVES * WG2_PART_F * 4;     // partial tiles of the weight-gradient waves (64 MB)
     W.sx_status = o;
     for (int l = 0; l < 2; ++l) W.sx_hl[l] = W.sx_hc[l] = o;
     if (seqx_train_shape(B, L, KX, H)) {
@@ -2227,7 +2238,9 @@ extern "C" int opseq_lstm_stack_train_backward_f32(const float *dy, const float 
             }
         }
         wb.abort = nullptr;       // (the stack's recurrences are launch chains: nothing can give up)
-    opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
+        const int nj = (int)(jobs.size() - j0 < OPNET_WGRAD_JOBS ? jobs.size() - j0 : OPNET_WGRAD_JOBS);
+        if (!wgrad_wave_tiles(wb.job, nj, T, RB, (float *)(w + W.wgpart), nullptr, st))
+            opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
     }
     if (dx0) {
         // dx0 [B*T][KX] = da0 [B*T][4H] . W_ih0 [4H][KX]  (k = 4*unit + gate on both sides) via the tiled GEMM
