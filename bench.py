@@ -567,6 +567,10 @@ def main():
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if args.force_dist:
+            # the product's own switch (objectpermanence_amd/parallel.py): every data-parallel branch - the gradient bucket's
+            # all-reduce on the comm stream, the guard slots, the gathers - runs even in a group of one rank
+            os.environ["OPNET_FORCE_DIST"] = "1"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)

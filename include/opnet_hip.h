@@ -37,6 +37,9 @@ extern "C" {
 #define OPNET_SLOTS 15
 #define OPNET_FEATS 6
 
+/* bumped whenever entry points are added or a signature changes; the Python mirror refuses a library of another version
+ * (objectpermanence_amd/_lib.py) instead of failing later on a missing symbol.  4 = round 4. */
+#define OPNET_HIP_ABI_VERSION 4
 int opnet_hip_abi_version(void);
 const char *opnet_last_error(void);
 
@@ -181,12 +184,18 @@ int opnet_adam_multi_step_f32(int count, float *const *params, const float *cons
                               float eps, int step, float grad_scale, void *stream);
 /* the same with device-side guards (each may be NULL): the whole update is skipped - parameters and moments untouched, no host
  * round trip - when *abort_u32 != 0 (status word of the persistent launches that produced the gradients), when *loss_f32 is
- * not finite, or when *guard_f32 != 0 (data parallel: the sum over ranks of their abort flags, carried by the gradient
- * all-reduce).  torch.optim.Adam (training_main.py:217) has no such guard: it would write NaN into every weight. */
+ * not finite, or when guard_f32[0] or guard_f32[1] != 0 (data parallel: the sums over ranks of their abort / non-finite-loss flags,
+ * carried by the gradient all-reduce; opnet_dp_guard_f32).  torch.optim.Adam (training_main.py:217) has no such guard: it would write NaN into every weight. */
 int opnet_adam_multi_step_guarded_f32(int count, float *const *params, const float *const *grads, float *const *exp_avgs,
                                       float *const *exp_avg_sqs, const long *numels, float lr, float beta1, float beta2,
                                       float eps, int step, float grad_scale, const unsigned *abort_u32, const float *loss_f32,
                                       const float *guard_f32, void *stream);
+/* data parallel: this rank's guard words, written on `stream` into the 4 floats the caller keeps behind its flat gradient
+ * bucket and all-reduces (sum) WITH the gradients: [0] = 1 if *abort_u32 != 0, [1] = 1 if *loss_f32 is not finite, [2] =
+ * *loss_f32 * loss_weight (n_local / n_global: the sum is the mean loss of the whole minibatch, training_main.py:212, without
+ * a collective of its own), [3] = 0; either pointer may be NULL (= 0).  After the sum `guard_f32` of the guarded Adam above points at them: nonzero [0] or [1]
+ * skips the update on EVERY rank alike (a rank-local skip would let weights and moments drift apart between the ranks). */
+int opnet_dp_guard_f32(float *guard4_f32, const unsigned *abort_u32, const float *loss_f32, float loss_weight, void *stream);
 
 /* ---- input encoder (host code; replaces baselines/datasets.py:130-196 / :265-336 _normalize_and_pad_predictions and
  *      :199-257 / :338-416 _get_closest_object_to_track_vector) -------------------------------------------------------

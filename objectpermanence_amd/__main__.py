@@ -4,6 +4,13 @@
 
 Same sub-commands and flags, so the reference's shell recipes and JSON configs carry over; only the learned reasoners
 are served (`--model_type` of the programmed heuristics / DaSiamRPN tracker is refused - out of scope).
+
+Multi-GPU: start it under torchrun, one rank per GPU -
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        -m objectpermanence_amd training --model_type opnet --model_config ... --training_config ...
+
+and every sub-command but `analysis` joins the RCCL group on `cuda:LOCAL_RANK` (parallel.init_from_env) and shards its work.
 """
 from __future__ import annotations
 
@@ -42,6 +49,19 @@ def build_parser() -> argparse.ArgumentParser:
 
 def main(argv=None) -> int:
     args = build_parser().parse_args(argv)
+    if args.mode == "analysis":          # offline CSV over prediction files: no device, no ranks
+        return _run(args)
+    # Data parallelism (not in the reference, which takes ONE device from its JSON: training_main.py:144, inference_main.py:189):
+    #   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m objectpermanence_amd training ...
+    # torchrun's environment (WORLD_SIZE / RANK / LOCAL_RANK) makes this process rank RANK of an RCCL group on cuda:LOCAL_RANK -
+    # the JSON's "device" is overridden by it - and the drivers shard clips / minibatches over the ranks (parallel.py);
+    # rank 0 writes the files.  Without that environment this is the reference's single-device run.
+    from . import parallel
+    with parallel.init_from_env():
+        return _run(args)
+
+
+def _run(args) -> int:
     if args.mode == "inference":
         from .inference_main import reasoning_inference_main
         reasoning_inference_main(args.model_type, args.results_dir, args.inference_config, args.model_config)

@@ -13,6 +13,7 @@ from . import build as _build
 _LIB = None
 
 OPNET_OK = 0
+ABI_VERSION = 4                            # include/opnet_hip.h OPNET_HIP_ABI_VERSION
 NO_OFFSET = ctypes.c_size_t(-1).value      # opnet_*_status_offset: "this shape never runs a persistent kernel"
 
 
@@ -210,6 +211,8 @@ def _declare(lib):
                                            c_void_p, c_void_p]
     lib.opnet_postprocess_iou.restype = c_int
     lib.opnet_postprocess_iou.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_void_p]
+    lib.opnet_dp_guard_f32.restype = c_int
+    lib.opnet_dp_guard_f32.argtypes = [fp, fp, fp, c_float, c_void_p]
 
 
 EXPORTS = [
@@ -221,7 +224,7 @@ EXPORTS = [
     "opnet_xcd_profile", "opnet_xcd_profile_read", "opnet_kernel_profile_read",
     "opnet_train_packed_weights_bytes", "opnet_train_pack_weights_f32", "opnet_train_workspace_bytes",
     "opnet_train_forward_f32", "opnet_train_backward_f32", "opnet_l1_loss_f32", "opnet_smooth_l1_loss_f32", "opnet_adam_step_f32", "opnet_adam_multi_step_f32",
-    "opnet_adam_multi_step_guarded_f32", "opnet_xcd4_status_offset", "opnet_train_status_offset", "opnet_xcd4_enable", "opnet_xcd4_enabled",
+    "opnet_adam_multi_step_guarded_f32", "opnet_dp_guard_f32", "opnet_xcd4_status_offset", "opnet_train_status_offset", "opnet_xcd4_enable", "opnet_xcd4_enabled",
     "opnet_mlp_pack_weights_f32", "opnet_mlp_forward_f32",
     "opnet_mlp_train_pack_weights_f32", "opnet_mlp_train_forward_f32", "opnet_mlp_train_backward_f32",
     "opseq_lstm_stack_packed_bytes", "opseq_lstm_stack_workspace_bytes", "opseq_lstm_stack_pack_weights_f32",
@@ -257,6 +260,12 @@ def load():
                 f"{path} not found: build it with `python -m objectpermanence_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
         lib = ctypes.CDLL(path)
+        lib.opnet_hip_abi_version.restype = c_int
+        lib.opnet_hip_abi_version.argtypes = []
+        found = int(lib.opnet_hip_abi_version())
+        if found != ABI_VERSION:
+            raise OpnetHipError(f"{path} implements ABI version {found}, this package needs {ABI_VERSION}: rebuild it with "
+                                "`python -m objectpermanence_amd.build`")
         _declare(lib)
         _LIB = lib
     return _LIB

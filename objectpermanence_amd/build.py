@@ -41,13 +41,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in user SGPRs at dispatch instead of through
     # a scalar load (used by opnet_step_pl; harmless for the struct-argument kernels, which have nothing to preload)
+    tmp = f"{LIB}.{os.getpid()}.tmp"
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-pass-failed", "-mllvm", "-amdgpu-kernarg-preload-count=10", "-o", LIB] + SOURCES
+           "-Wno-pass-failed", "-mllvm", "-amdgpu-kernarg-preload-count=10", "-o", tmp] + SOURCES
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, cwd=CSRC, check=True)
+    _run_then_publish(cmd, tmp, LIB, cwd=CSRC)
     build_encoder(force=True, verbose=verbose)
     return LIB
+
+
+def _run_then_publish(cmd, tmp: str, final: str, cwd=None) -> None:
+    """compile into a process-private file, then os.replace it over the library: another process (a DataLoader worker, a
+    second rank) either sees the old complete file or the new complete file, never a half-written one"""
+    try:
+        subprocess.run(cmd, cwd=cwd, check=True)
+        os.replace(tmp, final)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
 
 
 def build_encoder(force: bool = False, verbose: bool = False) -> str:
@@ -58,11 +70,12 @@ def build_encoder(force: bool = False, verbose: bool = False) -> str:
         return ENCODE_LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cxx = shutil.which("g++") or shutil.which("c++")
-    cmd = ([cxx, "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", ENCODE_LIB, src] if cxx else
-           [_hipcc(), "-x", "c++", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", ENCODE_LIB, src])
+    tmp = f"{ENCODE_LIB}.{os.getpid()}.tmp"
+    cmd = ([cxx, "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", tmp, src] if cxx else
+           [_hipcc(), "-x", "c++", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", tmp, src])
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    _run_then_publish(cmd, tmp, ENCODE_LIB)      # several workers may get here at once: each publishes a complete file
     return ENCODE_LIB
 
 

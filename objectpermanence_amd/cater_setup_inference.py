@@ -15,6 +15,7 @@ import pandas as pd
 import torch
 from torch.utils import data
 
+from . import parallel
 from .datasets import DatasetsFactory
 from .launch_monitor import verify_launches
 from .models_factory import ModelsFactory
@@ -40,9 +41,12 @@ def cater_setup_inference(model_name: str, results_dir: str, inference_config_pa
         config: Dict[str, str] = json.load(f)
     with open(model_config_path, "rb") as f:
         model_config: Dict[str, int] = json.load(f)
-    device = torch.device(config["device"])
+    device = parallel.resolve_device(config["device"])      # cuda:LOCAL_RANK as one rank of a torchrun job
     dataset = DatasetsFactory.get_inference_dataset(model_name, config["sample_dir"], config["labels_dir"])
-    loader = data.DataLoader(dataset, batch_size=int(config["batch_size"]), num_workers=int(config["num_workers"]))
+    # data parallel (not in the reference): this rank's share of the minibatches, last-frame boxes gathered by dataset index
+    world, rank, exchange = parallel.world_rank()
+    batches = parallel.plan_inference_batches(model_name, len(dataset), int(config["batch_size"]), world, rank)
+    loader = data.DataLoader(dataset, batch_sampler=batches, num_workers=int(config["num_workers"]))
     model = ModelsFactory.get_model(model_name, model_config, config["model_path"])
     model.eval()
     model.to(device)
@@ -55,10 +59,16 @@ def cater_setup_inference(model_name: str, results_dir: str, inference_config_pa
             output = out[0] if model_name in DOUBLE_OUTPUT_MODELS else out
             last.append(output[:, -1, :].cpu().numpy().reshape(-1, 4))                 # :77
             names.extend(video_names)
+    local = np.concatenate(last) if last else np.zeros((0, 4), dtype=np.float32)
+    if exchange:
+        index = torch.tensor([i for b in batches for i in b], dtype=torch.int64, device=device)
+        local = parallel.all_gather_by_index(torch.from_numpy(local).to(device), index, len(dataset)).cpu().numpy()
+        names = list(dataset.videos_names)          # dataset order = global index order
     frame_shapes = np.array([320, 240, 320, 240])
-    px = (np.concatenate(last) * frame_shapes).reshape((len(dataset), 4)).astype(np.int32)   # :91
+    px = (local * frame_shapes).reshape((len(dataset), 4)).astype(np.int32)   # :91
     classes = get_classes_predictions(transform_xyxy_to_w_h(px))
     results = pd.DataFrame({"video_names": [f"{n}.avi" for n in names], "class_predictions": classes})
-    Path(results_dir).mkdir(parents=True, exist_ok=True)
-    results.to_csv(f"{results_dir}/class_pred_results.csv", index=False)
+    if rank == 0:
+        Path(results_dir).mkdir(parents=True, exist_ok=True)
+        results.to_csv(f"{results_dir}/class_pred_results.csv", index=False)
     return results

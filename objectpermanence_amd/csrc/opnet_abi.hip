@@ -128,7 +128,7 @@ static void launch_attention(const float *qkv, float *att, int S, int E, int nhe
 
 static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
-extern "C" int opnet_hip_abi_version(void) { return 1; }
+extern "C" int opnet_hip_abi_version(void) { return OPNET_HIP_ABI_VERSION; }
 extern "C" const char *opnet_last_error(void) { return g_err; }
 
 // the step kernel comes in two register-chunk sizes (opnet_kernels.hip, load_a_chunk): 8 for one row block, 4 beyond;
@@ -1506,6 +1506,16 @@ extern "C" int opnet_adam_multi_step_guarded_f32(int count, float *const *params
     return OPNET_OK;
 }
 
+/* this rank's data-parallel guard words (see opnet_dp_guard): guard4_f32 = the 4 floats behind the flat gradient bucket */
+extern "C" int opnet_dp_guard_f32(float *guard4_f32, const unsigned *abort_u32, const float *loss_f32, float loss_weight,
+                                  void *stream)
+{
+    if (!guard4_f32) return fail(OPNET_EINVAL, "null pointer");
+    opnet_dp_guard<<<1, 64, 0, (hipStream_t)stream>>>(guard4_f32, abort_u32, loss_f32, loss_weight);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // sibling reasoners: stacked LSTM + head, slot embedding, transformer encoder layer
 // ------------------------------------------------------------------------------------------------
@@ -1983,7 +1993,11 @@ static StackTrainWs stack_train_ws_layout(int B, int T, int L, int KX, int H)
 extern "C" size_t opseq_lstm_stack_train_status_offset(int B, int T, int L, int KX, int H)
 {
     if (check_stack(B, T, L, KX, H) || !seqx_train_shape(B, L, KX, H)) return (size_t)-1;
-    return stack_train_ws_layout(B, T, L, KX, H).sx_status;
+    const auto W = stack_train_ws_layout(B, T, L, KX, H);
+    // the same predicate as the training forward's use_sx: a workspace of 2 GiB or more runs the launch chain (32-bit offsets
+    // in the persistent kernel), which has no status words
+    if (W.total >= ((size_t)1 << 31)) return (size_t)-1;
+    return W.sx_status;
 }
 
 extern "C" size_t opseq_lstm_stack_train_packed_bytes(int L, int KX, int H)

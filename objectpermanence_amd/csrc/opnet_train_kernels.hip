@@ -912,11 +912,27 @@ struct AdamBatch {
     int count;
     // guards (each may be null): the update is SKIPPED - parameters and moments untouched - when the abort word of the
     // persistent launches that made the gradients is nonzero, when the loss is not finite, or when the data-parallel guard
-    // (the sum over ranks of their abort flags, carried through the gradient all-reduce) is nonzero
+    // (two floats behind the gradient bucket, summed over the ranks by the gradient all-reduce: [0] ranks whose persistent
+    // launches gave up, [1] ranks whose loss is not finite - opnet_dp_guard) is nonzero
     const unsigned *abort_u32;
     const float *loss_f32;
     const float *guard_f32;
 };
+
+// this rank's contribution to the data-parallel guard (4 floats behind the flat gradient bucket, all-reduced WITH it):
+// [0] = 1 when the abort word of this rank's persistent launches is raised, [1] = 1 when this rank's loss is not finite,
+// [2] = this rank's share of the global mean loss (loss * n_local / n_global).  After the sum every rank holds the same two
+// counts, so every rank's guarded Adam takes the same decision, and the loss of the WHOLE minibatch (what the reference
+// prints, training_main.py:212) without a collective of its own.
+__global__ void opnet_dp_guard(float *__restrict__ guard, const unsigned *abort_u32, const float *loss_f32, float loss_weight)
+{
+    if (threadIdx.x == 0) {
+        guard[0] = (abort_u32 && *abort_u32 != 0u) ? 1.f : 0.f;
+        guard[1] = (loss_f32 && !isfinite(*loss_f32)) ? 1.f : 0.f;
+        guard[2] = loss_f32 ? *loss_f32 * loss_weight : 0.f;
+        guard[3] = 0.f;
+    }
+}
 
 // grid (blocks per tensor, tensors)
 __global__ void __launch_bounds__(256) opnet_adam_multi(const AdamBatch t, float b1, float b2, float eps, float step_size,
@@ -924,7 +940,7 @@ __global__ void __launch_bounds__(256) opnet_adam_multi(const AdamBatch t, float
 {
     if (t.abort_u32 && *t.abort_u32 != 0u) return;
     if (t.loss_f32 && !isfinite(*t.loss_f32)) return;
-    if (t.guard_f32 && *t.guard_f32 != 0.f) return;
+    if (t.guard_f32 && (t.guard_f32[0] != 0.f || t.guard_f32[1] != 0.f)) return;
     const int k = blockIdx.y;
     float *__restrict__ p = t.p[k];
     const float *__restrict__ gr = t.g[k];

@@ -48,12 +48,12 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
         model_config = json.load(f)
     batch_size = int(config["batch_size"])
     num_workers = int(config["num_workers"])
-    device = torch.device(config["device"])
+    # the JSON's device (inference_main.py:189) - or cuda:LOCAL_RANK when this process is one rank of a torchrun job
+    device = parallel.resolve_device(config["device"])
 
     dataset = DatasetsFactory.get_inference_dataset(model_name, config["sample_dir"], config["labels_dir"])
     n_total = len(dataset)
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    world, rank, exchange = parallel.world_rank()
     batches = parallel.plan_inference_batches(model_name, n_total, batch_size, world, rank)
     loader = data.DataLoader(dataset, batch_sampler=batches, num_workers=num_workers)
 
@@ -84,7 +84,7 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
     t_frames = preds[0].shape[1] if preds else 300
     local_pred = torch.cat(preds) if preds else torch.zeros((0, t_frames, 4), dtype=torch.int32, device=device)
     local_iou = torch.cat(ious) if ious else torch.zeros((0, t_frames), dtype=torch.float64, device=device)
-    if world > 1:
+    if exchange:
         index = torch.tensor([i for b in batches for i in b], dtype=torch.int64, device=device)
         all_pred = parallel.all_gather_by_index(local_pred, index, n_total)
         all_iou = parallel.all_gather_by_index(local_iou, index, n_total)

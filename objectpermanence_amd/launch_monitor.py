@@ -7,6 +7,10 @@ callers here must never consume such an output: behind every persistent launch t
 status words into pinned host memory and an event (`watch`); at the next point where the caller synchronises anyway it calls
 `verify`, which re-runs every aborted batch through the launch-per-step chain INTO THE SAME OUTPUT TENSORS (results the caller
 already holds views of are healed in place) and warns once.  Nothing here synchronises on the hot path.
+
+A watch entry keeps its launch's input alive through `redo` (NonLinearLstm's features: 4.6 MB per clip), so entries do not wait
+for `verify`: every `watch` first drops the entries whose launch has already completed clean (`event.query()`, no sync) - a
+driver that defers `verify` to the end of a data set holds the inputs of the launches still in flight, not of all of them.
 """
 from __future__ import annotations
 
@@ -22,7 +26,7 @@ _warned = False
 class LaunchMonitor:
     def __init__(self):
         self._host: Optional[torch.Tensor] = None          # pinned [SLOTS, 4] int32
-        self._next = 0
+        self._free: List[int] = list(range(_SLOTS))
         self._pending: List[Tuple[torch.cuda.Event, int, Optional[Callable[[], None]], str]] = []
         self.aborted = 0                                   # launches found aborted so far
         self.healed = 0                                    # ... of which re-run on the chain
@@ -32,10 +36,10 @@ class LaunchMonitor:
         workspace, `offset` the byte offset of its status words; `redo()` re-runs the batch on the chain into the same outputs"""
         if self._host is None:
             self._host = torch.zeros((_SLOTS, 4), dtype=torch.int32).pin_memory()
-        if len(self._pending) >= _SLOTS - 1:
-            self.verify(limit=1)                           # the oldest launch is long done: frees its slot
-        slot = self._next
-        self._next = (self._next + 1) % _SLOTS
+        self.reap()
+        if not self._free:
+            self.verify(limit=1)                           # 64 launches in flight: wait for the oldest, frees its slot
+        slot = self._free.pop()
         self._host[slot].copy_(workspace[offset:offset + 16].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(workspace.device))
@@ -43,6 +47,21 @@ class LaunchMonitor:
 
     def pending(self) -> int:
         return len(self._pending)
+
+    def reap(self) -> int:
+        """drop every watched launch that has completed with clean status words - without waiting for any (event.query()) -
+        and with it the reference to its input that `redo` holds; an aborted one stays for `verify` to heal.  Returns how
+        many entries were dropped."""
+        keep = []
+        for entry in self._pending:
+            ev, slot, _redo, _what = entry
+            if ev.query() and int(self._host[slot, 0]) == 0:
+                self._free.append(slot)
+            else:
+                keep.append(entry)
+        n = len(self._pending) - len(keep)
+        self._pending = keep
+        return n
 
     def verify(self, limit: Optional[int] = None) -> int:
         """wait for the watched launches (oldest first; at most `limit` of them) and heal the aborted ones; returns how many
@@ -54,6 +73,7 @@ class LaunchMonitor:
         for ev, slot, redo, what in todo:
             ev.synchronize()
             code, block, phase, _ = (int(v) for v in self._host[slot])
+            self._free.append(slot)
             if code == 0:
                 continue
             n_bad += 1

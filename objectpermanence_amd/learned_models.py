@@ -699,11 +699,16 @@ class _LstmStackRunner:
         off = _lib.load().opseq_lstm_stack_train_status_offset(B, T, self.L, self.KX, self.H)
         return None if off == _lib.NO_OFFSET else self.tws[off:off + 4].view(torch.int32)
 
-    def _wants_xcd(self, B: int) -> bool:
+    def _wants_xcd(self, B: int, T: Optional[int] = None) -> bool:
+        """the persistent launch takes (B, T) when the shape is supported on this device, the batch fits one launch and -
+        T given - its workspace stays below 2 GiB (opseq_xcd_workspace_bytes says 0 beyond: 32-bit offsets in the kernel;
+        e.g. NonLinearLstm's hoisted input products at long T); everything else runs the launch chain"""
         if self.use_xcd in ("0", 0, False):
             return False
         lib = _lib.load()
-        return bool(lib.opseq_xcd_supported(self.L, self.KX, self.H)) and B <= int(lib.opseq_xcd_max_batch(self.L))
+        if not (bool(lib.opseq_xcd_supported(self.L, self.KX, self.H)) and B <= int(lib.opseq_xcd_max_batch(self.L))):
+            return False
+        return T is None or int(lib.opseq_xcd_workspace_bytes(B, T, self.L, self.KX, self.H)) > 0
 
     def _run_xcd(self, x: torch.Tensor, ws_list, head: "LinearWeight") -> torch.Tensor:
         lib = _lib.load()
@@ -764,7 +769,7 @@ class _LstmStackRunner:
     def run(self, x: torch.Tensor, lstm: "LSTMWeights", head: "LinearWeight") -> torch.Tensor:
         ws_list = [getattr(lstm, f"weight_ih_l{l}") for l in range(self.L)] + \
                   [getattr(lstm, f"weight_hh_l{l}") for l in range(self.L)] + [head.weight]
-        if self._wants_xcd(int(x.shape[0])):
+        if self._wants_xcd(int(x.shape[0]), int(x.shape[1])):
             return self._run_xcd(x, ws_list, head)
         return self._run_chain(x, ws_list, head)
 

@@ -8,10 +8,109 @@ are independent.  Sorting / indexing follows the reference's da
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+FORCE_ENV = "OPNET_FORCE_DIST"      # "1": take every data-parallel branch even in a process group of ONE rank
+
+
+def forced() -> bool:
+    return os.environ.get(FORCE_ENV, "0") == "1"
+
+
+def is_active(group: Optional[dist.ProcessGroup] = None) -> bool:
+    """Is the data-parallel exchange to be run?  Yes in an initialised process group of more than one rank - and in a group
+    of one rank when OPNET_FORCE_DIST=1: the whole device side of the exchange (comm stream, in-place gradient bucket, RCCL
+    collectives, guard slot, gathers by index) then executes on a single GPU, which is how the `-m gpu` tests cover it."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or forced()
+
+
+def world_rank(group: Optional[dist.ProcessGroup] = None) -> Tuple[int, int, bool]:
+    """(world size, rank, exchange active?) of this process: (1, 0, False) outside torch.distributed"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, 0, False
+    return dist.get_world_size(group), dist.get_rank(group), is_active(group)
+
+
+class Launch:
+    """What `init_from_env` found: did this process join a group it must leave again, and which device is its own."""
+
+    def __init__(self, owned: bool, device: Optional[torch.device], world: int, rank: int, local_rank: int):
+        self.owned, self.device, self.world, self.rank, self.local_rank = owned, device, world, rank, local_rank
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        shutdown(self)
+        return False
+
+
+_launch: Optional[Launch] = None
+
+
+def init_from_env(backend: Optional[str] = None) -> Launch:
+    """The product entry points' way into data parallelism (`python -m torch.distributed.run --nproc-per-node N -m
+    objectpermanence_amd training ...`; the reference has one device per run from its JSON, training_main.py:144,
+    inference_main.py:189-207).  With WORLD_SIZE in the environment (torchrun's contract: RANK, LOCAL_RANK, WORLD_SIZE,
+    MASTER_ADDR, MASTER_PORT) - or OPNET_FORCE_DIST=1 for a group of one - the process joins the job: backend "nccl"
+    (= RCCL) bound to `cuda:LOCAL_RANK` when a GPU is visible, "gloo" otherwise (host-logic tests), and the device every
+    driver then uses is THAT one, whatever the JSON config says (`resolve_device`).  Without either it does nothing.
+    A group somebody else initialised is used as it is and not destroyed."""
+    global _launch
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    rank = int(os.environ.get("RANK", "0") or 0)
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)) or 0)
+    has_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local_rank) if has_gpu else None
+    if dist.is_available() and dist.is_initialized():
+        _launch = Launch(False, device if world else None, dist.get_world_size(), dist.get_rank(), local_rank)
+        return _launch
+    if world <= 0 and not forced():
+        _launch = Launch(False, None, 1, 0, 0)
+        return _launch
+    world = max(world, 1)
+    if has_gpu:
+        if local_rank >= torch.cuda.device_count():
+            raise RuntimeError(f"LOCAL_RANK {local_rank} but this node exposes {torch.cuda.device_count()} GPU(s): start at most "
+                               "one rank per GPU")
+        torch.cuda.set_device(device)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    backend = backend or ("nccl" if has_gpu else "gloo")
+    kw = {"device_id": device} if backend == "nccl" else {}
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    _launch = Launch(True, device, world, rank, local_rank)
+    return _launch
+
+
+def shutdown(launch: Optional[Launch] = None) -> None:
+    """leave the group `init_from_env` joined (all ranks meet first, so that no rank tears the communicator down under a
+    collective another rank is still in)"""
+    global _launch
+    launch = launch or _launch
+    if launch is not None and launch.owned and dist.is_initialized():
+        try:
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()
+        launch.owned = False
+    if launch is _launch:
+        _launch = None
+
+
+def resolve_device(config_device) -> torch.device:
+    """The device a driver runs on: the JSON's `device` (training_main.py:144, inference_main.py:189) - unless this process
+    was started as one rank of a job (`init_from_env`), where it is `cuda:LOCAL_RANK`: eight ranks that all read
+    "cuda:0" from the same config file would otherwise share one GPU."""
+    if _launch is not None and _launch.device is not None and dist.is_available() and dist.is_initialized():
+        return _launch.device
+    return torch.device(config_device)
 
 
 def shard_size(n_items: int, world: int) -> int:
@@ -107,13 +206,14 @@ class GradBucket:
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
-        # 4 extra floats behind the gradients: [n] is the GUARD - this rank's "my persistent launches gave up" flag, summed
-        # over the ranks by the same all-reduce, so that every rank's optimiser skips the step when any rank's gradients are
-        # NaN (optim.FusedAdam.guard_ptr); the rest is padding (16-byte multiple)
+        # 4 extra floats behind the gradients, the GUARD: [n] = this rank's "my persistent launches gave up" flag, [n+1] =
+        # "my loss is not finite" (opnet_dp_guard_f32 writes both), summed over the ranks by the same all-reduce, so that every
+        # rank's optimiser skips the step when any rank's gradients are unusable (optim.FusedAdam.guard_ptr); the rest is
+        # padding (16-byte multiple)
         self.n_grad = n
         self._buf = torch.zeros(n + 4, dtype=torch.float32, device=ref.device)
         self.flat = self._buf[:n]
-        self.guard = self._buf[n:n + 1]
+        self.guard = self._buf[n:n + 4]
         self.offsets, o = [], 0
         for p in self.params:
             self.offsets.append(o)

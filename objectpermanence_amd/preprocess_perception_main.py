@@ -133,7 +133,8 @@ def preprocess_main(results_dir: str, config_path: str, frames_per_pass: int = 1
     with open(config_path, "rb") as f:
         config = json.load(f)
     videos = get_experiment_videos(config)
-    device = torch.device(config.get("device", "cuda:0"))
+    from . import parallel
+    device = parallel.resolve_device(config.get("device", "cuda:0"))      # cuda:LOCAL_RANK as one rank of a torchrun job
     rank, world = 0, 1
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()

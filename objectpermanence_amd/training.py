@@ -11,6 +11,8 @@ stream, weighted n_local/n_global so the result equals the single-process mean-l
 """
 from __future__ import annotations
 
+import math
+import warnings
 from typing import Optional
 
 import torch
@@ -53,7 +55,7 @@ def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.O
     `comm_stream` as soon as the backward (its last kernel is the merged weight-gradient GEMM) is enqueued, `overlap()` -
     the caller's work that does not depend on the new weights: the next batch's host-to-device copies, its input packing -
     runs on the current stream meanwhile, and only then does the current stream wait for the collective and run Adam."""
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    distributed = parallel.is_active(group)       # > 1 rank, or a forced group of one (OPNET_FORCE_DIST=1: the GPU tests)
     bucket = getattr(model, "_grad_bucket", None)
     if bucket is None:
         bucket = model._grad_bucket = parallel.GradBucket(model.parameters())
@@ -77,17 +79,23 @@ def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.O
     bucket.collect(fill_missing=distributed)
     # device-side guards of the optimiser step (optim.FusedAdam): an aborted persistent launch (its gradients are NaN) or a
     # non-finite loss must not reach the weights; the host learns of it at its next sync point (step_aborted below)
+    abort_ptr = guard_word.data_ptr() if guard_word is not None else None
+    loss_ptr = loss.data_ptr() if (loss.is_cuda and n_local > 0) else None
+    on_device_dp = distributed and bucket.flat.is_cuda
+    n_glob = (n_global if n_global is not None else n_local * dist.get_world_size(group)) if distributed else n_local
+    if on_device_dp:
+        # this rank's abort word and "my loss is not finite" -> the guard slots the all-reduce sums over the ranks, so that
+        # every rank's optimiser takes the SAME decision (a rank-local skip would let the replicas drift apart)
+        from . import _lib
+        with torch.cuda.device(bucket.flat.device):
+            _lib.check(_lib.load().opnet_dp_guard_f32(bucket.guard.data_ptr(), abort_ptr, loss_ptr,
+                                                      float(n_local) / float(max(n_glob, 1)), torch.cuda.current_stream(bucket.flat.device).cuda_stream),
+                       "opnet_dp_guard_f32")
+        abort_ptr = loss_ptr = None         # both travel through the guard slots now
     if hasattr(optimizer, "abort_ptr"):
-        optimizer.abort_ptr = guard_word.data_ptr() if guard_word is not None else None
-        optimizer.loss_ptr = loss.data_ptr() if (loss.is_cuda and n_local > 0) else None
-        optimizer.guard_ptr = bucket.guard.data_ptr() if (distributed and bucket.flat.is_cuda) else None
-    if distributed and bucket.flat.is_cuda:
-        if guard_word is not None:      # this rank's abort word -> the guard slot the all-reduce sums over the ranks
-            bucket.guard.copy_(guard_word)
-        else:
-            bucket.guard.zero_()
+        optimizer.abort_ptr, optimizer.loss_ptr = abort_ptr, loss_ptr
+        optimizer.guard_ptr = bucket.guard.data_ptr() if on_device_dp else None
     if distributed:
-        n_glob = n_global if n_global is not None else n_local * dist.get_world_size(group)
         cur = torch.cuda.current_stream(bucket.flat.device) if bucket.flat.is_cuda else None
         st = comm_stream or cur
         if cur is not None:
@@ -109,7 +117,23 @@ def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.O
                 overlap()
     elif overlap is not None:
         overlap()
-    optimizer.step()
+    try:
+        optimizer.step()
+    finally:
+        # the guards are raw device addresses of THIS step's tensors (loss, workspace, bucket): a later optimizer.step() outside
+        # train_step must not read memory that has been freed or reused since
+        if hasattr(optimizer, "abort_ptr"):
+            optimizer.abort_ptr = optimizer.loss_ptr = optimizer.guard_ptr = None
+    return loss
+
+
+def global_loss(model: torch.nn.Module, loss: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """the loss of the WHOLE minibatch of the train_step that returned `loss` (what the reference prints per step,
+    training_main.py:212-214): data parallel on device it is the all-reduced guard slot 2 - sum over ranks of loss_r * n_r / n,
+    carried by the gradient all-reduce - otherwise `loss` itself"""
+    bucket = getattr(model, "_grad_bucket", None)
+    if bucket is not None and parallel.is_active(group) and bucket.flat.is_cuda:
+        return bucket.guard[2]
     return loss
 
 
@@ -120,10 +144,34 @@ def step_aborted(model: torch.nn.Module, group: Optional[dist.ProcessGroup] = No
     fn = getattr(model, "training_step_aborted", None)
     bad = bool(fn()) if fn is not None else False
     bucket = getattr(model, "_grad_bucket", None)
-    if bucket is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 \
-            and bucket.flat.is_cuda and float(bucket.guard) != 0.0:
+    if bucket is not None and parallel.is_active(group) and bucket.flat.is_cuda and float(bucket.guard[0]) != 0.0:
         bad = True
         from . import _lib              # some OTHER rank's launch gave up: every rank leaves the persistent kernels together
         _lib.load().opnet_xcd4_enable(0)
         _lib.load().opseq_xcd_enable(0)
     return bad
+
+
+_warned_nonfinite = False
+
+
+def step_skipped_nonfinite(model: torch.nn.Module, optimizer, loss_value: float,
+                           group: Optional[dist.ProcessGroup] = None) -> bool:
+    """Call after the driver's float(loss), next to step_aborted: was the update of that step skipped because a loss was not
+    finite?  The guarded Adam then left parameters and moments untouched (torch.optim.Adam, training_main.py:217, would have
+    written NaN into every weight); here the step COUNTERS are rolled back too - the bias correction must not advance over an
+    update that never happened - and the first occurrence warns.  Data parallel: the decision was taken from the all-reduced
+    guard slot, so every rank skipped together and every rank reports it, whichever rank's loss it was."""
+    global _warned_nonfinite
+    skipped = not math.isfinite(loss_value)
+    bucket = getattr(model, "_grad_bucket", None)
+    if bucket is not None and parallel.is_active(group) and bucket.flat.is_cuda and float(bucket.guard[1]) != 0.0:
+        skipped = True
+    if skipped:
+        if hasattr(optimizer, "rollback_step_count"):
+            optimizer.rollback_step_count()
+        if not _warned_nonfinite:
+            _warned_nonfinite = True
+            warnings.warn("objectpermanence_amd: a training step's loss is not finite; its optimiser update was skipped on every "
+                          "rank (weights, moments and step count unchanged)", RuntimeWarning, stacklevel=2)
+    return skipped

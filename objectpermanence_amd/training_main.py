@@ -33,7 +33,7 @@ from .launch_monitor import verify_launches
 from .models_factory import ModelsFactory
 from .optim import FusedAdam
 from .supported_models import DOUBLE_OUTPUT_MODELS
-from .training import compute_loss, step_aborted, train_step
+from .training import compute_loss, global_loss, step_aborted, step_skipped_nonfinite, train_step
 
 
 def save_checkpoint(model: torch.nn.Module, model_name: str, dev_iou: float, checkpoint_dir: str) -> str:
@@ -61,8 +61,7 @@ def inference_and_iou_comp(model_name: str, model: torch.nn.Module, device: torc
     """training_main.py:32-117: average loss, dataset mean IoU, containment-masked mean IoU.  Under data parallelism every
     rank evaluates its share of the minibatches (parallel.plan_inference_batches) and the per-frame IoUs / masks / loss
     sums are gathered, so all ranks return the same numbers."""
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    world, rank, exchange = parallel.world_rank()
     n_total = len(dataset)
     batches = parallel.plan_inference_batches(model_name, n_total, batch_size, world, rank)
     loader = data.DataLoader(dataset, batch_sampler=batches, num_workers=num_workers)
@@ -86,7 +85,7 @@ def inference_and_iou_comp(model_name: str, model: torch.nn.Module, device: torc
     t_frames = ious[0].shape[1] if ious else 300
     iou = torch.cat(ious) if ious else torch.zeros((0, t_frames), dtype=torch.float64, device=device)
     cm = torch.cat(contain) if contain else torch.zeros((0, t_frames), dtype=torch.bool, device=device)
-    if world > 1:
+    if exchange:
         index = torch.tensor([i for b in batches for i in b], dtype=torch.int64, device=device)
         iou = parallel.all_gather_by_index(iou, index, n_total)
         cm = parallel.all_gather_by_index(cm.to(torch.uint8), index, n_total).bool()
@@ -115,7 +114,8 @@ def training_batches(model_name: str, n_items: int, batch_size: int, world: int,
 
 
 def training_main(model_name: str, train_config: Dict[str, Any], model_config: Dict[str, int]) -> Dict[str, Any]:
-    device = torch.device(train_config["device"])
+    # the JSON's device (training_main.py:144) - or cuda:LOCAL_RANK when this process is one rank of a torchrun job
+    device = parallel.resolve_device(train_config["device"])
     train_ds = DatasetsFactory.get_training_dataset(model_name, train_config["train_sample_dir"], train_config["train_labels_dir"],
                                                     train_config["train_containment_file"])
     dev_ds = DatasetsFactory.get_training_dataset(model_name, train_config["dev_sample_dir"], train_config["dev_labels_dir"],
@@ -126,12 +126,11 @@ def training_main(model_name: str, train_config: Dict[str, Any], model_config: D
     optimizer = FusedAdam(model.parameters(), lr=train_config["learning_rate"])
     scheduler = ReduceLROnPlateau(optimizer, mode="min", factor=train_config["lr_scheduler_factor"],
                                   patience=train_config["lr_scheduler_patience"])
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    world, rank, exchange = parallel.world_rank()
     steps = training_batches(model_name, len(train_ds), bs, world, rank)
     # this rank's loader yields only its own non-empty slices, in step order
     training_loader = data.DataLoader(train_ds, batch_sampler=[idx for idx, _ in steps if idx], num_workers=nw)
-    comm = torch.cuda.Stream(device=device) if world > 1 else None
+    comm = torch.cuda.Stream(device=device) if exchange and device.type == "cuda" else None
 
     highest_dev_iou, best_path, history = 0.0, None, []
     start = time.time()
@@ -155,20 +154,24 @@ def training_main(model_name: str, train_config: Dict[str, Any], model_config: D
             loss = train_step(model_name, model, optimizer, *args, n_global=n_global,
                               comm_stream=comm, overlap=lambda: box.setdefault("n", fetch(k + 1)))
             nxt = box.get("n")
-            loss_value = float(loss)              # the reference's per-step .item() (training_main.py:212): the sync point
+            loss_value = float(global_loss(model, loss))   # the reference's per-step .item() (training_main.py:212): the sync point
             if step_aborted(model):
                 # a persistent launch of this step gave up: the guarded Adam kept the weights; repeat it on the launch chain
                 optimizer.rollback_step_count()
-                loss_value = float(train_step(model_name, model, optimizer, *args, n_global=n_global, comm_stream=comm))
+                loss_value = float(global_loss(model, train_step(model_name, model, optimizer, *args, n_global=n_global,
+                                                                 comm_stream=comm)))
+            # a non-finite loss on any rank: the update was skipped on every rank (guarded Adam); counters rolled back, warned
+            step_skipped_nonfinite(model, optimizer, loss_value)
             running += loss_value
-            if (k + 1) % train_config["print_step"] == 0:
+            if (k + 1) % train_config["print_step"] == 0 and rank == 0:
                 print("Train Epoch: {} [{}/{}]\t Average Loss: {:.4f} Training began {} seconds ago".format(
                     epoch + 1, (k + 1) * bs, len(train_ds), running / train_config["print_step"], int(time.time() - start)))
                 running = 0.0
         train_loss, train_miou, train_cmiou = inference_and_iou_comp(model_name, model, device, train_ds, ibs, nw)
         dev_loss, dev_miou, dev_cmiou = inference_and_iou_comp(model_name, model, device, dev_ds, ibs, nw)
-        print("Epoch {} Training Set: Loss {:.4f}, Mean IoU {:.6f}, Mask Mean Iou {:.6f}".format(epoch + 1, train_loss, train_miou, train_cmiou))
-        print("Epoch {} Dev Set: Loss {:.4f}, Mean IoU {:.6f}, Mask Mean Iou {:.6f}".format(epoch + 1, dev_loss, dev_miou, dev_cmiou))
+        if rank == 0:
+            print("Epoch {} Training Set: Loss {:.4f}, Mean IoU {:.6f}, Mask Mean Iou {:.6f}".format(epoch + 1, train_loss, train_miou, train_cmiou))
+            print("Epoch {} Dev Set: Loss {:.4f}, Mean IoU {:.6f}, Mask Mean Iou {:.6f}".format(epoch + 1, dev_loss, dev_miou, dev_cmiou))
         scheduler.step(train_loss)
         history.append({"epoch": epoch + 1, "train_loss": train_loss, "train_miou": train_miou, "dev_loss": dev_loss,
                         "dev_miou": dev_miou, "dev_containment_miou": dev_cmiou, "lr": optimizer.param_groups[0]["lr"]})
