@@ -537,12 +537,13 @@ def launcher_selftest(world, rank, mode="infer", batch=32):
         bucket = parallel.GradBucket(model.parameters())
         for i in range(len(bucket.params)):
             bucket.view(i).fill_(float(rank + 1))
-        bucket.guard.fill_(1.0 if rank == world - 1 else 0.0)          # "the last rank's persistent launch gave up"
+        bucket.guard.zero_()
+        bucket.guard[0] = 1.0 if rank == world - 1 else 0.0             # "the last rank's persistent launch gave up"
         bucket.all_reduce(batch, world * batch)
         want = sum(r + 1 for r in range(world)) / world
         assert bucket.flat.numel() == W_BYTES // 4 and torch.allclose(bucket.flat, torch.full_like(bucket.flat, want))
-        assert float(bucket.guard) == 1.0                               # every rank sees that SOME rank aborted
-        out.update({"mode": "train", "grad_bucket_floats": int(bucket.flat.numel()), "guard_after_allreduce": float(bucket.guard),
+        assert float(bucket.guard[0]) == 1.0 and float(bucket.guard[1]) == 0.0    # every rank sees that SOME rank aborted
+        out.update({"mode": "train", "grad_bucket_floats": int(bucket.flat.numel()), "guard_after_allreduce": float(bucket.guard[0]),
                     "config": {"global_batch": world * batch, "parallelism": f"dp{world}"}})
     if rank == 0:
         print(json.dumps(out), flush=True)

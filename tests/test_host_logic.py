@@ -42,7 +42,8 @@ def test_persistent_forward_workspace_is_rings_not_histories(monkeypatch):
 
 def test_size_queries_and_validation_without_gpu():
     lib = _lib()
-    assert lib.opnet_hip_abi_version() == 1
+    from objectpermanence_amd import _lib as binding
+    assert lib.opnet_hip_abi_version() == binding.ABI_VERSION == 4
     w = lib.opnet_workspace_bytes(32, 300, 256, 512)
     assert w > 32 * 300 * 96 * 4 and lib.opnet_workspace_bytes(64, 300, 256, 512) > w
     assert lib.opnet_workspace_bytes(33, 300, 256, 512) == lib.opnet_workspace_bytes(64, 300, 256, 512)
@@ -484,3 +485,123 @@ def test_small_batch_persistent_form_sizes_and_limits():
     t32, t256 = lib.opnet_train_workspace_bytes(32, 300, 256, 512), lib.opnet_train_workspace_bytes(256, 300, 256, 512)
     fixed = 1024 * 16384 * 4                              # partial tiles of the weight-gradient waves: one round of the SIMDs, any batch
     assert t32 - fixed > 32 * 5_000_000 and t256 - fixed > 7 * (t32 - fixed) * 0.9
+
+
+# ---- data parallelism through the product entry points (parallel.init_from_env) --------------------
+
+_ENTRY_RANK = r"""
+import json, os, sys
+import torch, torch.distributed as dist
+from objectpermanence_amd import parallel
+with parallel.init_from_env() as launch:
+    w, r, active = parallel.world_rank()
+    t = torch.tensor([float(r + 1)])
+    dist.all_reduce(t)
+    out = {"owned": launch.owned, "backend": dist.get_backend(), "world": w, "rank": r, "active": active, "sum": float(t),
+           "device": str(parallel.resolve_device("cpu"))}
+    open(os.path.join(sys.argv[1], f"rank{r}.json"), "w").write(json.dumps(out))
+assert not dist.is_initialized()
+"""
+
+
+def test_entry_points_join_the_job_torchrun_describes(tmp_path):
+    """WORLD_SIZE / RANK / LOCAL_RANK in the environment -> the process joins the group (gloo here: no GPU), every collective
+    spans the ranks, the group is left again at exit; the JSON's device stands when there is no GPU to bind"""
+    import subprocess
+    import sys
+    script = tmp_path / "rank.py"
+    script.write_text(_ENTRY_RANK)
+    port = str(33500 + os.getpid() % 1000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        env.pop("OPNET_FORCE_DIST", None)
+        procs.append(subprocess.Popen([sys.executable, str(script), str(tmp_path)], env=env, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        _, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+    import json
+    for r in range(2):
+        out = json.load(open(tmp_path / f"rank{r}.json"))
+        assert out == {"owned": True, "backend": "gloo", "world": 2, "rank": r, "active": True, "sum": 3.0, "device": "cpu"}
+
+
+def test_init_from_env_is_a_no_op_outside_a_job(monkeypatch):
+    import torch.distributed as dist
+    from objectpermanence_amd import parallel
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "OPNET_FORCE_DIST"):
+        monkeypatch.delenv(k, raising=False)
+    with parallel.init_from_env() as launch:
+        assert not launch.owned and not dist.is_initialized()
+        assert parallel.world_rank() == (1, 0, False) and not parallel.is_active()
+        assert parallel.resolve_device("cuda:3") == torch.device("cuda:3")     # the JSON's device, as the reference reads it
+
+
+def _forced_world_of_one_worker(rank, world, port, tmp):
+    """OPNET_FORCE_DIST=1 in a gloo group of ONE rank: train_step takes the data-parallel branch (bucket all-reduce, weight
+    n_local / n_global) and leaves the weights of the plain step"""
+    import torch.distributed as dist
+    from objectpermanence_amd import parallel, training
+    from oracle import synth, torch_port
+    os.environ.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    cfg = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 16, "videos_hidden_dim": 32}
+    boxes, labels = (torch.from_numpy(a) for a in synth.make_batch(0, 3, 8))
+    training.compute_loss = lambda name, out, lab, mask=None, kind="l1", **kw: (torch.mean(torch.abs(out - lab)),) * 3
+    res = {}
+    for forced in ("0", "1"):
+        os.environ["OPNET_FORCE_DIST"] = forced
+        with parallel.init_from_env() as launch:
+            # (WORLD_SIZE=1 alone joins a group of one too - torchrun with one rank - but its exchange stays off)
+            assert launch.owned and dist.get_world_size() == 1 and parallel.is_active() == (forced == "1")
+            model = torch_port.OPNetTorch(synth.opnet_synth_params(cfg))
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            calls = []
+            if forced == "1":
+                real = dist.all_reduce
+                dist.all_reduce = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+            for _ in range(2):
+                training.train_step("baseline_lstm", model, opt, boxes, labels, n_global=3)
+            if forced == "1":
+                dist.all_reduce = real
+                assert len(calls) == 2
+            res[forced] = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for k in res["0"]:
+        assert torch.equal(res["0"][k], res["1"][k]), k
+    open(os.path.join(tmp, "ok"), "w").write("ok")
+
+
+def test_forced_group_of_one_takes_the_data_parallel_branch(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_forced_world_of_one_worker, args=(1, 34500 + os.getpid() % 1000, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "ok")
+
+
+def test_launch_monitor_reaps_completed_entries_and_recycles_slots():
+    """ADVICE round 3: a watch entry (and the input its `redo` holds) goes as soon as its launch is seen complete and clean;
+    an aborted one stays for verify(); slots come from a free list"""
+    from objectpermanence_amd import launch_monitor as lm
+
+    class Ev:
+        def __init__(self, done):
+            self.done = done
+
+        def query(self):
+            return self.done
+
+        def synchronize(self):
+            self.done = True
+
+    mon = lm.LaunchMonitor()
+    mon._host = torch.zeros((lm._SLOTS, 4), dtype=torch.int32)
+    held = []
+    for i, (done, code) in enumerate([(True, 0), (False, 0), (True, 3), (True, 0)]):
+        slot = mon._free.pop()
+        mon._host[slot, 0] = code
+        mon._pending.append((Ev(done), slot, (lambda i=i: held.append(i)), f"launch {i}"))
+    assert mon.reap() == 2 and mon.pending() == 2 and len(mon._free) == lm._SLOTS - 2
+    import warnings
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        assert mon.verify() == 1
+    assert held == [2] and mon.pending() == 0 and sorted(mon._free) == list(range(lm._SLOTS))
