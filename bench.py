@@ -58,20 +58,38 @@ W_BYTES = 5_684_224            # all six fp32 weight tensors
 STATE_BYTES_PER_CLIP = 12_672  # per clip per time step: x_t + h,c read + h,c write of both LSTMs (8-d4)
 
 
+def _committed_pmc(stem):
+    """the newest committed profiles/r<N>_<stem>.json (rocprofv3 --pmc passes reduced by tools/pmc_reduce.py / pmc_traffic.py)"""
+    for rnd in (4, 3):
+        path = os.path.join(REPO, "profiles", f"r{rnd}_{stem}.json")
+        try:
+            with open(path) as f:
+                return json.load(f), f"profiles/r{rnd}_{stem}.json"
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
 def pmc_traffic(kernel, clips_per_launch):
     """`roofline.traffic`: HBM-side bytes per launch of `kernel`.  PMC counters cannot be sampled from inside the process
     that is being timed, so this is the figure of the committed rocprofv3 --pmc passes of this same command
-    (profiles/r3_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes, per launch, keyed by
+    (profiles/r<N>_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes, per launch, keyed by
     kernel and clips per launch); null when no pass of this build and shape is committed."""
-    path = os.path.join(REPO, "profiles", "r3_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f).get(kernel, {}).get(str(int(clips_per_launch)))
-    except (OSError, ValueError):
-        rec = None
+    data, src = _committed_pmc("pmc_traffic")
+    rec = (data or {}).get(kernel, {}).get(str(int(clips_per_launch)))
     if not rec:
         return {"traffic": None}
-    return {"traffic": rec["bytes_per_launch"], "traffic_source": f"profiles/r3_pmc_traffic.json ({rec.get('note', 'rocprofv3 --pmc')})"}
+    return {"traffic": rec["bytes_per_launch"], "traffic_source": f"{src} ({rec.get('note', 'rocprofv3 --pmc')})"}
+
+
+def pmc_mfma_busy(kernel, stem="mfma_util_transformer"):
+    """matrix-pipe busy fraction of `kernel` from the committed PMC pass of this command (SQ_VALU_MFMA_BUSY_CYCLES over
+    (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs, tools/pmc_reduce.py mfma); nothing when no pass is committed"""
+    data, src = _committed_pmc(stem)
+    for name, rec in (data or {}).get("kernels", {}).items():
+        if kernel in name and "mfma_util" in rec:
+            return {"mfma_busy": rec["mfma_util"], "mfma_busy_source": src}
+    return {}
 
 
 def accuracy_block(dev):
@@ -301,6 +319,56 @@ def detector_flops_per_frame(h=800, w=1088, rois=1000, classes=193):
     return total
 
 
+def detector_block(dev, nf=16, passes=3):
+    """BASELINE.json config 4's front-end next to the headline (outside the timed region; `--mode detect` is the full
+    measurement): `passes` calls of CaterObjectDetector.detect_batch on `nf` 240x320 frames, two passes in flight.
+    Parity of this stage is UNPINNED (no torchvision in the image: DESIGN.md section 11)."""
+    from objectpermanence_amd.detector import CaterObjectDetector
+    from synthdata import detector as sd
+    t0 = time.perf_counter()
+    params = {**sd.synth_backbone_params(), **sd.synth_head_params()}
+    det = CaterObjectDetector(None)
+    det.load_state_dict(params, dev)
+    frames = [f for f in np.random.default_rng(0).integers(0, 256, size=(nf, 240, 320, 3), dtype=np.uint8)]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+
+    def run(n):
+        prev, out = None, None
+        for k in range(n):
+            with torch.cuda.stream(streams[k % 2]):
+                h = det.detect_batch_async(frames, dev)
+            if prev is not None:
+                out = prev()
+            prev = h
+        return prev() if prev is not None else out
+
+    run(2)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    out = run(passes)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t1
+    one = [frames[0]]
+    det.detect_batch(one, dev)
+    torch.cuda.synchronize(dev)
+    t2 = time.perf_counter()
+    for _ in range(5):
+        det.detect_batch(one, dev)
+    torch.cuda.synchronize(dev)
+    single = (time.perf_counter() - t2) / 5
+    fl = detector_flops_per_frame()
+    tf = fl * nf * passes / dt / 1e12
+    return {"detector": {
+        "workload": f"Faster-RCNN R50-FPN (193 classes) eval on 240x320 frames -> 800x1066, {nf} frames per pass, synthetic weights",
+        "frames_per_s": round(nf * passes / dt, 1), "ms_per_pass": round(dt / passes * 1e3, 2),
+        "single_frame_call": {"ms": round(single * 1e3, 2), "frames_per_s": round(1.0 / single, 1)},
+        "kernel": "conv2d_nhwc_glds (dominant; all dense launches of a pass over the whole-pass time incl. selection stages)",
+        "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": round(tf / MFMA_F32_PEAK_TF, 4), "gflop_per_frame": round(fl / 1e9, 1)},
+        "parity": "unpinned (checked against the build-authored oracle/detector_oracle.py only)",
+        "detections_per_frame": [len(o["scores"]) for o in out][:4], "block_seconds": round(time.perf_counter() - t0, 1)}}
+
+
 def bench_detect(args, world, rank, dev, dist):
     """Detector throughput (config 4's front-end, not the BASELINE headline): one step = CaterObjectDetector.detect_batch
     on `--batch` 240x320 frames per GPU (frames are independent: weak scaling, no collective)."""
@@ -370,36 +438,122 @@ def bench_detect(args, world, rank, dev, dist):
         emit(line)
 
 
-def bench_transformer(args, world, rank, dev, dist):
-    """BASELINE.json config 3: transformer_lstm (d_model 256, `--heads` heads, 2 encoder layers, 2 LSTM layers of 512),
-    one step = one forward of `--batch` clips (default ONE clip: S = 300 tokens - the reference's sequence-first encoder
-    attends over all B x 300 frames of a minibatch, so the clip count IS the sequence length).  Clips of different steps
-    are independent: weak scaling over ranks, no collective."""
-    from objectpermanence_amd import ModelsFactory, _lib
+def _transformer_model(heads, dev):
+    from objectpermanence_amd import ModelsFactory
     from synthdata import opnet as synth
-    lib = _lib.load()
-    cfg = {"boxes_features_dim": 256, "num_attention_heads": args.heads, "num_attention_layers": 2, "num_lstm_layers": 2,
+    cfg = {"boxes_features_dim": 256, "num_attention_heads": heads, "num_attention_layers": 2, "num_lstm_layers": 2,
            "lstm_hidden_dim": 512}
-    B = args.batch or 1
     params = synth.transformer_lstm_synth_params(cfg)
     model = ModelsFactory.get_model("transformer_lstm", cfg)
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
-    model.eval().to(dev)
-    boxes_np, _ = synth.make_batch(rank * B, B, T_FRAMES)
-    x_np = synth.boxes5(boxes_np)
-    x = torch.from_numpy(x_np).to(dev)
+    return model.eval().to(dev), params
+
+
+def _median_forward_ms(fn, dev, reps=11):
+    fn()
+    torch.cuda.synchronize(dev)
+    times = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        times.append(e0.elapsed_time(e1))
+    return sorted(times)[len(times) // 2]
+
+
+def transformer_serving(model, reqs, per_pass, dev, lib, rounds=5):
+    """`reqs` (independent transformer_lstm requests of one shape) through a ReasonerServer that merges up to `per_pass` of them
+    into one pass; returns (results of the last round, seconds per round by HIP events, seqx / attention profile)."""
+    from objectpermanence_amd import _lib
+    from objectpermanence_amd.serving import ReasonerServer
+    b = int(reqs[0].shape[0])
+    server = ReasonerServer(model, "transformer_lstm", max_clips=per_pass * b)
+
+    def one_round():
+        hs = [server.submit(x) for x in reqs]
+        server.flush()
+        return [h.result() for h in hs]
+
+    with torch.no_grad():
+        one_round()
+        torch.cuda.synchronize(dev)
+        lib.opnet_xcd_profile(1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(rounds):
+            outs = one_round()
+        e1.record()
+        torch.cuda.synchronize(dev)
+    prof = {}
+    for tag, name in ((1, "seqx"), (2, "attn")):
+        kms, nl = ctypes.c_double(0.0), ctypes.c_int(0)
+        _lib.check(lib.opnet_kernel_profile_read(tag, ctypes.byref(kms), ctypes.byref(nl)), "opnet_kernel_profile_read")
+        prof[name] = (kms.value, nl.value)
+    lib.opnet_xcd_profile(0)
+    return outs, e0.elapsed_time(e1) * 1e-3 / rounds, prof
+
+
+def transformer_block(dev, heads=4, n_req=16):
+    """BASELINE.json config 3 next to the headline (outside the timed region; `--mode transformer` is the full measurement):
+    one one-clip request alone, and `n_req` independent one-clip requests served in one pass."""
+    from objectpermanence_amd import _lib
+    from synthdata import opnet as synth
+    lib = _lib.load()
+    model, _ = _transformer_model(heads, dev)
+    reqs = [torch.from_numpy(synth.boxes5(synth.make_batch(5000 + i, 1, T_FRAMES)[0])).to(dev) for i in range(n_req)]
+    with torch.no_grad():
+        lone_ms = _median_forward_ms(lambda: model(reqs[0]), dev)
+        lone = model(reqs[0]).clone()
+    outs, sec, prof = transformer_serving(model, reqs, n_req, dev, lib)
+    E, H = 256, 512
+    stack_flop = 2 * T_FRAMES * (4 * H * (E + H) + 4 * H * (H + H))                  # per clip
+    seqx_ms = prof["seqx"][0] / max(prof["seqx"][1], 1)
+    tf = n_req * stack_flop / (seqx_ms * 1e-3) / 1e12 if prof["seqx"][1] else None
+    return {"transformer_step": {
+        "workload": f"transformer_lstm (d_model 256, {heads} heads, 2 encoder layers, 2 x LSTM 512), seq_len 300 per request",
+        "lone_request": {"ms_per_forward": round(lone_ms, 3), "clips_per_s": round(1e3 / lone_ms, 1)},
+        "served": {"requests_per_pass": n_req, "ms_per_pass": round(sec * 1e3, 3), "clips_per_s": round(n_req / sec, 1),
+                   "bit_identical_to_lone_forward": bool(torch.equal(outs[0], lone))},
+        "kernel": "seqx_forward<64, 2>", "kernel_ms": round(seqx_ms, 4),
+        "roofline": None if tf is None else {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
+                                             "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4)}}}
+
+
+def bench_transformer(args, world, rank, dev, dist):
+    """BASELINE.json config 3: transformer_lstm (d_model 256, `--heads` heads, 2 encoder layers, 2 LSTM layers of 512).  One step
+    = one REQUEST of `--batch` clips (default ONE clip: seq_len S = 300 - the reference's sequence-first encoder attends over
+    all B x 300 frames of a call, so a request's clip count IS its sequence length).  The requests are independent; they are
+    submitted to a serving.ReasonerServer, which merges up to `--inflight` (default 16) pending requests into one pass -
+    token-wise stages over all tokens, attention inside a request, ONE persistent stacked-LSTM launch over all clips - and
+    returns every request the bits its lone forward gives (checked below).  Weak scaling over ranks, no collective."""
+    from objectpermanence_amd import _lib
+    from objectpermanence_amd.serving import ReasonerServer
+    from synthdata import opnet as synth
+    lib = _lib.load()
+    B = args.batch or 1
+    per_pass = max(1, args.inflight or 16)
+    model, params = _transformer_model(args.heads, dev)
+    per_pass = min(per_pass, model.max_requests_per_pass(B, T_FRAMES))
+    # DISTINCT clips in every request of the timed region
+    n_req = args.steps
+    req_np = [synth.boxes5(synth.make_batch((rank * n_req + i) * B, B, T_FRAMES)[0]) for i in range(n_req)]
+    reqs = [torch.from_numpy(a).to(dev) for a in req_np]
+    server = ReasonerServer(model, "transformer_lstm", max_clips=per_pass * B)
     last = {}
 
     def region():
         with torch.no_grad():
-            for _ in range(args.steps):
-                last["y"] = model(x)
+            hs = [server.submit(x) for x in reqs]
+            server.flush()
+            last["y"] = [h.result() for h in hs]
 
-    with torch.no_grad():
-        for _ in range(max(args.warmup, 1)):
-            model(x)
+    for _ in range(max(1, (args.warmup + n_req - 1) // n_req)):
+        region()
     torch.cuda.synchronize(dev)
     lib.opnet_xcd_profile(1)
+    f0 = server.forwards
     elapsed, t_min, t_max, _all = timed_repeats(args, dev, dist, world, region)
     prof = {}
     for tag, name in ((1, "seqx"), (2, "attn")):
@@ -415,13 +569,20 @@ def bench_transformer(args, world, rank, dev, dist):
         dist.destroy_process_group()
     if rank != 0:
         return
+    R = max(1, args.repeats)
+    passes = (server.forwards - f0) // R
     S, E, H, FFN = B * T_FRAMES, 256, 512, 2048
-    clips_per_s = world * B * args.steps / elapsed
+    clips_per_s = world * B * n_req / elapsed
+    # every request's served result against its LONE forward (the reference's call pattern): bit for bit
+    with torch.no_grad():
+        lone_ms = _median_forward_ms(lambda: model(reqs[0]), dev)
+        identical = all(torch.equal(model(reqs[i]), last["y"][i]) for i in range(n_req))
     # algorithmic work: the stacked LSTM 2 x T x (4H (E + H) + 4H (H + H)) flop per clip; attention 4 S^2 E
-    # per layer (Q K^T and P V); the live encoder (slot 0 only) per layer S (E 3E + E E + 2 E FFN) MAC + attention
-    stack_flop = 2 * B * T_FRAMES * (4 * H * (E + H) + 4 * H * (H + H))
-    attn_flop = 4 * S * S * E                      # one attention call
+    # per layer (Q K^T and P V) per request; the live encoder (slot 0 only) per layer S (E 3E + E E + 2 E FFN) MAC + attention
+    stack_flop = 2 * B * T_FRAMES * (4 * H * (E + H) + 4 * H * (H + H))              # per request
+    attn_flop = 4 * S * S * E                                                      # one attention call of ONE request
     enc_flop = 2 * (2 * S * (E * 3 * E + E * E + 2 * E * FFN) + attn_flop)
+    req_per_launch = n_req / max(passes, 1)
     stack_ms = prof["seqx"][0] / max(prof["seqx"][1], 1)
     attn_ms = prof["attn"][0] / max(prof["attn"][1], 1)
     persistent = prof["seqx"][1] > 0
@@ -429,65 +590,65 @@ def bench_transformer(args, world, rank, dev, dist):
         "metric": "CATER clips/sec transformer_lstm inference (BASELINE.json config 3)",
         "value": round(clips_per_s, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "repeats": max(1, args.repeats), "value_is": "median over the repeats of the timed region",
-        "value_min": round(world * B * args.steps / t_max, 1), "value_max": round(world * B * args.steps / t_min, 1),
+        "repeats": R, "value_is": "median over the repeats of the timed region",
+        "value_min": round(world * B * n_req / t_max, 1), "value_max": round(world * B * n_req / t_min, 1),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"transformer_lstm inference, {B} clip(s) per step x 300 frames = one sequence of S = {S} tokens "
-                               f"(seq_len 300 per clip), d_model 256, {args.heads} heads, 2 encoder layers (FFN 2048), 2 LSTM "
-                               "layers of 512, slot-0 path (exact: slots 1..14 never reach the output), input resident in HBM",
+        "config": {"workload": f"transformer_lstm inference, one step = one independent request of {B} clip(s) x 300 frames = one "
+                               f"sequence of S = {S} tokens (seq_len 300 per clip), d_model 256, {args.heads} heads, 2 encoder layers "
+                               "(FFN 2048), 2 LSTM layers of 512, slot-0 path (exact: slots 1..14 never reach the output), inputs "
+                               f"resident in HBM; a ReasonerServer merges up to {per_pass} pending requests into one pass "
+                               "(segmented attention, one persistent stacked-LSTM launch), every result bit-identical to the "
+                               "request's lone forward",
                    "global_batch": world * B, "frames": T_FRAMES, "parallelism": f"dp{world}", "heads": args.heads,
+                   "requests_per_pass": per_pass, "passes": passes,
                    "weights": "synthetic (synthdata/opnet.py counter RNG), fp32",
                    "engine": "stacked LSTM as one persistent launch (seqx_forward)" if persistent else "launch per time step"},
-        "flop_per_step": {"lstm_stack": stack_flop, "encoder_live": enc_flop},
+        "served_results_bit_identical_to_lone_forward": bool(identical), "requests_checked": n_req,
+        "lone_request": {"ms_per_forward": round(lone_ms, 3), "clips_per_s": round(B * 1e3 / lone_ms, 1),
+                         "note": "one request alone (the reference's call pattern): a latency, 2 of 8 XCDs busy"},
+        "flop_per_request": {"lstm_stack": stack_flop, "encoder_live": enc_flop},
         "whole_job_mfma_frac": round(clips_per_s / world / B * (stack_flop + enc_flop) / (MFMA_F32_PEAK_TF * 1e12), 4),
     }
+    if not identical:
+        raise SystemExit("bench: a served request differs from its lone forward")
     if persistent:
-        tf = stack_flop / (stack_ms * 1e-3) / 1e12
+        tf = req_per_launch * stack_flop / (stack_ms * 1e-3) / 1e12
         # north_star's per-time-step weight-streaming model of the same recurrence: all LSTM weights once per step per launch
         w_bytes = 4 * (4 * H * (E + H) + 4 * H * (H + H))
-        model_gbs = T_FRAMES * (w_bytes + B * 4 * (E + 4 * H * 2)) / (stack_ms * 1e-3) / 1e9
+        model_gbs = T_FRAMES * (w_bytes + req_per_launch * B * 4 * (E + 4 * H * 2)) / (stack_ms * 1e-3) / 1e9
         line["roofline"] = {"bound": "mfma", "achieved": round(tf, 3), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                            "frac": round(tf / MFMA_F32_PEAK_TF, 4), **pmc_traffic("seqx_forward", B),
-                            "kernel": "seqx_forward<64, 2> (both LSTM layers, all 300 steps, one launch; 2 of 8 XCDs busy with one "
-                                      "4-clip group - a latency chain of 300 dependent steps, not a throughput kernel)",
-                            "launch_ms": round(stack_ms, 4), "launches": prof["seqx"][1], "alg_flop_per_launch": stack_flop,
-                            "us_per_time_step": round(stack_ms * 1e3 / T_FRAMES, 3),
+                            "frac": round(tf / MFMA_F32_PEAK_TF, 4), **pmc_traffic("seqx_forward", int(req_per_launch * B)),
+                            "kernel": f"seqx_forward<64, 2> (both LSTM layers, all 300 steps, one launch over the {int(req_per_launch * B)} "
+                                      "clips of a pass: 4-clip groups on 4 XCD pairs - a latency chain of 300 dependent steps per group)",
+                            "launch_ms": round(stack_ms, 4), "launches": prof["seqx"][1],
+                            "alg_flop_per_launch": int(req_per_launch * stack_flop),
+                            "us_per_time_step": round(stack_ms * 1e3 / T_FRAMES, 3), **pmc_mfma_busy("seqx_forward"),
                             "timing": "HIP events around every launch of the kernel on its stream (opnet_xcd_profile)"}
         line["roofline_hbm_model"] = {"bound": "hbm", "achieved": round(model_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(model_gbs / HBM_PEAK_GBS, 4),
                                       "note": "SURVEY.md 8-d4 streaming-model bytes (14.7 MB of LSTM weights once per time step) "
                                               "over the kernel time; the kernel itself reads the weights once per launch"}
     if prof["attn"][1] > 0:
-        tfa = attn_flop / (attn_ms * 1e-3) / 1e12
+        tfa = req_per_launch * attn_flop / (attn_ms * 1e-3) / 1e12
         line["roofline_attention"] = {"bound": "mfma", "achieved": round(tfa, 3), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                      "frac": round(tfa / MFMA_F32_PEAK_TF, 4), "kernel": "attention_glds (+ attention_merge when the "
-                                      "key sweep is split)", "call_ms": round(attn_ms, 4), "calls": prof["attn"][1],
-                                      "alg_flop_per_call": attn_flop}
-    # other minibatch sizes (S = B x 300): one forward each, outside the timed region
+                                      "frac": round(tfa / MFMA_F32_PEAK_TF, 4), "kernel": "attention_glds (one call = the segments of "
+                                      "all requests of a pass)", "call_ms": round(attn_ms, 4), "calls": prof["attn"][1],
+                                      "alg_flop_per_call": int(req_per_launch * attn_flop)}
+    # coupled minibatches (the reference's training / evaluation call: ONE sequence of S = b x 300): one forward each
     extra = {}
     for b in (16, 32):
-        if b == B:
-            continue
         bx, _ = synth.make_batch(0, b, T_FRAMES)
         xb = torch.from_numpy(synth.boxes5(bx)).to(dev)
         with torch.no_grad():
-            model(xb)
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                model(xb)
-            e1.record()
-            torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / 5
+            ms = _median_forward_ms(lambda: model(xb), dev, reps=5)
         extra[str(b)] = {"ms_per_forward": round(ms, 3), "clips_per_s": round(b / ms * 1e3, 1), "S": b * T_FRAMES}
-    line["other_minibatches"] = extra
+    line["coupled_minibatches"] = extra
     if world == 1 and not args.no_cpu_baseline:
         from oracle import torch_port                                   # cpu_baseline leg + parity of the last output
         threads = max(1, min(os.cpu_count() or 1, 16))
         torch.set_num_threads(threads)
         pt = {k: torch.from_numpy(v) for k, v in params.items()}
-        xt = torch.from_numpy(x_np)
+        xt = torch.from_numpy(req_np[-1])
         with torch.no_grad():
             y_cpu = torch_port.transformer_lstm_forward(xt, pt, args.heads)
             t1, n_cpu = time.perf_counter(), 0
@@ -496,9 +657,9 @@ def bench_transformer(args, world, rank, dev, dist):
                 n_cpu += 1
             dt = time.perf_counter() - t1
         line["cpu_baseline"] = {"value": round(n_cpu * B / dt, 2), "unit": "clips/s", "cores": threads, "kind": "port",
-                                "sample": f"{n_cpu} forwards of {B} clip(s) x 300 frames, oracle/torch_port.transformer_lstm_forward "
+                                "sample": f"{n_cpu} forwards of one request ({B} clip(s) x 300 frames), oracle/torch_port.transformer_lstm_forward "
                                           f"(slot-0 path on torch CPU ops, fp32), {dt:.1f} s"}
-        err = float((last["y"].cpu() - y_cpu).abs().max())
+        err = float((last["y"][-1].cpu() - y_cpu).abs().max())
         line["parity_max_abs_dy_vs_cpu_port"] = err
         if not err < 1e-4:
             raise SystemExit(f"bench: HIP output differs from the CPU port by {err}")
@@ -580,7 +741,7 @@ def main():
 
     if args.mode == "transformer":
         if args.steps == 200:
-            args.steps, args.warmup = 50, 5
+            args.steps, args.warmup = 64, 16      # four passes of 16 one-clip requests
         return bench_transformer(args, world, rank, dev, dist)
     if args.mode == "detect":
         args.batch = args.batch or 16     # frames per pass
@@ -617,7 +778,13 @@ def main():
     if args.engine == "chain":
         out, y = bench_infer_chain(args, model, boxes, world, rank, dev, dist)
     else:
-        out, y = bench_infer_xcd(args, model, boxes, world, rank, dev, dist)
+        # DISTINCT clips in every step (up to 32 batches = one full launch; a longer run cycles through them): rank r owns
+        # clips [r * nd * B, (r + 1) * nd * B) of the synthetic set
+        nd = max(1, min(args.steps, 32))
+        all_np, _ = synth.make_batch(rank * nd * B, nd * B, T_FRAMES)
+        all_dev = torch.from_numpy(all_np).to(dev)
+        batches = [all_dev[i * B:(i + 1) * B] for i in range(nd)]
+        out, y = bench_infer_xcd(args, model, batches, world, rank, dev, dist)
     # the ranks part here: everything below is rank 0's own (no collective), so that no rank waits in a process-group
     # shutdown while rank 0 is still measuring the extras
     if dist is not None:
@@ -627,13 +794,27 @@ def main():
         out.update(accuracy_block(dev))
         out.update(other_batches(model, boxes, dev))
         out.update(training_block(params, boxes, labels, dev))
+        out.update(transformer_block(dev))
+        out.update(detector_block(dev))
         if world == 1 and not args.no_cpu_baseline:
             cb, y_cpu = cpu_baseline(boxes_np, params, args.cpu_seconds)
             out["cpu_baseline"] = cb
-            # every timed step is the same B clips: EVERY B-clip slice of the last launch's output is held against the port
             y_np = y.cpu().numpy()
-            err = max(float(np.abs(y_np[lo:lo + B] - y_cpu).max()) for lo in range(0, y_np.shape[0], B))
-            out["parity_clips_checked"] = int(y_np.shape[0])
+            if args.engine == "chain":
+                # every timed step is the same B clips
+                err = max(float(np.abs(y_np[lo:lo + B] - y_cpu).max()) for lo in range(0, y_np.shape[0], B))
+                out["parity_clips_checked"] = int(B)
+            else:
+                # the LAST launch of the timed region carried steps [steps - n_last, steps): its clips - distinct while the
+                # launch holds at most 32 batches - through the C port, every one of them
+                from oracle import c_oracle
+                n_last = y_np.shape[0] // B
+                ids = [(i % nd) for i in range(args.steps - n_last, args.steps)]
+                x_last = np.concatenate([all_np[i * B:(i + 1) * B] for i in ids])
+                y_port, _ = c_oracle.opnet_forward(np.ascontiguousarray(x_last), params, c_oracle.usable_cores())
+                err = float(np.abs(y_np - y_port).max())
+                out["parity_clips_checked"] = int(len(set(ids)) * B)
+                out["parity_note"] = "distinct clips of the last timed launch, each held against oracle/opnet_oracle.c"
             out["parity_max_abs_dy_vs_cpu_port"] = err
             if not err < 1e-4 and not os.environ.get("OPNET_HIP_LIB"):
                 raise SystemExit(f"bench: HIP output of the last timed step differs from the CPU port by {err}")
@@ -757,14 +938,16 @@ def other_batches(model, boxes, dev):
     return {"reference_batch_sizes": res}
 
 
-def bench_infer_xcd(args, model, boxes, world, rank, dev, dist):
+def bench_infer_xcd(args, model, batches, world, rank, dev, dist):
     """Request batching into the per-XCD persistent forward: every step submits its batch to a ReasonerServer, which runs
     `per_launch` pending batches as one launch; the post-process (and, N > 1, the all-gather of the int32 predictions) runs
-    once per launch on the launch's whole output."""
+    once per launch on the launch's whole output.  Step i submits batches[i % len(batches)]: DISTINCT clips in every step of
+    the driver's --steps 20 (640 distinct clips per launch)."""
     from objectpermanence_amd import _lib, metrics
     from objectpermanence_amd.serving import ReasonerServer
     lib = _lib.load()
-    B = int(boxes.shape[0])
+    B = int(batches[0].shape[0])
+    nd = len(batches)
     cap = max(1, int(lib.opnet_xcd_max_batch()) // B)
     if args.inflight > 0:
         per_launch = min(args.inflight, cap)
@@ -802,8 +985,8 @@ def bench_infer_xcd(args, model, boxes, world, rank, dev, dist):
         state["y"], state["pred"] = y, pred_px
 
     def run(n):
-        for _ in range(n):
-            server.submit(boxes)
+        for i in range(n):
+            server.submit(batches[i % nd])
             after_flush()
         server.flush()
         after_flush()
@@ -846,9 +1029,21 @@ def bench_infer_xcd(args, model, boxes, world, rank, dev, dist):
                 "15 slots (10 objects) x 6 features, precomputed bbox input resident in HBM, int32 pixel-box post-process on "
                 f"device; steps are requests to a ReasonerServer that runs up to {per_launch} pending batches "
                 f"({per_launch * B} clips) as one per-XCD persistent forward",
-                {"engine": "xcd", "batches_per_launch": per_launch, "launches": launches}, spread=(t_min, t_max))
+                {"engine": "xcd", "batches_per_launch": per_launch, "launches": launches,
+                 "distinct_clips_per_timed_region": min(nd, args.steps) * B}, spread=(t_min, t_max))
+    cpl = clips // max(launches, 1)
+    traffic = pmc_traffic("opnet_xcd_forward", cpl)
+    if traffic.get("traffic"):
+        # the launch's companions and SURVEY.md 8-d4's compulsory model (130 800 B per clip + the 5.68 MB of weights once per
+        # launch) next to the kernel's own bytes: what the whole forward moves per launch
+        pack = pmc_traffic("opnet_xcd_pack_input", cpl).get("traffic")
+        compulsory = cpl * 130_800 + W_BYTES
+        traffic["traffic_pack_kernel"] = pack
+        traffic["compulsory_bytes_8d4"] = compulsory
+        traffic["traffic_over_compulsory_8d4"] = round(traffic["traffic"] / compulsory, 3)
+        traffic["forward_total_over_compulsory_8d4"] = round((traffic["traffic"] + (pack or 0)) / compulsory, 3)
     out["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                       "frac": round(tf / MFMA_F32_PEAK_TF, 4), **pmc_traffic("opnet_xcd_forward", clips // max(launches, 1)),
+                       "frac": round(tf / MFMA_F32_PEAK_TF, 4), **traffic,
                        "kernel": "opnet_xcd_forward", "launch_ms": round(kms.value / max(launches * R, 1), 4),
                        "launches": launches, "alg_flop_per_launch": int(clips * FLOP_PER_CLIP / max(launches, 1)),
                        "timing": "HIP events around every launch of the kernel on its stream (opnet_xcd_profile)"}

@@ -306,6 +306,16 @@ int opseq_encoder_layer_f32(float *z, const float *in_w, const float *in_b, cons
                             const float *l2_b, const float *n1_w, const float *n1_b, const float *n2_w,
                             const float *n2_b, void *workspace, size_t workspace_bytes, long S, int E,
                             int nhead, int ffn, void *stream);
+/* The same layer over n_seg INDEPENDENT sequences of S tokens each, z [n_seg * S, E] in place: the requests a server merges
+ * into one pass (learned_models.py:176-197 called once per request by the reference).  The token-wise stages run over all
+ * n_seg * S rows, attention stays inside a sequence, and every kernel is chosen from S alone - each sequence's rows are
+ * bit-identical to opseq_encoder_layer_f32 on that sequence by itself.  workspace >= opseq_encoder_workspace_bytes(n_seg * S,
+ * ...); n_seg * S * ffn * 4 must stay below 2 GiB (OPNET_ESHAPE beyond: split the requests over passes). */
+int opseq_encoder_layer_segmented_f32(float *z, const float *in_w, const float *in_b, const float *out_w,
+                                      const float *out_b, const float *l1_w, const float *l1_b, const float *l2_w,
+                                      const float *l2_b, const float *n1_w, const float *n1_b, const float *n2_w,
+                                      const float *n2_b, void *workspace, size_t workspace_bytes, long S, int n_seg,
+                                      int E, int nhead, int ffn, void *stream);
 
 /* ---- detector backbone primitives (torchvision fasterrcnn_resnet50_fpn built at
  *      object_detection/models.py:6-20, called at baselines/detector.py:71-86).  fp32, NHWC.  The

@@ -32,10 +32,15 @@ __device__ __forceinline__ int att_kswz(int row)
 // (O, running max m, running sum l) per query and head; attention_merge combines them.  Wave-tasks come in units of
 // "16 QF queries x all keys"; when their number is a small non-multiple of the SIMD count (S = 9600, 2 heads: 1200
 // tasks on 1024 SIMDs) the busiest SIMD carries twice the average - splitting the keys makes the units 1/KS the size.
+//
+// Segments (nseg > 1; serving independent requests in one pass): qkv / out hold nseg sequences of S tokens back to back and
+// every sequence attends to itself only.  blockIdx.x = segment * (gridDim.x / nseg) + query tile; a workgroup rebases its
+// pointers to its segment and then runs EXACTLY the single-sequence code on it (same tiles, same sweep, same arithmetic), so a
+// segment's output is bit-identical to that sequence run alone.  The key-split partials are indexed by the global row.
 template <int HD, int QF>
 __global__ void __launch_bounds__(256) attention_glds(const float *__restrict__ qkv, float *__restrict__ out, int S,
                                                       int E, float scale, float *__restrict__ opart,
-                                                      float2 *__restrict__ ml)
+                                                      float2 *__restrict__ ml, int nseg)
 {
     constexpr int NS = 3;                                     // LDS stages
     constexpr int PPR = HD / 4;                               // pieces per row
@@ -50,8 +55,14 @@ __global__ void __launch_bounds__(256) attention_glds(const float *__restrict__ 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kk = lane >> 4;
     const int head = blockIdx.y;
-    const int q0 = (blockIdx.x * 4 + w) * (16 * QF);
+    const int xtiles = (int)gridDim.x / nseg;                 // query tiles per segment
+    const int seg = (int)blockIdx.x / xtiles;
+    const int q0 = (((int)blockIdx.x - seg * xtiles) * 4 + w) * (16 * QF);
     const long ld = 3L * E;
+    const long row0 = (long)seg * S;                          // first global row of this workgroup's segment
+    const long Stot = (long)nseg * S;
+    qkv += row0 * ld;
+    out += row0 * E;
 
     conv_u32x4 rs;
     {
@@ -209,8 +220,8 @@ __global__ void __launch_bounds__(256) attention_glds(const float *__restrict__ 
         if (q >= S) continue;
         const bool partial = gridDim.z > 1;
         const float inv = partial ? 1.0f : 1.0f / l_run[f];
-        float *op = (partial ? opart + ((long)blockIdx.z * S + q) * E : out + (long)q * E) + (long)head * HD;
-        if (partial && kk == 0) ml[((long)blockIdx.z * S + q) * gridDim.y + head] = make_float2(m_run[f], l_run[f]);
+        float *op = (partial ? opart + ((long)blockIdx.z * Stot + row0 + q) * E : out + (long)q * E) + (long)head * HD;
+        if (partial && kk == 0) ml[((long)blockIdx.z * Stot + row0 + q) * gridDim.y + head] = make_float2(m_run[f], l_run[f]);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll

@@ -92,37 +92,43 @@ static int attention_key_split(long S, int nhead, int QF)
     return best;
 }
 
+// nseg sequences of S tokens back to back, each attending to itself: every choice below (query fragments per wave, key split)
+// is made from ONE segment's shape, so a segment is computed exactly as that sequence alone would be (bit-identical); the
+// segments only add workgroups (grid.x).  The key split's scratch covers all nseg * S rows.
 template <int HD>
-static void launch_attention_hd(const float *qkv, float *att, int S, int E, int nhead, void *scratch,
+static void launch_attention_hd(const float *qkv, float *att, int S, int nseg, int E, int nhead, void *scratch,
                                 size_t scratch_bytes, hipStream_t st)
 {
     const float scale = 1.0f / sqrtf((float)HD);
     const int QF = (long)((S + 127) / 128) * nhead >= 256 ? 2 : 1;
-    int KS = attention_key_split(S, nhead, QF);
-    while (KS > 1 && (!scratch || attention_scratch_bytes(S, E, nhead, KS) > scratch_bytes)) --KS;
+    const long Stot = (long)S * nseg;
+    int KS = attention_key_split(S, nhead, QF);                   // from the segment's shape alone, like QF: same arithmetic as alone
+    while (KS > 1 && (!scratch || attention_scratch_bytes(nseg > 1 ? Stot : S, E, nhead, KS) > scratch_bytes)) --KS;
     float *opart = KS > 1 ? (float *)scratch : nullptr;
-    float2 *ml = KS > 1 ? (float2 *)((char *)scratch + (size_t)KS * S * E * 4) : nullptr;
+    float2 *ml = KS > 1 ? (float2 *)((char *)scratch + (size_t)KS * Stot * E * 4) : nullptr;
     if (QF == 2)
-        attention_glds<HD, 2><<<dim3((S + 127) / 128, nhead, KS), 256, 0, st>>>(qkv, att, S, E, scale, opart, ml);
+        attention_glds<HD, 2><<<dim3((unsigned)((S + 127) / 128) * nseg, nhead, KS), 256, 0, st>>>(qkv, att, S, E, scale, opart, ml, nseg);
     else
-        attention_glds<HD, 1><<<dim3((S + 63) / 64, nhead, KS), 256, 0, st>>>(qkv, att, S, E, scale, opart, ml);
+        attention_glds<HD, 1><<<dim3((unsigned)((S + 63) / 64) * nseg, nhead, KS), 256, 0, st>>>(qkv, att, S, E, scale, opart, ml, nseg);
     if (KS > 1) {
-        const long n = (long)S * (E / 4);
-        attention_merge<<<(unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), 256, 0, st>>>(opart, ml, att, S, E, nhead, KS);
+        const long n = Stot * (E / 4);
+        attention_merge<<<(unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), 256, 0, st>>>(opart, ml, att, (int)Stot, E, nhead, KS);
     }
 }
 
-static void launch_attention(const float *qkv, float *att, int S, int E, int nhead, int hd, void *scratch,
+static void launch_attention(const float *qkv, float *att, int S, int nseg, int E, int nhead, int hd, void *scratch,
                              size_t scratch_bytes, hipStream_t st)
 {
     if ((long)S * 3 * E * 4 >= (1L << 31)) hd = 0;      // 32-bit buffer offsets: fall through to the direct kernel
     switch (hd) {
-    case 16: launch_attention_hd<16>(qkv, att, S, E, nhead, scratch, scratch_bytes, st); break;
-    case 32: launch_attention_hd<32>(qkv, att, S, E, nhead, scratch, scratch_bytes, st); break;
-    case 64: launch_attention_hd<64>(qkv, att, S, E, nhead, scratch, scratch_bytes, st); break;
-    case 128: launch_attention_hd<128>(qkv, att, S, E, nhead, scratch, scratch_bytes, st); break;
+    case 16: launch_attention_hd<16>(qkv, att, S, nseg, E, nhead, scratch, scratch_bytes, st); break;
+    case 32: launch_attention_hd<32>(qkv, att, S, nseg, E, nhead, scratch, scratch_bytes, st); break;
+    case 64: launch_attention_hd<64>(qkv, att, S, nseg, E, nhead, scratch, scratch_bytes, st); break;
+    case 128: launch_attention_hd<128>(qkv, att, S, nseg, E, nhead, scratch, scratch_bytes, st); break;
     default:
-        attention_f32<<<dim3((S + 63) / 64, nhead, 1), 256, 0, st>>>(qkv, att, S, E, E / nhead, 1.0f / sqrtf((float)(E / nhead)));
+        for (int g = 0; g < nseg; ++g)
+            attention_f32<<<dim3((S + 63) / 64, nhead, 1), 256, 0, st>>>(qkv + (size_t)g * S * 3 * E, att + (size_t)g * S * E, S, E,
+                                                                          E / nhead, 1.0f / sqrtf((float)(E / nhead)));
     }
 }
 
@@ -2330,38 +2336,47 @@ extern "C" int opseq_attention_f32(const float *qkv, float *out, long S, int E, 
     if (S <= 0 || S > 0x7fffffffL || E <= 0 || nhead <= 0 || E % nhead) return fail(OPNET_ESHAPE, "bad attention shape");
     const int hd = E / nhead;
     if ((hd & 15) || hd > 128) return fail(OPNET_ESHAPE, "head size %d: must be a multiple of 16, <= 128", hd);
-    launch_attention(qkv, out, (int)S, E, nhead, hd, workspace, workspace ? workspace_bytes : 0, (hipStream_t)stream);
+    launch_attention(qkv, out, (int)S, 1, E, nhead, hd, workspace, workspace ? workspace_bytes : 0, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }
 
-/* one post-LN nn.TransformerEncoderLayer (eval), in place on z [S][E] */
-extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float *in_b, const float *out_w,
-                                       const float *out_b, const float *l1_w, const float *l1_b, const float *l2_w,
-                                       const float *l2_b, const float *n1_w, const float *n1_b, const float *n2_w,
-                                       const float *n2_b, void *workspace, size_t workspace_bytes, long S, int E,
-                                       int nhead, int ffn, void *stream)
+/* one post-LN nn.TransformerEncoderLayer (eval), in place on z [nseg * S][E]: nseg independent sequences of S tokens each.
+ * Token-wise stages (the four products, the two layer norms) run over all nseg * S rows at once; attention stays inside a
+ * sequence.  EVERY kernel choice is made from ONE sequence's shape (S), never from nseg * S, and every kernel computes an
+ * output row from its own input row in an order that does not depend on where the row sits - so each sequence comes out
+ * bit-identical to that sequence run alone (nseg = 1), which is the contract serving.ReasonerServer relies on. */
+static int encoder_layer(float *z, const float *in_w, const float *in_b, const float *out_w, const float *out_b, const float *l1_w,
+                         const float *l1_b, const float *l2_w, const float *l2_b, const float *n1_w, const float *n1_b,
+                         const float *n2_w, const float *n2_b, void *workspace, size_t workspace_bytes, long S, int nseg, int E,
+                         int nhead, int ffn, void *stream)
 {
     if (int rc = check_encoder(S, E, nhead, ffn)) return rc;
+    if (nseg <= 0 || S * nseg > 0x7fffffffL) return fail(OPNET_ESHAPE, "n_seg=%d x S=%ld out of range", nseg, S);
     if (!z || !in_w || !in_b || !out_w || !out_b || !l1_w || !l1_b || !l2_w || !l2_b || !n1_w || !n1_b || !n2_w ||
         !n2_b || !workspace)
         return fail(OPNET_EINVAL, "null pointer");
     if (!aligned16(z) || !aligned16(workspace) || !aligned16(in_w) || !aligned16(out_w) || !aligned16(l1_w) || !aligned16(l2_w))
         return fail(OPNET_EINVAL, "z / workspace / weight matrices must be 16-byte aligned");
-    if (workspace_bytes < opseq_encoder_workspace_bytes(S, E, nhead, ffn)) return fail(OPNET_EWORKSPACE, "workspace too small");
+    const long St = S * nseg;
+    // one pass addresses its buffers with the offsets a single sequence's kernels use (32-bit in the tiled GEMM): keep the
+    // largest (hid [St][ffn]) below 2 GiB so that the kernel choice cannot differ from the lone sequence's
+    if (nseg > 1 && (St * (long)ffn * 4 >= (1L << 31) || St * 3L * E * 4 >= (1L << 31)))
+        return fail(OPNET_ESHAPE, "n_seg=%d x S=%ld tokens exceed one pass (2 GiB buffers): split the requests", nseg, S);
+    if (workspace_bytes < opseq_encoder_workspace_bytes(St, E, nhead, ffn)) return fail(OPNET_EWORKSPACE, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float *qkv = (float *)workspace;
-    float *att = qkv + (size_t)S * 3 * E;
-    float *proj = att + (size_t)S * E;
-    float *z1 = proj + (size_t)S * E;
-    float *hid = z1 + (size_t)S * E;
-    const int M = (int)S, hd = E / nhead;
+    float *att = qkv + (size_t)St * 3 * E;
+    float *proj = att + (size_t)St * E;
+    float *z1 = proj + (size_t)St * E;
+    float *hid = z1 + (size_t)St * E;
+    const int M = (int)St, Ms = (int)S, hd = E / nhead;      // M rows are computed, Ms (one sequence) picks the kernel
     // C[M][N] = act(A[M][K] W[N][K]^T + b) = a 1x1 "convolution" over M pixels: the LDS-staged tiled kernel
     auto gemm = [&](const float *A, const float *Wt, const float *b, float *C, int N, int K, int act) {
-        if ((long)((M + 127) / 128) * ((N + 127) / 128) < 256) {   // too few 128-tiles to fill the chip
+        if ((long)((Ms + 127) / 128) * ((N + 127) / 128) < 256) {   // too few 128-tiles to fill the chip
             // ... and with fewer than 256 64-tiles (one clip: S = 300) even those leave CUs idle behind long serial K walks:
             // 32 x 32 tiles with K split over the workgroup's waves
-            if ((K & 63) == 0 && (long)((M + 63) / 64) * ((N + 63) / 64) < 256 && env_int("OPSEQ_GEMM_KS", 1))
+            if ((K & 63) == 0 && (long)((Ms + 63) / 64) * ((N + 63) / 64) < 256 && env_int("OPSEQ_GEMM_KS", 1))
                 gemm_bias_act_ks<<<dim3((M + 31) / 32, (N + 31) / 32, 1), 256, 0, st>>>(A, Wt, b, C, M, N, K, act);
             else
                 gemm_bias_act<<<dim3((M + 63) / 64, (N + 63) / 64, 1), 256, 0, st>>>(A, Wt, b, C, M, N, K, act);
@@ -2377,7 +2392,7 @@ extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float 
     {
         ProfPair pe{};
         const bool prof = prof_begin(st, &pe);
-        launch_attention(qkv, att, M, E, nhead, hd, hid, (size_t)S * ffn * sizeof(float), st);   // hid is free until the FFN
+        launch_attention(qkv, att, Ms, nseg, E, nhead, hd, hid, (size_t)St * ffn * sizeof(float), st);   // hid is free until the FFN
         if (prof) prof_end(PROF_ATTN, st, pe);
     }
     gemm(att, out_w, out_b, proj, E, E, 0);
@@ -2387,6 +2402,29 @@ extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float 
     add_layernorm<<<(M + 3) / 4, 256, 0, st>>>(z1, proj, n2_w, n2_b, z, M, E, 1e-5f);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
+}
+
+extern "C" int opseq_encoder_layer_f32(float *z, const float *in_w, const float *in_b, const float *out_w,
+                                       const float *out_b, const float *l1_w, const float *l1_b, const float *l2_w,
+                                       const float *l2_b, const float *n1_w, const float *n1_b, const float *n2_w,
+                                       const float *n2_b, void *workspace, size_t workspace_bytes, long S, int E,
+                                       int nhead, int ffn, void *stream)
+{
+    return encoder_layer(z, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b, workspace, workspace_bytes, S, 1,
+                         E, nhead, ffn, stream);
+}
+
+/* the same layer over n_seg independent sequences of S tokens each, z [n_seg * S][E] (requests served in one pass: each
+ * sequence attends only to itself and comes out bit-identical to opseq_encoder_layer_f32 on it alone); workspace >=
+ * opseq_encoder_workspace_bytes(n_seg * S, ...) */
+extern "C" int opseq_encoder_layer_segmented_f32(float *z, const float *in_w, const float *in_b, const float *out_w,
+                                                 const float *out_b, const float *l1_w, const float *l1_b, const float *l2_w,
+                                                 const float *l2_b, const float *n1_w, const float *n1_b, const float *n2_w,
+                                                 const float *n2_b, void *workspace, size_t workspace_bytes, long S, int n_seg,
+                                                 int E, int nhead, int ffn, void *stream)
+{
+    return encoder_layer(z, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b, workspace, workspace_bytes, S,
+                         n_seg, E, nhead, ffn, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

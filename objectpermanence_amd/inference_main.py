@@ -9,8 +9,9 @@ video IO is outside the hot path).  Differences, al
     blocks for the clip-independent reasoners; WHOLE reference minibatches for transformer_lstm*, whose attention couples
     the clips of a minibatch - a split batch would change its outputs) and the int32 predictions are all-gathered by
     dataset index; every rank returns the full result, rank 0 writes;
-  * the clip-independent reasoners do not run one forward per DataLoader minibatch: the minibatches are submitted to a
-    serving.ReasonerServer, which runs up to 1024 pending clips as one forward (same outputs, clips are independent);
+  * there is not one forward per DataLoader minibatch: the minibatches are submitted to a serving.ReasonerServer, which runs
+    up to 1024 pending clips as one forward (clip-independent reasoners: same outputs, clips are independent) or merges the
+    pending minibatches as segments of one pass (transformer_lstm*: each minibatch still attends only to itself);
   * predictions are written for every dataset video (the reference writes only those it also finds as .avi).
 """
 from __future__ import annotations
@@ -60,7 +61,10 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
     model = ModelsFactory.get_model(model_name, model_config, config.get("model_path"))
     model.eval()
     model.to(device)
-    server = None if parallel.couples_clips(model_name) else ReasonerServer(model, model_name)
+    # every DataLoader minibatch is one request.  Clip-independent reasoners: pending requests are concatenated into one
+    # forward; transformer_lstm* (attention couples the clips of a minibatch): merged as SEGMENTS - each minibatch still attends
+    # only to itself, exactly the reference's per-minibatch call (serving.py)
+    server = ReasonerServer(model, model_name)
 
     names: List[str] = []
     pending, preds, gts, ious = [], [], [], []
@@ -68,17 +72,13 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
     with torch.no_grad():
         for (boxes, _index_to_track), (labels, _), video_names in loader:
             names.extend(video_names)
-            if server is None:
-                pending.append((model(boxes.to(device)), labels.to(device)))
-            else:
-                pending.append((server.submit(boxes.to(device)), labels.to(device)))
-        if server is not None:
-            server.flush()
+            pending.append((server.submit(boxes.to(device)), labels.to(device)))
+        server.flush()
         # The sync point of this driver.  A persistent launch that gave up (bounded spins, NaN outputs) is re-run on the
         # launch chain into the same output tensors here - NaN never reaches the int32 post-process or the JSON files.
         verify_launches(model)
         for handle, labels_dev in pending:
-            output = output_boxes(model_name, handle.result() if server is not None else handle)
+            output = output_boxes(model_name, handle.result())
             pred_px, gt_px, iou = metrics.postprocess_and_iou(output, labels_dev)
             preds.append(pred_px); gts.append(gt_px); ious.append(iou)
     t_frames = preds[0].shape[1] if preds else 300

@@ -989,18 +989,57 @@ class TransformerLstm(AbstractCaterModel):
         if _wants_grad(self):
             with torch.cuda.device(x.device):
                 return self._forward_train(x)
+        return self._forward_eval(x, 1)
+
+    # tokens one merged pass may carry: the FFN activation [tokens][2048] fp32 has to stay below 2 GiB (include/opnet_hip.h)
+    MAX_TOKENS_PER_PASS = 192 * 1024
+
+    def forward_segments(self, x: torch.Tensor, n_seg: int) -> torch.Tensor:
+        """x [n_seg * b, T, 15, 5] = n_seg INDEPENDENT requests of b clips each, back to back -> y [n_seg * b, T, 4] where every
+        request's rows are bit-identical to `forward(request)` alone.  The reference serves a request per call
+        (learned_models.py:176-197: attention over S = b * T, the clips OF THAT CALL); here the token-wise stages (embedding,
+        in / out projection, FFN, layer norms) run over all requests' tokens at once, attention stays inside a request
+        (opseq_encoder_layer_segmented_f32) and ONE persistent launch runs the stacked LSTM over all clips - a one-clip
+        request alone leaves 6 of 8 XCDs and 3 of 4 MFMA columns of that launch idle.  Inference only."""
+        _check_input(self, x, 5)
+        if n_seg <= 0 or int(x.shape[0]) % n_seg:
+            raise ValueError(f"{int(x.shape[0])} clips do not split into {n_seg} equal requests")
+        if _wants_grad(self):
+            raise RuntimeError("forward_segments is the serving path: call it under torch.no_grad() / after eval()")
+        return self._forward_eval(x.contiguous().float(), int(n_seg))
+
+    def max_requests_per_pass(self, b: int, T: int) -> int:
+        """how many requests of b clips x T frames `forward_segments` can take in one pass and still return each request's
+        lone result: the token limit above, and the stacked LSTM must run on the SAME engine as for the lone request (the
+        persistent launch carries at most opseq_xcd_max_batch clips; the launch chain sums in another order)"""
+        n = max(1, self.MAX_TOKENS_PER_PASS // max(b * T, 1))
+        r = self._runner
+        alone = r._wants_xcd(b, T)
+        if alone:
+            n = min(n, max(1, int(_lib.load().opseq_xcd_max_batch(r.L)) // b))
+        while n > 1 and r._wants_xcd(n * b, T) != alone:
+            n -= 1
+        return n
+
+    def _forward_eval(self, x: torch.Tensor, n_seg: int) -> torch.Tensor:
+        if n_seg > 1 and n_seg > self.max_requests_per_pass(int(x.shape[0]) // n_seg, int(x.shape[1])):
+            raise ValueError(f"{n_seg} requests of {int(x.shape[0]) // n_seg} clips x {int(x.shape[1])} frames exceed one pass "
+                             f"(max_requests_per_pass = {self.max_requests_per_pass(int(x.shape[0]) // n_seg, int(x.shape[1]))})")
         if self.training and self.dropout > 0:
             raise RuntimeError("TransformerLstm: train mode without gradients would still apply dropout; call eval() "
                                "for inference")
         lib = _lib.load()
         B, T = int(x.shape[0]), int(x.shape[1])
-        S, e, dev = B * T, self._e, x.device
+        St, e, dev = B * T, self._e, x.device
+        S = St // n_seg                          # tokens of one request: what attention spans and every kernel is chosen by
+        if n_seg > 1 and St > self.MAX_TOKENS_PER_PASS:
+            raise ValueError(f"{St} tokens in one pass (limit {self.MAX_TOKENS_PER_PASS}): split the requests")
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
-            z = torch.empty((S, e), dtype=torch.float32, device=dev)
-            rc = lib.opseq_slot_embed_relu_f32(x.data_ptr(), self.boxes_linear.weight.data_ptr(), z.data_ptr(), S, 1, e, stream)
+            z = torch.empty((St, e), dtype=torch.float32, device=dev)
+            rc = lib.opseq_slot_embed_relu_f32(x.data_ptr(), self.boxes_linear.weight.data_ptr(), z.data_ptr(), St, 1, e, stream)
             _lib.check(rc, "opseq_slot_embed_relu_f32")
-            nb = lib.opseq_encoder_workspace_bytes(S, e, self._nhead, self.FFN)
+            nb = lib.opseq_encoder_workspace_bytes(St, e, self._nhead, self.FFN)
             if nb == 0:
                 _lib.check(-2, "opseq_encoder_workspace_bytes")
             if self._ews is None or self._ews.numel() < nb or self._ews.device != dev:
@@ -1010,9 +1049,14 @@ class TransformerLstm(AbstractCaterModel):
                 for t_ in ts:
                     if t_.device != dev or not t_.is_contiguous() or t_.dtype != torch.float32:
                         raise RuntimeError("parameters must be contiguous fp32 on the input's device")
-                rc = lib.opseq_encoder_layer_f32(z.data_ptr(), *(t_.data_ptr() for t_ in ts), self._ews.data_ptr(),
-                                                 self._ews.numel(), S, e, self._nhead, self.FFN, stream)
-                _lib.check(rc, "opseq_encoder_layer_f32")
+                if n_seg == 1:
+                    rc = lib.opseq_encoder_layer_f32(z.data_ptr(), *(t_.data_ptr() for t_ in ts), self._ews.data_ptr(),
+                                                     self._ews.numel(), S, e, self._nhead, self.FFN, stream)
+                    _lib.check(rc, "opseq_encoder_layer_f32")
+                else:
+                    rc = lib.opseq_encoder_layer_segmented_f32(z.data_ptr(), *(t_.data_ptr() for t_ in ts), self._ews.data_ptr(),
+                                                               self._ews.numel(), S, n_seg, e, self._nhead, self.FFN, stream)
+                    _lib.check(rc, "opseq_encoder_layer_segmented_f32")
             return self._runner.run(z.view(B, T, e), self.video_LSTM, self.predictions_layer)
 
 

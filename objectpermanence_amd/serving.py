@@ -8,8 +8,11 @@ and gives 99 k clips/s there against 26 k for one 32-clip batch alone (DESIGN.md
 runs them as ONE forward when `max_clips` are pending (or on `flush()`), and hands every request its own slice of the
 outputs.  Results are bit-identical to running the concatenation through `model(...)` directly.
 
-TransformerLstm is deliberately refused: its attention spans all clips of a minibatch, so merging
-requests would change its results.
+TransformerLstm's attention spans all clips of a minibatch: concatenating requests would change its
+results.  Its requests are therefore merged as SEGMENTS (`TransformerLstm.forward_segments`): every submitted minibatch stays
+one sequence that attends only to itself, the token-wise stages of all pending requests run as one set of launches and one
+persistent launch runs the stacked LSTM over all their clips - each request's result is bit-identical to `model(request)` alone
+(config 3: one clip per request; 16 of them cost about what one costs).  Requests of one pass must have the same shape [b, T].
 """
 from __future__ import annotations
 
@@ -41,9 +44,8 @@ class PendingResult:
 
 class ReasonerServer:
     def __init__(self, model: torch.nn.Module, model_name: str = "opnet", max_clips: int = 1024, concat: bool = True):
-        if type(model).__name__ == "TransformerLstm":
-            raise ValueError("TransformerLstm couples the clips of a minibatch (sequence-first attention): requests "
-                             "cannot be merged without changing its outputs")
+        # a model whose clips are coupled inside a request (TransformerLstm) merges requests as segments, never by concatenation
+        self.segmented = hasattr(model, "forward_segments")
         self.model, self.model_name, self.max_clips = model, model_name, int(max_clips)
         # concat = False: OPNet's persistent launch reads the request tensors where they lie (OPNet.forward_requests) instead
         # of one torch.cat - it saves the 108 KB/clip copy, but the pack kernel then walks up to 64 sources and the host
@@ -68,12 +70,15 @@ class ReasonerServer:
             if boxes.device != first.device or boxes.dtype != first.dtype:
                 raise ValueError(f"request on {boxes.device} / {boxes.dtype} while {first.device} / {first.dtype} requests are "
                                  "pending: requests of one server share a launch and must share device and dtype")
-            if tuple(boxes.shape[1:]) != tuple(first.shape[1:]):
-                self.flush()         # a different clip length cannot share a launch
+            if tuple(boxes.shape[1:]) != tuple(first.shape[1:]) or (self.segmented and boxes.shape[0] != first.shape[0]):
+                self.flush()         # a different clip length (segments: a different request shape) cannot share a launch
         h = PendingResult(self, int(boxes.shape[0]))
         self._queue.append((boxes, h))
         self._pending += h.n_clips
-        if self._pending >= self.max_clips:
+        limit = self.max_clips
+        if self.segmented:           # as many requests as one pass returns bit-identical to their lone forwards
+            limit = min(limit, self.model.max_requests_per_pass(int(boxes.shape[0]), int(boxes.shape[1])) * int(boxes.shape[0]))
+        if self._pending >= limit:
             self.flush()
         return h
 
@@ -83,7 +88,12 @@ class ReasonerServer:
             return
         queue, self._queue, self._pending = self._queue, [], 0
         try:
-            if len(queue) > 1 and not self.concat and hasattr(self.model, "forward_requests"):
+            if self.segmented:
+                x = queue[0][0] if len(queue) == 1 else torch.cat([q[0] for q in queue], dim=0)
+                if self.before_launch is not None:
+                    self.before_launch()
+                out = self.model(x) if len(queue) == 1 else self.model.forward_segments(x, len(queue))
+            elif len(queue) > 1 and not self.concat and hasattr(self.model, "forward_requests"):
                 if self.before_launch is not None:
                     self.before_launch()
                 out = self.model.forward_requests([q[0] for q in queue])     # OPNet: one launch over the requests where they lie

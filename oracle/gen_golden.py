@@ -23,7 +23,8 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 REF = os.environ.get("OPNET_REFERENCE", "/root/reference")
-OUT = os.path.join(REPO, "tests", "golden")
+# OPNET_GOLDEN_OUT: write somewhere else (tests/test_golden_regeneration.py regenerates into a temp dir and compares)
+OUT = os.environ.get("OPNET_GOLDEN_OUT") or os.path.join(REPO, "tests", "golden")
 
 sys.path.insert(0, REPO)
 from oracle import synth  # noqa: E402
