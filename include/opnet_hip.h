@@ -208,6 +208,18 @@ int opnet_dp_guard_f32(float *guard4_f32, const unsigned *abort_u32, const float
 int opnet_encode_clips_f32(const int32_t *counts, const int32_t *ids, const int32_t *bb, const int64_t *clip_first_frame,
                            const int64_t *clip_first_det, int n_clips, int T, int n_tracks, const uint8_t *is_cone, int n_classes,
                            float *boxes_out, int64_t *index_out);
+/* The reference's clip FILES read by native host code (replaces pickle.load at baselines/datasets.py:60-64, 583-587 and the
+ * json.load + label arithmetic of :33-45) and encoded as above, n_clips at a time: pkl_paths[c] = <video>.pkl as
+ * preprocess_perception_main.py:87-96 writes it - a pickled dict whose "bb" / "labels" entries are lists of T numeric ndarrays
+ * [n_t, 4] / [n_t] (protocols 2-5; other keys are parsed and ignored) - read by a RESTRICTED unpickler: a stack machine over
+ * the opcodes such a file uses with a whitelist of numpy's ndarray / dtype reconstruction callables; nothing is imported or
+ * executed, anything else is refused.  json_paths[c] (array or entries may be NULL) = <video>_bb.json: labels_out [c][T][4] =
+ * the snitch's [x, y, x + w, y + h] / [320, 240, 320, 240] (float64 division, fp32 cast).  HOST pointers; boxes_out
+ * [n_clips][T][15][n_tracks], index_out [n_clips][T] (may be NULL), labels_out (may be NULL).  Returns 0, or -5 (a file cannot be
+ * read), -6 (refused / malformed), -7 (not T frames), -1 / -3 (arguments) with a message naming the file in err[err_len]. */
+int opnet_load_clips_f32(const char *const *pkl_paths, const char *const *json_paths, int n_clips, int T, int n_tracks,
+                         const uint8_t *is_cone, int n_classes, float *boxes_out, int64_t *index_out, float *labels_out, char *err,
+                         int err_len);
 
 /* ---- sibling reasoners (reference learned_models.py:55-197) ----------------------------------------
  * OPNetLstmMlp (:55-89): OPNet whose video LSTM is relu(Linear 6->H2) (hidden_layer.weight [H2,6]);

@@ -212,6 +212,9 @@ def _declare(lib):
     lib.opnet_encode_clips_f32.restype = c_int
     lib.opnet_encode_clips_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                            c_void_p, c_void_p]
+    lib.opnet_load_clips_f32.restype = c_int
+    lib.opnet_load_clips_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_char_p, c_int]
     lib.opnet_postprocess_iou.restype = c_int
     lib.opnet_postprocess_iou.argtypes = [fp, fp, fp, fp, fp, c_int, c_int, c_void_p]
     lib.opnet_dp_guard_f32.restype = c_int
@@ -221,7 +224,7 @@ def _declare(lib):
 EXPORTS = [
     "opnet_hip_abi_version", "opnet_last_error", "opnet_packed_weights_bytes", "opnet_pack_weights_f32",
     "opnet_workspace_bytes", "opnet_forward_f32", "opnet_plan_create", "opnet_plan_forward",
-    "opnet_plan_destroy", "opnet_postprocess_iou", "opnet_encode_clips_f32",
+    "opnet_plan_destroy", "opnet_postprocess_iou", "opnet_encode_clips_f32", "opnet_load_clips_f32",
     "opnet_xcd_max_batch", "opnet_xcd_supported", "opnet_xcd_workspace_bytes", "opnet_xcd_forward_f32", "opnet_xcd_forward_multi_f32", "opnet_xcd_set_trace", "opnet_xcd4_set_trace", "opnet_xcd4_last_status", "opnet_xcd4_max_batch", "opnet_xcd4_packed_weights_bytes",
     "opnet_xcd4_workspace_bytes", "opnet_xcd4_pack_weights_f32", "opnet_xcd4_forward_f32",
     "opnet_xcd_profile", "opnet_xcd_profile_read", "opnet_kernel_profile_read",

@@ -10,7 +10,8 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libopnet_hip.so")
 ENCODE_LIB = os.path.join(LIBDIR, "libopnet_encode.so")      # encode_host.cpp alone (host code only): what dataset workers load
-SOURCES = ["opnet_abi.hip", "opdet_abi.hip", "encode_host.cpp"]
+SOURCES = ["opnet_abi.hip", "opdet_abi.hip", "encode_host.cpp", "clipfile_host.cpp"]
+ENCODE_SOURCES = ["encode_host.cpp", "clipfile_host.cpp"]      # host code only: the input encoder + the clip-file reader
 
 
 def _deps():
@@ -63,16 +64,16 @@ def _run_then_publish(cmd, tmp: str, final: str, cwd=None) -> None:
 
 
 def build_encoder(force: bool = False, verbose: bool = False) -> str:
-    """the input encoder as its own small host library (g++ or hipcc's clang, no device code): a DataLoader worker that only
+    """the input encoder and the clip-file reader as their own small host library (g++ or hipcc's clang, no device code): a DataLoader worker that only
     encodes clips should not load the 5 MB GPU library and start the HIP runtime (measured: 1.1 s before a worker's first sample)"""
-    src = os.path.join(CSRC, "encode_host.cpp")
-    if not force and os.path.exists(ENCODE_LIB) and os.path.getmtime(ENCODE_LIB) >= os.path.getmtime(src):
+    srcs = [os.path.join(CSRC, f) for f in ENCODE_SOURCES]
+    if not force and os.path.exists(ENCODE_LIB) and os.path.getmtime(ENCODE_LIB) >= max(os.path.getmtime(f) for f in srcs):
         return ENCODE_LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cxx = shutil.which("g++") or shutil.which("c++")
     tmp = f"{ENCODE_LIB}.{os.getpid()}.tmp"
-    cmd = ([cxx, "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", tmp, src] if cxx else
-           [_hipcc(), "-x", "c++", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", tmp, src])
+    cmd = ([cxx, "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", tmp] + srcs if cxx else
+           [_hipcc(), "-x", "c++", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-o", tmp] + srcs)
     if verbose:
         print(" ".join(cmd))
     _run_then_publish(cmd, tmp, ENCODE_LIB)      # several workers may get here at once: each publishes a complete file

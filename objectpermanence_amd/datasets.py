@@ -184,8 +184,44 @@ def _encoder_lib():
         vp = ctypes.c_void_p
         lib.opnet_encode_clips_f32.restype = ctypes.c_int
         lib.opnet_encode_clips_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]
+        lib.opnet_load_clips_f32.restype = ctypes.c_int
+        lib.opnet_load_clips_f32.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp,
+                                             ctypes.c_char_p, ctypes.c_int]
         _ENC_LIB = lib
     return _ENC_LIB
+
+
+class ClipFileError(ValueError):
+    """a <video>.pkl / <video>_bb.json that the native reader refuses (anything but the reference's own format) or cannot read"""
+
+
+def native_reader_enabled() -> bool:
+    """the restricted native reader of the reference's clip files (csrc/clipfile_host.cpp); OPNET_NATIVE_PKL=0 = pickle.load +
+    json.load + the encoder on their arrays, as before"""
+    return os.environ.get("OPNET_NATIVE_PKL", "1") != "0" and native_encoder_available()
+
+
+def load_clips_native(pkl_paths: List[str], json_paths: List[str] = None, T: int = VIDEO_NUM_FRAMES, n_tracks: int = 6,
+                      with_index: bool = True):
+    """files -> (boxes fp32 [n, T, 15, n_tracks], index int64 [n, T] | None, labels fp32 [n, T, 4] | None) in ONE native call:
+    the restricted unpickler of csrc/clipfile_host.cpp (exactly what preprocess_perception_main.py:87-96 writes: a dict of
+    lists of numeric ndarrays, protocols 2-5; everything else is refused with ClipFileError), the snitch's labels out of the
+    `_bb.json` files (datasets.py:33-45) and the input encoder - bit-identical to pickle.load / json.load + encode_boxes."""
+    import ctypes
+    lib = _encoder_lib()
+    n = len(pkl_paths)
+    boxes = np.empty((n, T, MAX_OBJECTS, n_tracks), dtype=np.float32)
+    idx = np.empty((n, T), dtype=np.int64) if with_index else None
+    labels = np.zeros((n, T, 4), dtype=np.float32) if json_paths is not None else None
+    enc = lambda ps: (ctypes.c_char_p * n)(*[os.fsencode(p) if p is not None else None for p in ps])
+    cone = _cone_table()
+    err = ctypes.create_string_buffer(512)
+    rc = lib.opnet_load_clips_f32(enc(pkl_paths), enc(json_paths) if json_paths is not None else None, n, T, n_tracks,
+                                  cone.ctypes.data, int(cone.shape[0]), boxes.ctypes.data, idx.ctypes.data if with_index else None,
+                                  labels.ctypes.data if labels is not None else None, err, len(err))
+    if rc != 0:
+        raise ClipFileError(f"opnet_load_clips_f32 failed (code {rc}): {err.value.decode(errors='replace')}")
+    return boxes, idx, labels
 
 
 def native_encoder_available() -> bool:
@@ -271,6 +307,7 @@ class CaterAbstractDataset(Dataset):
         self.videos_names: List[str] = []
         self.label_paths: Dict[str, str] = {}
         self._native = None          # decided at the first sample (in the process that encodes it - a DataLoader worker)
+        self._native_reader = None   # ... and so is the native file reader
 
     def _init_dataset_if_not_initiated(self) -> None:
         if len(self.videos_names) == 0:
@@ -282,8 +319,27 @@ class CaterAbstractDataset(Dataset):
         self._init_dataset_if_not_initiated()
         return len(self.videos_names)
 
+    def _encode_many(self, indices):
+        """-> boxes [n, T, 15, F], index vectors [n, T], labels [n, T, 4] (torch, fp32 / int64 / fp32) and the names of dataset
+        items `indices`: ONE native call over their files when the native reader is on, sample by sample otherwise"""
+        self._init_dataset_if_not_initiated()
+        names = [self.videos_names[i] for i in indices]
+        if self._native_reader is None:
+            self._native_reader = native_reader_enabled()
+        if self._native_reader:
+            boxes, idx, labels = load_clips_native([str(self.predictions_dir / (n + ".pkl")) for n in names],
+                                                   [self.label_paths[n] for n in names], VIDEO_NUM_FRAMES, self.n_tracks)
+            return torch.from_numpy(boxes), torch.from_numpy(idx), torch.from_numpy(labels), names
+        parts = [self._encode(i) for i in indices]
+        return torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), torch.stack([p[2] for p in parts]), names
+
     def _encode(self, idx: int):
         self._init_dataset_if_not_initiated()
+        if self._native_reader is None:
+            self._native_reader = native_reader_enabled()
+        if self._native_reader:
+            boxes, ivec, labels, names = self._encode_many([idx])
+            return boxes[0], ivec[0], labels[0], names[0]
         name = self.videos_names[idx]
         labels = load_snitch_labels(self.label_paths[name])
         with open(str(self.predictions_dir / (name + ".pkl")), "rb") as f:
@@ -304,6 +360,12 @@ class CaterAbstractDataset(Dataset):
         boxes, idx_vec, labels, name = self._encode(idx)
         return (boxes, idx_vec), (labels, torch.tensor([])), name
 
+    def __getitems__(self, indices):
+        """a whole minibatch of a DataLoader worker in one native call over its files (torch's fetcher calls this when the
+        loader batches: the samples come back as views of one [n, ...] buffer, ready to be collated)"""
+        boxes, ivec, labels, names = self._encode_many(list(indices))
+        return [((boxes[k], ivec[k]), (labels[k], torch.tensor([])), names[k]) for k in range(len(names))]
+
 
 class _TrainingMixin:
     def _init_mask(self, mask_annotations_path: str):
@@ -320,6 +382,15 @@ class _TrainingMixin:
         mask = np.zeros((VIDEO_NUM_FRAMES, 4), dtype=bool)
         mask[self.mask_frames[name], :] = True                                                   # datasets.py:545-547
         return (boxes, idx_vec), (labels, torch.tensor(mask)), name
+
+    def __getitems__(self, indices):
+        boxes, ivec, labels, names = self._encode_many(list(indices))
+        out = []
+        for k, name in enumerate(names):
+            mask = np.zeros((VIDEO_NUM_FRAMES, 4), dtype=bool)
+            mask[self.mask_frames[name], :] = True
+            out.append(((boxes[k], ivec[k]), (labels[k], torch.tensor(mask)), name))
+        return out
 
 
 class Cater6TracksForObjectsInferenceDataset(CaterAbstractDataset):

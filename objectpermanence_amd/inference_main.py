@@ -17,6 +17,7 @@ video IO is outside the hot path).  Differences, al
 from __future__ import annotations
 
 import json
+import time
 from pathlib import Path
 from typing import Dict, List
 
@@ -68,9 +69,12 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
 
     names: List[str] = []
     pending, preds, gts, ious = [], [], [], []
+    t_start, t_first, n_first = time.perf_counter(), None, 0
 
     with torch.no_grad():
         for (boxes, _index_to_track), (labels, _), video_names in loader:
+            if t_first is None:          # the loader's workers are up and the first minibatch has arrived: steady state from here
+                t_first, n_first = time.perf_counter(), len(video_names)
             names.extend(video_names)
             pending.append((server.submit(boxes.to(device)), labels.to(device)))
         server.flush()
@@ -97,4 +101,9 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
         Path(results_dir).mkdir(parents=True, exist_ok=True)
         for name, p in zip(names, pred_np):
             write_bb_predictions_to_file(name, results_dir, p)
-    return {"video_names": names, "predictions": pred_np, "mean_iou": mean_iou, "map_0.5": map50}
+    t_end = time.perf_counter()
+    n_local = sum(len(b) for b in batches)
+    timing = {"startup_s": (t_first or t_end) - t_start, "total_s": t_end - t_start,
+              # files -> predictions on the host, this rank's clips, without the DataLoader's worker start-up and first batch
+              "steady_clips_per_s": (n_local - n_first) / max(t_end - t_first, 1e-9) if t_first is not None and n_local > n_first else None}
+    return {"video_names": names, "predictions": pred_np, "mean_iou": mean_iou, "map_0.5": map50, "timing": timing}

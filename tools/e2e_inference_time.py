@@ -15,8 +15,8 @@ from objectpermanence_amd.inference_main import reasoning_inference_main  # noqa
 from synthdata import opnet as synth  # noqa: E402
 
 CFG = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-workers = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
+workers = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 with tempfile.TemporaryDirectory() as tmp:
     s, l = os.path.join(tmp, "s"), os.path.join(tmp, "l")
     os.mkdir(s); os.mkdir(l)
@@ -33,13 +33,16 @@ with tempfile.TemporaryDirectory() as tmp:
     json.dump({"batch_size": 16, "num_workers": workers, "device": "cuda:0", "model_path": os.path.join(tmp, "opnet.pth"),
                "videos_dir": "unused", "sample_dir": s, "labels_dir": l}, open(os.path.join(tmp, "infer.json"), "w"))
     res = {}
-    for native in ("1", "0", "1"):
-        os.environ["OPNET_NATIVE_ENCODE"] = native
+    # native file reader + encoder | pickle.load / json.load + native encoder | ... + numpy encoder | native again
+    for tag, pkl, enc in (("native reader", "1", "1"), ("pickle + native encoder", "0", "1"), ("pickle + numpy encoder", "0", "0"),
+                          ("native reader", "1", "1")):
+        os.environ["OPNET_NATIVE_PKL"], os.environ["OPNET_NATIVE_ENCODE"] = pkl, enc
         t0 = time.perf_counter()
         out = reasoning_inference_main("opnet", os.path.join(tmp, "out"), os.path.join(tmp, "infer.json"), os.path.join(tmp, "model.json"),
                                        write_files=False)
         dt = time.perf_counter() - t0
-        res[native] = n / dt
-        print(f"native encoder {native}: {n} clips, {workers} workers, batch 16: {dt:.2f} s = {n / dt:.0f} clips/s (mean IoU {out['mean_iou']:.4f})",
-              flush=True)
-    print(f"end to end: {res['1'] / res['0']:.2f} x with the native encoder")
+        tm = out["timing"]
+        res[tag] = tm["steady_clips_per_s"]
+        print(f"{tag}: {n} clips, {workers} workers, batch 16: {dt:.2f} s = {n / dt:.0f} clips/s; start-up {tm['startup_s']:.2f} s, "
+              f"steady state {tm['steady_clips_per_s']:.0f} clips/s (mean IoU {out['mean_iou']:.4f})", flush=True)
+    print(f"steady state: {res['native reader'] / res['pickle + native encoder']:.2f} x with the native file reader")
