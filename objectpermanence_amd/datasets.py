@@ -187,6 +187,8 @@ def _encoder_lib():
         lib.opnet_load_clips_f32.restype = ctypes.c_int
         lib.opnet_load_clips_f32.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp,
                                              ctypes.c_char_p, ctypes.c_int]
+        lib.opnet_load_clips_mt_f32.restype = ctypes.c_int
+        lib.opnet_load_clips_mt_f32.argtypes = lib.opnet_load_clips_f32.argtypes + [ctypes.c_int]
         _ENC_LIB = lib
     return _ENC_LIB
 
@@ -202,23 +204,34 @@ def native_reader_enabled() -> bool:
 
 
 def load_clips_native(pkl_paths: List[str], json_paths: List[str] = None, T: int = VIDEO_NUM_FRAMES, n_tracks: int = 6,
-                      with_index: bool = True):
+                      with_index: bool = True, threads: int = 1, out=None):
     """files -> (boxes fp32 [n, T, 15, n_tracks], index int64 [n, T] | None, labels fp32 [n, T, 4] | None) in ONE native call:
     the restricted unpickler of csrc/clipfile_host.cpp (exactly what preprocess_perception_main.py:87-96 writes: a dict of
     lists of numeric ndarrays, protocols 2-5; everything else is refused with ClipFileError), the snitch's labels out of the
-    `_bb.json` files (datasets.py:33-45) and the input encoder - bit-identical to pickle.load / json.load + encode_boxes."""
+    `_bb.json` files (datasets.py:33-45) and the input encoder - bit-identical to pickle.load / json.load + encode_boxes.
+    threads > 1: the clips are spread over that many host threads inside the call (the GIL is released); out = (boxes, idx,
+    labels) numpy views to fill instead of fresh arrays (a loader's pinned buffers)."""
     import ctypes
     lib = _encoder_lib()
     n = len(pkl_paths)
-    boxes = np.empty((n, T, MAX_OBJECTS, n_tracks), dtype=np.float32)
-    idx = np.empty((n, T), dtype=np.int64) if with_index else None
-    labels = np.zeros((n, T, 4), dtype=np.float32) if json_paths is not None else None
+    if out is not None:
+        boxes, idx, labels = out
+        if boxes.shape != (n, T, MAX_OBJECTS, n_tracks) or boxes.dtype != np.float32 or not boxes.flags.c_contiguous:
+            raise ValueError("out[0] must be a C-contiguous float32 [n, T, 15, n_tracks] array")
+        if labels is not None:
+            labels[...] = 0
+    else:
+        boxes = np.empty((n, T, MAX_OBJECTS, n_tracks), dtype=np.float32)
+        idx = np.empty((n, T), dtype=np.int64) if with_index else None
+        labels = np.zeros((n, T, 4), dtype=np.float32) if json_paths is not None else None
     enc = lambda ps: (ctypes.c_char_p * n)(*[os.fsencode(p) if p is not None else None for p in ps])
     cone = _cone_table()
     err = ctypes.create_string_buffer(512)
-    rc = lib.opnet_load_clips_f32(enc(pkl_paths), enc(json_paths) if json_paths is not None else None, n, T, n_tracks,
-                                  cone.ctypes.data, int(cone.shape[0]), boxes.ctypes.data, idx.ctypes.data if with_index else None,
-                                  labels.ctypes.data if labels is not None else None, err, len(err))
+    rc = lib.opnet_load_clips_mt_f32(enc(pkl_paths), enc(json_paths) if json_paths is not None else None, n, T, n_tracks,
+                                     cone.ctypes.data, int(cone.shape[0]), boxes.ctypes.data,
+                                     idx.ctypes.data if idx is not None else None,
+                                     labels.ctypes.data if (labels is not None and json_paths is not None) else None, err, len(err),
+                                     max(1, int(threads)))
     if rc != 0:
         raise ClipFileError(f"opnet_load_clips_f32 failed (code {rc}): {err.value.decode(errors='replace')}")
     return boxes, idx, labels
@@ -415,6 +428,114 @@ class Cater5TracksForObjectsTrainingDataset(_TrainingMixin, CaterAbstractDataset
     def __init__(self, predictions_dir: str, label_dir: str, mask_annotations_path: str):
         CaterAbstractDataset.__init__(self, predictions_dir, label_dir)
         self._init_mask(mask_annotations_path)
+
+
+class ClipFileLoader:
+    """The drivers' loader when the native file reader is on: yields what `DataLoader(dataset, batch_sampler=batches)` yields -
+    ((boxes, index), (labels, mask), names) per minibatch - but produced by ONE multi-threaded native call per minibatch
+    (opnet_load_clips_mt_f32, `threads` host threads; the JSON config's num_workers) on a prefetch thread, written straight into
+    pinned buffers and - given a CUDA device - already on their way to the GPU: boxes / labels / mask are device tensors whose
+    copies run on a side stream; the consumer's stream is made to wait for them when the minibatch is handed over.  No worker
+    processes, no inter-process queue, no collate copy.  (The reference: torch DataLoader over its Dataset classes,
+    baselines/inference_main.py:177, training_main.py:155-159 - kept, and equal tensor for tensor: tests/test_datasets.py.)"""
+
+    def __init__(self, dataset: "CaterAbstractDataset", batches, device=None, threads: int = 8, depth: int = 3):
+        dataset._init_dataset_if_not_initiated()
+        self.ds, self.batches = dataset, [list(b) for b in batches]
+        self.device = torch.device(device) if device is not None else None
+        self.cuda = self.device is not None and self.device.type == "cuda"
+        self.threads, self.depth = max(1, int(threads)), max(2, int(depth))
+        self.with_mask = hasattr(dataset, "mask_frames")
+
+    def __len__(self):
+        return len(self.batches)
+
+    def _slot(self, cap: int):
+        F = self.ds.n_tracks
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory() if self.cuda else torch.empty(shape, dtype=dt)
+        return {"boxes": mk((cap, VIDEO_NUM_FRAMES, MAX_OBJECTS, F), torch.float32), "idx": torch.empty((cap, VIDEO_NUM_FRAMES), dtype=torch.int64),
+                "labels": mk((cap, VIDEO_NUM_FRAMES, 4), torch.float32), "mask": mk((cap, VIDEO_NUM_FRAMES, 4), torch.bool), "event": None}
+
+    def __iter__(self):
+        import queue
+        import threading
+        if not self.batches:
+            return
+        cap = max(len(b) for b in self.batches)
+        slots = [self._slot(cap) for _ in range(self.depth + 1)]
+        q: "queue.Queue" = queue.Queue(maxsize=self.depth - 1)
+        stop = threading.Event()
+        side = torch.cuda.Stream(device=self.device) if self.cuda else None
+
+        def produce():
+            try:
+                for k, b in enumerate(self.batches):
+                    if stop.is_set():
+                        return
+                    slot, n = slots[k % len(slots)], len(b)
+                    if slot["event"] is not None:
+                        slot["event"].synchronize()          # the copies out of this pinned buffer have left it
+                    names = [self.ds.videos_names[i] for i in b]
+                    load_clips_native([str(self.ds.predictions_dir / (m + ".pkl")) for m in names], [self.ds.label_paths[m] for m in names],
+                                      VIDEO_NUM_FRAMES, self.ds.n_tracks, threads=self.threads,
+                                      out=(slot["boxes"][:n].numpy(), slot["idx"][:n].numpy(), slot["labels"][:n].numpy()))
+                    mask = None
+                    if self.with_mask:
+                        mview = slot["mask"][:n]
+                        mview.zero_()
+                        for r, m in enumerate(names):
+                            mview[r, torch.from_numpy(np.asarray(self.ds.mask_frames[m], dtype=np.int64))] = True
+                        mask = mview
+                    idx = slot["idx"][:n].clone()
+                    if self.cuda:
+                        with torch.cuda.stream(side):
+                            boxes = slot["boxes"][:n].to(self.device, non_blocking=True)
+                            labels = slot["labels"][:n].to(self.device, non_blocking=True)
+                            mask = mask.to(self.device, non_blocking=True) if mask is not None else None
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                        slot["event"] = ev
+                    else:
+                        boxes, labels, ev = slot["boxes"][:n].clone(), slot["labels"][:n].clone(), None
+                        mask = mask.clone() if mask is not None else None
+                    q.put((boxes, idx, labels, mask, names, ev))
+                q.put(None)
+            except BaseException as e:          # hand the failure (a refused file, say) to the consumer
+                q.put(e)
+
+        th = threading.Thread(target=produce, name="opnet-clip-loader", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                boxes, idx, labels, mask, names, ev = item
+                if ev is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ev)
+                    for t_ in (boxes, labels, mask):
+                        if t_ is not None:
+                            t_.record_stream(torch.cuda.current_stream(self.device))
+                # (an inference dataset's empty per-sample mask collates to [n, 0], inference_main.py:191)
+                yield (boxes, idx), (labels, mask if mask is not None else torch.empty((len(names), 0))), names
+        finally:
+            stop.set()
+            while th.is_alive():            # unblock a producer waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(timeout=0.05)
+
+
+def make_loader(dataset, batches, device, num_workers: int, pin_memory: bool = False):
+    """the minibatch source of the drivers: ClipFileLoader when the native clip-file reader is on (OPNET_NATIVE_PKL / _ENCODE not
+    0; OPNET_NATIVE_LOADER=0 keeps torch's DataLoader), else `DataLoader(dataset, batch_sampler=batches, num_workers)`"""
+    if native_reader_enabled() and os.environ.get("OPNET_NATIVE_LOADER", "1") != "0":
+        return ClipFileLoader(dataset, batches, device, threads=max(1, int(num_workers)))
+    from torch.utils import data
+    return data.DataLoader(dataset, batch_sampler=batches, num_workers=num_workers, pin_memory=pin_memory)
 
 
 class DatasetsFactory(object):

@@ -17,6 +17,7 @@ video IO is outside the hot path).  Differences, al
 from __future__ import annotations
 
 import json
+import os
 import time
 from pathlib import Path
 from typing import Dict, List
@@ -27,10 +28,13 @@ import torch.distributed as dist
 from torch.utils import data
 
 from . import metrics, parallel
-from .datasets import DatasetsFactory
+from .datasets import DatasetsFactory, make_loader
 from .launch_monitor import verify_launches
 from .models_factory import ModelsFactory
 from .serving import ReasonerServer, output_boxes
+
+
+LOADER_MIN_BATCH = 256     # clips per DataLoader round trip for the clip-independent reasoners (see reasoning_inference_main)
 
 
 def write_bb_predictions_to_file(video_name: str, results_dir: str, predictions) -> str:
@@ -56,8 +60,15 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
     dataset = DatasetsFactory.get_inference_dataset(model_name, config["sample_dir"], config["labels_dir"])
     n_total = len(dataset)
     world, rank, exchange = parallel.world_rank()
-    batches = parallel.plan_inference_batches(model_name, n_total, batch_size, world, rank)
-    loader = data.DataLoader(dataset, batch_sampler=batches, num_workers=num_workers)
+    # What the loader hands over per round trip.  transformer_lstm*: exactly the reference's minibatch (its attention couples
+    # the clips of a call).  Clip-independent reasoners: any cut of the clips gives the same outputs, and a minibatch of 16
+    # (configs/inference_config.json) costs one round trip just like one of 256 - so at least LOADER_MIN_BATCH clips travel
+    # together (tools/e2e_inference_time.py: a torch DataLoader with 8 workers and batch 16 delivers 6.3 k clips/s from files on
+    # the box, bound by the receiving process's per-batch work; datasets.ClipFileLoader: no processes, no queue, pinned buffers)
+    loader_batch = batch_size if parallel.couples_clips(model_name) else max(batch_size, LOADER_MIN_BATCH)
+    batches = parallel.plan_inference_batches(model_name, n_total, loader_batch, world, rank)
+    pin = device.type == "cuda" and num_workers > 0
+    loader = make_loader(dataset, batches, device, num_workers, pin_memory=pin)
 
     model = ModelsFactory.get_model(model_name, model_config, config.get("model_path"))
     model.eval()
@@ -76,7 +87,7 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
             if t_first is None:          # the loader's workers are up and the first minibatch has arrived: steady state from here
                 t_first, n_first = time.perf_counter(), len(video_names)
             names.extend(video_names)
-            pending.append((server.submit(boxes.to(device)), labels.to(device)))
+            pending.append((server.submit(boxes.to(device, non_blocking=pin)), labels.to(device, non_blocking=pin)))
         server.flush()
         # The sync point of this driver.  A persistent launch that gave up (bounded spins, NaN outputs) is re-run on the
         # launch chain into the same output tensors here - NaN never reaches the int32 post-process or the JSON files.

@@ -28,7 +28,7 @@ from torch.optim.lr_scheduler import ReduceLROnPlateau
 from torch.utils import data
 
 from . import metrics, parallel
-from .datasets import DatasetsFactory
+from .datasets import DatasetsFactory, make_loader
 from .launch_monitor import verify_launches
 from .models_factory import ModelsFactory
 from .optim import FusedAdam
@@ -64,7 +64,7 @@ def inference_and_iou_comp(model_name: str, model: torch.nn.Module, device: torc
     world, rank, exchange = parallel.world_rank()
     n_total = len(dataset)
     batches = parallel.plan_inference_batches(model_name, n_total, batch_size, world, rank)
-    loader = data.DataLoader(dataset, batch_sampler=batches, num_workers=num_workers)
+    loader = make_loader(dataset, batches, device, num_workers)
     model.eval()
     loss_sum = torch.zeros((), dtype=torch.float64, device=device)
     ious, contain, outs = [], [], []
@@ -129,7 +129,7 @@ def training_main(model_name: str, train_config: Dict[str, Any], model_config: D
     world, rank, exchange = parallel.world_rank()
     steps = training_batches(model_name, len(train_ds), bs, world, rank)
     # this rank's loader yields only its own non-empty slices, in step order
-    training_loader = data.DataLoader(train_ds, batch_sampler=[idx for idx, _ in steps if idx], num_workers=nw)
+    training_loader = make_loader(train_ds, [idx for idx, _ in steps if idx], device, nw)
     comm = torch.cuda.Stream(device=device) if exchange and device.type == "cuda" else None
 
     highest_dev_iou, best_path, history = 0.0, None, []

@@ -34,15 +34,17 @@ with tempfile.TemporaryDirectory() as tmp:
                "videos_dir": "unused", "sample_dir": s, "labels_dir": l}, open(os.path.join(tmp, "infer.json"), "w"))
     res = {}
     # native file reader + encoder | pickle.load / json.load + native encoder | ... + numpy encoder | native again
-    for tag, pkl, enc in (("native reader", "1", "1"), ("pickle + native encoder", "0", "1"), ("pickle + numpy encoder", "0", "0"),
-                          ("native reader", "1", "1")):
-        os.environ["OPNET_NATIVE_PKL"], os.environ["OPNET_NATIVE_ENCODE"] = pkl, enc
+    # ClipFileLoader (threads) | torch DataLoader (processes) over the native reader | ... over pickle.load | ... + numpy encoder
+    for tag, pkl, enc, nat in (("native reader", "1", "1", "1"), ("DataLoader + native reader", "1", "1", "0"),
+                               ("pickle + native encoder", "0", "1", "0"), ("pickle + numpy encoder", "0", "0", "0"),
+                               ("native reader", "1", "1", "1")):
+        os.environ["OPNET_NATIVE_PKL"], os.environ["OPNET_NATIVE_ENCODE"], os.environ["OPNET_NATIVE_LOADER"] = pkl, enc, nat
         t0 = time.perf_counter()
         out = reasoning_inference_main("opnet", os.path.join(tmp, "out"), os.path.join(tmp, "infer.json"), os.path.join(tmp, "model.json"),
                                        write_files=False)
         dt = time.perf_counter() - t0
         tm = out["timing"]
         res[tag] = tm["steady_clips_per_s"]
-        print(f"{tag}: {n} clips, {workers} workers, batch 16: {dt:.2f} s = {n / dt:.0f} clips/s; start-up {tm['startup_s']:.2f} s, "
+        print(f"{tag}: {n} clips, {workers} workers / threads, batch 16: {dt:.2f} s = {n / dt:.0f} clips/s; start-up {tm['startup_s']:.2f} s, "
               f"steady state {tm['steady_clips_per_s']:.0f} clips/s (mean IoU {out['mean_iou']:.4f})", flush=True)
     print(f"steady state: {res['native reader'] / res['pickle + native encoder']:.2f} x with the native file reader")
