@@ -362,6 +362,13 @@ int opseq_encoder_layer_train_forward_f32(const float *z_in, float *z_out, const
                                           const float *n2_w, const float *n2_b, void *saved, size_t saved_bytes,
                                           void *scratch, size_t scratch_bytes, long S, int E, int nhead, int ffn,
                                           float p_drop, unsigned long long seed, void *stream);
+/* TEST-ONLY: layer calls made with `seed` take their dropout masks from these device buffers (one byte per element, nonzero =
+ * keep; site 0 attention weights [nhead][S][S], 1 after out_proj [S][E], 2 after ReLU [S][ffn], 3 after linear2 [S][E]) instead of
+ * the counter generator: the masks a reference training step drew (learned_models.py:166-168 at p = 0.1) are fed in this way
+ * (tests/golden/transformer_dropout_train.npz).  slot 0..7; _clear empties the table.  Both synchronise the device. */
+int opseq_encoder_test_masks_set(int slot, unsigned long long seed, const unsigned char *m0, const unsigned char *m1,
+                                 const unsigned char *m2, const unsigned char *m3);
+int opseq_encoder_test_masks_clear(void);
 int opseq_encoder_layer_train_backward_f32(const float *dz_out, float *dz_in, const float *in_w, const float *out_w,
                                            const float *l1_w, const float *l2_w, const float *n1_w, const float *n2_w,
                                            float *g_in_w, float *g_in_b, float *g_out_w, float *g_out_b, float *g_l1_w,

@@ -6,8 +6,8 @@
 //
 // Dropout (p = 0.1 in the reference's train mode, four sites per layer) uses a counter-based generator keyed by
 // (seed, site, element index): masks are regenerated in the backward pass instead of stored.  The reference's own
-// masks come from torch's generator and cannot be reproduced, so parity is pinned with p = 0 and the p > 0 path is
-// checked statistically.
+// masks come from torch's generator; train-mode parity at p = 0.1 is pinned by FEEDING the layer the masks one reference
+// training step drew (tests/golden/transformer_dropout_train.npz) through the test-only table below.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,11 +21,21 @@ __device__ __forceinline__ unsigned enc_hash(unsigned long long seed, unsigned s
     return (unsigned)((z ^ (z >> 31)) >> 32);
 }
 
+// TEST-ONLY: dropout masks from buffers.  A layer call whose `seed` is registered here (opseq_encoder_test_masks_set) keeps
+// element idx of site s iff masks[s][idx] != 0 instead of asking the generator - forward and backward alike, since both go
+// through enc_keep.  g_enc_test_n is 0 in production: one scalar load per kernel.
+#define ENC_TEST_MASK_SLOTS 8
+struct EncTestMasks { unsigned long long seed; const unsigned char *m[4]; };
+__constant__ int g_enc_test_n;
+__constant__ EncTestMasks g_enc_test[ENC_TEST_MASK_SLOTS];
+
 // multiplier of element idx at a dropout site: 0 (dropped) or 1/(1-p); thresh = p * 2^32 (0 => always 1)
 __device__ __forceinline__ float enc_keep(unsigned long long seed, unsigned site, unsigned long long idx, unsigned thresh,
                                           float inv_keep)
 {
     if (thresh == 0u) return 1.0f;
+    for (int t = 0; t < g_enc_test_n; ++t)
+        if (g_enc_test[t].seed == seed) return g_enc_test[t].m[site & 3][idx] ? inv_keep : 0.0f;
     return enc_hash(seed, site, idx) >= thresh ? inv_keep : 0.0f;
 }
 

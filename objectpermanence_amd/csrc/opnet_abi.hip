@@ -2562,6 +2562,40 @@ extern "C" size_t opseq_encoder_train_scratch_bytes(long S, int E, int nhead, in
     return enc_scratch_layout(S, E, nhead, ffn).total * sizeof(float);
 }
 
+/* TEST-ONLY (tests/test_siblings_train.py): the layer calls made with `seed` take their four dropout masks (device pointers,
+ * one byte per element, nonzero = keep; sites 0 attention weights [nhead][S][S], 1 [S][E], 2 [S][ffn], 3 [S][E]) from these buffers
+ * instead of the counter generator - how the reference's own masks are fed in.  slot 0..7; *_clear() empties the table.  Both
+ * synchronise the device (constant memory is rewritten). */
+extern "C" int opseq_encoder_test_masks_set(int slot, unsigned long long seed, const unsigned char *m0, const unsigned char *m1,
+                                            const unsigned char *m2, const unsigned char *m3)
+{
+    if (slot < 0 || slot >= ENC_TEST_MASK_SLOTS || !m0 || !m1 || !m2 || !m3) return fail(OPNET_EINVAL, "bad test-mask slot / null mask");
+    HIP_TRY(hipDeviceSynchronize());
+    EncTestMasks e;
+    e.seed = seed; e.m[0] = m0; e.m[1] = m1; e.m[2] = m2; e.m[3] = m3;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_enc_test), &e, sizeof(e), (size_t)slot * sizeof(e), hipMemcpyHostToDevice));
+    int n = 0;
+    HIP_TRY(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_enc_test_n), sizeof(n), 0, hipMemcpyDeviceToHost));
+    if (n < slot + 1) {
+        // slots between the old count and this one must not match by accident: give them a seed no call uses
+        for (int q = n; q < slot; ++q) {
+            EncTestMasks z;
+            z.seed = ~0ull; z.m[0] = m0; z.m[1] = m1; z.m[2] = m2; z.m[3] = m3;
+            HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_enc_test), &z, sizeof(z), (size_t)q * sizeof(z), hipMemcpyHostToDevice));
+        }
+        n = slot + 1;
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_enc_test_n), &n, sizeof(n), 0, hipMemcpyHostToDevice));
+    }
+    return OPNET_OK;
+}
+extern "C" int opseq_encoder_test_masks_clear(void)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    const int n = 0;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_enc_test_n), &n, sizeof(n), 0, hipMemcpyHostToDevice));
+    return OPNET_OK;
+}
+
 struct EncDrop { unsigned thresh; float inv_keep; unsigned long long seed; };
 
 static EncDrop enc_drop(float p, unsigned long long seed)

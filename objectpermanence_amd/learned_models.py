@@ -968,6 +968,9 @@ class TransformerLstm(AbstractCaterModel):
         self._ews = None
         self._tscratch = None
         self._calls = 0
+        # tests only: {layer: (attention [nhead, S, S], after out_proj [S, E], after ReLU [S, ffn], after linear2 [S, E])} uint8
+        # device tensors, nonzero = keep - the NEXT training forward draws its dropout from them instead of the generator
+        self._test_dropout_masks = None
 
     def _forward_train(self, x: torch.Tensor) -> torch.Tensor:
         B, T = int(x.shape[0]), int(x.shape[1])
@@ -980,6 +983,10 @@ class TransformerLstm(AbstractCaterModel):
                 if t_.device != x.device or not t_.is_contiguous() or t_.dtype != torch.float32:
                     raise RuntimeError("parameters must be contiguous fp32 on the input's device")
             seed = (int(self.dropout_seed) + 1000003 * self._calls + 7919 * li) & 0xFFFFFFFFFFFF
+            if self._test_dropout_masks is not None:        # tests: this layer's four masks from buffers (the reference's draws)
+                m = self._test_dropout_masks[li]
+                _lib.check(_lib.load().opseq_encoder_test_masks_set(li, seed, *(t_.data_ptr() for t_ in m)),
+                           "opseq_encoder_test_masks_set")
             z = _EncoderLayerTrainFunction.apply(z, self, p, seed, *ts)
         return self._runner.run_train(z.view(B, T, self._e), self.video_LSTM, self.predictions_layer)
 

@@ -355,6 +355,71 @@ def gen_sibling_train(lm):
     np.savez_compressed(os.path.join(OUT, "siblings_train.npz"), **out)
 
 
+def gen_transformer_dropout(lm):
+    """TransformerLstm's TRAIN mode as the reference runs it (training_main.py:167 model.train(); learned_models.py:166-168:
+    nn.TransformerEncoderLayer's default dropout 0.1 live at four sites per layer): one training step of the reference's own
+    class with the dropout masks it drew RECORDED - the fixture holds the masks of slot 0 (the only slot that reaches the loss),
+    the loss and the gradients, so that the HIP encoder, fed the same masks, can be held to them at p = 0.1.
+    How the masks are seen: torch.nn.functional.dropout is wrapped (draw bernoulli(1 - p), multiply, record) - every nn.Dropout
+    goes through it - and scaled_dot_product_attention, whose dropout is internal in torch 2.x, is replaced for the duration of
+    the run by softmax(q k^T / sqrt(d)) -> dropout -> @ v, i.e. torch 1.4's MultiheadAttention arithmetic
+    (environment.yml:97), which calls the wrapped dropout."""
+    import torch.nn.functional as F
+    out = {}
+    cases = [("tiny", {"boxes_features_dim": 32, "num_attention_heads": 2, "num_attention_layers": 2, "num_lstm_layers": 2,
+                       "lstm_hidden_dim": 32}, 2, 10),
+             ("real", {"boxes_features_dim": 256, "num_attention_heads": 2, "num_attention_layers": 2, "num_lstm_layers": 2,
+                       "lstm_hidden_dim": 512}, 2, 50),
+             ("heads4", {"boxes_features_dim": 256, "num_attention_heads": 4, "num_attention_layers": 2, "num_lstm_layers": 2,
+                         "lstm_hidden_dim": 512}, 1, 37)]
+    real_dropout, real_sdpa = F.dropout, F.scaled_dot_product_attention
+    for tag, cfg, n, t in cases:
+        torch.manual_seed(1234)
+        model = lm.TransformerLstm(cfg)
+        _load_params(model, synth.transformer_lstm_synth_params(cfg))
+        model.train(True)
+        drawn = []
+
+        def dropout(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            keep = torch.bernoulli(torch.full_like(x, 1.0 - p))
+            drawn.append(keep.to(torch.bool))
+            return x * (keep / (1.0 - p))
+
+        def sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, **kw):
+            assert attn_mask is None and not is_causal
+            w = torch.softmax(q @ k.transpose(-2, -1) / (q.shape[-1] ** 0.5 if scale is None else 1.0 / scale), dim=-1)
+            return dropout(w, dropout_p, True) @ v
+
+        F.dropout, F.scaled_dot_product_attention = dropout, sdpa
+        try:
+            boxes, labels = synth.make_batch(0, n, t)
+            y = model(torch.from_numpy(synth.boxes5(boxes)))
+            loss = torch.mean(torch.nn.L1Loss(reduction="none")(y, torch.from_numpy(labels)))
+            loss.backward()
+        finally:
+            F.dropout, F.scaled_dot_product_attention = real_dropout, real_sdpa
+        S, E, H = n * t, cfg["boxes_features_dim"], cfg["num_attention_heads"]
+        assert len(drawn) == 4 * cfg["num_attention_layers"], [tuple(d.shape) for d in drawn]
+        pre = f"{tag}/"
+        out[pre + "cfg"] = np.array(json.dumps(cfg)); out[pre + "shape"] = np.array([n, t]); out[pre + "loss"] = np.float64(loss.item())
+        for li in range(cfg["num_attention_layers"]):
+            a, d1, f, d2 = drawn[4 * li:4 * li + 4]
+            # attention weights [15 slots, heads, S, S] (the encoder's batch axis is the slot axis), the others [S, 15, *]
+            assert tuple(a.shape) == (15, H, S, S) and tuple(d1.shape) == (S, 15, E) and tuple(f.shape) == (S, 15, 2048) and tuple(d2.shape) == (S, 15, E)
+            for site, m in enumerate((a[0], d1[:, 0], f[:, 0], d2[:, 0])):
+                out[pre + f"mask/{li}/{site}"] = np.packbits(m.numpy().reshape(-1))
+                out[pre + f"mask_shape/{li}/{site}"] = np.array(m.shape)
+        for k, v in model.named_parameters():
+            g = v.grad.detach().numpy()
+            out[pre + "gnorm/" + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            out[pre + "gval/" + k] = g.reshape(-1)[sample_indices(k, g.size)].copy()
+        out[pre + "y"] = y.detach().numpy()
+        print(f"transformer dropout train {tag}: loss {loss.item():.5f}, kept {float(drawn[2].float().mean()):.4f}")
+    np.savez_compressed(os.path.join(OUT, "transformer_dropout_train.npz"), **out)
+
+
 def gen_metric(tu, y, labels):
     """ResultsAnalyzer goldens on integer boxes (tracking_utils.py:137-159, 251-256, 278-288)."""
     frame_shapes = np.array([320, 240, 320, 240])
@@ -495,6 +560,8 @@ def main():
     if want("siblings"):
         gen_siblings(lm)
         gen_sibling_train(lm)
+    if want("transformer_dropout"):
+        gen_transformer_dropout(lm)
     if want("datasets"):
         gen_datasets()
     if want("cone_ids"):

@@ -255,3 +255,51 @@ def test_long_sequence_training_step_runs_in_bounded_memory():
     assert np.isfinite(float(loss.detach()))
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
     assert torch.cuda.max_memory_allocated() < 6 * 2 ** 30
+
+
+# ---- TransformerLstm's TRAIN mode at the reference's dropout 0.1 -------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stack_engine", ["auto", "chain"], indirect=True)
+@pytest.mark.parametrize("tag", ["tiny", "real", "heads4"])
+def test_transformer_train_mode_with_the_references_dropout_masks(golden_dir, tag, stack_engine):
+    """One training step of the reference's own TransformerLstm under model.train() (training_main.py:167: dropout 0.1 live at
+    four sites per encoder layer, learned_models.py:166-168) with the masks it drew recorded
+    (tests/golden/transformer_dropout_train.npz, oracle/gen_golden.py gen_transformer_dropout).  The HIP encoder is fed the same
+    masks through its test-only table (opseq_encoder_test_masks_set) and must reproduce y, the loss and every gradient."""
+    import torch
+    from objectpermanence_amd import ModelsFactory, _lib, l1_mean
+    g = np.load(os.path.join(golden_dir, "transformer_dropout_train.npz"))
+    pre = f"{tag}/"
+    cfg = json.loads(str(g[pre + "cfg"]))
+    n, t = (int(v) for v in g[pre + "shape"])
+    boxes, labels = synth.make_batch(0, n, t)
+    x = synth.boxes5(boxes)
+    m = ModelsFactory.get_model("transformer_lstm", cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in PARAMS["transformer_lstm"](cfg).items()})
+    m.to("cuda:0").train(True)
+    assert m.dropout == 0.1                                   # the reference's nn.TransformerEncoderLayer default, untouched
+    masks = {}
+    for li in range(cfg["num_attention_layers"]):
+        per_site = []
+        for site in range(4):
+            shape = tuple(int(v) for v in g[pre + f"mask_shape/{li}/{site}"])
+            bits = np.unpackbits(g[pre + f"mask/{li}/{site}"])[:int(np.prod(shape))]
+            per_site.append(torch.from_numpy(bits.astype(np.uint8)).cuda().contiguous())
+        masks[li] = tuple(per_site)
+        assert 0.85 < float(per_site[2].float().mean()) < 0.95
+    m._test_dropout_masks = masks
+    try:
+        y = m(torch.from_numpy(x).cuda())
+        loss = l1_mean(y, torch.from_numpy(labels).cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        m._test_dropout_masks = None
+        _lib.check(_lib.load().opseq_encoder_test_masks_clear(), "opseq_encoder_test_masks_clear")
+    assert np.abs(y.detach().cpu().numpy() - g[pre + "y"]).max() < 5e-5
+    _check(g, pre, float(loss.detach()), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}, 5e-4)
+    # ... and the masks mattered: the same step at p = 0 gives another loss
+    m.dropout = 0.0
+    loss0 = l1_mean(m(torch.from_numpy(x).cuda()), torch.from_numpy(labels).cuda())
+    assert abs(float(loss0) - float(g[pre + "loss"])) > 1e-4
