@@ -151,6 +151,7 @@ def test_forced_abort_reaches_the_optimiser_through_the_guard_slot(rccl_world_of
         assert all(int(st["step"]) == 1 for st in opt.state.values())
     finally:
         lib.opnet_xcd4_enable(1)
+        lib.opseq_xcd_enable(1)          # (a data-parallel abort takes every rank off BOTH persistent kernel families)
 
 
 def test_non_finite_loss_is_skipped_on_every_rank_and_reported(rccl_world_of_one, monkeypatch):
