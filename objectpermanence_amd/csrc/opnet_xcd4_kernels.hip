@@ -106,6 +106,28 @@ typedef float x4_f32x4 __attribute__((ext_vector_type(4)));
 #define X4_MFMA_W(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
 #endif
 #define X4_MFMA_V(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv))
+// the FIRST MFMA of a chain takes the constant 0 as C: no accumulator is cleared beforehand (a wave64 v_mov occupies the SIMD for 4
+// cycles; twelve accumulator quads a phase were 48 of them = ~190 cycles of the step's critical chain, profiles/r4_xcd4_experiments.txt)
+#if X4_AG
+#define X4_MFMA0_W(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&v"(acc) : "a"(av), "v"(bv))
+#else
+#define X4_MFMA0_W(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(av), "v"(bv))
+#endif
+#define X4_MFMA0_V(acc, av, bv) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(av), "v"(bv))
+// lane l of every row of 16 lanes receives lane l ^ 8 / l ^ 4 of its row through DPP (row_ror) instead of ds_bpermute (what
+// __shfl_xor compiles to: a trip through the LDS crossbar, ~120 cycles each, and the head's softmax + einsum chains 16 of them).
+// Same partners as __shfl_xor, so the same sums bit for bit.
+__device__ __forceinline__ float x4_xor8(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));      // row_ror:8
+}
+__device__ __forceinline__ float x4_xor4(float v)
+{
+    const int vi = __float_as_int(v);
+    int t = __builtin_amdgcn_update_dpp(vi, vi, 0x12c, 0xf, 0x5, false);   // row_ror:12 (lane i <- i + 4): banks 0, 2
+    t = __builtin_amdgcn_update_dpp(t, vi, 0x124, 0xf, 0xa, false);        // row_ror:4  (lane i <- i - 4): banks 1, 3
+    return __int_as_float(t);
+}
 #define X4_MFMA_DRAIN8(c0, c1, c2, c3, c4, c5, c6, c7) \
     asm volatile("s_nop 7" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7))
 
@@ -375,9 +397,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
             const float4 *FH = S + X4B_H1 + (16 * w + (b >> 2)) * 4 + j;
             // (four chains per product: with two, LSTM1's 44 and the head's 16 MFMAs wait for each other's results - a dependent
             // v_mfma_f32_4x4x1 issues every ~30 cycles, the pipe takes one every 9.5)
-            x4_f32x4 c2[4], c1[4], cH[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c2[q] = c1[q] = cH[q] = (x4_f32x4){0.f, 0.f, 0.f, 0.f};
+            x4_f32x4 c2[4], c1[4], cH[4];      // (not cleared: the first MFMA of every chain has C = 0)
             // 47 B fragments (32 LSTM2 | 11 LSTM1 | 4 head) through a ring of X4_RING registers quads, fetched X4_AHEAD
             // fragments (~40 cycles of MFMA each) ahead: with one ds_read in flight per 4 MFMAs (what the compiler schedules
             // when left alone) every fragment's LDS latency is exposed (measured 2 750 cycles for the 194 MFMAs instead of
@@ -395,17 +415,32 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
                 if (idx + X4_AHEAD < 47) bf[(idx + X4_AHEAD) % X4_RING] = *frag(idx + X4_AHEAD);
                 __builtin_amdgcn_sched_barrier(0);
                 const float4 bq = bf[idx % X4_RING];
-                if (idx < 32) {
+                if (idx == 0) {
+                    X4_MFMA0_W(c2[0], a2[0].x, bq.x);
+                    X4_MFMA0_W(c2[1], a2[0].y, bq.y);
+                    X4_MFMA0_W(c2[2], a2[0].z, bq.z);
+                    X4_MFMA0_W(c2[3], a2[0].w, bq.w);
+                } else if (idx < 32) {
                     X4_MFMA_W(c2[0], a2[idx < 32 ? idx : 0].x, bq.x);
                     X4_MFMA_W(c2[1], a2[idx < 32 ? idx : 0].y, bq.y);
                     X4_MFMA_W(c2[2], a2[idx < 32 ? idx : 0].z, bq.z);
                     X4_MFMA_W(c2[3], a2[idx < 32 ? idx : 0].w, bq.w);
+                } else if (idx == 32) {
+                    X4_MFMA0_V(c1[0], a1[0].x, bq.x);
+                    X4_MFMA0_V(c1[1], a1[0].y, bq.y);
+                    X4_MFMA0_V(c1[2], a1[0].z, bq.z);
+                    X4_MFMA0_V(c1[3], a1[0].w, bq.w);
                 } else if (idx < 43) {
                     const int m = idx < 43 ? idx - 32 : 0;
                     X4_MFMA_V(c1[0], a1[m].x, bq.x);
                     X4_MFMA_V(c1[1], a1[m].y, bq.y);
                     X4_MFMA_V(c1[2], a1[m].z, bq.z);
                     X4_MFMA_V(c1[3], a1[m].w, bq.w);
+                } else if (idx == 43) {
+                    X4_MFMA0_V(cH[0], as_[0].x, bq.x);
+                    X4_MFMA0_V(cH[1], as_[0].y, bq.y);
+                    X4_MFMA0_V(cH[2], as_[0].z, bq.z);
+                    X4_MFMA0_V(cH[3], as_[0].w, bq.w);
                 } else {
                     const int m = idx - 43;
                     X4_MFMA_V(cH[0], as_[m].x, bq.x);
@@ -515,15 +550,15 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
                 const int rg = lane >> 2;
                 float m = fmaxf(fmaxf(v[0], v[1]), v[2]);
                 if (rg < 3) m = fmaxf(m, v[3]);                 // slot 15 does not exist
-                m = fmaxf(m, __shfl_xor(m, 4));
-                m = fmaxf(m, __shfl_xor(m, 8));
+                m = fmaxf(m, x4_xor4(m));
+                m = fmaxf(m, x4_xor8(m));
                 float e[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) e[r] = __expf(v[r] - m);
                 if (rg == 3) e[3] = 0.f;
                 float sum = (e[0] + e[1]) + (e[2] + e[3]);
-                sum += __shfl_xor(sum, 4);
-                sum += __shfl_xor(sum, 8);
+                sum += x4_xor4(sum);
+                sum += x4_xor8(sum);
                 const float inv = 1.0f / sum;
                 const float pr[4] = {e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
                 // frames_boxes[j][f] = sum_o boxes[j][t][o][f] p[o] (einsum "bfot,bfo->bft"): this lane's slots 4 rg .. 4 rg + 3
@@ -542,8 +577,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
                     acc = fmaf(pr[1], xf[6 + f], acc);
                     acc = fmaf(pr[2], xf[12 + f], acc);
                     acc = fmaf(pr[3], xf[18 + f], acc);
-                    acc += __shfl_xor(acc, 4);
-                    acc += __shfl_xor(acc, 8);
+                    acc += x4_xor4(acc);
+                    acc += x4_xor8(acc);
                     fbv[f] = acc;
                 }
                 fbv[6] = fbv[7] = 0.f;
@@ -1018,8 +1053,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                             dp[r] = acc;
                             dot = fmaf(pv[r], acc, dot);          // p of the non-existent slot 15 is 0
                         }
-                        dot += __shfl_xor(dot, 4);
-                        dot += __shfl_xor(dot, 8);
+                        dot += x4_xor4(dot);
+                        dot += x4_xor8(dot);
                         float4 dl;
                         dl.x = pv[0] * (dp[0] - dot);
                         dl.y = pv[1] * (dp[1] - dot);
@@ -1079,8 +1114,7 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
             // one accumulator chain per (row set, fragment element): a dependent v_mfma_f32_4x4x1 can issue every ~30 cycles, so with the
             // three chains of the first version (d2a / d2b alternating, d1 alone) the 160 MFMAs took ~2 900 cycles instead of the
             // pipe's 1 500.  (W_hh2's columns are AccVGPR operands, as in the forward.)
-            const x4_f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            x4_f32x4 e2a[4] = {z4, z4, z4, z4}, e2b[4] = {z4, z4, z4, z4}, e1[4] = {z4, z4, z4, z4};
+            x4_f32x4 e2a[4], e2b[4], e1[4];     // (not cleared: the first MFMA of every chain has C = 0)
             float4 bf[X4_RING];
             // 24 B fragments: 16 of da2 (each feeds set 0 and set 1: 8 MFMAs) | 8 of da1 (4 MFMAs), X4_AHEAD ahead
             auto frag = [&](int idx) -> const float4 * { return idx < 16 ? F2 + idx * 4 : F1 + (idx - 16) * 4; };
@@ -1091,12 +1125,24 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
                 if (idx + X4_AHEAD < 24) bf[(idx + X4_AHEAD) % X4_RING] = *frag(idx + X4_AHEAD);
                 __builtin_amdgcn_sched_barrier(0);
                 const float4 bq = bf[idx % X4_RING];
-                if (idx < 16) {
+                if (idx == 0) {
+                    const float4 wa = b2[0], wb = b2[16];
+                    X4_MFMA0_W(e2a[0], wa.x, bq.x); X4_MFMA0_W(e2b[0], wb.x, bq.x);
+                    X4_MFMA0_W(e2a[1], wa.y, bq.y); X4_MFMA0_W(e2b[1], wb.y, bq.y);
+                    X4_MFMA0_W(e2a[2], wa.z, bq.z); X4_MFMA0_W(e2b[2], wb.z, bq.z);
+                    X4_MFMA0_W(e2a[3], wa.w, bq.w); X4_MFMA0_W(e2b[3], wb.w, bq.w);
+                } else if (idx < 16) {
                     const float4 wa = b2[idx < 16 ? idx : 0], wb = b2[idx < 16 ? 16 + idx : 16];
                     X4_MFMA_W(e2a[0], wa.x, bq.x); X4_MFMA_W(e2b[0], wb.x, bq.x);
                     X4_MFMA_W(e2a[1], wa.y, bq.y); X4_MFMA_W(e2b[1], wb.y, bq.y);
                     X4_MFMA_W(e2a[2], wa.z, bq.z); X4_MFMA_W(e2b[2], wb.z, bq.z);
                     X4_MFMA_W(e2a[3], wa.w, bq.w); X4_MFMA_W(e2b[3], wb.w, bq.w);
+                } else if (idx == 16) {
+                    const float4 wc = b1[0];
+                    X4_MFMA0_V(e1[0], wc.x, bq.x);
+                    X4_MFMA0_V(e1[1], wc.y, bq.y);
+                    X4_MFMA0_V(e1[2], wc.z, bq.z);
+                    X4_MFMA0_V(e1[3], wc.w, bq.w);
                 } else {
                     const float4 wc = b1[idx - 16];
                     X4_MFMA_V(e1[0], wc.x, bq.x);
