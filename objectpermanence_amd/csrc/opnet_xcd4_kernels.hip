@@ -131,6 +131,24 @@ __device__ __forceinline__ float x4_xor4(float v)
 #define X4_MFMA_DRAIN8(c0, c1, c2, c3, c4, c5, c6, c7) \
     asm volatile("s_nop 7" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7))
 
+// history accesses through the workspace's buffer descriptor: lane offset (loop-invariant, computed once) + wave-uniform scalar
+// offset.  As pointer arithmetic every one of them cost ~10 VALU instructions of 64-bit address math per phase - 4 cycles each on
+// a wave64 - on the cell waves, i.e. on the step's critical chain (profiles/r4_xcd4_experiments.txt).
+__device__ __forceinline__ void x4_st1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void x4_st4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v)
+{
+    xcd_u32x4 u;
+    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+}
+__device__ __forceinline__ float x4_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 __device__ __forceinline__ float4 x4_as_float4(xcd_u32x4 r)
 {
     return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
@@ -377,6 +395,11 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
                             S + X4B_H2 + w * 256, a.status, phase);
     };
 
+    // lane offsets (bytes) of the history stores: LSTM2 unit u2 = 16 c + b, LSTM1 unit u1 = 8 c + b, clip cb + j
+    const unsigned u2 = 16 * c + b, u1 = 8 * c + b;
+    const unsigned vh2 = ((u2 >> 2) * 128 + (cb + j) * 4 + (u2 & 3)) * 4, vc2 = (u2 * 32 + cb + j) * 4, vg2 = (u2 * 32 + cb + j) * 16;
+    const unsigned vh1 = ((u1 >> 2) * 128 + (cb + j) * 4 + (u1 & 3)) * 4, vc1 = (u1 * 32 + cb + j) * 4, vg1 = (u1 * 32 + cb + j) * 16;
+
     if (!gather(0, 0, 0, 0)) XCD_LDS_ST(sAbort, 1);
     __syncthreads();
     if (XCD_LDS_LD(sAbort)) return;
@@ -499,12 +522,11 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
                 }
                 if (tracer) a.trace[(long)p * 8 + 3] = clock64();
                 // the histories of the backward pass / the output head
-                const size_t u = 16 * c + b;
-                if (!(a.debug & 2))
-                ((float *)(a.ws + a.h2_off))[(((size_t)(t + 1) * RB + rb) * 128 + (u >> 2)) * 128 + (cb + j) * 4 + (u & 3)] = h;
+                const unsigned row1 = (unsigned)((t + 1) * RB + rb), row0 = (unsigned)(t * RB + rb);
+                if (!(a.debug & 2)) x4_st1(rws, vh2, a.h2_off + row1 * (128 * 128 * 4), h);
                 if (TRAIN && !(a.debug & 2)) {
-                    ((float *)(a.ws + a.c2_off))[(((size_t)(t + 1) * RB + rb) * 512 + u) * 32 + cb + j] = cc;
-                    ((float4 *)(a.ws + a.g2_off))[(((size_t)t * RB + rb) * 512 + u) * 32 + cb + j] = gs;
+                    x4_st1(rws, vc2, a.c2_off + row1 * (512 * 32 * 4), cc);
+                    x4_st4(rws, vg2, a.g2_off + row0 * (512 * 32 * 16), gs);
                 }
             }
         } else if (w == 1) {
@@ -527,12 +549,11 @@ __global__ void __launch_bounds__(256) opnet_xcd4_forward(const Xcd4Args a)
                     xcd_store16(rws, vo, a.h1x_off + ((gg * X4_SLOTS + ((s + 1) & 3)) * 64 + 2 * c) * 64, hv, local);
                     xcd_store16(rws, vo, a.h1x_off + ((gg * X4_SLOTS + ((s + 3) & 3)) * 64 + 2 * c) * 64, sentf, local);
                 }
-                const size_t u = 8 * c + b;
-                if (TRAIN && !(a.debug & 2))
-                ((float *)(a.ws + a.h1_off))[(((size_t)(t + 1) * RB + rb) * 64 + (u >> 2)) * 128 + (cb + j) * 4 + (u & 3)] = h;
                 if (TRAIN && !(a.debug & 2)) {
-                    ((float *)(a.ws + a.c1_off))[(((size_t)(t + 1) * RB + rb) * 256 + u) * 32 + cb + j] = cc;
-                    ((float4 *)(a.ws + a.g1_off))[(((size_t)t * RB + rb) * 256 + u) * 32 + cb + j] = gs;
+                    const unsigned row1 = (unsigned)((t + 1) * RB + rb), row0 = (unsigned)(t * RB + rb);
+                    x4_st1(rws, vh1, a.h1_off + row1 * (64 * 128 * 4), h);
+                    x4_st1(rws, vc1, a.c1_off + row1 * (256 * 32 * 4), cc);
+                    x4_st4(rws, vg1, a.g1_off + row0 * (256 * 32 * 16), gs);
                 }
             }
         } else if (w == 2) {
@@ -909,6 +930,8 @@ __global__ void __launch_bounds__(256) opnet_xcd4_backward(const Xcd4BArgs a)
     // Infinity Cache
     float4 cg = make_float4(0.f, 0.f, 0.f, 0.f), cdy = cg, ng_ = cg, ndy = cg;      // gates, dy of the current / next phase
     float cct = 0.f, ccp = 0.f, nct = 0.f, ncp = 0.f;                                   // c_t, c_{t-1}
+    // (pointer loads: as buffer loads through the workspace's descriptor - the forward's history stores went that way - the cell
+    // phase grew from 1 740 to 2 100 cycles: the compiler then orders them against the descriptor's stores and waits)
     auto fetch = [&](int gi, int n, float4 &g, float4 &dy, float &ct, float &cp) {
         const int rb = gi;
         if (w == 0) {
