@@ -605,3 +605,37 @@ def test_launch_monitor_reaps_completed_entries_and_recycles_slots():
         warnings.simplefilter("always")
         assert mon.verify() == 1
     assert held == [2] and mon.pending() == 0 and sorted(mon._free) == list(range(lm._SLOTS))
+
+
+def test_server_merges_segmenting_models_by_request_not_by_concatenation():
+    """host logic of ReasonerServer for a model whose clips are coupled inside a request (TransformerLstm): pending requests of one
+    shape go to forward_segments(x, n) - never to a plain forward of the concatenation -, a request of another shape or the
+    model's per-pass limit cuts the pass, a lone request takes the plain forward (stub model, no GPU)"""
+    from objectpermanence_amd.serving import ReasonerServer
+
+    class Stub(torch.nn.Module):
+        calls = []
+
+        def max_requests_per_pass(self, b, T):
+            return 3
+
+        def forward(self, x):
+            Stub.calls.append(("plain", tuple(x.shape)))
+            return x.sum(dim=(2, 3), keepdim=False).unsqueeze(-1).repeat(1, 1, 4)
+
+        def forward_segments(self, x, n):
+            Stub.calls.append(("segments", tuple(x.shape), n))
+            return self.forward(x)
+
+    m = Stub()
+    server = ReasonerServer(m, "transformer_lstm")
+    assert server.segmented
+    reqs = [torch.full((1, 5, 15, 5), float(i)) for i in range(4)] + [torch.full((2, 5, 15, 5), 9.0)]
+    hs = [server.submit(r) for r in reqs]           # the third submit fills a pass (limit 3); the fifth has another shape
+    outs = [h.result() for h in hs]
+    kinds = [c for c in Stub.calls if c[0] == "segments"]
+    assert kinds == [("segments", (3, 5, 15, 5), 3)]                       # one merged pass of three requests
+    assert ("plain", (1, 5, 15, 5)) in Stub.calls and ("plain", (2, 5, 15, 5)) in Stub.calls   # the lone ones: plain forwards
+    for r, o in zip(reqs, outs):
+        assert o.shape == (r.shape[0], 5, 4) and float(o[0, 0, 0]) == float(r[0, 0].sum())
+    assert server.forwards == 3
