@@ -406,6 +406,14 @@ int opdet_detections_f32(const float *class_logits, const float *box_regression,
                          const int *count, int max_rois, int num_classes, int image_h, int image_w, int orig_h,
                          int orig_w, float score_thresh, float nms_thresh, int max_det, float *boxes, float *scores,
                          long long *labels, int *n_det, void *workspace, size_t workspace_bytes, void *stream);
+/* TEST-ONLY: the detector's own stable radix sort of (key, value) pairs (csrc/det_sort_kernels.hip; it orders the RPN candidates and
+ * the detections - the role torch.sort / topk plays in torchvision's filter_proposals / postprocess_detections), by itself, so a
+ * test can hold it against torch.sort(stable=True).  Ascending by the low `bits` bits of the keys (8-byte keys when key64 != 0, else
+ * 4-byte); both buffer pairs hold n elements and are overwritten; *result_in_out = 1: the sorted pairs are in (keys_out, vals_out),
+ * 0: in (keys_in, vals_in) (an even number of 8-bit passes). */
+size_t opdet_test_sort_scratch_bytes(long n);
+int opdet_test_sort_pairs(void *keys_in, unsigned *vals_in, void *keys_out, unsigned *vals_out, long n, int bits, int key64,
+                          void *scratch, size_t scratch_bytes, int *result_in_out, void *stream);
 
 /* ---- output post-processing + metric (replaces inference_main.py:219 and
  *      tracking_utils.py:137-159,251-256,278-288) ------------------------------------------------

@@ -184,6 +184,11 @@ def _declare(lib):
     lib.opseq_encoder_test_masks_set.argtypes = [c_int, ctypes.c_ulonglong, fp, fp, fp, fp]
     lib.opseq_encoder_test_masks_clear.restype = c_int
     lib.opseq_encoder_test_masks_clear.argtypes = []
+    lib.opdet_test_sort_scratch_bytes.restype = c_size_t
+    lib.opdet_test_sort_scratch_bytes.argtypes = [ctypes.c_long]
+    lib.opdet_test_sort_pairs.restype = c_int
+    lib.opdet_test_sort_pairs.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p, c_size_t,
+                                          ctypes.POINTER(c_int), c_void_p]
     lib.opseq_encoder_layer_f32.restype = c_int
     lib.opseq_encoder_layer_f32.argtypes = [fp] * 13 + [c_void_p, c_size_t, ctypes.c_long, c_int, c_int, c_int, c_void_p]
     lib.opseq_encoder_layer_segmented_f32.restype = c_int
@@ -251,7 +256,7 @@ EXPORTS = [
     "opseq_encoder_layer_train_backward_f32", "opseq_encoder_test_masks_set", "opseq_encoder_test_masks_clear",
     "opdet_conv2d_f32", "opdet_maxpool3x3s2_f32", "opdet_subsample2_f32", "opdet_upsample_add_f32",
     "opdet_preprocess_frame_f32", "opdet_rpn_workspace_bytes", "opdet_rpn_proposals_f32", "opdet_roi_align_f32",
-    "opdet_detections_workspace_bytes", "opdet_detections_f32",
+    "opdet_detections_workspace_bytes", "opdet_detections_f32", "opdet_test_sort_scratch_bytes", "opdet_test_sort_pairs",
 ]
 
 
