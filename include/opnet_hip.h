@@ -338,6 +338,14 @@ int opseq_encoder_layer_segmented_f32(float *z, const float *in_w, const float *
 int opdet_conv2d_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,
                      int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int KP,
                      int relu, void *stream);
+/* The same conv with scratch for a K split: the deep, spatially small layers of ONE frame and the 1000-row FCs give too few 128-row
+ * tiles to fill 256 CUs, so their K is walked by several workgroups per tile (partial sums in the workspace, added in slice order by a
+ * second launch - deterministic).  _workspace_bytes: 0 when the shape is not split (the call then equals opdet_conv2d_f32 and
+ * workspace may be null).  bias / residual / workspace 16-byte aligned. */
+size_t opdet_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int KP);
+int opdet_conv2d_ws_f32(const float *x, const float *w, const float *bias, const float *residual, float *y, int N, int H, int W,
+                        int Cin, int Cout, int KH, int KW, int stride, int pad, int KP, int relu, void *workspace,
+                        size_t workspace_bytes, void *stream);
 int opdet_maxpool3x3s2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
 int opdet_subsample2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
 int opdet_upsample_add_f32(const float *lateral, const float *top, float *y, int N, int H, int W, int C,

@@ -30,6 +30,10 @@ struct ConvArgs {
     // row strides in floats, 0 = dense (XS = Cin, WS = KP, YS = Cout).  Honoured by conv2d_nhwc_glds only: they let
     // the GEMMs of the encoder backward read / write column slices of wider matrices (one head of qkv, d qkv ...)
     int XS, WS, YS;
+    // split K (conv2d_nhwc_glds only, ksplit >= 2): workgroup z walks K steps [z * ksteps, (z + 1) * ksteps) and stores its raw
+    // 128 x BN sums to P[z][M][Cout]; conv_splitk_reduce adds the slices in order and applies bias / residual / ReLU
+    float *P;
+    int ksplit, ksteps;
 };
 
 __global__ void __launch_bounds__(256) conv2d_nhwc(const ConvArgs a)
@@ -470,8 +474,18 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
         woff[j] = r < a.Cout ? (unsigned)(((long)r * WS + 4 * lkq) * 4) : 0x80000000u;
     }
 
-    int t_c0 = 0, t_dx = 0, t_dy = 0;   // wave-uniform tap walk of the next stage to issue
-    auto issue = [&](int q) {
+    // K steps of this workgroup: all of them, or slice blockIdx.z of a split
+    const int nhex_all = a.KP >> 4;
+    const int qb = a.ksplit > 1 ? (int)blockIdx.z * a.ksteps : 0;
+    const int nhex = a.ksplit > 1 ? min(nhex_all - qb, a.ksteps) : nhex_all;
+    int t_c0, t_dx, t_dy;               // wave-uniform tap walk of the next stage to issue
+    {
+        const int k0 = qb * 16, tap = k0 / a.Cin;
+        t_c0 = k0 - tap * a.Cin;
+        t_dy = tap / a.KW;
+        t_dx = tap - t_dy * a.KW;
+    }
+    auto issue = [&](int q) {           // q: step within the slice
         const unsigned sbase = lds0 + (unsigned)(q % NS) * (STAGE_F4 * 16);
         const int toff = ((t_dy * a.W + t_dx) * XS + t_c0) * 4;
 #pragma unroll
@@ -481,7 +495,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
         }
 #pragma unroll
         for (int j = 0; j < WLD; ++j)
-            conv_glds16(rwt, woff[j] == 0x80000000u ? woff[j] : woff[j] + q * 64, sbase + BM * 64 + ((BN / 4) * w + 16 * j) * 64);
+            conv_glds16(rwt, woff[j] == 0x80000000u ? woff[j] : woff[j] + (qb + q) * 64, sbase + BM * 64 + ((BN / 4) * w + 16 * j) * 64);
         t_c0 += 16;
         if (t_c0 == a.Cin) {
             t_c0 = 0;
@@ -495,7 +509,6 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
 #pragma unroll
         for (int y = 0; y < FN; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nhex = a.KP >> 4;
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0)
         if (s0 < nhex) issue(s0);
@@ -539,6 +552,20 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
         __builtin_amdgcn_s_barrier();
     }
     // epilogue: D fragment lane = (pixel column l&15, channel rows 4*(l>>4)+r)
+    if (a.ksplit > 1) {                 // raw sums of this K slice (Cout % 4 == 0, dense rows: the host's split plan)
+        float *P = a.P + (long)blockIdx.z * M * a.Cout;
+#pragma unroll
+        for (int x = 0; x < FM; ++x) {
+            const long pp = m0 + wm * (FM * 16) + x * 16 + i;
+            if (pp >= M) continue;
+#pragma unroll
+            for (int y = 0; y < FN; ++y) {
+                const int co = n0 + wn * 64 + y * 16 + 4 * kk;
+                if (co < a.Cout) *(float4 *)(P + pp * a.Cout + co) = make_float4(acc[x][y][0], acc[x][y][1], acc[x][y][2], acc[x][y][3]);
+            }
+        }
+        return;
+    }
     const bool vec = (a.Cout & 3) == 0 && (YS & 3) == 0;
 #pragma unroll
     for (int x = 0; x < FM; ++x) {
@@ -571,5 +598,31 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
                 }
             }
         }
+    }
+}
+
+// Y = act( sum_z P[z] + bias (+ R) ): the K slices of a split conv2d_nhwc_glds added in slice order (one float4 per thread)
+__global__ void __launch_bounds__(256) conv_splitk_reduce(const float *__restrict__ P, int S, long M, int Cout,
+                                                          const float *__restrict__ bias, const float *__restrict__ R,
+                                                          float *__restrict__ Y, int relu)
+{
+    const long n4 = M * Cout / 4, slice4 = n4;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n4; g += (long)gridDim.x * 256) {
+        float4 v = ((const float4 *)P)[g];
+        for (int z = 1; z < S; ++z) {
+            const float4 t = ((const float4 *)P)[(long)z * slice4 + g];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const int co = (int)((g * 4) % Cout);
+        if (bias) {
+            const float4 b = *(const float4 *)(bias + co);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (R) {
+            const float4 r = ((const float4 *)R)[g];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        ((float4 *)Y)[g] = v;
     }
 }

@@ -2777,30 +2777,106 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
 // ------------------------------------------------------------------------------------------------
 static unsigned ew_blocks(long n) { return (unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256); }
 
+static int conv_args(ConvArgs *a, const float *x, const float *w, const float *bias, const float *residual, float *y, int N, int H, int W,
+                     int Cin, int Cout, int KH, int KW, int stride, int pad, int KP, int relu)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+        return fail(OPNET_ESHAPE, "bad conv shape (Cin must be a multiple of 4)");
+    if ((KP & 15) || KP < KH * KW * Cin) return fail(OPNET_ESHAPE, "KP=%d must be a multiple of 16 >= KH*KW*Cin=%d", KP, KH * KW * Cin);
+    *a = ConvArgs{};
+    a->X = x; a->Wt = w; a->bias = bias; a->R = residual; a->Y = y;
+    a->N = N; a->H = H; a->W = W; a->Cin = Cin; a->Cout = Cout; a->KH = KH; a->KW = KW; a->stride = stride; a->pad = pad;
+    a->OH = (H + 2 * pad - KH) / stride + 1;
+    a->OW = (W + 2 * pad - KW) / stride + 1;
+    a->KP = KP; a->relu = relu;
+    if (a->OH <= 0 || a->OW <= 0) return fail(OPNET_ESHAPE, "empty conv output");
+    return OPNET_OK;
+}
+
+// LDS-staged 128 x {128, 64} tiles when they give >= one workgroup per CU
+static bool conv_fills_chip(const ConvArgs &a, long M)
+{
+    const long t128 = ((M + 127) / 128) * ((a.Cout + 127) / 128), t64 = ((M + 127) / 128) * ((a.Cout + 63) / 64);
+    return (a.Cout > 64 && t128 >= 256) || (a.Cout <= 64 && t64 >= 256);
+}
+
+// The deep, spatially small layers of ONE frame (25x34 .. 50x68 maps; the 1000-row FCs) give 28 .. 216 of those tiles: with scratch
+// for the partial sums their K is split over blockIdx.z so that ~2.5 workgroups per CU run the LDS-DMA kernel (>= 16 K steps each).
+// -> number of slices (1 = no split) and K steps per slice
+static int conv_split_plan(const ConvArgs &a, long M, int *ksteps)
+{
+    *ksteps = a.KP >> 4;
+    if (conv_fills_chip(a, M) || (a.Cin & 15) || (a.Cout & 3) || a.KP != a.KH * a.KW * a.Cin) return 1;
+    if ((long)a.N * a.H * a.W * a.Cin * 4 >= (1L << 31) || (long)a.Cout * a.KP * 4 >= (1L << 31)) return 1;
+    const int nhex = a.KP >> 4;
+    const long tiles = ((M + 127) / 128) * (a.Cout > 64 ? (a.Cout + 127) / 128 : (a.Cout + 63) / 64);
+    long S = (640 + tiles - 1) / tiles;
+    if (S > nhex / 16) S = nhex / 16;
+    if (S > 32) S = 32;
+    if (S < 2) return 1;
+    const int per = (int)((nhex + S - 1) / S);
+    *ksteps = per;
+    return (nhex + per - 1) / per;          // no empty slice
+}
+
+static void launch_conv(const ConvArgs &a, long M, hipStream_t st)
+{
+    // Fewer tiles than CUs: the LDS-DMA kernel still wins from ~100 tiles up (measured on one frame's layer3 1x1s, 216 tiles x 16 K
+    // steps: 25 us against 40); below that the un-staged 64 x 64 tiles keep more of the chip busy
+    const long tiles = ((M + 127) / 128) * (a.Cout > 64 ? (a.Cout + 127) / 128 : (a.Cout + 63) / 64);
+    if (conv_fills_chip(a, M) || (!(a.Cin & 15) && tiles >= 100)) launch_conv_tiled(a, M, st);
+    else conv2d_nhwc<<<dim3((unsigned)((M + 63) / 64), (a.Cout + 63) / 64, 1), 256, 0, st>>>(a);
+}
+
 extern "C" int opdet_conv2d_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,
                                 int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int KP,
                                 int relu, void *stream)
 {
     if (!x || !w || !y) return fail(OPNET_EINVAL, "null pointer");
     if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return fail(OPNET_EINVAL, "x / w / y must be 16-byte aligned");
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
-        return fail(OPNET_ESHAPE, "bad conv shape (Cin must be a multiple of 4)");
-    if ((KP & 15) || KP < KH * KW * Cin) return fail(OPNET_ESHAPE, "KP=%d must be a multiple of 16 >= KH*KW*Cin=%d", KP, KH * KW * Cin);
-    ConvArgs a = {};
-    a.X = x; a.Wt = w; a.bias = bias; a.R = residual; a.Y = y;
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
-    a.OH = (H + 2 * pad - KH) / stride + 1;
-    a.OW = (W + 2 * pad - KW) / stride + 1;
-    a.KP = KP; a.relu = relu;
-    if (a.OH <= 0 || a.OW <= 0) return fail(OPNET_ESHAPE, "empty conv output");
+    ConvArgs a;
+    if (int rc = conv_args(&a, x, w, bias, residual, y, N, H, W, Cin, Cout, KH, KW, stride, pad, KP, relu)) return rc;
+    launch_conv(a, (long)N * a.OH * a.OW, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" size_t opdet_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int KP)
+{
+    ConvArgs a;
+    if (conv_args(&a, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, KH, KW, stride, pad, KP, 0)) return 0;
     const long M = (long)N * a.OH * a.OW;
-    // LDS-staged 128 x {128, 64} tiles when they still give >= one workgroup per CU; the deep, spatially
-    // small layers (25x34 .. 50x68 maps at batch 1) keep the un-staged 64 x 64 tiles for parallelism
-    const long t128 = ((M + 127) / 128) * ((Cout + 127) / 128), t64 = ((M + 127) / 128) * ((Cout + 63) / 64);
-    if ((Cout > 64 && t128 >= 256) || (Cout <= 64 && t64 >= 256))
-        launch_conv_tiled(a, M, (hipStream_t)stream);
-    else
-        conv2d_nhwc<<<dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, 1), 256, 0, (hipStream_t)stream>>>(a);
+    int ksteps;
+    const int S = conv_split_plan(a, M, &ksteps);
+    return S > 1 ? (size_t)S * M * Cout * 4 : 0;
+}
+
+extern "C" int opdet_conv2d_ws_f32(const float *x, const float *w, const float *bias, const float *residual, float *y,
+                                   int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int KP,
+                                   int relu, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!x || !w || !y) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(x) || !aligned16(w) || !aligned16(y) || !aligned16(workspace) || !aligned16(bias) || !aligned16(residual))
+        return fail(OPNET_EINVAL, "x / w / y / bias / residual / workspace must be 16-byte aligned");
+    ConvArgs a;
+    if (int rc = conv_args(&a, x, w, bias, residual, y, N, H, W, Cin, Cout, KH, KW, stride, pad, KP, relu)) return rc;
+    const long M = (long)N * a.OH * a.OW;
+    int ksteps;
+    const int S = conv_split_plan(a, M, &ksteps);
+    hipStream_t st = (hipStream_t)stream;
+    if (S <= 1) {
+        launch_conv(a, M, st);
+    } else {
+        const size_t need = (size_t)S * M * Cout * 4;
+        if (!workspace || workspace_bytes < need) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", workspace_bytes, need);
+        a.P = (float *)workspace; a.ksplit = S; a.ksteps = ksteps;
+        const unsigned gx = (unsigned)((M + 127) / 128);
+        if (Cout > 64) conv2d_nhwc_glds<128, 3><<<dim3(gx, (Cout + 127) / 128, S), 256, 0, st>>>(a);
+        else conv2d_nhwc_glds<64, 3><<<dim3(gx, (Cout + 63) / 64, S), 256, 0, st>>>(a);
+        const long n4 = M * Cout / 4;
+        conv_splitk_reduce<<<(unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256), 256, 0, st>>>(a.P, S, M, Cout, bias, residual, y,
+                                                                                                    relu);
+    }
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

@@ -51,6 +51,7 @@ class _Conv:
         self.w = packed.contiguous().to(device)
         self.b = b.contiguous().to(device)
         self.cin, self.cout, self.kh, self.kw, self.stride, self.pad = cin_p, cout, kh, kw, stride, pad
+        self._ws_bytes: Dict[tuple, int] = {}
 
     def __call__(self, x: torch.Tensor, relu: bool, residual: torch.Tensor = None) -> torch.Tensor:
         lib = _lib.load()
@@ -59,10 +60,15 @@ class _Conv:
         oh = (h + 2 * self.pad - self.kh) // self.stride + 1
         ow = (w + 2 * self.pad - self.kw) // self.stride + 1
         y = torch.empty((n, oh, ow, self.cout), dtype=torch.float32, device=x.device)
-        rc = lib.opdet_conv2d_f32(x.data_ptr(), self.w.data_ptr(), self.b.data_ptr(),
-                                  None if residual is None else residual.data_ptr(), y.data_ptr(), n, h, w, c,
-                                  self.cout, self.kh, self.kw, self.stride, self.pad, self.kp, int(relu), _stream(x.device))
-        _lib.check(rc, "opdet_conv2d_f32")
+        shape = (n, h, w, c, self.cout, self.kh, self.kw, self.stride, self.pad, self.kp)
+        nws = self._ws_bytes.get(shape)
+        if nws is None:                 # > 0: too few output tiles for 256 CUs (one frame's deep maps, the FCs) - K is split
+            nws = self._ws_bytes[shape] = int(lib.opdet_conv2d_workspace_bytes(*shape))
+        ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None       # (caching allocator: stream-ordered reuse)
+        rc = lib.opdet_conv2d_ws_f32(x.data_ptr(), self.w.data_ptr(), self.b.data_ptr(),
+                                     None if residual is None else residual.data_ptr(), y.data_ptr(), *shape, int(relu),
+                                     None if ws is None else ws.data_ptr(), nws, _stream(x.device))
+        _lib.check(rc, "opdet_conv2d_ws_f32")
         return y
 
 

@@ -64,6 +64,59 @@ def test_conv2d_tiled_matches_torch(cin, cout, k, stride, pad, h, w):
         assert (got - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,pad,n,h,w,slices", [
+    (512, 512, 3, 1, 1, 1, 25, 34, 18),     # layer4 3x3 of one frame: 28 tiles of 128 x 128, 288 K steps
+    (256, 256, 3, 1, 1, 1, 50, 68, 9),      # layer3 3x3: 54 tiles, 144 K steps
+    (1024, 512, 1, 1, 0, 1, 25, 34, 4),     # 1x1, 64 K steps
+    (256, 48, 3, 2, 1, 1, 50, 68, 9),       # BN = 64 tiles, stride 2, Cout % 16 != 0
+    (64, 64, 1, 1, 0, 2, 20, 27, 1),        # K too short: not split (0 bytes of scratch), same entry point
+])
+def test_conv2d_split_k_matches_torch(cin, cout, k, stride, pad, n, h, w, slices):
+    """one frame's deep layers: K split over blockIdx.z, partial sums added in slice order by conv_splitk_reduce"""
+    from objectpermanence_amd import _lib
+    from objectpermanence_amd.detector import _Conv
+    sd = {"w": synth.synth_tensor(f"sw{cin}{cout}{k}", (cout, cin, k, k), float(np.sqrt(6.0 / (cin * k * k)))),
+          "b": synth.synth_tensor("sb", (cout,), 0.2)}
+    x = torch.from_numpy(synth.synth_tensor("sx", (n, cin, h, w), 1.0))
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.from_numpy(synth.synth_tensor("sr", (n, cout, oh, ow), 1.0))
+    conv = _Conv(sd, "w", bias="b", stride=stride, pad=pad)
+    nws = _lib.load().opdet_conv2d_workspace_bytes(n, h, w, cin, cout, k, k, stride, pad, conv.kp)
+    assert nws == (slices * n * oh * ow * cout * 4 if slices > 1 else 0)
+    y = conv(_nhwc(x).cuda(), relu=True, residual=_nhwc(res).cuda())
+    y2 = conv(_nhwc(x).cuda(), relu=False)
+    y3 = conv(_nhwc(x).cuda(), relu=False)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y3)                                  # slice order is fixed: run-to-run identical
+    lin = F.conv2d(x.double(), torch.from_numpy(sd["w"]).double(), torch.from_numpy(sd["b"]).double(), stride=stride, padding=pad)
+    for got, ref in ((y, F.relu(lin + res.double())), (y2, lin)):
+        got = got.cpu().permute(0, 3, 1, 2).double()
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max())
+
+
+def test_linear_rows_split_k_and_refusals():
+    """TwoMLPHead.fc6 of one frame (1000 x 12544 -> 1024): 64 tiles, 784 K steps -> 10 slices"""
+    from objectpermanence_amd import _lib
+    from objectpermanence_amd.detector import _Linear
+    lib = _lib.load()
+    wt = torch.from_numpy(synth.synth_tensor("fc6w", (1024, 12544), 0.02))
+    b = torch.from_numpy(synth.synth_tensor("fc6b", (1024,), 0.2))
+    x = torch.from_numpy(synth.synth_tensor("fc6x", (1000, 12544), 1.0))
+    fc = _Linear(wt, b, "cuda:0")
+    assert lib.opdet_conv2d_workspace_bytes(1, 1, 1000, 12544, 1024, 1, 1, 1, 0, fc.kp) == 10 * 1000 * 1024 * 4
+    y = fc.rows(x.cuda(), relu=True)
+    torch.cuda.synchronize()
+    ref = F.relu(x.double() @ wt.double().t() + b.double())
+    assert (y.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max())
+    # too little scratch for a split shape is refused, not silently run another way
+    xs, ys = x.cuda(), torch.empty((1000, 1024), device="cuda:0")
+    small = torch.empty(1024, dtype=torch.uint8, device="cuda:0")
+    rc = lib.opdet_conv2d_ws_f32(xs.data_ptr(), fc.w.data_ptr(), fc.b.data_ptr(), None, ys.data_ptr(), 1, 1, 1000, 12544, 1024, 1, 1, 1, 0,
+                                 fc.kp, 1, small.data_ptr(), small.numel(), None)
+    assert rc != 0 and b"workspace" in lib.opnet_last_error()
+
+
 def test_preprocess_matches_oracle():
     from objectpermanence_amd.detector import preprocess_frame
     rng = np.random.default_rng(0)
