@@ -418,7 +418,7 @@ int opdet_detections_f32(const float *class_logits, const float *box_regression,
  * the detections - the role torch.sort / topk plays in torchvision's filter_proposals / postprocess_detections), by itself, so a
  * test can hold it against torch.sort(stable=True).  Ascending by the low `bits` bits of the keys (8-byte keys when key64 != 0, else
  * 4-byte); both buffer pairs hold n elements and are overwritten; *result_in_out = 1: the sorted pairs are in (keys_out, vals_out),
- * 0: in (keys_in, vals_in) (an even number of 8-bit passes). */
+ * 0: in (keys_in, vals_in) (an even number of passes). */
 size_t opdet_test_sort_scratch_bytes(long n);
 int opdet_test_sort_pairs(void *keys_in, unsigned *vals_in, void *keys_out, unsigned *vals_out, long n, int bits, int key64,
                           void *scratch, size_t scratch_bytes, int *result_in_out, void *stream);

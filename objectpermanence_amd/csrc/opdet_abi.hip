@@ -4,6 +4,7 @@
 #include "det_sort_kernels.hip"
 
 #include <string.h>
+#include <atomic>
 
 #include <math.h>
 #include <stdarg.h>
@@ -34,21 +35,23 @@ static int fail(int code, const char *fmt, ...)
 static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // ---- stable radix sort of (key, value) pairs (det_sort_kernels.hip) ----------------------------------------------------------------
-// scratch: the digit histograms of the tiles, a block per pass ([8][tiles][512] words at most)
-static size_t sort_scratch_bytes(size_t n) { return up256(8 * 512 * ((n + RS_TILE - 1) / RS_TILE) * 4); }
-// Sorts ascending by the low `bits` bits of the keys, ONE launch.  (kin, vin) and (kout, vout) are both overwritten (ping-pong); the
-// result is in (kout, vout) when the return value is 1 and in (kin, vin) when it is 0 (an even number of passes).  4-byte keys,
-// n <= RS_SMALL_MAX: result always in (kout, vout).  bar: a word the caller has ZEROED on this stream (the kernel's grid barrier).
+// scratch: the digit histograms of the tiles ([tiles][512] words at most)
+static size_t sort_scratch_bytes(size_t n) { return up256(512 * ((n + RS_TILE - 1) / RS_TILE) * 4); }
+// Sorts ascending by the low `bits` bits of the keys.  (kin, vin) and (kout, vout) are both overwritten (ping-pong); the result is in
+// (kout, vout) when the return value is 1 and in (kin, vin) when it is 0 (an even number of passes).  4-byte keys, n <= RS_SMALL_MAX:
+// one workgroup, result always in (kout, vout); otherwise two launches per pass of 8 (4-byte keys) or 9 bits.
 template <typename K>
-static int sort_pairs(K *kin, unsigned *vin, K *kout, unsigned *vout, size_t n, int bits, void *scratch, unsigned *bar, hipStream_t st)
+static int sort_pairs(K *kin, unsigned *vin, K *kout, unsigned *vout, size_t n, int bits, void *scratch, hipStream_t st)
 {
     if constexpr (sizeof(K) == 4) {
         if (n <= RS_SMALL_MAX) {
             const size_t lds = (size_t)RS_SMALL_MAX * 16;
-            static bool raised = false;
-            if (!raised) {                  // > 64 KB of dynamic LDS has to be asked for once
+            static std::atomic<unsigned long long> raised{0};      // (> 64 KB of dynamic LDS has to be asked for once per device)
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev < 0 || dev >= 64 || !((raised.load(std::memory_order_relaxed) >> dev) & 1ull)) {
                 (void)hipFuncSetAttribute((const void *)rs_sort_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                raised = true;
+                if (dev >= 0 && dev < 64) raised.fetch_or(1ull << dev, std::memory_order_relaxed);
             }
             rs_sort_small<<<1, 1024, lds, st>>>(kin, vin, kout, vout, (int)n, bits);
             return 1;
@@ -56,9 +59,16 @@ static int sort_pairs(K *kin, unsigned *vin, K *kout, unsigned *vout, size_t n, 
     }
     constexpr int RB = sizeof(K) == 8 ? 9 : 8;
     const size_t ntiles = (n + RS_TILE - 1) / RS_TILE;
-    const unsigned grid = (unsigned)(ntiles < RS_MAX_GRID ? ntiles : RS_MAX_GRID);
-    rs_sort_tiled<K, RB><<<grid, 256, 0, st>>>(kin, vin, kout, vout, (long)n, bits, (unsigned *)scratch, bar);
-    return ((bits + RB - 1) / RB) & 1;
+    unsigned *hist = (unsigned *)scratch;
+    int where = 0;
+    for (int shift = 0; shift < bits; shift += RB) {
+        rs_pass_count<K, RB><<<(unsigned)ntiles, 256, 0, st>>>(kin, vin, (long)n, bits, shift, hist);
+        rs_pass_scatter<K, RB><<<(unsigned)ntiles, 256, 0, st>>>(kin, vin, kout, vout, (long)n, bits, shift, hist);
+        K *tk = kin; kin = kout; kout = tk;
+        unsigned *tv = vin; vin = vout; vout = tv;
+        where ^= 1;
+    }
+    return where;
 }
 
 /* TEST-ONLY (tests/test_detector_sort_gpu.py): the sort by itself.  keys: 8-byte (key64 != 0) or 4-byte; both buffer pairs hold n
@@ -67,19 +77,16 @@ extern "C" int opdet_test_sort_pairs(void *keys_in, unsigned *vals_in, void *key
                                      void *scratch, size_t scratch_bytes, int *result_in_out, void *stream)
 {
     if (!keys_in || !vals_in || !keys_out || !vals_out || !scratch || !result_in_out) return fail(OPNET_EINVAL, "null pointer");
-    if (n <= 0 || bits <= 0 || bits > (key64 ? 64 : 32)) return fail(OPNET_ESHAPE, "bad sort sizes");
-    if (scratch_bytes < sort_scratch_bytes((size_t)n) + 256) return fail(OPNET_EWORKSPACE, "scratch too small");
-    // (the barrier word: the last 256 bytes of the scratch)
-    unsigned *bar = (unsigned *)((char *)scratch + sort_scratch_bytes((size_t)n));
-    HIP_TRY(hipMemsetAsync(bar, 0, 4, (hipStream_t)stream));
+    if (n <= 0 || n > 0x7fffffffL || bits <= 0 || bits > (key64 ? 64 : 32)) return fail(OPNET_ESHAPE, "bad sort sizes");
+    if (scratch_bytes < sort_scratch_bytes((size_t)n)) return fail(OPNET_EWORKSPACE, "scratch too small");
     *result_in_out = key64 ? sort_pairs<unsigned long long>((unsigned long long *)keys_in, vals_in, (unsigned long long *)keys_out, vals_out,
-                                                             (size_t)n, bits, scratch, bar, (hipStream_t)stream)
+                                                             (size_t)n, bits, scratch, (hipStream_t)stream)
                            : sort_pairs<unsigned>((unsigned *)keys_in, vals_in, (unsigned *)keys_out, vals_out, (size_t)n, bits, scratch,
-                                                  bar, (hipStream_t)stream);
+                                                  (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }
-extern "C" size_t opdet_test_sort_scratch_bytes(long n) { return n > 0 ? sort_scratch_bytes((size_t)n) + 256 : 0; }
+extern "C" size_t opdet_test_sort_scratch_bytes(long n) { return n > 0 ? sort_scratch_bytes((size_t)n) : 0; }
 static const float kBoxClip = 4.135166556742356f;   // log(1000 / 16), BoxCoder.bbox_xform_clip
 
 // ---- shared NMS stage: sorted boxes -> kept indices -------------------------------------------------
@@ -205,17 +212,17 @@ extern "C" int opdet_rpn_proposals_f32(const float *const *head_out, int n_level
     int *counters = (int *)p; p += 256;      // [0] boxes that pass the size test, [1] boxes kept by NMS
     unsigned long long *mask = (unsigned long long *)p;
 
-    HIP_TRY(hipMemsetAsync(counters, 0, 16, st));     // ... [2], [3]: the grid barriers of the two sorts
+    HIP_TRY(hipMemsetAsync(counters, 0, 8, st));
     HIP_TRY(hipMemsetAsync(fkeys, 0xff, c * 4, st));
     rpn_make_keys<<<(unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256), 256, 0, st>>>(P.L, k_in, v_in);
-    const unsigned *v_sorted = sort_pairs<unsigned long long>(k_in, v_in, k_out, v_out, n, 35, tmp1, (unsigned *)counters + 2, st) ? v_out : v_in;
+    const unsigned *v_sorted = sort_pairs<unsigned long long>(k_in, v_in, k_out, v_out, n, 35, tmp1, st) ? v_out : v_in;
     rpn_decode_topk<<<(unsigned)((c + 255) / 256), 256, 0, st>>>(P.L, v_sorted, cbox, cscore, ck_in, cv_in, counters,
                                                                 (float)image_w, (float)image_h, min_size, kBoxClip);
     // per-level NMS on the level-major, score-descending candidates, then ONE sort of the survivors by score
     rpn_nms_mask<<<dim3(P.nb, P.nb, n_levels), 64, 0, st>>>(P.L, cbox, ck_in, nms_thresh, mask, P.nb);
     rpn_nms_scan<<<n_levels, 64, 0, st>>>(P.L, mask, P.nb, ck_in, post_nms_top_n, fkeys, counters + 1);
     // (the survivors' keys are only needed in order of their values: fkeys / cv_in are spent here)
-    const unsigned *cv_sorted = sort_pairs<unsigned>(fkeys, cv_in, ck_out, cv_out, c, 32, tmp2, (unsigned *)counters + 3, st) ? cv_out : cv_in;
+    const unsigned *cv_sorted = sort_pairs<unsigned>(fkeys, cv_in, ck_out, cv_out, c, 32, tmp2, st) ? cv_out : cv_in;
     rpn_emit_sorted<<<(post_nms_top_n + 255) / 256, 256, 0, st>>>(cv_sorted, counters + 1, post_nms_top_n, cbox, cscore,
                                                                   (float4 *)proposals, scores, count);
     HIP_TRY(hipGetLastError());
@@ -300,11 +307,11 @@ extern "C" int opdet_detections_f32(const float *class_logits, const float *box_
     NmsBuffers nb;
     carve_nms(p, P.cap, &nb);
 
-    HIP_TRY(hipMemsetAsync(n_valid, 0, 8, st));      // ... [1]: the sort's grid barrier
+    HIP_TRY(hipMemsetAsync(n_valid, 0, 4, st));
     det_score_boxes<<<max_rois, 256, 0, st>>>(class_logits, box_regression, (const float4 *)proposals, count, num_classes,
                                               (float)image_w, (float)image_h, score_thresh, 1e-2f, kBoxClip, cbox, cgroup,
                                               cscore, ck_in, cv_in, n_valid);
-    const unsigned *cv_sorted = sort_pairs<unsigned>(ck_in, cv_in, ck_out, cv_out, c, 32, tmp, (unsigned *)n_valid + 1, st) ? cv_out : cv_in;
+    const unsigned *cv_sorted = sort_pairs<unsigned>(ck_in, cv_in, ck_out, cv_out, c, 32, tmp, st) ? cv_out : cv_in;
     det_gather_sorted<<<(unsigned)((P.cap + 255) / 256), 256, 0, st>>>(cv_sorted, cbox, cgroup, cscore, nb.sbox, nb.sgroup,
                                                                       nb.sscore, n_valid, P.cap);
     if (int rc = run_nms(nb, n_valid, P.cap, nms_thresh, max_det, st)) return rc;

@@ -88,8 +88,8 @@ def test_refusals():
 
 
 def test_many_sorts_in_a_row_agree():
-    """The one-launch sort exchanges pairs between workgroups through write-through stores and a grid barrier: 300 sorts of fresh
-    keys at the RPN's size, each checked (a lost or late store would show up as a wrong permutation)."""
+    """300 sorts of fresh keys at the RPN's size, each checked (a race between the passes' launches or inside the wave-private
+    ranking would show up as a wrong permutation)."""
     lib = _lib.load()
     dev = torch.device("cuda:0")
     n = 217413
