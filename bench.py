@@ -891,19 +891,20 @@ def training_block(params, boxes, labels, dev):
     m = m.to(dev).train(True)
     opt = FusedAdam(m.parameters(), lr=1e-3)
     B = int(boxes.shape[0])
-    for _ in range(2):
+    n_warm, n_timed = 5, 20          # (5 timed steps charged the host's run-up to the first launch at ~30 us per step)
+    for _ in range(n_warm):
         train_step("opnet", m, opt, boxes, labels, n_global=B, comm_stream=None, loss_kind="l1")
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5):
+    for _ in range(n_timed):
         train_step("opnet", m, opt, boxes, labels, n_global=B, comm_stream=None, loss_kind="l1")
     e1.record()
     torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / 5
+    ms = e0.elapsed_time(e1) / n_timed
     persistent = (B <= int(os.environ.get("OPNET_XCD4_MAX_B", "32")) and os.environ.get("OPNET_XCD4", "1") != "0"
                   and bool(_lib.load().opnet_xcd_supported(CFG["object_to_track_hidden_dim"], CFG["videos_hidden_dim"])))
-    return {"training_step": {"batch": B, "ms_per_step": round(ms, 3), "clips_per_s": round(B / ms * 1e3, 1), "loss": "l1",
+    return {"training_step": {"batch": B, "ms_per_step": round(ms, 3), "clips_per_s": round(B / ms * 1e3, 1), "loss": "l1", "steps": n_timed, "warmup": n_warm,
                               "engine": "xcd4 (forward and reverse recurrence as one persistent launch each)" if persistent
                               else "chain (one launch per time step)"}}
 
