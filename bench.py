@@ -724,6 +724,7 @@ def main():
         return launcher_selftest(world, rank, args.mode, args.batch or 32)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    quiet_stdout()
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
@@ -849,14 +850,32 @@ def timed_repeats(args, dev, dist, world, region):
     return srt[len(srt) // 2], srt[0], srt[-1], times
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """file descriptor 1 -> stderr until the line is printed: RCCL writes a version banner through C stdio when the first
+    communicator is made (five lines on rank 0's stdout), and the contract is ONE JSON line there"""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
 def emit(out):
-    """the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which is only flushed at
-    exit - flush it first"""
+    """the JSON line is the ONLY thing on stdout: what C stdio still buffers (the RCCL banner) is flushed to where fd 1 points
+    now - stderr - before the real stdout comes back"""
+    global _REAL_STDOUT
     sys.stdout.flush()
     try:
         ctypes.CDLL(None).fflush(None)
     except OSError:
         pass
+    if _REAL_STDOUT is not None:
+        os.dup2(_REAL_STDOUT, 1)
+        os.close(_REAL_STDOUT)
+        _REAL_STDOUT = None
     print(json.dumps(out), flush=True)
 
 

@@ -36,6 +36,9 @@ python bench.py --mode transformer > $O/bench_transformer.json 2> $O/bench_trans
 python bench.py --mode train --steps 20 --warmup 5 --loss l1 > $O/bench_train_b32.json 2> $O/bench_train_b32.err
 python bench.py --mode train --force-dist --steps 20 --warmup 5 --loss l1 --no-cpu-baseline > $O/bench_train_b32_forcedist.json 2> $O/bench_train_b32_forcedist.err
 python bench.py --mode detect > $O/bench_detect16.json 2> $O/bench_detect16.err
+python bench.py --mode detect --batch 1 --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_detect1.json 2> $O/bench_detect1.err
+PYTHONPATH=$R python tools/sort_time.py > $O/detector_sort_time.txt 2>&1
+python tools/detector_full_time.py 1 2 4 16 > $O/detector_full_time.txt 2>&1
 # per-launch durations of the persistent forward out of the kernel trace (the stats CSV only has the mean over all launch shapes)
 python - <<'PY' > $O/bench_xcd_forward_launches.csv 2>&1
 import csv, glob, os
