@@ -2810,7 +2810,7 @@ static int conv_split_plan(const ConvArgs &a, long M, int *ksteps)
     if ((long)a.N * a.H * a.W * a.Cin * 4 >= (1L << 31) || (long)a.Cout * a.KP * 4 >= (1L << 31)) return 1;
     const int nhex = a.KP >> 4;
     const long tiles = ((M + 127) / 128) * (a.Cout > 64 ? (a.Cout + 127) / 128 : (a.Cout + 63) / 64);
-    long S = (640 + tiles - 1) / tiles;
+    long S = (640 + tiles - 1) / tiles;      // (swept on the one-frame call: 400 .. 1024 workgroups x >= 8 .. 32 steps; this is the minimum)
     if (S > nhex / 16) S = nhex / 16;
     if (S > 32) S = 32;
     if (S < 2) return 1;
