@@ -799,9 +799,14 @@ extern "C" size_t opnet_train_workspace_bytes(int B, int T, int H1, int H2)
 // launch-chain step; a batch that trains on the 4-clip persistent kernels reads the x4 images and the output-head tiles.
 // opnet_train_pack_weights_f32 therefore packs those three eagerly and leaves the rest to the first launch-chain call that
 // follows (train_chain_layouts) - the caller's weight pointers are remembered per packed buffer until then.
-struct TrainPackState { const float *w[6]; int H1, H2; bool chain_stale; };
+// g_tp holds ONLY buffers whose chain layouts are still owed (an entry is dropped when they are packed, when the buffer is packed
+// again, or when it becomes an OPNetLstmMlp image); it is never pruned - a pruned entry would make the next launch-chain step read
+// layouts that were never written - and when it is full (entries of modules that died unpacked linger: their addresses are only
+// ever looked up again after a new pack has replaced the entry) a new buffer is simply packed in full.
+struct TrainPackState { const float *w[6]; int H1, H2; };
 static std::mutex g_tp_mu;
 static std::map<const float *, TrainPackState> g_tp;
+static const size_t kTrainPackPending = 4096;
 
 static int pack_chain_train_layouts(const float *w_ih1, const float *w_hh1, const float *w_sel, const float *w_ih2,
                                     const float *w_hh2, const float *w_out, float *packed, int H1, int H2, hipStream_t st)
@@ -825,10 +830,10 @@ static int train_chain_layouts(const float *packed, hipStream_t st)
 {
     std::lock_guard<std::mutex> lock(g_tp_mu);
     auto it = g_tp.find(packed);
-    if (it == g_tp.end() || !it->second.chain_stale) return OPNET_OK;
-    TrainPackState &t = it->second;
+    if (it == g_tp.end()) return OPNET_OK;
+    const TrainPackState t = it->second;
     if (int rc = pack_chain_train_layouts(t.w[0], t.w[1], t.w[2], t.w[3], t.w[4], t.w[5], (float *)packed, t.H1, t.H2, st)) return rc;
-    t.chain_stale = false;
+    g_tp.erase(it);
     return OPNET_OK;
 }
 
@@ -856,7 +861,11 @@ extern "C" int opnet_train_pack_weights_f32(const float *w_ih1, const float *w_h
     if (packed_bytes < L.total * sizeof(float))
         return fail(OPNET_EWORKSPACE, "packed buffer %zu B < %zu B", packed_bytes, L.total * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
-    const bool lazy = x4_dims(H1, H2) && x4_on() && x4_device();
+    bool lazy = x4_dims(H1, H2) && x4_on() && x4_device();
+    if (lazy) {
+        std::lock_guard<std::mutex> lock(g_tp_mu);
+        if (g_tp.find(packed) == g_tp.end() && g_tp.size() >= kTrainPackPending) lazy = false;      // no room to owe: pack in full
+    }
     if (!lazy) {
         if (int rc = pack_chain_train_layouts(w_ih1, w_hh1, w_sel, w_ih2, w_hh2, w_out, packed, H1, H2, st)) return rc;
     }
@@ -869,9 +878,8 @@ extern "C" int opnet_train_pack_weights_f32(const float *w_ih1, const float *w_h
     HIP_TRY(hipGetLastError());
     {
         std::lock_guard<std::mutex> lock(g_tp_mu);
-        if (g_tp.size() > 64) g_tp.clear();          // buffers come and go with their modules: forgetting one only costs a full pack
-        TrainPackState t = {{w_ih1, w_hh1, w_sel, w_ih2, w_hh2, w_out}, H1, H2, lazy};
-        g_tp[packed] = t;
+        if (lazy) g_tp[packed] = TrainPackState{{w_ih1, w_hh1, w_sel, w_ih2, w_hh2, w_out}, H1, H2};
+        else g_tp.erase(packed);
     }
     return OPNET_OK;
 }
