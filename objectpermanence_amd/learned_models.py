@@ -965,7 +965,7 @@ class TransformerLstm(AbstractCaterModel):
         self.video_LSTM = LSTMWeights(e, h, num_layers=ll)
         self.predictions_layer = LinearWeight(h, self.bb_out_dim)
         self._runner = _LstmStackRunner(ll, e, h)
-        self._ews = None
+        self._ews: Dict[int, torch.Tensor] = {}      # encoder workspace per stream
         self._tscratch = None
         self._calls = 0
         # tests only: {layer: (attention [nhead, S, S], after out_proj [S, E], after ReLU [S, ffn], after linear2 [S, E])} uint8
@@ -1049,20 +1049,24 @@ class TransformerLstm(AbstractCaterModel):
             nb = lib.opseq_encoder_workspace_bytes(St, e, self._nhead, self.FFN)
             if nb == 0:
                 _lib.check(-2, "opseq_encoder_workspace_bytes")
-            if self._ews is None or self._ews.numel() < nb or self._ews.device != dev:
-                self._ews = torch.empty(nb, dtype=torch.uint8, device=dev)
+            # one encoder workspace per stream: a server keeps two passes in flight on two streams (serving.py)
+            ews = self._ews.get(stream)
+            if ews is None or ews.numel() < nb or ews.device != dev:
+                if len(self._ews) >= 4:
+                    self._ews.pop(next(iter(self._ews)))
+                ews = self._ews[stream] = torch.empty(nb, dtype=torch.uint8, device=dev)
             for layer in self.attention_encoder.layers:
                 ts = layer.tensors()
                 for t_ in ts:
                     if t_.device != dev or not t_.is_contiguous() or t_.dtype != torch.float32:
                         raise RuntimeError("parameters must be contiguous fp32 on the input's device")
                 if n_seg == 1:
-                    rc = lib.opseq_encoder_layer_f32(z.data_ptr(), *(t_.data_ptr() for t_ in ts), self._ews.data_ptr(),
-                                                     self._ews.numel(), S, e, self._nhead, self.FFN, stream)
+                    rc = lib.opseq_encoder_layer_f32(z.data_ptr(), *(t_.data_ptr() for t_ in ts), ews.data_ptr(),
+                                                     ews.numel(), S, e, self._nhead, self.FFN, stream)
                     _lib.check(rc, "opseq_encoder_layer_f32")
                 else:
-                    rc = lib.opseq_encoder_layer_segmented_f32(z.data_ptr(), *(t_.data_ptr() for t_ in ts), self._ews.data_ptr(),
-                                                               self._ews.numel(), S, n_seg, e, self._nhead, self.FFN, stream)
+                    rc = lib.opseq_encoder_layer_segmented_f32(z.data_ptr(), *(t_.data_ptr() for t_ in ts), ews.data_ptr(),
+                                                               ews.numel(), S, n_seg, e, self._nhead, self.FFN, stream)
                     _lib.check(rc, "opseq_encoder_layer_segmented_f32")
             return self._runner.run(z.view(B, T, e), self.video_LSTM, self.predictions_layer)
 

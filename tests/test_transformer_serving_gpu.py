@@ -82,6 +82,32 @@ def test_server_merges_transformer_requests_as_segments():
         assert torch.equal(o, a)
 
 
+def test_two_passes_in_flight_return_the_lone_results():
+    """a segmented server issues its passes on two side streams in turn (one pass's encoder under the other's recurrence): 80
+    one-clip requests = five passes of 16; every result - read in any order, consumed on the caller's stream with no host wait -
+    is the lone forward's, and a one-stream server gives the same"""
+    from objectpermanence_amd.serving import ReasonerServer
+    m = _model(dict(REAL, num_attention_heads=4))
+    reqs = _requests(2100, 80, 1, 300)
+    with torch.no_grad():
+        alone = [m(r).clone() for r in reqs]
+    torch.cuda.synchronize()
+    for streams in (None, 1):
+        server = ReasonerServer(m, "transformer_lstm", max_clips=16, streams=streams)
+        handles = [server.submit(r) for r in reqs]
+        assert server.forwards == 5 and all(h.done() for h in handles)
+        assert (handles[0]._event is not None) == (streams is None)
+        total = torch.zeros((), device="cuda:0")
+        for k in list(range(79, -1, -7)) + list(range(80)):                      # any order, some twice
+            y = handles[k].result()
+            assert handles[k]._event is None
+            total = total + (y - alone[k]).abs().sum()                              # enqueued on the caller's stream, no sync before
+        torch.cuda.synchronize()
+        assert float(total) == 0.0
+        for h, a in zip(handles, alone):
+            assert torch.equal(h.result(), a)
+
+
 def test_a_pass_is_cut_where_the_lone_engine_would_change():
     """the persistent stack launch carries 128 clips (L = 2): the server flushes there instead of letting the merged batch fall
     to the launch chain, whose sums differ in the last bits from the lone request's"""
