@@ -57,6 +57,10 @@ def main(argv=None) -> int:
     # the JSON's "device" is overridden by it - and the drivers shard clips / minibatches over the ranks (parallel.py);
     # rank 0 writes the files.  Without that environment this is the reference's single-device run.
     from . import parallel
+    import os
+    if os.environ.get("OPNET_SEED"):     # a reproducible random initialisation (the reference leaves torch's seed alone)
+        import torch
+        torch.manual_seed(int(os.environ["OPNET_SEED"]))
     with parallel.init_from_env():
         return _run(args)
 

@@ -76,13 +76,15 @@ def init_from_env(backend: Optional[str] = None) -> Launch:
         return _launch
     world = max(world, 1)
     if has_gpu:
-        if local_rank >= torch.cuda.device_count():
+        if local_rank >= torch.cuda.device_count():      # (with gloo, LOCAL_RANK may repeat: ranks sharing a device)
             raise RuntimeError(f"LOCAL_RANK {local_rank} but this node exposes {torch.cuda.device_count()} GPU(s): start at most "
                                "one rank per GPU")
         torch.cuda.set_device(device)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
-    backend = backend or ("nccl" if has_gpu else "gloo")
+    # OPNET_DIST_BACKEND=gloo: several ranks on ONE device (RCCL refuses that) - how a box with a single GPU runs world size 2
+    # (tests/test_dp_two_ranks_gpu.py); gloo moves device tensors through the host
+    backend = backend or os.environ.get("OPNET_DIST_BACKEND") or ("nccl" if has_gpu else "gloo")
     kw = {"device_id": device} if backend == "nccl" else {}
     dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     _launch = Launch(True, device, world, rank, local_rank)
@@ -111,6 +113,17 @@ def resolve_device(config_device) -> torch.device:
     if _launch is not None and _launch.device is not None and dist.is_available() and dist.is_initialized():
         return _launch.device
     return torch.device(config_device)
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:
+    """every rank starts from rank `src`'s weights: the reference builds its model with torch's random initialisation
+    (training_main.py:144-150, one process) - N processes doing the same would hold N different models, and averaging their
+    gradients would train none of them.  In place, before the first forward (nothing is packed yet).  No-op outside a job."""
+    if not is_active(group):
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src, group=group)
 
 
 def shard_size(n_items: int, world: int) -> int:

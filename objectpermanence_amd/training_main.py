@@ -123,6 +123,7 @@ def training_main(model_name: str, train_config: Dict[str, Any], model_config: D
     bs, nw = train_config["batch_size"], train_config["num_workers"]
     ibs = train_config["inference_batch_size"]
     model = ModelsFactory.get_model(model_name, model_config).to(device)
+    parallel.broadcast_parameters(model)          # data parallel: every rank trains rank 0's random initialisation
     optimizer = FusedAdam(model.parameters(), lr=train_config["learning_rate"])
     scheduler = ReduceLROnPlateau(optimizer, mode="min", factor=train_config["lr_scheduler_factor"],
                                   patience=train_config["lr_scheduler_patience"])

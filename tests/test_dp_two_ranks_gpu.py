@@ -5,10 +5,13 @@ with IDENTICAL weights, and those must be the single-process full-minibatch weig
 contract for a sharded run: N-GPU == 1-GPU, training_main.py:183-217).  The persistent engines are switched off in the workers (two
 processes cannot both hold all 256 CUs): what runs is the launch chain, the same arithmetic behind the same exchange.
 tests/test_dp_rccl_gpu.py has the RCCL transport (world of one, bit-identical); test_host_logic.py the gloo logic on CPU."""
+import json
 import os
+import pickle
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -65,3 +68,82 @@ def test_two_ranks_on_one_gpu_train_to_the_single_process_weights(tmp_path, B, T
         if B % 2 == 0:
             assert r0["losses"][k][0] != r1["losses"][k][0]                          # (their own shards' losses differ)
     assert float(r0["guard"][0]) == 0.0 and float(r0["guard"][1]) == 0.0
+
+
+def _two_ranks(args, tmp_path, seeds=("0", "0")):
+    """`python -m objectpermanence_amd <args>` as two ranks on cuda:0 (what torchrun would start, but LOCAL_RANK 0 twice)"""
+    env = dict(os.environ, WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 200),
+               OPNET_DIST_BACKEND="gloo", OPNET_XCD4="0", OPNET_XCD="0", PYTHONPATH=REPO)
+    env.pop("OPNET_FORCE_DIST", None)
+    procs = [subprocess.Popen([sys.executable, "-m", "objectpermanence_amd"] + args, env=dict(env, RANK=str(r), OPNET_SEED=seeds[r]), cwd=str(tmp_path),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    return outs
+
+
+def _write_videos(tmp_path, tag, n, first, with_mask=False):
+    s, l = tmp_path / f"{tag}_s", tmp_path / f"{tag}_l"
+    s.mkdir(); l.mkdir()
+    lines = []
+    for i in range(n):
+        name = f"{tag}{i:02d}"
+        bb, lab, gt = synth.make_raw_video(first + i, "plain")
+        pickle.dump({"bb": bb, "labels": lab}, open(s / (name + ".pkl"), "wb"), pickle.HIGHEST_PROTOCOL)
+        json.dump(gt, open(l / (name + "_bb.json"), "w"))
+        lines.append(name + "\t" + ",".join(str(x) for x in range(10 * i, 10 * i + 25)) + "\n")
+    if with_mask:
+        open(tmp_path / f"{tag}_mask.txt", "w").writelines(lines)
+    return str(s), str(l), str(tmp_path / f"{tag}_mask.txt")
+
+
+def test_inference_entry_point_at_world_size_two_writes_the_single_process_files(tmp_path, monkeypatch):
+    """`python -m objectpermanence_amd inference` as two ranks: clips sharded 4 + 3, predictions and IoUs gathered by dataset index,
+    rank 0 alone writes - the files equal the single-process run's byte for byte (same engine: clips are independent)"""
+    from objectpermanence_amd.inference_main import reasoning_inference_main
+    s, l, _ = _write_videos(tmp_path, "v", 7, 40)
+    torch.save({k: torch.from_numpy(v) for k, v in synth.opnet_synth_params(CFG).items()}, tmp_path / "opnet.pth")
+    json.dump(CFG, open(tmp_path / "model.json", "w"))
+    json.dump({"batch_size": 3, "num_workers": 0, "device": "cuda:0", "model_path": str(tmp_path / "opnet.pth"), "videos_dir": "unused",
+               "sample_dir": s, "labels_dir": l}, open(tmp_path / "infer.json", "w"))
+    _two_ranks(["inference", "--model_type", "opnet", "--results_dir", str(tmp_path / "out2"), "--inference_config",
+                str(tmp_path / "infer.json"), "--model_config", str(tmp_path / "model.json")], tmp_path)
+    monkeypatch.setenv("OPNET_XCD4", "0")
+    monkeypatch.setenv("OPNET_XCD", "0")
+    plain = reasoning_inference_main("opnet", str(tmp_path / "out1"), str(tmp_path / "infer.json"), str(tmp_path / "model.json"))
+    assert len(plain["video_names"]) == 7
+    for n in plain["video_names"]:
+        assert open(tmp_path / "out1" / (n + "_bb.json")).read() == open(tmp_path / "out2" / (n + "_bb.json")).read(), n
+
+
+def test_training_entry_point_at_world_size_two_checkpoints_the_single_process_weights(tmp_path, monkeypatch):
+    """`python -m objectpermanence_amd training` as two ranks: every minibatch of 4 split 2 + 2, gradients all-reduced, the
+    per-epoch evaluation sharded and gathered, rank 0 alone checkpoints - the weights are the single-process run's up to the
+    order of the fp32 sums through six Adam steps.  The ranks are seeded DIFFERENTLY (0 and 123): rank 1 must take rank 0's random
+    initialisation (parallel.broadcast_parameters), as N processes of the reference's unseeded construction would differ"""
+    from objectpermanence_amd.training_main import training_main
+    tr = _write_videos(tmp_path, "train", 8, 100, with_mask=True)
+    dv = _write_videos(tmp_path, "dev", 3, 100, with_mask=True)
+
+    def cfg(tag):
+        return {"batch_size": 4, "inference_batch_size": 400, "num_workers": 0, "num_epochs": 3, "print_step": 100,
+                "learning_rate": 0.001, "lr_scheduler_patience": 2, "lr_scheduler_factor": 0.8, "device": "cuda:0",
+                "checkpoints_path": str(tmp_path / f"ckpt_{tag}"),
+                "train_sample_dir": tr[0], "train_labels_dir": tr[1], "train_containment_file": tr[2],
+                "dev_sample_dir": dv[0], "dev_labels_dir": dv[1], "dev_containment_file": dv[2]}
+
+    json.dump(CFG, open(tmp_path / "model.json", "w"))
+    json.dump(cfg("dp"), open(tmp_path / "train.json", "w"))
+    _two_ranks(["training", "--model_type", "opnet", "--model_config", str(tmp_path / "model.json"), "--training_config",
+                str(tmp_path / "train.json")], tmp_path, seeds=("0", "123"))
+    monkeypatch.setenv("OPNET_XCD4", "0")
+    monkeypatch.setenv("OPNET_XCD", "0")
+    torch.manual_seed(0)
+    plain = training_main("opnet", cfg("plain"), CFG)
+    got = sorted((tmp_path / "ckpt_dp").rglob("*.pth"))
+    want = sorted((tmp_path / "ckpt_plain").rglob("*.pth"))
+    assert want and [p.name for p in got] == [p.name for p in want]      # same epochs checkpointed (same dev-loss history), by rank 0 only
+    a, b = torch.load(got[-1]), torch.load(want[-1])
+    assert set(a) == set(b)
+    for k in a:
+        assert float((a[k].float() - b[k].float()).abs().max()) <= 1e-4, k

@@ -639,3 +639,33 @@ def test_server_merges_segmenting_models_by_request_not_by_concatenation():
     for r, o in zip(reqs, outs):
         assert o.shape == (r.shape[0], 5, 4) and float(o[0, 0, 0]) == float(r[0, 0].sum())
     assert server.forwards == 3
+
+
+def _broadcast_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    from objectpermanence_amd import parallel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                       # N processes of the reference's unseeded construction: N different models
+    m = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.BatchNorm1d(3))
+    m[1].running_mean.fill_(float(rank + 1))
+    before = [p.detach().clone() for p in m.parameters()]
+    parallel.broadcast_parameters(m)
+    torch.save({"after": [t.detach().clone() for t in list(m.parameters()) + list(m.buffers())], "before": before},
+               os.path.join(tmp, f"b{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_every_rank_starts_from_rank_zeros_weights(tmp_path):
+    """training_main builds its model with torch's random initialisation on every rank: broadcast_parameters makes them one model
+    (without it, averaging the gradients of N different models trains none of them); a no-op outside a job"""
+    import torch.multiprocessing as mp
+    from objectpermanence_amd import parallel
+    mp.spawn(_broadcast_worker, args=(2, 36100 + os.getpid() % 1000, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"b{r}.pt")) for r in range(2))
+    assert not torch.equal(r0["before"][0], r1["before"][0])
+    assert all(torch.equal(a, b) for a, b in zip(r0["after"], r1["after"]))                 # parameters AND buffers
+    assert all(torch.equal(a, b) for a, b in zip(r0["after"][:len(r0["before"])], r0["before"]))   # ... rank 0's
+    lone = torch.nn.Linear(2, 2)
+    w = lone.weight.detach().clone()
+    parallel.broadcast_parameters(lone)
+    assert torch.equal(lone.weight, w)
