@@ -739,7 +739,9 @@ def main():
             os.environ["OPNET_FORCE_DIST"] = "1"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        # (OPNET_DIST_BACKEND=gloo: several ranks on ONE device - how a single-GPU box rehearses `--gpus 2`, tests/test_dp_two_ranks_gpu.py)
+        backend = os.environ.get("OPNET_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
 

@@ -147,3 +147,25 @@ def test_training_entry_point_at_world_size_two_checkpoints_the_single_process_w
     assert set(a) == set(b)
     for k in a:
         assert float((a[k].float() - b[k].float()).abs().max()) <= 1e-4, k
+
+
+@pytest.mark.parametrize("mode_args", [["--engine", "chain"], ["--mode", "train"]])
+def test_bench_as_two_ranks_prints_one_line_from_rank_zero(tmp_path, mode_args):
+    """the driver's `--gpus N` command, rehearsed at N = 2 on the one GPU (gloo, launch-chain engines): the barrier / max-over-ranks
+    timing, the periodic all-gather of predictions (inference) or the bucket all-reduce (training) run, rank 0 prints exactly one JSON
+    line with n_gpus 2 and dp2, rank 1 prints nothing"""
+    env = dict(os.environ, WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29300 + os.getpid() % 200),
+               OPNET_DIST_BACKEND="gloo", OPNET_XCD4="0", OPNET_XCD="0", PYTHONPATH=REPO)
+    env.pop("OPNET_FORCE_DIST", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2",
+           "--no-cpu-baseline"] + mode_args
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+    res = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(e.decode(errors="replace")[-2000:] for _, e in res)
+    out0, out1 = res[0][0].decode().strip(), res[1][0].decode().strip()
+    assert out1 == "" and len(out0.splitlines()) == 1
+    line = json.loads(out0)
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["steps"] == 3 and line["warmup"] == 1
+    if "train" in mode_args:
+        assert line["allreduce_ms_per_step"] is not None and np.isfinite(line["final_loss"])
