@@ -73,7 +73,7 @@ def test_two_ranks_on_one_gpu_train_to_the_single_process_weights(tmp_path, B, T
 def _two_ranks(args, tmp_path, seeds=("0", "0")):
     """`python -m objectpermanence_amd <args>` as two ranks on cuda:0 (what torchrun would start, but LOCAL_RANK 0 twice)"""
     env = dict(os.environ, WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 200),
-               OPNET_DIST_BACKEND="gloo", OPNET_XCD4="0", OPNET_XCD="0", PYTHONPATH=REPO)
+               OPNET_DIST_BACKEND="gloo", OPNET_XCD4="0", OPNET_XCD="0", OPSEQ_XCD="0", PYTHONPATH=REPO)
     env.pop("OPNET_FORCE_DIST", None)
     procs = [subprocess.Popen([sys.executable, "-m", "objectpermanence_amd"] + args, env=dict(env, RANK=str(r), OPNET_SEED=seeds[r]), cwd=str(tmp_path),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
@@ -169,3 +169,40 @@ def test_bench_as_two_ranks_prints_one_line_from_rank_zero(tmp_path, mode_args):
     assert line["value"] > 0 and line["steps"] == 3 and line["warmup"] == 1
     if "train" in mode_args:
         assert line["allreduce_ms_per_step"] is not None and np.isfinite(line["final_loss"])
+
+
+def test_cater_inference_entry_point_at_world_size_two_writes_the_single_process_csv(tmp_path, monkeypatch):
+    """`python -m objectpermanence_amd cater_inference` as two ranks: minibatches dealt to the ranks, last-frame boxes gathered by
+    dataset index, rank 0 writes class_pred_results.csv - the same file as the single-process run"""
+    from objectpermanence_amd.cater_setup_inference import cater_setup_inference
+    s, l, _ = _write_videos(tmp_path, "CATER_new_0000", 7, 40)
+    torch.save({k: torch.from_numpy(v) for k, v in synth.opnet_synth_params(CFG).items()}, tmp_path / "opnet.pth")
+    json.dump(CFG, open(tmp_path / "model.json", "w"))
+    json.dump({"batch_size": 2, "num_workers": 0, "device": "cuda:0", "model_path": str(tmp_path / "opnet.pth"), "sample_dir": s,
+               "labels_dir": l}, open(tmp_path / "infer.json", "w"))
+    _two_ranks(["cater_inference", "--results_dir", str(tmp_path / "out2"), "--inference_config", str(tmp_path / "infer.json"),
+                "--model_config", str(tmp_path / "model.json")], tmp_path)
+    monkeypatch.setenv("OPNET_XCD4", "0")
+    monkeypatch.setenv("OPNET_XCD", "0")
+    df = cater_setup_inference("opnet", str(tmp_path / "out1"), str(tmp_path / "infer.json"), str(tmp_path / "model.json"))
+    assert len(df) == 7
+    assert open(tmp_path / "out1" / "class_pred_results.csv").read() == open(tmp_path / "out2" / "class_pred_results.csv").read()
+
+
+def test_transformer_inference_at_world_size_two_keeps_the_reference_minibatches(tmp_path, monkeypatch):
+    """transformer_lstm couples the clips of a minibatch (attention over B x T tokens): the ranks take WHOLE reference minibatches
+    (7 clips at batch_size 2: minibatches 0, 2 / 1, 3), never a cut through one - the files equal the single-process run's"""
+    from objectpermanence_amd.inference_main import reasoning_inference_main
+    cfg = {"boxes_features_dim": 256, "num_attention_heads": 4, "num_attention_layers": 2, "num_lstm_layers": 2, "lstm_hidden_dim": 512}
+    s, l, _ = _write_videos(tmp_path, "v", 7, 60)
+    torch.save({k: torch.from_numpy(v) for k, v in synth.transformer_lstm_synth_params(cfg).items()}, tmp_path / "t.pth")
+    json.dump(cfg, open(tmp_path / "model.json", "w"))
+    json.dump({"batch_size": 2, "num_workers": 0, "device": "cuda:0", "model_path": str(tmp_path / "t.pth"), "videos_dir": "unused",
+               "sample_dir": s, "labels_dir": l}, open(tmp_path / "infer.json", "w"))
+    _two_ranks(["inference", "--model_type", "transformer_lstm", "--results_dir", str(tmp_path / "out2"), "--inference_config",
+                str(tmp_path / "infer.json"), "--model_config", str(tmp_path / "model.json")], tmp_path)
+    monkeypatch.setenv("OPSEQ_XCD", "0")
+    plain = reasoning_inference_main("transformer_lstm", str(tmp_path / "out1"), str(tmp_path / "infer.json"), str(tmp_path / "model.json"))
+    assert len(plain["video_names"]) == 7
+    for n in plain["video_names"]:
+        assert open(tmp_path / "out1" / (n + "_bb.json")).read() == open(tmp_path / "out2" / (n + "_bb.json")).read(), n
