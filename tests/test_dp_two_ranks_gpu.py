@@ -206,3 +206,29 @@ def test_transformer_inference_at_world_size_two_keeps_the_reference_minibatches
     assert len(plain["video_names"]) == 7
     for n in plain["video_names"]:
         assert open(tmp_path / "out1" / (n + "_bb.json")).read() == open(tmp_path / "out2" / (n + "_bb.json")).read(), n
+
+
+def test_preprocess_entry_point_at_world_size_two_deals_the_videos(tmp_path):
+    """`python -m objectpermanence_amd preprocess` as two ranks: videos dealt round-robin (no collective), every rank writes the
+    <video>.pkl files of its own videos into the shared directory - together exactly the single-process run's files"""
+    from oracle import detector_oracle as do
+    from objectpermanence_amd.preprocess_perception_main import preprocess_main
+    vids = tmp_path / "videos"
+    vids.mkdir()
+    rng = np.random.default_rng(3)
+    for i in range(3):
+        np.save(vids / f"cater_{i:03d}.npy", rng.integers(0, 256, size=(300, 60, 80, 3), dtype=np.uint8))
+    np.save(vids / "cater_short.npy", rng.integers(0, 256, size=(299, 60, 80, 3), dtype=np.uint8))      # not 300 frames: never written
+    sd = {k: torch.from_numpy(v) for k, v in {**do.synth_backbone_params(), **do.synth_head_params()}.items()}
+    torch.save({"model_state_dict": sd}, tmp_path / "detection_model.pth")
+    json.dump({"videos_dir": str(vids), "od_model_weights": str(tmp_path / "detection_model.pth"), "device": "cuda:0"},
+              open(tmp_path / "preprocess.json", "w"))
+    (tmp_path / "res2").mkdir()
+    (tmp_path / "res1").mkdir()
+    _two_ranks(["preprocess", "--results_dir", str(tmp_path / "res2"), "--config", str(tmp_path / "preprocess.json")], tmp_path)
+    assert preprocess_main(str(tmp_path / "res1"), str(tmp_path / "preprocess.json")) == 3
+    names = sorted(os.listdir(tmp_path / "res1"))
+    assert names == sorted(os.listdir(tmp_path / "res2")) == [f"cater_{i:03d}.pkl" for i in range(3)]
+    for n in names:
+        a, b = pickle.load(open(tmp_path / "res1" / n, "rb")), pickle.load(open(tmp_path / "res2" / n, "rb"))
+        assert all(np.array_equal(x, y) for x, y in zip(a["bb"], b["bb"])) and all(np.array_equal(x, y) for x, y in zip(a["labels"], b["labels"]))
