@@ -232,3 +232,24 @@ def test_preprocess_entry_point_at_world_size_two_deals_the_videos(tmp_path):
     for n in names:
         a, b = pickle.load(open(tmp_path / "res1" / n, "rb")), pickle.load(open(tmp_path / "res2" / n, "rb"))
         assert all(np.array_equal(x, y) for x, y in zip(a["bb"], b["bb"])) and all(np.array_equal(x, y) for x, y in zip(a["labels"], b["labels"]))
+
+
+def test_transformer_training_entry_point_runs_at_world_size_two(tmp_path):
+    """`training --model_type transformer_lstm` as two ranks (whole reference minibatches per rank, dropout live, the encoder's
+    gradients through the same bucket): it must finish - an uneven number of minibatches per rank (3 minibatches, 2 ranks) once hung
+    the all-reduce on CPU (test_host_logic) - and rank 0 alone checkpoints finite weights"""
+    tr = _write_videos(tmp_path, "train", 6, 100, with_mask=True)
+    dv = _write_videos(tmp_path, "dev", 2, 100, with_mask=True)
+    cfg = {"boxes_features_dim": 256, "num_attention_heads": 4, "num_attention_layers": 2, "num_lstm_layers": 2, "lstm_hidden_dim": 512}
+    json.dump(cfg, open(tmp_path / "model.json", "w"))
+    json.dump({"batch_size": 2, "inference_batch_size": 2, "num_workers": 0, "num_epochs": 2, "print_step": 100, "learning_rate": 0.001,
+               "lr_scheduler_patience": 2, "lr_scheduler_factor": 0.8, "device": "cuda:0", "checkpoints_path": str(tmp_path / "ckpt"),
+               "train_sample_dir": tr[0], "train_labels_dir": tr[1], "train_containment_file": tr[2],
+               "dev_sample_dir": dv[0], "dev_labels_dir": dv[1], "dev_containment_file": dv[2]}, open(tmp_path / "train.json", "w"))
+    outs = _two_ranks(["training", "--model_type", "transformer_lstm", "--model_config", str(tmp_path / "model.json"), "--training_config",
+                       str(tmp_path / "train.json")], tmp_path, seeds=("0", "5"))
+    assert "Epoch 2 Dev Set" in outs[0] and "Epoch" not in outs[1]                  # rank 0 alone reports
+    ck = sorted((tmp_path / "ckpt").rglob("*.pth"))
+    assert ck
+    sd = torch.load(ck[-1])
+    assert all(bool(torch.isfinite(v.float()).all()) for v in sd.values())
