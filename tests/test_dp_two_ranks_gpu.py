@@ -19,6 +19,14 @@ from oracle import synth
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> str:
+    """a port nobody listens on right now (every launch gets its own: a rendezvous port in TIME_WAIT must not fail the next test)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
 CFG = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
 
 
@@ -43,7 +51,7 @@ def _single(B, T, steps):
 @pytest.mark.parametrize("B,T", [(12, 10), (7, 25)])          # (7, 25): shards of 4 and 3 clips - unequal weights n_local / n_global
 def test_two_ranks_on_one_gpu_train_to_the_single_process_weights(tmp_path, B, T):
     steps = 3
-    env = dict(os.environ, WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200),
+    env = dict(os.environ, WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(),
                OPNET_XCD4="0", OPNET_XCD="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=REPO)
     env.pop("OPNET_FORCE_DIST", None)
     procs = [subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "_dp2_worker.py"), str(tmp_path), str(B), str(T), str(steps)],
@@ -72,7 +80,7 @@ def test_two_ranks_on_one_gpu_train_to_the_single_process_weights(tmp_path, B, T
 
 def _two_ranks(args, tmp_path, seeds=("0", "0")):
     """`python -m objectpermanence_amd <args>` as two ranks on cuda:0 (what torchrun would start, but LOCAL_RANK 0 twice)"""
-    env = dict(os.environ, WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 200),
+    env = dict(os.environ, WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(),
                OPNET_DIST_BACKEND="gloo", OPNET_XCD4="0", OPNET_XCD="0", OPSEQ_XCD="0", PYTHONPATH=REPO)
     env.pop("OPNET_FORCE_DIST", None)
     procs = [subprocess.Popen([sys.executable, "-m", "objectpermanence_amd"] + args, env=dict(env, RANK=str(r), OPNET_SEED=seeds[r]), cwd=str(tmp_path),
@@ -154,7 +162,7 @@ def test_bench_as_two_ranks_prints_one_line_from_rank_zero(tmp_path, mode_args):
     """the driver's `--gpus N` command, rehearsed at N = 2 on the one GPU (gloo, launch-chain engines): the barrier / max-over-ranks
     timing, the periodic all-gather of predictions (inference) or the bucket all-reduce (training) run, rank 0 prints exactly one JSON
     line with n_gpus 2 and dp2, rank 1 prints nothing"""
-    env = dict(os.environ, WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29300 + os.getpid() % 200),
+    env = dict(os.environ, WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(),
                OPNET_DIST_BACKEND="gloo", OPNET_XCD4="0", OPNET_XCD="0", PYTHONPATH=REPO)
     env.pop("OPNET_FORCE_DIST", None)
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2",
