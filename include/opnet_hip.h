@@ -39,7 +39,7 @@ extern "C" {
 
 /* bumped whenever entry points are added or a signature changes; the Python mirror refuses a library of another version
  * (objectpermanence_amd/_lib.py) instead of failing later on a missing symbol.  4 = round 4. */
-#define OPNET_HIP_ABI_VERSION 4
+#define OPNET_HIP_ABI_VERSION 5
 int opnet_hip_abi_version(void);
 const char *opnet_last_error(void);
 
@@ -276,6 +276,26 @@ int opseq_xcd_pack_weights_f32(const float *const *w_ih, const float *const *w_h
                                int L, int KX, int H, void *stream);
 int opseq_xcd_forward_f32(const float *x, const float *packed, const float *w_head, float *y, void *workspace,
                           size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream);
+/* ---- the same stack as ONE persistent launch, THROUGHPUT form (csrc/seq_xcdt_kernels.hip) -----------------------------------
+ * For batches (the inference driver over a dataset, the per-epoch evaluation, a server's merged passes): groups of SIXTEEN clips
+ * on v_mfma_f32_16x16x4_f32, a product wave and a finish wave per SIMD (the scheme of opnet_xcd_forward_f32).  H = 512;
+ * L = 1 with KX <= 80 (learned_models.py:99-101: one copy of the layer per XCD) or L = 2 with KX % 16 == 0 (:135-137, :170-171:
+ * the layer-0 input product as one GEMM before the launch, the two layers on a pair of XCDs).  At most
+ * opseq_xcdt_max_batch(T, ...) clips per launch (callers loop).  Results agree with opseq_xcd_forward_f32 /
+ * opseq_lstm_stack_forward_f32 to rounding (another summation order), and are reproduced bit for bit from run to run.
+ * Same conventions as above (own packed image, w_head where the caller holds it, status words, NaN in y after an abort). */
+int opseq_xcdt_supported(int L, int KX, int H);
+void opseq_xcdt_enable(int on);
+int opseq_xcdt_max_batch(int T, int L, int KX, int H);
+size_t opseq_xcdt_packed_bytes(int L, int KX, int H);
+size_t opseq_xcdt_workspace_bytes(int B, int T, int L, int KX, int H);
+size_t opseq_xcdt_status_offset(int B, int T, int L, int KX, int H);
+int opseq_xcdt_pack_weights_f32(const float *const *w_ih, const float *const *w_hh, float *packed, size_t packed_bytes,
+                                int L, int KX, int H, void *stream);
+int opseq_xcdt_forward_f32(const float *x, const float *packed, const float *w_head, float *y, void *workspace,
+                           size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream);
+/* tools: device buffer of >= 2 * (T + 1) * 8 * 8 uint64 receiving s_memtime stamps of blocks 0 and 1 (NULL = off) */
+void opseq_xcdt_set_trace(void *device_buffer);
 /* opseq_lstm_stack_train_forward_f32 runs the same persistent launch on the shapes above (B <= opseq_xcd_max_batch(L)) and
  * writes the h / c / gate histories its backward reads; its status words sit at this offset of the TRAINING workspace
  * ((size_t)-1: this shape trains on the launch chain) */

@@ -13,7 +13,7 @@ from . import build as _build
 _LIB = None
 
 OPNET_OK = 0
-ABI_VERSION = 4                            # include/opnet_hip.h OPNET_HIP_ABI_VERSION
+ABI_VERSION = 5                            # include/opnet_hip.h OPNET_HIP_ABI_VERSION
 NO_OFFSET = ctypes.c_size_t(-1).value      # opnet_*_status_offset: "this shape never runs a persistent kernel"
 
 
@@ -145,6 +145,24 @@ def _declare(lib):
     lib.opseq_xcd_forward_f32.argtypes = [fp, fp, fp, fp, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.opseq_lstm_stack_train_status_offset.restype = c_size_t
     lib.opseq_lstm_stack_train_status_offset.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    lib.opseq_xcdt_supported.restype = c_int
+    lib.opseq_xcdt_supported.argtypes = [c_int, c_int, c_int]
+    lib.opseq_xcdt_enable.restype = None
+    lib.opseq_xcdt_enable.argtypes = [c_int]
+    lib.opseq_xcdt_max_batch.restype = c_int
+    lib.opseq_xcdt_max_batch.argtypes = [c_int, c_int, c_int, c_int]
+    lib.opseq_xcdt_packed_bytes.restype = c_size_t
+    lib.opseq_xcdt_packed_bytes.argtypes = [c_int, c_int, c_int]
+    lib.opseq_xcdt_workspace_bytes.restype = c_size_t
+    lib.opseq_xcdt_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    lib.opseq_xcdt_status_offset.restype = c_size_t
+    lib.opseq_xcdt_status_offset.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    lib.opseq_xcdt_pack_weights_f32.restype = c_int
+    lib.opseq_xcdt_pack_weights_f32.argtypes = [POINTER(c_void_p), POINTER(c_void_p), fp, c_size_t, c_int, c_int, c_int, c_void_p]
+    lib.opseq_xcdt_forward_f32.restype = c_int
+    lib.opseq_xcdt_forward_f32.argtypes = [fp, fp, fp, fp, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.opseq_xcdt_set_trace.restype = None
+    lib.opseq_xcdt_set_trace.argtypes = [c_void_p]
     lib.opseq_xcd_set_trace.restype = None
     lib.opseq_xcd_set_trace.argtypes = [c_void_p]
     lib.opseq_graph_cache_clear.restype = None
@@ -250,6 +268,8 @@ EXPORTS = [
     "opseq_lstm_stack_forward_f32", "opseq_lstm_stack_forward_graph_f32", "opseq_graph_cache_clear",
     "opseq_xcd_supported", "opseq_xcd_enable", "opseq_xcd_max_batch", "opseq_xcd_packed_bytes", "opseq_xcd_workspace_bytes",
     "opseq_xcd_status_offset", "opseq_xcd_pack_weights_f32", "opseq_xcd_forward_f32", "opseq_lstm_stack_train_status_offset", "opseq_xcd_set_trace",
+    "opseq_xcdt_supported", "opseq_xcdt_enable", "opseq_xcdt_max_batch", "opseq_xcdt_packed_bytes", "opseq_xcdt_workspace_bytes",
+    "opseq_xcdt_status_offset", "opseq_xcdt_pack_weights_f32", "opseq_xcdt_forward_f32", "opseq_xcdt_set_trace",
     "opseq_slot_embed_relu_f32", "opseq_slot_embed_relu_bwd_f32",
     "opseq_lstm_stack_train_packed_bytes", "opseq_lstm_stack_train_workspace_bytes",
     "opseq_lstm_stack_train_pack_weights_f32", "opseq_lstm_stack_train_forward_f32",

@@ -6,6 +6,7 @@
 #include "opnet_xcd4_kernels.hip"
 #include "seq_kernels.hip"
 #include "seq_xcd_kernels.hip"
+#include "seq_xcdt_kernels.hip"
 #include "conv_kernels.hip"
 #include "attn_kernels.hip"
 #include "enc_train_kernels.hip"
@@ -369,12 +370,13 @@ static hipEvent_t g_xcd_done[64] = {};
 static int g_xcd_cus[64] = {};
 
 // Measurement (bench.py): with profiling on, every launch of a profiled kernel (tag 0: opnet_xcd_forward, 1: seqx_forward,
-// 2: the attention kernel(s) of one attention call) is bracketed by a pair of HIP events on the caller's stream;
+// 2: the attention kernel(s) of one attention call, 3: seqt_forward) is bracketed by a pair of HIP events on the caller's stream;
 // opnet_kernel_profile_read waits for them and returns the summed kernel time of a tag.
 #define PROF_XCD 0
 #define PROF_SEQX 1
 #define PROF_ATTN 2
-#define PROF_TAGS 3
+#define PROF_SEQT 3
+#define PROF_TAGS 4
 typedef std::pair<hipEvent_t, hipEvent_t> ProfPair;
 static bool g_xcd_prof = false;
 static std::vector<ProfPair> g_prof_ev[PROF_TAGS];
@@ -1938,6 +1940,178 @@ extern "C" int opseq_xcd_forward_f32(const float *x, const float *packed, const 
 }
 
 // ---- training of the stacked LSTM ---------------------------------------------------------------------
+// ---- the stacked LSTM as ONE persistent launch, throughput form (seq_xcdt_kernels.hip) ---------------------------------
+// 16-clip column groups on v_mfma_f32_16x16x4_f32, the two-role scheme of opnet_xcd_forward.  Shapes: H = 512 and
+//   L = 1 with a direct input of KX <= 80 (BaselineLstm): one copy of the layer per XCD;
+//   L = 2 with KX % 16 == 0 (TransformerLstm 256, NonLinearLstm 3840): the layer-0 input product is hoisted into ONE GEMM
+//         (G [B T][2048]) and a pair of XCDs carries the two layers (layer 0 + the lower K half of W_ih1 | the rest of layer 1).
+static int seqt_mode(int L, int KX, int H)
+{
+    if (H != ST_H || KX <= 0) return 0;
+    if (L == 1 && KX <= 16 * ST_NXH1) return 1;
+    if (L == 2 && (KX & 15) == 0) return 2;
+    return 0;
+}
+static std::atomic<int> g_seqt_enabled{1};
+static unsigned long long *g_seqt_trace = nullptr;
+extern "C" void opseq_xcdt_set_trace(void *device_buffer) { g_seqt_trace = (unsigned long long *)device_buffer; }
+extern "C" void opseq_xcdt_enable(int on) { g_seqt_enabled.store(on ? 1 : 0); }
+extern "C" int opseq_xcdt_supported(int L, int KX, int H)
+{
+    if (!seqt_mode(L, KX, H) || g_seqt_enabled.load() == 0 || env_int("OPSEQ_XCDT", 1) == 0) return 0;
+    return x4_device() ? 1 : 0;
+}
+struct SeqTHostPacked { size_t regs, wih0g, total; };          // floats
+static SeqTHostPacked seqt_host_packed(int mode, int KX)
+{
+    SeqTHostPacked P;
+    P.regs = 0;
+    P.wih0g = align_up((size_t)(mode == 1 ? 1 : 2) * 128 * (mode == 1 ? ST_NH1 : ST_NH2) * 256, 64);
+    P.total = P.wih0g + (mode == 2 ? (size_t)4 * ST_H * KX : 0);
+    return P;
+}
+// one buffer: [status | flags | xp | histories] addressed through one descriptor (< 2 GiB), then G and P1 behind their own
+struct SeqTWs { size_t status, flags, xp, hl[2], hc, ws1, g, p1, total; int NGT; };  // bytes
+static SeqTWs seqt_ws_layout(int B, int T, int mode, int KX)
+{
+    (void)KX;
+    SeqTWs W;
+    const size_t NGT = (B + 15) / 16;
+    W.NGT = (int)NGT;
+    size_t o = 0;
+    W.status = o; o += 2048;
+    W.flags = o;  o += align_up(NGT * 96 * 4, 256);
+    W.xp = o;     if (mode == 1) o += NGT * (size_t)T * 20 * 256;
+    o = align_up(o, 4096);
+    for (int l = 0; l < 2; ++l) { W.hl[l] = o; if (l < (mode == 1 ? 1 : 2)) o += NGT * (size_t)(T + 1) * 128 * 256; }
+    W.hc = o;     if (mode == 2) o += NGT * (size_t)(T + 1) * 64 * 256;
+    W.ws1 = o = align_up(o, 4096);
+    W.g = o;      if (mode == 2) o += align_up((size_t)B * T * 4 * ST_H * 4, 4096);
+    W.p1 = o;     if (mode == 2) o += NGT * (size_t)T * 128 * 1024;
+    W.total = align_up(o, 4096);
+    return W;
+}
+/* clips one launch carries at T frames (0 = unsupported shape): ST_NGMAX groups per XCD (pair), and every descriptor < 2 GiB */
+extern "C" int opseq_xcdt_max_batch(int T, int L, int KX, int H)
+{
+    const int mode = seqt_mode(L, KX, H);
+    if (!mode || T <= 0) return 0;
+    long ng = (long)ST_NGMAX * (mode == 1 ? 8 : 4);
+    const long lim = ((long)1 << 31) - (1 << 20);
+    while (ng > 0) {
+        const SeqTWs W = seqt_ws_layout((int)(ng * 16), T, mode, KX);
+        if ((long)W.ws1 < lim && (long)(W.p1 - W.g) < lim && (long)(W.total - W.p1) < lim) break;
+        --ng;
+    }
+    return (int)(ng * 16);
+}
+static int check_seqt(int B, int T, int L, int KX, int H)
+{
+    if (B <= 0 || T <= 0) return fail(OPNET_ESHAPE, "B=%d T=%d must be positive", B, T);
+    if (!seqt_mode(L, KX, H))
+        return fail(OPNET_ESHAPE, "the throughput form of the persistent stacked LSTM is built for H=512, (L=1, KX<=80) or (L=2, KX a "
+                                  "multiple of 16); got L=%d KX=%d H=%d", L, KX, H);
+    if (B > opseq_xcdt_max_batch(T, L, KX, H))
+        return fail(OPNET_ESHAPE, "B=%d > %d clips per launch at T=%d", B, opseq_xcdt_max_batch(T, L, KX, H), T);
+    return OPNET_OK;
+}
+extern "C" size_t opseq_xcdt_packed_bytes(int L, int KX, int H)
+{
+    const int mode = seqt_mode(L, KX, H);
+    return mode ? seqt_host_packed(mode, KX).total * sizeof(float) : 0;
+}
+extern "C" size_t opseq_xcdt_workspace_bytes(int B, int T, int L, int KX, int H)
+{
+    if (check_seqt(B, T, L, KX, H)) return 0;
+    return seqt_ws_layout(B, T, seqt_mode(L, KX, H), KX).total;
+}
+extern "C" size_t opseq_xcdt_status_offset(int B, int T, int L, int KX, int H)
+{
+    if (check_seqt(B, T, L, KX, H)) return (size_t)-1;
+    return seqt_ws_layout(B, T, seqt_mode(L, KX, H), KX).status;
+}
+extern "C" int opseq_xcdt_pack_weights_f32(const float *const *w_ih, const float *const *w_hh, float *packed, size_t packed_bytes,
+                                           int L, int KX, int H, void *stream)
+{
+    const int mode = seqt_mode(L, KX, H);
+    if (!mode) return fail(OPNET_ESHAPE, "unsupported shape for the throughput form of the persistent stacked LSTM (L=%d KX=%d H=%d)", L, KX, H);
+    if (!w_ih || !w_hh || !packed) return fail(OPNET_EINVAL, "null pointer");
+    for (int l = 0; l < L; ++l)
+        if (!w_ih[l] || !w_hh[l]) return fail(OPNET_EINVAL, "null weight pointer (layer %d)", l);
+    if (!aligned16(packed)) return fail(OPNET_EINVAL, "packed must be 16-byte aligned");
+    const SeqTHostPacked P = seqt_host_packed(mode, KX);
+    if (packed_bytes < P.total * sizeof(float)) return fail(OPNET_EWORKSPACE, "packed buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    seqt_pack<<<2048, 256, 0, st>>>(packed + P.regs, w_ih[0], w_hh[0], L == 2 ? w_ih[1] : nullptr, L == 2 ? w_hh[1] : nullptr, mode, KX);
+    if (mode == 2) {
+        const size_t n = (size_t)4 * H * KX;
+        stack_pack_wih_rows<<<(unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), 256, 0, st>>>(w_ih[0], packed + P.wih0g, H, KX, KX);
+    }
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+/* y [B][T][4] = head(LSTM stack(x [B][T][KX])) as ONE persistent launch of 16-clip groups (+ input pack / hoisted GEMM before,
+ * the 4-row head after).  packed: opseq_xcdt_pack_weights_f32 image; w_head: predictions_layer.weight [4][H]. */
+extern "C" int opseq_xcdt_forward_f32(const float *x, const float *packed, const float *w_head, float *y, void *workspace,
+                                      size_t workspace_bytes, int B, int T, int L, int KX, int H, void *stream)
+{
+    if (int rc = check_seqt(B, T, L, KX, H)) return rc;
+    if (!x || !packed || !w_head || !y || !workspace) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(packed) || !aligned16(y) || !aligned16(workspace) || !aligned16(w_head))
+        return fail(OPNET_EINVAL, "packed/w_head/y/workspace must be 16-byte aligned");
+    const int mode = seqt_mode(L, KX, H);
+    const SeqTWs W = seqt_ws_layout(B, T, mode, KX);
+    if (workspace_bytes < W.total) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", workspace_bytes, W.total);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (xcd_device_cus(dev) < XCD_COUNT * XCD_CUS)
+        return fail(OPNET_ESHAPE, "device %d exposes %d CUs; the persistent launch needs %d resident workgroups", dev,
+                    xcd_device_cus(dev), XCD_COUNT * XCD_CUS);
+    const SeqTHostPacked PK = seqt_host_packed(mode, KX);
+    hipStream_t st = (hipStream_t)stream;
+    char *w = (char *)workspace;
+    SeqTArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.mode = mode; a.NGT = W.NGT; a.KX = KX;
+    a.pk = packed + PK.regs;
+    a.whead = w_head;
+    a.ws = w;
+    a.xp_off = (unsigned)W.xp; a.hl_off[0] = (unsigned)W.hl[0]; a.hl_off[1] = (unsigned)W.hl[1]; a.hc_off = (unsigned)W.hc;
+    a.flags_off = (unsigned)W.flags; a.status_off = (unsigned)W.status;
+    a.status = (unsigned *)(w + W.status);
+    a.G = mode == 2 ? (const float *)(w + W.g) : nullptr;
+    a.P1 = mode == 2 ? (float4 *)(w + W.p1) : nullptr;
+    a.y = (float4 *)y;
+    a.force_safe = env_int("OPNET_XCD_SAFE", 0);
+    a.debug = env_int("OPSEQ_XCDT_DEBUG", 0);
+    a.trace = g_seqt_trace;
+    if (mode == 2) {
+        if (!aligned16(x)) return fail(OPNET_EINVAL, "x must be 16-byte aligned");
+        // G [B*T][4H] = x [B*T][KX] . W_ih0^T (a 1 x 1 "conv" over B*T pixels); the layer-0 cell reads it where it lies
+        ConvArgs c = {};
+        c.X = x; c.Wt = packed + PK.wih0g; c.bias = nullptr; c.R = nullptr; c.Y = (float *)(w + W.g);
+        c.N = 1; c.H = 1; c.W = B * T; c.Cin = KX; c.Cout = 4 * H; c.KH = 1; c.KW = 1; c.stride = 1; c.pad = 0;
+        c.OH = 1; c.OW = B * T; c.KP = KX; c.relu = 0;
+        launch_conv_tiled(c, (long)B * T, st);
+    }
+    seqt_init<<<1024, 256, 0, st>>>(a, x);
+    {
+        std::lock_guard<std::mutex> lock(g_xcd_mu);           // two persistent grids must never be co-resident
+        if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
+        else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
+        ProfPair pe{};
+        const bool prof = prof_begin(st, &pe);
+        if (mode == 1) seqt_forward<1><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
+        else seqt_forward<2><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(a);
+        if (prof) prof_end(PROF_SEQT, st, pe);
+        HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
+    }
+    seqt_out_head<<<dim3(T, a.NGT), 256, 0, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
 struct StackTrainPacked { size_t fwd_total, whh_t[SEQ_MAX_LAYERS], wih_t[SEQ_MAX_LAYERS], whead, wih0_t, seqx, total; };
 
 static StackTrainPacked stack_train_packed_layout(int L, int KX, int H)

@@ -679,6 +679,12 @@ class _LstmStackRunner:
         self._xws: Dict[tuple, torch.Tensor] = {}
         self._monitor = LaunchMonitor()
         self.xcd_launches = 0            # statistics: forwards that ran as one persistent launch
+        # ... and its throughput form (csrc/seq_xcdt_kernels.hip): "auto" = batches of at least XCDT_MIN_BATCH clips, "1" = every
+        # supported batch, "0" = never
+        self.use_xcdt = os.environ.get("OPSEQ_XCDT", "auto")
+        self._tpacked: Dict[int, Tuple[tuple, torch.Tensor]] = {}
+        self._tws: Dict[tuple, torch.Tensor] = {}
+        self.xcdt_launches = 0
 
     def _note_training_abort(self) -> None:
         self._train_aborted = True
@@ -766,9 +772,76 @@ class _LstmStackRunner:
                 raise RuntimeError("parameters must be contiguous fp32 on the input's device")
         return _StackTrainFunction.apply(self, x.contiguous(), *ws_list)
 
+    # batches from here on run the throughput form (16-clip groups, csrc/seq_xcdt_kernels.hip); below, the 4-clip latency form
+    # keeps lone / small requests (and its bit-identity between a served request and its lone forward)
+    XCDT_MIN_BATCH = 64
+
+    def _wants_xcdt(self, B: int, T: int) -> bool:
+        if self.use_xcdt in ("0", 0, False) or self.use_xcd in ("0", 0, False):
+            return False
+        lib = _lib.load()
+        if not bool(lib.opseq_xcdt_supported(self.L, self.KX, self.H)) or int(lib.opseq_xcdt_max_batch(T, self.L, self.KX, self.H)) < 16:
+            return False
+        return self.use_xcdt in ("1", 1, True) or B >= self.XCDT_MIN_BATCH
+
+    def _run_xcdt(self, x: torch.Tensor, ws_list, head: "LinearWeight") -> torch.Tensor:
+        """one persistent launch of 16-clip groups per chunk of opseq_xcdt_max_batch clips"""
+        lib = _lib.load()
+        dev = x.device
+        B, T = int(x.shape[0]), int(x.shape[1])
+        stream = _stream_ptr(dev)
+        key = _weights_key(ws_list, dev)
+        entry = self._tpacked.get(stream)
+        if entry is None or entry[0] != key:
+            for w in ws_list:
+                if w.device != dev or w.dtype != torch.float32 or not w.is_contiguous():
+                    raise RuntimeError("parameters must be contiguous fp32 on the input's device")
+            nbytes = lib.opseq_xcdt_packed_bytes(self.L, self.KX, self.H)
+            if nbytes == 0:
+                _lib.check(-2, "opseq_xcdt_packed_bytes")
+            if entry is None or entry[1].device != dev:
+                if len(self._tpacked) >= 4:
+                    self._tpacked.pop(next(iter(self._tpacked)))
+                buf = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            else:
+                buf = entry[1]
+            arr = _lib.c_void_p * self.L
+            ih = arr(*[w.data_ptr() for w in ws_list[:self.L]])
+            hh = arr(*[w.data_ptr() for w in ws_list[self.L:2 * self.L]])
+            _lib.check(lib.opseq_xcdt_pack_weights_f32(ih, hh, buf.data_ptr(), nbytes, self.L, self.KX, self.H, stream),
+                       "opseq_xcdt_pack_weights_f32")
+            self._tpacked[stream] = (key, buf)
+        packed = self._tpacked[stream][1]
+        step = int(lib.opseq_xcdt_max_batch(T, self.L, self.KX, self.H))
+        y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+        for b0 in range(0, B, step):
+            n = min(step, B - b0)
+            wkey = (n, T, str(dev), stream)
+            if wkey not in self._tws:
+                nb = lib.opseq_xcdt_workspace_bytes(n, T, self.L, self.KX, self.H)
+                if nb == 0:
+                    _lib.check(-2, "opseq_xcdt_workspace_bytes")
+                if len(self._tws) >= 4:
+                    self._tws.pop(next(iter(self._tws)))
+                self._tws[wkey] = torch.empty(nb, dtype=torch.uint8, device=dev)
+            ws = self._tws[wkey]
+            xc, yc = x[b0:b0 + n], y[b0:b0 + n]
+            _lib.check(lib.opseq_xcdt_forward_f32(xc.data_ptr(), packed.data_ptr(), head.weight.data_ptr(), yc.data_ptr(), ws.data_ptr(),
+                                                  ws.numel(), n, T, self.L, self.KX, self.H, stream), "opseq_xcdt_forward_f32")
+
+            def redo(xc=xc, yc=yc):      # the launch gave up: the same clips through the launch-per-step chain, into the same y
+                with torch.no_grad(), torch.cuda.device(dev):
+                    yc.copy_(self._run_chain(xc, ws_list, head))
+
+            self._monitor.watch(ws, lib.opseq_xcdt_status_offset(n, T, self.L, self.KX, self.H), redo, "seqt_forward")
+            self.xcdt_launches += 1
+        return y
+
     def run(self, x: torch.Tensor, lstm: "LSTMWeights", head: "LinearWeight") -> torch.Tensor:
         ws_list = [getattr(lstm, f"weight_ih_l{l}") for l in range(self.L)] + \
                   [getattr(lstm, f"weight_hh_l{l}") for l in range(self.L)] + [head.weight]
+        if self._wants_xcdt(int(x.shape[0]), int(x.shape[1])):
+            return self._run_xcdt(x, ws_list, head)
         if self._wants_xcd(int(x.shape[0]), int(x.shape[1])):
             return self._run_xcd(x, ws_list, head)
         return self._run_chain(x, ws_list, head)
