@@ -348,6 +348,14 @@ int opseq_encoder_layer_segmented_f32(float *z, const float *in_w, const float *
                                       const float *l2_b, const float *n1_w, const float *n1_b, const float *n2_w,
                                       const float *n2_b, void *workspace, size_t workspace_bytes, long S, int n_seg,
                                       int E, int nhead, int ffn, void *stream);
+/* the same with the token-wise products chosen by ALL n_seg * S rows (a served pass in its throughput form: large LDS-DMA tiles
+ * instead of one sequence's K-split tiles); attention stays inside a sequence.  Each sequence agrees with its lone forward to
+ * rounding (another summation order), not bit for bit. */
+int opseq_encoder_layer_batched_f32(float *z, const float *in_w, const float *in_b, const float *out_w,
+                                      const float *out_b, const float *l1_w, const float *l1_b, const float *l2_w,
+                                      const float *l2_b, const float *n1_w, const float *n1_b, const float *n2_w,
+                                      const float *n2_b, void *workspace, size_t workspace_bytes, long S, int n_seg,
+                                      int E, int nhead, int ffn, void *stream);
 
 /* ---- detector backbone primitives (torchvision fasterrcnn_resnet50_fpn built at
  *      object_detection/models.py:6-20, called at baselines/detector.py:71-86).  fp32, NHWC.  The

@@ -2531,7 +2531,7 @@ extern "C" int opseq_attention_f32(const float *qkv, float *out, long S, int E, 
 static int encoder_layer(float *z, const float *in_w, const float *in_b, const float *out_w, const float *out_b, const float *l1_w,
                          const float *l1_b, const float *l2_w, const float *l2_b, const float *n1_w, const float *n1_b,
                          const float *n2_w, const float *n2_b, void *workspace, size_t workspace_bytes, long S, int nseg, int E,
-                         int nhead, int ffn, void *stream)
+                         int nhead, int ffn, void *stream, bool batched = false)
 {
     if (int rc = check_encoder(S, E, nhead, ffn)) return rc;
     if (nseg <= 0 || S * nseg > 0x7fffffffL) return fail(OPNET_ESHAPE, "n_seg=%d x S=%ld out of range", nseg, S);
@@ -2552,7 +2552,11 @@ static int encoder_layer(float *z, const float *in_w, const float *in_b, const f
     float *proj = att + (size_t)St * E;
     float *z1 = proj + (size_t)St * E;
     float *hid = z1 + (size_t)St * E;
-    const int M = (int)St, Ms = (int)S, hd = E / nhead;      // M rows are computed, Ms (one sequence) picks the kernel
+    const int M = (int)St, hd = E / nhead;
+    // M rows are computed; Ms picks the token-wise kernels: ONE sequence's rows (each sequence then comes out bit-identical to its
+    // lone forward), or - batched: the throughput form of a served pass - all of them (128 x 128 LDS-DMA tiles once they fill the
+    // chip: another K order, results agree with the lone forward to rounding)
+    const int Ms = batched ? M : (int)S;
     // C[M][N] = act(A[M][K] W[N][K]^T + b) = a 1x1 "convolution" over M pixels: the LDS-staged tiled kernel
     auto gemm = [&](const float *A, const float *Wt, const float *b, float *C, int N, int K, int act) {
         if ((long)((Ms + 127) / 128) * ((N + 127) / 128) < 256) {   // too few 128-tiles to fill the chip
@@ -2574,7 +2578,7 @@ static int encoder_layer(float *z, const float *in_w, const float *in_b, const f
     {
         ProfPair pe{};
         const bool prof = prof_begin(st, &pe);
-        launch_attention(qkv, att, Ms, nseg, E, nhead, hd, hid, (size_t)St * ffn * sizeof(float), st);   // hid is free until the FFN
+        launch_attention(qkv, att, (int)S, nseg, E, nhead, hd, hid, (size_t)St * ffn * sizeof(float), st);   // hid is free until the FFN
         if (prof) prof_end(PROF_ATTN, st, pe);
     }
     gemm(att, out_w, out_b, proj, E, E, 0);
@@ -2607,6 +2611,19 @@ extern "C" int opseq_encoder_layer_segmented_f32(float *z, const float *in_w, co
 {
     return encoder_layer(z, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b, workspace, workspace_bytes, S,
                          n_seg, E, nhead, ffn, stream);
+}
+
+/* the same n_seg independent sequences with the token-wise products chosen by ALL n_seg * S rows (the throughput form of a served
+ * pass: 128 x 128 LDS-DMA tiles once they fill the chip instead of one sequence's K-split 32 x 32 tiles); attention as above.
+ * Each sequence agrees with opseq_encoder_layer_f32 on it alone to rounding (another summation order), not bit for bit. */
+extern "C" int opseq_encoder_layer_batched_f32(float *z, const float *in_w, const float *in_b, const float *out_w,
+                                               const float *out_b, const float *l1_w, const float *l1_b, const float *l2_w,
+                                               const float *l2_b, const float *n1_w, const float *n1_b, const float *n2_w,
+                                               const float *n2_b, void *workspace, size_t workspace_bytes, long S, int n_seg,
+                                               int E, int nhead, int ffn, void *stream)
+{
+    return encoder_layer(z, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b, workspace, workspace_bytes, S,
+                         n_seg, E, nhead, ffn, stream, true);
 }
 
 // ------------------------------------------------------------------------------------------------

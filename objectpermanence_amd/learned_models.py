@@ -682,6 +682,7 @@ class _LstmStackRunner:
         # ... and its throughput form (csrc/seq_xcdt_kernels.hip): "auto" = batches of at least XCDT_MIN_BATCH clips, "1" = every
         # supported batch, "0" = never
         self.use_xcdt = os.environ.get("OPSEQ_XCDT", "auto")
+        self.XCDT_MIN_BATCH = int(os.environ.get("OPSEQ_XCDT_MIN_BATCH", 80 if layers == 1 else 40))
         self._tpacked: Dict[int, Tuple[tuple, torch.Tensor]] = {}
         self._tws: Dict[tuple, torch.Tensor] = {}
         self.xcdt_launches = 0
@@ -772,9 +773,12 @@ class _LstmStackRunner:
                 raise RuntimeError("parameters must be contiguous fp32 on the input's device")
         return _StackTrainFunction.apply(self, x.contiguous(), *ws_list)
 
-    # batches from here on run the throughput form (16-clip groups, csrc/seq_xcdt_kernels.hip); below, the 4-clip latency form
-    # keeps lone / small requests (and its bit-identity between a served request and its lone forward)
-    XCDT_MIN_BATCH = 64
+    # Batches from XCDT_MIN_BATCH clips on run the throughput form (16-clip groups, csrc/seq_xcdt_kernels.hip); below, the 4-clip
+    # latency form keeps lone / small requests (and its bit-identity between a served request and its lone forward).  Measured
+    # cross-over (one forward, T = 300, MI355X): L = 1: 64 clips 1.28 ms against 1.08, 128 clips 1.30 against 1.95 (the latency form
+    # carries 32 clips per 0.52-ms round, the throughput form up to 128 in 1.28 ms) -> 80; L = 2: the latency form carries 16 clips
+    # per 0.67-ms round, the throughput form up to 64 in 1.67 ms -> 40
+    XCDT_MIN_BATCH = 64          # (class default; per instance by layer count, see __init__)
 
     def _wants_xcdt(self, B: int, T: int) -> bool:
         if self.use_xcdt in ("0", 0, False) or self.use_xcd in ("0", 0, False):
@@ -837,12 +841,23 @@ class _LstmStackRunner:
             self.xcdt_launches += 1
         return y
 
-    def run(self, x: torch.Tensor, lstm: "LSTMWeights", head: "LinearWeight") -> torch.Tensor:
+    def engine(self, B: int, T: int) -> str:
+        """what a forward of B clips x T frames runs on: "t" the persistent launch of 16-clip groups (csrc/seq_xcdt_kernels.hip),
+        "x" the persistent launch of 4-clip groups (csrc/seq_xcd_kernels.hip), "c" one launch per time step"""
+        if self._wants_xcdt(B, T):
+            return "t"
+        return "x" if self._wants_xcd(B, T) else "c"
+
+    def run(self, x: torch.Tensor, lstm: "LSTMWeights", head: "LinearWeight", engine: Optional[str] = None) -> torch.Tensor:
+        """engine: None = by this batch's shape; a caller that merged independent requests and wants each of them computed as it
+        would be alone passes the lone request's engine"""
         ws_list = [getattr(lstm, f"weight_ih_l{l}") for l in range(self.L)] + \
                   [getattr(lstm, f"weight_hh_l{l}") for l in range(self.L)] + [head.weight]
-        if self._wants_xcdt(int(x.shape[0]), int(x.shape[1])):
+        if engine is None:
+            engine = self.engine(int(x.shape[0]), int(x.shape[1]))
+        if engine == "t":
             return self._run_xcdt(x, ws_list, head)
-        if self._wants_xcd(int(x.shape[0]), int(x.shape[1])):
+        if engine == "x":
             return self._run_xcd(x, ws_list, head)
         return self._run_chain(x, ws_list, head)
 
@@ -1074,44 +1089,59 @@ class TransformerLstm(AbstractCaterModel):
     # tokens one merged pass may carry: the FFN activation [tokens][2048] fp32 has to stay below 2 GiB (include/opnet_hip.h)
     MAX_TOKENS_PER_PASS = 192 * 1024
 
-    def forward_segments(self, x: torch.Tensor, n_seg: int) -> torch.Tensor:
-        """x [n_seg * b, T, 15, 5] = n_seg INDEPENDENT requests of b clips each, back to back -> y [n_seg * b, T, 4] where every
-        request's rows are bit-identical to `forward(request)` alone.  The reference serves a request per call
-        (learned_models.py:176-197: attention over S = b * T, the clips OF THAT CALL); here the token-wise stages (embedding,
-        in / out projection, FFN, layer norms) run over all requests' tokens at once, attention stays inside a request
-        (opseq_encoder_layer_segmented_f32) and ONE persistent launch runs the stacked LSTM over all clips - a one-clip
-        request alone leaves 6 of 8 XCDs and 3 of 4 MFMA columns of that launch idle.  Inference only."""
+    def forward_segments(self, x: torch.Tensor, n_seg: int, exact: bool = False) -> torch.Tensor:
+        """x [n_seg * b, T, 15, 5] = n_seg INDEPENDENT requests of b clips each, back to back -> y [n_seg * b, T, 4].  The reference
+        serves a request per call (learned_models.py:176-197: attention over S = b * T, the clips OF THAT CALL); here the token-wise
+        stages (embedding, in / out projection, FFN, layer norms) run over all requests' tokens at once, attention stays inside a
+        request and ONE persistent launch runs the stacked LSTM over all clips - a one-clip request alone leaves 6 of 8 XCDs and 3
+        of 4 MFMA columns of that launch idle.  Two forms:
+          * a pass below _LstmStackRunner.XCDT_MIN_BATCH clips, or exact = True: every kernel is the one the LONE request would run
+            (opseq_encoder_layer_segmented_f32, the 4-clip persistent stack): every request's rows are bit-identical to
+            `forward(request)` alone;
+          * otherwise the throughput form: token-wise products on large tiles chosen by all rows
+            (opseq_encoder_layer_batched_f32), the stacked LSTM on 16-clip groups (csrc/seq_xcdt_kernels.hip): each request agrees
+            with its lone forward to rounding (other summation orders; both are held to the reference goldens).
+        Inference only."""
         _check_input(self, x, 5)
         if n_seg <= 0 or int(x.shape[0]) % n_seg:
             raise ValueError(f"{int(x.shape[0])} clips do not split into {n_seg} equal requests")
         if _wants_grad(self):
             raise RuntimeError("forward_segments is the serving path: call it under torch.no_grad() / after eval()")
-        return self._forward_eval(x.contiguous().float(), int(n_seg))
+        return self._forward_eval(x.contiguous().float(), int(n_seg), bool(exact))
 
-    def max_requests_per_pass(self, b: int, T: int) -> int:
-        """how many requests of b clips x T frames `forward_segments` can take in one pass and still return each request's
-        lone result: the token limit above, and the stacked LSTM must run on the SAME engine as for the lone request (the
-        persistent launch carries at most opseq_xcd_max_batch clips; the launch chain sums in another order)"""
-        n = max(1, self.MAX_TOKENS_PER_PASS // max(b * T, 1))
+    def max_requests_per_pass(self, b: int, T: int, exact: bool = False) -> int:
+        """how many requests of b clips x T frames `forward_segments` takes in one pass: the token limit above; exact: the stacked
+        LSTM must run on the SAME engine as for the lone request (the 4-clip persistent launch carries at most opseq_xcd_max_batch
+        clips; the launch chain sums in another order); otherwise one launch of the throughput form (opseq_xcdt_max_batch clips)"""
+        n_tok = max(1, self.MAX_TOKENS_PER_PASS // max(b * T, 1))
         r = self._runner
-        alone = r._wants_xcd(b, T)
-        if alone:
-            n = min(n, max(1, int(_lib.load().opseq_xcd_max_batch(r.L)) // b))
-        while n > 1 and r._wants_xcd(n * b, T) != alone:
-            n -= 1
-        return n
+        lib = _lib.load()
+        n_exact = n_tok
+        if r.engine(b, T) == "x":
+            n_exact = min(n_tok, max(1, int(lib.opseq_xcd_max_batch(r.L)) // b))
+        if exact or not r._wants_xcdt(max(n_tok * b, r.XCDT_MIN_BATCH), T):
+            return n_exact
+        n_t = min(n_tok, max(1, int(lib.opseq_xcdt_max_batch(T, r.L, r.KX, r.H)) // b))
+        return n_t if n_t * b >= r.XCDT_MIN_BATCH and n_t > n_exact else n_exact
 
-    def _forward_eval(self, x: torch.Tensor, n_seg: int) -> torch.Tensor:
-        if n_seg > 1 and n_seg > self.max_requests_per_pass(int(x.shape[0]) // n_seg, int(x.shape[1])):
+    def _forward_eval(self, x: torch.Tensor, n_seg: int, exact: bool = False) -> torch.Tensor:
+        if n_seg > 1 and n_seg > self.max_requests_per_pass(int(x.shape[0]) // n_seg, int(x.shape[1]), exact):
             raise ValueError(f"{n_seg} requests of {int(x.shape[0]) // n_seg} clips x {int(x.shape[1])} frames exceed one pass "
-                             f"(max_requests_per_pass = {self.max_requests_per_pass(int(x.shape[0]) // n_seg, int(x.shape[1]))})")
+                             f"(max_requests_per_pass = {self.max_requests_per_pass(int(x.shape[0]) // n_seg, int(x.shape[1]), exact)})")
         if self.training and self.dropout > 0:
             raise RuntimeError("TransformerLstm: train mode without gradients would still apply dropout; call eval() "
                                "for inference")
         lib = _lib.load()
         B, T = int(x.shape[0]), int(x.shape[1])
         St, e, dev = B * T, self._e, x.device
-        S = St // n_seg                          # tokens of one request: what attention spans and every kernel is chosen by
+        S = St // n_seg                          # tokens of one request: what attention spans (exact form: and every kernel is chosen by)
+        # the stacked LSTM's engine: the lone request's (every request then comes out as it would alone), or - a pass of at least
+        # XCDT_MIN_BATCH clips that need not be bit-identical - the throughput form
+        lone = self._runner.engine(B // n_seg, T)
+        engine = lone if (exact or n_seg == 1) else self._runner.engine(B, T)
+        if engine != "t":
+            engine = lone
+        self.last_pass_engine = engine
         if n_seg > 1 and St > self.MAX_TOKENS_PER_PASS:
             raise ValueError(f"{St} tokens in one pass (limit {self.MAX_TOKENS_PER_PASS}): split the requests")
         with torch.cuda.device(dev):
@@ -1138,10 +1168,11 @@ class TransformerLstm(AbstractCaterModel):
                                                      ews.numel(), S, e, self._nhead, self.FFN, stream)
                     _lib.check(rc, "opseq_encoder_layer_f32")
                 else:
-                    rc = lib.opseq_encoder_layer_segmented_f32(z.data_ptr(), *(t_.data_ptr() for t_ in ts), ews.data_ptr(),
-                                                               ews.numel(), S, n_seg, e, self._nhead, self.FFN, stream)
+                    fn = lib.opseq_encoder_layer_batched_f32 if engine == "t" and lone != "t" else lib.opseq_encoder_layer_segmented_f32
+                    rc = fn(z.data_ptr(), *(t_.data_ptr() for t_ in ts), ews.data_ptr(), ews.numel(), S, n_seg, e, self._nhead,
+                            self.FFN, stream)
                     _lib.check(rc, "opseq_encoder_layer_segmented_f32")
-            return self._runner.run(z.view(B, T, e), self.video_LSTM, self.predictions_layer)
+            return self._runner.run(z.view(B, T, e), self.video_LSTM, self.predictions_layer, engine=engine)
 
 
 class OPNetLstmMlp(AbstractCaterModel):

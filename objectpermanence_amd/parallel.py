@@ -47,7 +47,11 @@ class Launch:
         return self
 
     def __exit__(self, *exc):
-        shutdown(self)
+        # An exception is propagating (a refused clip file, an out-of-memory, an ABI error): this rank must DIE, not meet the
+        # others at a barrier they will never reach - they are inside a gradient all-reduce or a gather of another size, the
+        # mismatched collectives would hang until the watchdog fires, and torchrun only reaps the peers once this process has
+        # exited with its traceback.  The barrier belongs to the clean path only.
+        shutdown(self, failed=exc[0] is not None)
         return False
 
 
@@ -81,7 +85,15 @@ def init_from_env(backend: Optional[str] = None) -> Launch:
                                "one rank per GPU")
         torch.cuda.set_device(device)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
+    if "MASTER_PORT" not in os.environ:
+        if world > 1:
+            raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: start the ranks with torch.distributed.run (or export MASTER_ADDR / "
+                               "MASTER_PORT)")
+        # a forced group of one: any free port (a fixed one would collide between two such runs on one box)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     # OPNET_DIST_BACKEND=gloo: several ranks on ONE device (RCCL refuses that) - how a box with a single GPU runs world size 2
     # (tests/test_dp_two_ranks_gpu.py); gloo moves device tensors through the host
     backend = backend or os.environ.get("OPNET_DIST_BACKEND") or ("nccl" if has_gpu else "gloo")
@@ -91,16 +103,25 @@ def init_from_env(backend: Optional[str] = None) -> Launch:
     return _launch
 
 
-def shutdown(launch: Optional[Launch] = None) -> None:
-    """leave the group `init_from_env` joined (all ranks meet first, so that no rank tears the communicator down under a
-    collective another rank is still in)"""
+def shutdown(launch: Optional[Launch] = None, failed: bool = False) -> None:
+    """leave the group `init_from_env` joined.  Clean path: all ranks meet first, so that no rank tears the communicator down
+    under a collective another rank is still in.  failed: this rank is on its way out with an exception - no barrier, no
+    orderly destroy (both would wait for peers that are in other collectives): the communicator is aborted where the backend
+    offers it and the process goes on to exit non-zero, which is what lets the launcher kill the other ranks."""
     global _launch
     launch = launch or _launch
     if launch is not None and launch.owned and dist.is_initialized():
-        try:
-            dist.barrier()
-        finally:
-            dist.destroy_process_group()
+        if failed:
+            try:                             # (nccl: tears the communicator down without waiting for its peers; a no-op elsewhere)
+                from torch.distributed.distributed_c10d import _abort_process_group
+                _abort_process_group()
+            except Exception:
+                pass
+        else:
+            try:
+                dist.barrier()
+            finally:
+                dist.destroy_process_group()
         launch.owned = False
     if launch is _launch:
         _launch = None

@@ -54,7 +54,7 @@ class PendingResult:
 
 class ReasonerServer:
     def __init__(self, model: torch.nn.Module, model_name: str = "opnet", max_clips: int = 1024, concat: bool = True,
-                 streams: Optional[int] = None):
+                 streams: Optional[int] = None, exact: bool = False):
         # a model whose clips are coupled inside a request (TransformerLstm) merges requests as segments, never by concatenation
         self.segmented = hasattr(model, "forward_segments")
         # passes in flight: 2 for a segmented model on a GPU (module docstring), else the forward runs on the caller's stream
@@ -67,6 +67,10 @@ class ReasonerServer:
         # builds the pointer table: measured 118-122 k clips/s against 120-124 k for twenty 32-clip requests, so the copy stays
         # the default
         self.concat = bool(concat)
+        # segmented models: exact = True keeps every pass on the kernels a lone request runs (each result bit-identical to
+        # `model(request)`); False lets a pass of _LstmStackRunner.XCDT_MIN_BATCH clips or more take the throughput form (16-clip column groups, large GEMM tiles:
+        # agrees with the lone forward to rounding) and carry up to opseq_xcdt_max_batch clips
+        self.exact = bool(exact)
         self._queue: List[Tuple[torch.Tensor, PendingResult]] = []
         self._pending = 0
         # optional callable run on the host right before the forward is enqueued (after the requests were concatenated): a
@@ -91,8 +95,8 @@ class ReasonerServer:
         self._queue.append((boxes, h))
         self._pending += h.n_clips
         limit = self.max_clips
-        if self.segmented:           # as many requests as one pass returns bit-identical to their lone forwards
-            limit = min(limit, self.model.max_requests_per_pass(int(boxes.shape[0]), int(boxes.shape[1])) * int(boxes.shape[0]))
+        if self.segmented:           # as many requests as one pass takes (exact: and returns bit-identical to their lone forwards)
+            limit = min(limit, self.model.max_requests_per_pass(int(boxes.shape[0]), int(boxes.shape[1]), self.exact) * int(boxes.shape[0]))
         if self._pending >= limit:
             self.flush()
         return h
@@ -110,7 +114,7 @@ class ReasonerServer:
             x = queue[0][0] if len(queue) == 1 else torch.cat([q[0] for q in queue], dim=0)
             if self.before_launch is not None:
                 self.before_launch()
-            return self.model(x) if len(queue) == 1 else self.model.forward_segments(x, len(queue))
+            return self.model(x) if len(queue) == 1 else self.model.forward_segments(x, len(queue), self.exact)
         if len(queue) > 1 and not self.concat and hasattr(self.model, "forward_requests"):
             if self.before_launch is not None:
                 self.before_launch()

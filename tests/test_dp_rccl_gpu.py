@@ -292,3 +292,24 @@ def test_bench_train_force_dist_reports_the_allreduce(tmp_path):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["allreduce_ms_per_step"] is not None and 0 < line["allreduce_ms_per_step"] < 5.0
     assert line["engine"] == "xcd4" and np.isfinite(line["final_loss"])
+    c = line["collective"]                               # the line proves its own exchange: backend, ranks one all-reduce saw, its time
+    assert c["backend"] == "nccl" and c["ranks_seen"] == c["world_size"] == 1 and c["allreduce_ms_per_step"] == line["allreduce_ms_per_step"]
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_bench_inference_force_dist_reports_the_allgather(tmp_path, overlap):
+    """the headline command with --force-dist = the N > 1 inference line on one GPU (RCCL group of one): the persistent engine, one
+    all-gather per launch on the side stream, and the `collective` block that answers "did RCCL see N ranks" from the line itself;
+    OPNET_DP_OVERLAP=1 lets the launch start without waiting for the previous gather (the A/B switch for the first multi-GPU run)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MASTER_PORT"] = str(29700 + os.getpid() % 90)
+    env["OPNET_DP_OVERLAP"] = overlap
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--force-dist", "--steps", "8", "--warmup", "2", "--repeats", "3",
+                        "--inflight", "4", "--no-cpu-baseline"], cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    c = line["collective"]
+    assert c["backend"] == "nccl" and c["ranks_seen"] == c["world_size"] == 1
+    assert c["allgathers"] == 2 * 3 and 0 < c["allgather_ms_per_launch"] < 5.0 and c["bytes_per_rank_per_launch"] == 4 * 32 * 300 * 4 * 4
+    assert c["launch_waits_for_gather"] == (overlap == "0")
+    assert line["config"]["engine"] == "xcd" and line["value"] > 0

@@ -175,8 +175,13 @@ def test_bench_as_two_ranks_prints_one_line_from_rank_zero(tmp_path, mode_args):
     line = json.loads(out0)
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
     assert line["value"] > 0 and line["steps"] == 3 and line["warmup"] == 1
+    # the line answers "did the collective see N ranks" itself
+    assert line["collective"]["backend"] == "gloo" and line["collective"]["ranks_seen"] == line["collective"]["world_size"] == 2
     if "train" in mode_args:
         assert line["allreduce_ms_per_step"] is not None and np.isfinite(line["final_loss"])
+        assert line["collective"]["allreduce_ms_per_step"] == line["allreduce_ms_per_step"]
+    else:
+        assert line["collective"]["launch_waits_for_gather"] is False
 
 
 def test_cater_inference_entry_point_at_world_size_two_writes_the_single_process_csv(tmp_path, monkeypatch):

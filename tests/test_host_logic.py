@@ -577,6 +577,51 @@ def test_forced_group_of_one_takes_the_data_parallel_branch(tmp_path):
     assert os.path.exists(tmp_path / "ok")
 
 
+def _failing_rank_worker(rank, world, port, tmp):
+    """rank 1 raises inside the launch context while rank 0 is in a collective: rank 1 must leave at once (no barrier)"""
+    import time
+    import torch.distributed as dist
+    from objectpermanence_amd import parallel
+    os.environ.update({"WORLD_SIZE": str(world), "RANK": str(rank), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port), "OPNET_DIST_BACKEND": "gloo"})
+    t0 = time.time()
+    try:
+        with parallel.init_from_env():
+            dist.all_reduce(torch.ones(1))                 # both ranks: the job is up
+            if rank == 1:
+                raise ValueError("a refused clip file")
+            dist.all_reduce(torch.ones(4))                 # rank 0: a collective rank 1 never joins
+    except ValueError:
+        open(os.path.join(tmp, "failed_rank_left_after"), "w").write(f"{time.time() - t0:.1f}")
+        raise SystemExit(3)
+    except Exception:                                      # rank 0: its peer died under the collective - it must not hang either
+        open(os.path.join(tmp, "peer_saw_the_failure"), "w").write("ok")
+        raise SystemExit(4)
+
+
+def test_a_failing_rank_leaves_without_waiting_at_a_barrier(tmp_path):
+    """Launch.__exit__ used to call shutdown() - and with it dist.barrier() - while an exception was
+    propagating; the failing rank then waited for peers that were inside other collectives until the watchdog fired.  Now the
+    barrier is on the clean path only: the failing rank is out within seconds with its own exception."""
+    import time
+    import torch.multiprocessing as mp
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    t0 = time.time()
+    ctx = mp.spawn(_failing_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=False)
+    procs = ctx.processes
+    procs[1].join(60)
+    assert not procs[1].is_alive(), "the failing rank is still waiting (barrier under an exception?)"
+    assert procs[1].exitcode == 3
+    assert float(open(tmp_path / "failed_rank_left_after").read()) < 30 and time.time() - t0 < 60
+    procs[0].join(60)                                      # gloo notices the closed connection
+    if procs[0].is_alive():
+        procs[0].terminate()
+        procs[0].join()
+
+
 def test_launch_monitor_reaps_completed_entries_and_recycles_slots():
     """ADVICE round 3: a watch entry (and the input its `redo` holds) goes as soon as its launch is seen complete and clean;
     an aborted one stays for verify(); slots come from a free list"""
@@ -616,14 +661,14 @@ def test_server_merges_segmenting_models_by_request_not_by_concatenation():
     class Stub(torch.nn.Module):
         calls = []
 
-        def max_requests_per_pass(self, b, T):
+        def max_requests_per_pass(self, b, T, exact=False):
             return 3
 
         def forward(self, x):
             Stub.calls.append(("plain", tuple(x.shape)))
             return x.sum(dim=(2, 3), keepdim=False).unsqueeze(-1).repeat(1, 1, 4)
 
-        def forward_segments(self, x, n):
+        def forward_segments(self, x, n, exact=False):
             Stub.calls.append(("segments", tuple(x.shape), n))
             return self.forward(x)
 

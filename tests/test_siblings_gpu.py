@@ -21,18 +21,24 @@ def gold(golden_dir):
 
 
 def _model(name, cfg, engine="auto"):
-    """engine: "auto" = the product's choice (the persistent stack launch of csrc/seq_xcd_kernels.hip for H = 512 stacks),
-    "chain" = one launch per time step (csrc/seq_kernels.hip)"""
+    """engine: "auto" = the product's choice (H = 512 stacks: the persistent launch of 4-clip groups, csrc/seq_xcd_kernels.hip,
+    below 64 clips and of 16-clip groups, csrc/seq_xcdt_kernels.hip, from there on), "latency" / "throughput" = one of the two
+    whatever the batch, "chain" = one launch per time step (csrc/seq_kernels.hip)"""
     from objectpermanence_amd import ModelsFactory
     m = ModelsFactory.get_model(name, cfg)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in PARAMS[name](cfg).items()})
-    if engine == "chain" and hasattr(m, "_runner"):
-        m._runner.use_xcd = "0"
+    if hasattr(m, "_runner"):
+        if engine == "chain":
+            m._runner.use_xcd = "0"
+        elif engine == "latency":
+            m._runner.use_xcdt = "0"
+        elif engine == "throughput":
+            m._runner.use_xcdt = "1"
     return m.eval().to("cuda:0")
 
 
-def _persistent(m):
-    return getattr(getattr(m, "_runner", None), "xcd_launches", 0)
+def _persistent(m, form="latency"):
+    return getattr(getattr(m, "_runner", None), "xcdt_launches" if form == "throughput" else "xcd_launches", 0)
 
 
 def _run(m, x):
@@ -47,11 +53,12 @@ CASES = [("baseline_lstm", "tiny"), ("baseline_lstm", "real"), ("non_linear_lstm
          ("transformer_lstm", "real_b1"), ("transformer_lstm", "real_b2"), ("transformer_lstm", "heads4_b1")]
 
 
-@pytest.mark.parametrize("engine", ["auto", "chain"])
+@pytest.mark.parametrize("engine", ["auto", "chain", "throughput"])
 @pytest.mark.parametrize("name,tag", CASES)
 def test_matches_reference_golden(gold, name, tag, engine):
-    """both engines of the stacked LSTM against the reference's own outputs: the persistent launch (what "auto" picks for the
-    real configs: H = 512) and the launch-per-step chain"""
+    """the three engines of the stacked LSTM against the reference's own outputs: the persistent launch of 4-clip groups (what
+    "auto" picks for the goldens' few clips at the real configs: H = 512), the launch-per-step chain, and the persistent launch of
+    16-clip groups (what batches of 64 clips or more run)"""
     cfg = json.loads(str(gold[f"{name}/{tag}/cfg"]))
     n, t = (int(v) for v in gold[f"{name}/{tag}/shape"])
     boxes, _ = synth.make_batch(0, n, t)
@@ -59,7 +66,10 @@ def test_matches_reference_golden(gold, name, tag, engine):
     m = _model(name, cfg, engine)
     out = _run(m, x)
     real_stack = name != "opnet_lstm_mlp" and tag != "tiny"
+    if engine == "throughput" and not real_stack:
+        pytest.skip("the throughput form is built for the H = 512 stacks")
     assert _persistent(m) == (1 if (engine == "auto" and real_stack) else 0)
+    assert _persistent(m, "throughput") == (1 if engine == "throughput" else 0)
     if hasattr(m, "_runner"):
         assert m._runner._monitor.verify() == 0
     y = (out[0] if isinstance(out, tuple) else out).cpu().numpy()
@@ -158,13 +168,87 @@ def test_persistent_stack_matches_oracle_ragged(name, B, T):
     cfg = REAL[name]
     boxes, _ = synth.make_batch(500, B, T)
     x = synth.boxes5(boxes)
-    m = _model(name, cfg)
+    m = _model(name, cfg, "latency")
     y = _run(m, x).cpu().numpy()
     assert _persistent(m) == 1 and m._runner._monitor.verify() == 0
     y_ref = ORACLE[name](x, PARAMS[name](cfg), cfg)
     assert np.isfinite(y).all() and np.abs(y - y_ref).max() < 3e-5, float(np.abs(y - y_ref).max())
     y_chain = _run(_model(name, cfg, "chain"), x).cpu().numpy()
     assert np.abs(y - y_chain).max() < 1e-5
+
+
+# one clip / ragged last groups / one group on some XCDs (pairs) only / every XCD (pair) busy / two and three groups per XCD
+# (pair), T = 1 and 2 (the lagging layer's start-up), per model
+@pytest.mark.parametrize("name,B,T", [("baseline_lstm", 1, 1), ("baseline_lstm", 3, 7), ("baseline_lstm", 37, 5),
+                                      ("baseline_lstm", 128, 6), ("baseline_lstm", 200, 5), ("baseline_lstm", 380, 4),
+                                      ("non_linear_lstm", 1, 2), ("non_linear_lstm", 17, 6), ("non_linear_lstm", 70, 1),
+                                      ("non_linear_lstm", 100, 5), ("transformer_lstm", 1, 11), ("transformer_lstm", 19, 4),
+                                      ("transformer_lstm", 64, 3), ("transformer_lstm", 150, 2)])
+def test_throughput_stack_matches_oracle_ragged(name, B, T):
+    """the persistent launch of 16-clip groups (csrc/seq_xcdt_kernels.hip) on ragged shapes vs the fp64 oracle, and against the
+    4-clip form on the same input (different summation order: rounding-level agreement)"""
+    cfg = REAL[name]
+    boxes, _ = synth.make_batch(500, B, T)
+    x = synth.boxes5(boxes)
+    m = _model(name, cfg, "throughput")
+    y = _run(m, x).cpu().numpy()
+    assert _persistent(m, "throughput") == 1 and _persistent(m) == 0 and m._runner._monitor.verify() == 0
+    y_ref = ORACLE[name](x, PARAMS[name](cfg), cfg)
+    assert np.isfinite(y).all() and np.abs(y - y_ref).max() < 3e-5, float(np.abs(y - y_ref).max())
+    if B <= 128:
+        y_lat = _run(_model(name, cfg, "latency"), x).cpu().numpy()
+        assert np.abs(y - y_lat).max() < 1e-5
+
+
+def test_batches_are_routed_to_the_throughput_form():
+    """"auto": below _LstmStackRunner.XCDT_MIN_BATCH clips the 4-clip latency form, from there on the 16-clip throughput form"""
+    cfg = REAL["baseline_lstm"]
+    m = _model("baseline_lstm", cfg)
+    lo = m._runner.XCDT_MIN_BATCH
+    for B, form in ((lo - 1, "latency"), (lo, "throughput"), (300, "throughput")):
+        before = (_persistent(m), _persistent(m, "throughput"))
+        x = synth.boxes5(synth.make_batch(20, B, 3)[0])
+        y = _run(m, x).cpu().numpy()
+        after = (_persistent(m), _persistent(m, "throughput"))
+        assert (after[0] - before[0], after[1] - before[1]) == ((1, 0) if form == "latency" else (0, 1)), (B, form)
+        assert np.abs(y - oo.baseline_lstm_forward(x, PARAMS["baseline_lstm"](cfg))).max() < 3e-5
+
+
+@pytest.mark.parametrize("name,B,T", [("baseline_lstm", 300, 30), ("transformer_lstm", 150, 25)])
+def test_throughput_stack_is_deterministic_and_protocol_independent(monkeypatch, name, B, T):
+    """run to run and XCD-local stores vs the write-through protocol (OPNET_XCD_SAFE): the same bits - a stale hand-off would
+    not reproduce; a clip's result does not depend on which column of which group it rides in"""
+    cfg = REAL[name]
+    x = synth.boxes5(synth.make_batch(7, B, T)[0])
+    m = _model(name, cfg, "throughput")
+    y0 = _run(m, x).cpu().numpy()
+    for _ in range(3):
+        assert np.array_equal(_run(m, x).cpu().numpy(), y0)
+    monkeypatch.setenv("OPNET_XCD_SAFE", "1")
+    assert np.array_equal(_run(m, x).cpu().numpy(), y0)
+    monkeypatch.delenv("OPNET_XCD_SAFE")
+    if name == "baseline_lstm":                  # clips are independent there: a reversed batch gives the reversed result
+        assert np.array_equal(_run(m, x[::-1].copy()).cpu().numpy(), y0[::-1])
+
+
+def test_throughput_stack_abort_is_healed(monkeypatch):
+    """OPSEQ_XCDT_DEBUG bit 3 switches the publish off: the launch gives up after its bounded wait, y is NaN, and verify_launches
+    re-runs the batch on the launch chain into the same tensor"""
+    import warnings
+    from objectpermanence_amd.launch_monitor import verify_launches
+    cfg = REAL["baseline_lstm"]
+    x = synth.boxes5(synth.make_batch(9, 70, 6)[0])
+    m = _model("baseline_lstm", cfg, "throughput")
+    monkeypatch.setenv("OPSEQ_XCDT_DEBUG", "8")
+    y = _run(m, x)
+    assert torch.isnan(y).all()
+    monkeypatch.delenv("OPSEQ_XCDT_DEBUG")
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        assert verify_launches(m) == 1
+    y_ref = oo.baseline_lstm_forward(x, PARAMS["baseline_lstm"](cfg))
+    assert np.abs(y.cpu().numpy() - y_ref).max() < 3e-5
+    assert np.abs(_run(m, x).cpu().numpy() - y_ref).max() < 3e-5      # the next launch is healthy
 
 
 def test_persistent_stack_is_deterministic_and_protocol_independent(monkeypatch):

@@ -115,18 +115,69 @@ def test_a_pass_is_cut_where_the_lone_engine_would_change():
     from objectpermanence_amd.serving import ReasonerServer
     m = _model(REAL)
     cap = int(_lib.load().opseq_xcd_max_batch(2))
-    assert m.max_requests_per_pass(1, 10) == cap and m.max_requests_per_pass(3, 10) == cap // 3
+    assert m.max_requests_per_pass(1, 10, exact=True) == cap and m.max_requests_per_pass(3, 10, exact=True) == cap // 3
     reqs = _requests(1200, cap + 3, 1, 10)
     with torch.no_grad():
         alone = [m(r).clone() for r in reqs[:2] + reqs[-2:]]
-    server = ReasonerServer(m, "transformer_lstm", max_clips=4096)
+    server = ReasonerServer(m, "transformer_lstm", max_clips=4096, exact=True)
     handles = [server.submit(r) for r in reqs]
     server.flush()
     assert server.forwards == 2
     for h, a in zip(handles[:2] + handles[-2:], alone):
         assert torch.equal(h.result(), a)
     with pytest.raises(ValueError, match="exceed one pass"), torch.no_grad():
-        m.forward_segments(torch.cat(reqs), len(reqs))
+        m.forward_segments(torch.cat(reqs), len(reqs), exact=True)
+
+
+@pytest.mark.parametrize("heads,n,b,T", [(2, 70, 1, 40), (4, 40, 2, 30), (2, 130, 1, 12)])
+def test_a_large_pass_takes_the_throughput_form_and_agrees_to_rounding(heads, n, b, T):
+    """_LstmStackRunner.XCDT_MIN_BATCH clips or more in one pass (exact = False, the default): token-wise products on large tiles, the stacked LSTM on 16-clip
+    groups (csrc/seq_xcdt_kernels.hip) - every request agrees with its lone forward to rounding, the pass reproduces itself bit
+    for bit, exact = True still returns the lone bits (cut into passes the 4-clip launch carries), and requests do not mix"""
+    cfg = dict(REAL, num_attention_heads=heads)
+    m = _model(cfg)
+    reqs = _requests(300, n, b, T)
+    lib_cap = m.max_requests_per_pass(b, T)
+    assert lib_cap >= n
+    with torch.no_grad():
+        alone = [m(r).clone() for r in reqs]
+        before = m._runner.xcdt_launches
+        merged = m.forward_segments(torch.cat(reqs), n)
+        assert m.last_pass_engine == "t" and m._runner.xcdt_launches == before + 1
+        again = m.forward_segments(torch.cat(reqs), n)
+        # the same requests in another order: each still gets its own result (segments do not see each other)
+        perm = list(range(n))[::-1]
+        shuffled = m.forward_segments(torch.cat([reqs[i] for i in perm]), n)
+    torch.cuda.synchronize()
+    assert m._runner._monitor.verify() == 0
+    assert torch.equal(merged, again)
+    worst = max(float((merged[r * b:(r + 1) * b] - alone[r]).abs().max()) for r in range(n))
+    assert worst < 1e-5, worst
+    for k, i in enumerate(perm):
+        assert float((shuffled[k * b:(k + 1) * b] - merged[i * b:(i + 1) * b]).abs().max()) < 1e-5
+    cap = m.max_requests_per_pass(b, T, exact=True)
+    with torch.no_grad():
+        for lo in range(0, n, cap):
+            part = m.forward_segments(torch.cat(reqs[lo:lo + cap]), len(reqs[lo:lo + cap]), exact=True) if len(reqs[lo:lo + cap]) > 1 else m(reqs[lo])
+            for k, r in enumerate(range(lo, min(n, lo + cap))):
+                assert torch.equal(part[k * b:(k + 1) * b], alone[r])
+
+
+@pytest.mark.parametrize("tag", ["real_b1", "heads4_b1", "real_b2"])
+def test_throughput_pass_matches_the_reference_golden(golden_dir, tag):
+    """the golden request (outputs of the reference's own class) rides in a throughput pass of 70 requests and still matches"""
+    gold = np.load(os.path.join(golden_dir, "siblings.npz"))
+    cfg = json.loads(str(gold[f"transformer_lstm/{tag}/cfg"]))
+    n, t = (int(v) for v in gold[f"transformer_lstm/{tag}/shape"])
+    x = torch.from_numpy(synth.boxes5(synth.make_batch(0, n, t)[0])).cuda()
+    others = _requests(500, 69, n, t)
+    m = _model(cfg)
+    with torch.no_grad():
+        y = m.forward_segments(torch.cat(others[:30] + [x] + others[30:]), 70)[30 * n:31 * n]
+    torch.cuda.synchronize()
+    assert m.last_pass_engine == "t"
+    y_ref = gold[f"transformer_lstm/{tag}/y"]
+    assert np.abs(y.cpu().numpy() - y_ref).max() < 3e-5
 
 
 def test_inference_driver_serves_transformer_minibatches_as_segments(tmp_path):
