@@ -13,14 +13,14 @@ from typing import Dict, List
 import numpy as np
 import pandas as pd
 import torch
-from torch.utils import data
 
 from . import parallel
-from .datasets import DatasetsFactory
-from .launch_monitor import verify_launches
+from .datasets import DatasetsFactory, make_loader
+from .inference_main import LOADER_MIN_BATCH
+from .launch_monitor import DeferredConsumer, HostEvent, verify_launches
+from .serving import ReasonerServer, output_boxes
 from .models_factory import ModelsFactory
 from .proj_utils import get_class_predictions
-from .supported_models import DOUBLE_OUTPUT_MODELS
 
 W_FRAME = 320
 H_FRAME = 240
@@ -45,20 +45,49 @@ def cater_setup_inference(model_name: str, results_dir: str, inference_config_pa
     dataset = DatasetsFactory.get_inference_dataset(model_name, config["sample_dir"], config["labels_dir"])
     # data parallel (not in the reference): this rank's share of the minibatches, last-frame boxes gathered by dataset index
     world, rank, exchange = parallel.world_rank()
-    batches = parallel.plan_inference_batches(model_name, len(dataset), int(config["batch_size"]), world, rank)
-    loader = data.DataLoader(dataset, batch_sampler=batches, num_workers=int(config["num_workers"]))
+    # What the loader hands over per round trip (as reasoning_inference_main): the reference's minibatch for transformer_lstm*
+    # (its attention couples the clips of a call); clip-independent reasoners travel at least LOADER_MIN_BATCH together
+    batch_size = int(config["batch_size"])
+    loader_batch = batch_size if parallel.couples_clips(model_name) else max(batch_size, LOADER_MIN_BATCH)
+    batches = parallel.plan_inference_batches(model_name, len(dataset), loader_batch, world, rank)
+    num_workers = int(config["num_workers"])
+    pin = device.type == "cuda" and num_workers > 0
+    loader = make_loader(dataset, batches, device, num_workers, pin_memory=pin)
     model = ModelsFactory.get_model(model_name, model_config, config["model_path"])
     model.eval()
     model.to(device)
+    # every minibatch is a request to the server (clip-independent reasoners: concatenated into one persistent launch;
+    # transformer_lstm*: merged as segments); of each output only the LAST frame is kept (:77) - 16 B per clip - as soon as its
+    # forward is seen complete and clean; one host copy at the end instead of a .cpu() per minibatch
+    server = ReasonerServer(model, model_name)
     names: List[str] = []
-    last: List[np.ndarray] = []
+    last: List[torch.Tensor] = []
+
+    def consume(handle):
+        last.append(output_boxes(model_name, handle.result())[:, -1, :].reshape(-1, 4).clone())          # :77
+
+    deferred = DeferredConsumer(model, consume, max_pending=64)
+    waiting = []
+
+    def hand_over():
+        while waiting and waiting[0].done():
+            handle = waiting.pop(0)
+            ready = handle._event
+            if ready is None:
+                ready = torch.cuda.Event() if device.type == "cuda" else HostEvent()
+                ready.record()
+            deferred.add(ready, handle)
+
     with torch.no_grad():
         for (boxes, _index_to_track), _y, video_names in loader:
-            out = model(boxes.to(device))
-            verify_launches(model)       # (the .cpu() below synchronises anyway) an aborted persistent launch is re-run first
-            output = out[0] if model_name in DOUBLE_OUTPUT_MODELS else out
-            last.append(output[:, -1, :].cpu().numpy().reshape(-1, 4))                 # :77
             names.extend(video_names)
+            waiting.append(server.submit(boxes.to(device, non_blocking=pin)))
+            hand_over()
+        server.flush()
+        hand_over()
+        deferred.drain(block=True, all_=True)
+        verify_launches(model)
+    last = [t.cpu().numpy() for t in ([torch.cat(last)] if last else [])]
     local = np.concatenate(last) if last else np.zeros((0, 4), dtype=np.float32)
     if exchange:
         index = torch.tensor([i for b in batches for i in b], dtype=torch.int64, device=device)

@@ -197,6 +197,24 @@ class ClipFileError(ValueError):
     """a <video>.pkl / <video>_bb.json that the native reader refuses (anything but the reference's own format) or cannot read"""
 
 
+_refusal_warned = False
+
+
+def refused_by_native_reader(err: "ClipFileError") -> None:
+    """The restricted native reader refuses what it was not built for (a pkl rewritten by another numpy / pickle path, a
+    Fortran-ordered or big-endian array, object dtype ...) - the reference's pickle.load reads all of these.  By default the
+    caller falls back to pickle.load + encode for that minibatch and this warns once; OPNET_NATIVE_STRICT=1 (untrusted inputs:
+    nothing but the restricted reader may touch the files) makes the refusal final."""
+    global _refusal_warned
+    if os.environ.get("OPNET_NATIVE_STRICT", "0") == "1":
+        raise err
+    if not _refusal_warned:
+        _refusal_warned = True
+        import warnings
+        warnings.warn(f"objectpermanence_amd: the native clip-file reader refused a file ({err}); reading such minibatches with "
+                      "pickle.load instead (OPNET_NATIVE_STRICT=1 makes this an error)", RuntimeWarning, stacklevel=3)
+
+
 def native_reader_enabled() -> bool:
     """the restricted native reader of the reference's clip files (csrc/clipfile_host.cpp); OPNET_NATIVE_PKL=0 = pickle.load +
     json.load + the encoder on their arrays, as before"""
@@ -340,10 +358,15 @@ class CaterAbstractDataset(Dataset):
         if self._native_reader is None:
             self._native_reader = native_reader_enabled()
         if self._native_reader:
-            boxes, idx, labels = load_clips_native([str(self.predictions_dir / (n + ".pkl")) for n in names],
-                                                   [self.label_paths[n] for n in names], VIDEO_NUM_FRAMES, self.n_tracks)
-            return torch.from_numpy(boxes), torch.from_numpy(idx), torch.from_numpy(labels), names
-        parts = [self._encode(i) for i in indices]
+            try:
+                boxes, idx, labels = load_clips_native([str(self.predictions_dir / (n + ".pkl")) for n in names],
+                                                       [self.label_paths[n] for n in names], VIDEO_NUM_FRAMES, self.n_tracks)
+                return torch.from_numpy(boxes), torch.from_numpy(idx), torch.from_numpy(labels), names
+            except ClipFileError as e:
+                refused_by_native_reader(e)          # (re-raises when OPNET_NATIVE_STRICT=1) - this minibatch through pickle.load
+            parts = [self._encode_python(i) for i in indices]
+        else:
+            parts = [self._encode(i) for i in indices]
         return torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), torch.stack([p[2] for p in parts]), names
 
     def _encode(self, idx: int):
@@ -353,6 +376,11 @@ class CaterAbstractDataset(Dataset):
         if self._native_reader:
             boxes, ivec, labels, names = self._encode_many([idx])
             return boxes[0], ivec[0], labels[0], names[0]
+        return self._encode_python(idx)
+
+    def _encode_python(self, idx: int):
+        """the reference's own way in (datasets.py:60-64: pickle.load + json.load), then the encoder"""
+        self._init_dataset_if_not_initiated()
         name = self.videos_names[idx]
         labels = load_snitch_labels(self.label_paths[name])
         with open(str(self.predictions_dir / (name + ".pkl")), "rb") as f:
@@ -476,9 +504,15 @@ class ClipFileLoader:
                     if slot["event"] is not None:
                         slot["event"].synchronize()          # the copies out of this pinned buffer have left it
                     names = [self.ds.videos_names[i] for i in b]
-                    load_clips_native([str(self.ds.predictions_dir / (m + ".pkl")) for m in names], [self.ds.label_paths[m] for m in names],
-                                      VIDEO_NUM_FRAMES, self.ds.n_tracks, threads=self.threads,
-                                      out=(slot["boxes"][:n].numpy(), slot["idx"][:n].numpy(), slot["labels"][:n].numpy()))
+                    try:
+                        load_clips_native([str(self.ds.predictions_dir / (m + ".pkl")) for m in names], [self.ds.label_paths[m] for m in names],
+                                          VIDEO_NUM_FRAMES, self.ds.n_tracks, threads=self.threads,
+                                          out=(slot["boxes"][:n].numpy(), slot["idx"][:n].numpy(), slot["labels"][:n].numpy()))
+                    except ClipFileError as e:
+                        refused_by_native_reader(e)      # (re-raises when OPNET_NATIVE_STRICT=1) - this minibatch through pickle.load
+                        for r, i in enumerate(b):
+                            bx, iv, lb, _ = self.ds._encode_python(i)
+                            slot["boxes"][r].copy_(bx); slot["idx"][r].copy_(iv); slot["labels"][r].copy_(lb)
                     mask = None
                     if self.with_mask:
                         mview = slot["mask"][:n]

@@ -29,7 +29,7 @@ from torch.utils import data
 
 from . import metrics, parallel
 from .datasets import DatasetsFactory, make_loader
-from .launch_monitor import verify_launches
+from .launch_monitor import DeferredConsumer, HostEvent, verify_launches
 from .models_factory import ModelsFactory
 from .serving import ReasonerServer, output_boxes
 
@@ -79,23 +79,42 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
     server = ReasonerServer(model, model_name)
 
     names: List[str] = []
-    pending, preds, gts, ious = [], [], [], []
+    preds, ious = [], []
     t_start, t_first, n_first = time.perf_counter(), None, 0
+
+    def consume(handle, labels_dev):
+        """one request's output -> int32 pixel boxes + per-frame IoUs (4.8 + 2.4 KB per clip); the output itself is dropped"""
+        output = output_boxes(model_name, handle.result())
+        pred_px, _gt_px, iou = metrics.postprocess_and_iou(output, labels_dev)
+        preds.append(pred_px); ious.append(iou)
+
+    # A request is post-processed as soon as its forward is seen complete and clean - a persistent launch that gave up (bounded
+    # spins, NaN outputs) is re-run on the launch chain into the same output tensors first, so NaN never reaches the int32
+    # post-process or the JSON files - instead of holding every output of the data set until one sync at its end
+    deferred = DeferredConsumer(model, consume, max_pending=64)
+    waiting = []                         # submitted, forward not issued yet (the server is still collecting its pass)
+
+    def hand_over():
+        """requests whose forward has been enqueued go to the deferred consumer, in submission order"""
+        while waiting and waiting[0][0].done():
+            handle, labels_dev = waiting.pop(0)
+            ready = handle._event
+            if ready is None:
+                ready = torch.cuda.Event() if device.type == "cuda" else HostEvent()
+                ready.record()
+            deferred.add(ready, handle, labels_dev)
 
     with torch.no_grad():
         for (boxes, _index_to_track), (labels, _), video_names in loader:
             if t_first is None:          # the loader's workers are up and the first minibatch has arrived: steady state from here
                 t_first, n_first = time.perf_counter(), len(video_names)
             names.extend(video_names)
-            pending.append((server.submit(boxes.to(device, non_blocking=pin)), labels.to(device, non_blocking=pin)))
+            waiting.append((server.submit(boxes.to(device, non_blocking=pin)), labels.to(device, non_blocking=pin)))
+            hand_over()
         server.flush()
-        # The sync point of this driver.  A persistent launch that gave up (bounded spins, NaN outputs) is re-run on the
-        # launch chain into the same output tensors here - NaN never reaches the int32 post-process or the JSON files.
+        hand_over()
+        deferred.drain(block=True, all_=True)    # the sync point of this driver
         verify_launches(model)
-        for handle, labels_dev in pending:
-            output = output_boxes(model_name, handle.result())
-            pred_px, gt_px, iou = metrics.postprocess_and_iou(output, labels_dev)
-            preds.append(pred_px); gts.append(gt_px); ious.append(iou)
     t_frames = preds[0].shape[1] if preds else 300
     local_pred = torch.cat(preds) if preds else torch.zeros((0, t_frames, 4), dtype=torch.int32, device=device)
     local_iou = torch.cat(ious) if ious else torch.zeros((0, t_frames), dtype=torch.float64, device=device)
@@ -115,6 +134,9 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
     t_end = time.perf_counter()
     n_local = sum(len(b) for b in batches)
     timing = {"startup_s": (t_first or t_end) - t_start, "total_s": t_end - t_start,
+              # outputs alive at once (requests whose forward had been enqueued but not yet post-processed) and the allocator's peak
+              "peak_pending_outputs": deferred.peak_pending,
+              "peak_device_bytes": int(torch.cuda.max_memory_allocated(device)) if device.type == "cuda" else None,
               # files -> predictions on the host, this rank's clips, without the DataLoader's worker start-up and first batch
               "steady_clips_per_s": (n_local - n_first) / max(t_end - t_first, 1e-9) if t_first is not None and n_local > n_first else None}
     return {"video_names": names, "predictions": pred_np, "mean_iou": mean_iou, "map_0.5": map50, "timing": timing}

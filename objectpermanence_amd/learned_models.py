@@ -676,6 +676,7 @@ class _LstmStackRunner:
         # shape on this device (H = 512; the reference's three stacked reasoners) and the batch fits one launch; "0" = never
         self.use_xcd = os.environ.get("OPSEQ_XCD", "auto")
         self._xpacked: Dict[int, Tuple[tuple, torch.Tensor]] = {}     # per stream: (weights key, register image)
+        self._cpacked: Dict[int, Tuple[tuple, torch.Tensor]] = {}     # per stream: (weights key, the launch chain's packed image)
         self._xws: Dict[tuple, torch.Tensor] = {}
         self._monitor = LaunchMonitor()
         self.xcd_launches = 0            # statistics: forwards that ran as one persistent launch
@@ -868,28 +869,40 @@ class _LstmStackRunner:
         B, T = int(x.shape[0]), int(x.shape[1])
         stream = _stream_ptr(dev)
         key = _weights_key(ws_list, dev)
-        if self.key != key:
+        # packed image and workspace PER STREAM (as _run_xcd): a server issues a segmented model's passes on two side streams in
+        # turn - a pass on stream B must neither read an image stream A is still packing nor share A's workspace
+        entry = self._cpacked.get(stream)
+        if entry is None or entry[0] != key:
             for w in ws_list:
                 if w.device != dev or w.dtype != torch.float32 or not w.is_contiguous():
                     raise RuntimeError("parameters must be contiguous fp32 on the input's device")
             nbytes = lib.opseq_lstm_stack_packed_bytes(self.L, self.KX, self.H)
             if nbytes == 0:
                 _lib.check(-2, "opseq_lstm_stack_packed_bytes")
-            if self.packed is None or self.packed.device != dev:
-                self.packed = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            if entry is None or entry[1].device != dev:
+                if len(self._cpacked) >= 4:
+                    self._cpacked.pop(next(iter(self._cpacked)))
+                buf = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            else:
+                buf = entry[1]
             arr = _lib.c_void_p * self.L
             ih = arr(*[w.data_ptr() for w in ws_list[:self.L]])
             hh = arr(*[w.data_ptr() for w in ws_list[self.L:2 * self.L]])
-            rc = lib.opseq_lstm_stack_pack_weights_f32(ih, hh, head.weight.data_ptr(), self.packed.data_ptr(), nbytes,
+            rc = lib.opseq_lstm_stack_pack_weights_f32(ih, hh, head.weight.data_ptr(), buf.data_ptr(), nbytes,
                                                        self.L, self.KX, self.H, stream)
             _lib.check(rc, "opseq_lstm_stack_pack_weights_f32")
-            self.key = key
+            self._cpacked[stream] = (key, buf)
+        self.packed, self.key = self._cpacked[stream][1], key
         wkey = (B, T, str(dev), stream)
         if wkey not in self.ws:
             nb = lib.opseq_lstm_stack_workspace_bytes(B, T, self.L, self.KX, self.H)
             if nb == 0:
                 _lib.check(-2, "opseq_lstm_stack_workspace_bytes")
-            self.ws = {wkey: torch.empty(nb, dtype=torch.uint8, device=dev)}   # keep one shape at a time
+            # one shape per stream at a time (the cached hipGraph is keyed by the workspace: a new buffer is a new graph)
+            self.ws = {k: v for k, v in self.ws.items() if k[3] != stream}
+            if len(self.ws) >= 4:
+                self.ws.pop(next(iter(self.ws)))
+            self.ws[wkey] = torch.empty(nb, dtype=torch.uint8, device=dev)
         ws = self.ws[wkey]
         y = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
         fwd = lib.opseq_lstm_stack_forward_f32 if os.environ.get("OPNET_HIP_EAGER", "0") == "1" \

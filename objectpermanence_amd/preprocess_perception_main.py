@@ -57,13 +57,21 @@ def read_video_frames(video: Union[str, Path, np.ndarray, Iterable[np.ndarray]])
         except ImportError as e:            # pragma: no cover - cv2 is absent from this image
             raise RuntimeError(f"decoding {path.suffix} needs cv2 (reference tracking_utils.VideoHandling); "
                                "pass a frame array or a .npy/.npz frame stack instead") from e
-        cap = cv2.VideoCapture(str(path))    # pragma: no cover
-        while True:                          # pragma: no cover
-            ok, frame = cap.read()
-            if not ok:
-                break
-            yield frame
-        cap.release()                        # pragma: no cover
+        # reference tracking_utils.VideoHandling (:23-30, :44-45, :56-61): cv2 reports one frame more than the labels cover, so
+        # exactly CAP_PROP_FRAME_COUNT - 1 frames are read - a 301-count CATER file yields the 300 frames its labels align with
+        # (reading to EOF would yield 301 detections, and preprocess_video only writes a pkl for exactly 300)
+        cap = cv2.VideoCapture(str(path))
+        if not cap.isOpened():
+            raise RuntimeError(f"Unable to open video {path}")
+        n_valid = int(cap.get(cv2.CAP_PROP_FRAME_COUNT)) - 1
+        try:
+            for _ in range(max(n_valid, 0)):
+                ok, frame = cap.read()
+                if not ok or frame is None:  # (a short file: the reference would hand None to the detector and crash)
+                    break
+                yield frame
+        finally:
+            cap.release()
         return
     yield from video
 

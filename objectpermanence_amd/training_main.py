@@ -29,7 +29,7 @@ from torch.utils import data
 
 from . import metrics, parallel
 from .datasets import DatasetsFactory, make_loader
-from .launch_monitor import verify_launches
+from .launch_monitor import DeferredConsumer, HostEvent as _HostEvent, verify_launches
 from .models_factory import ModelsFactory
 from .optim import FusedAdam
 from .supported_models import DOUBLE_OUTPUT_MODELS
@@ -67,21 +67,30 @@ def inference_and_iou_comp(model_name: str, model: torch.nn.Module, device: torc
     loader = make_loader(dataset, batches, device, num_workers)
     model.eval()
     loss_sum = torch.zeros((), dtype=torch.float64, device=device)
-    ious, contain, outs = [], [], []
+    ious, contain = [], []
+
+    def consume(output, labels, mask):
+        """one minibatch's outputs -> its loss share, per-frame IoUs and containment mask; the outputs themselves are dropped"""
+        nonlocal loss_sum
+        loss, _, _ = compute_loss(model_name, output, labels, mask, with_consistency=False)
+        _, _, iou = metrics.postprocess_and_iou(output, labels)
+        ious.append(iou)
+        contain.append(torch.sum(mask, dim=-1).type(torch.bool))
+        loss_sum += loss.double() * output.shape[0]
+
+    # No sync per minibatch and none that holds the data set: a minibatch is post-processed as soon as its launch is seen
+    # complete and clean (an aborted persistent launch is re-run on the launch chain, into the same output tensors, before
+    # anything is derived from its output); at most 16 minibatches' outputs are alive at any time
+    deferred = DeferredConsumer(model, consume)
     with torch.no_grad():
         for (boxes, _), (labels, mask), _names in loader:
             boxes, labels, mask = boxes.to(device), labels.to(device), mask.to(device)
             out = model(boxes)
-            outs.append((out[0] if model_name in DOUBLE_OUTPUT_MODELS else out, labels, mask))
-        # ONE sync for the whole set: an aborted persistent launch is re-run on the launch chain (into the same output
-        # tensors) before anything is derived from its output
+            ready = torch.cuda.Event() if device.type == "cuda" else _HostEvent()
+            ready.record()
+            deferred.add(ready, out[0] if model_name in DOUBLE_OUTPUT_MODELS else out, labels, mask)
+        deferred.drain(block=True, all_=True)
         verify_launches(model)
-        for output, labels, mask in outs:
-            loss, _, _ = compute_loss(model_name, output, labels, mask, with_consistency=False)
-            _, _, iou = metrics.postprocess_and_iou(output, labels)
-            ious.append(iou)
-            contain.append(torch.sum(mask, dim=-1).type(torch.bool))
-            loss_sum += loss.double() * output.shape[0]
     t_frames = ious[0].shape[1] if ious else 300
     iou = torch.cat(ious) if ious else torch.zeros((0, t_frames), dtype=torch.float64, device=device)
     cm = torch.cat(contain) if contain else torch.zeros((0, t_frames), dtype=torch.bool, device=device)
@@ -133,11 +142,16 @@ def training_main(model_name: str, train_config: Dict[str, Any], model_config: D
     training_loader = make_loader(train_ds, [idx for idx, _ in steps if idx], device, nw)
     comm = torch.cuda.Stream(device=device) if exchange and device.type == "cuda" else None
 
+    if exchange and parallel.couples_clips(model_name) and world > 1 and rank == 0:
+        # (the reference has one process: one optimiser step per minibatch)
+        print(f"data parallel over {world} ranks with {model_name}: attention couples the clips of a minibatch, so every rank takes "
+              f"WHOLE reference minibatches and one optimiser step consumes {world} of them - effective batch {world * bs} at the "
+              f"configured learning rate, {world}x fewer updates per epoch than the reference's single process")
     highest_dev_iou, best_path, history = 0.0, None, []
     start = time.time()
     for epoch in range(train_config["num_epochs"]):
         model.train(mode=True)
-        running = 0.0
+        running, consumed = 0.0, 0
         it = iter(training_loader)
 
         def fetch(step_idx):
@@ -164,9 +178,10 @@ def training_main(model_name: str, train_config: Dict[str, Any], model_config: D
             # a non-finite loss on any rank: the update was skipped on every rank (guarded Adam); counters rolled back, warned
             step_skipped_nonfinite(model, optimizer, loss_value)
             running += loss_value
+            consumed += n_global                 # clips this step actually trained on, over all ranks (the reference: (k + 1) * batch_size)
             if (k + 1) % train_config["print_step"] == 0 and rank == 0:
                 print("Train Epoch: {} [{}/{}]\t Average Loss: {:.4f} Training began {} seconds ago".format(
-                    epoch + 1, (k + 1) * bs, len(train_ds), running / train_config["print_step"], int(time.time() - start)))
+                    epoch + 1, consumed, len(train_ds), running / train_config["print_step"], int(time.time() - start)))
                 running = 0.0
         train_loss, train_miou, train_cmiou = inference_and_iou_comp(model_name, model, device, train_ds, ibs, nw)
         dev_loss, dev_miou, dev_cmiou = inference_and_iou_comp(model_name, model, device, dev_ds, ibs, nw)

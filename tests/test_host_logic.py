@@ -714,3 +714,98 @@ def test_every_rank_starts_from_rank_zeros_weights(tmp_path):
     w = lone.weight.detach().clone()
     parallel.broadcast_parameters(lone)
     assert torch.equal(lone.weight, w)
+
+
+def test_cv2_branch_reads_frame_count_minus_one_frames(tmp_path, monkeypatch):
+    """reference tracking_utils.VideoHandling (:27-30, :44-45): cv2 "always returns an extra frame", the labels align with the first
+    300, so CAP_PROP_FRAME_COUNT - 1 frames are read.  cv2 is absent from this image: a stub module stands in for it."""
+    import sys
+    import types
+    from objectpermanence_amd.preprocess_perception_main import read_video_frames
+
+    class Cap:
+        released = 0
+
+        def __init__(self, path, n):
+            self.n, self.i = n, 0
+
+        def isOpened(self):
+            return self.n >= 0
+
+        def get(self, prop):
+            assert prop == 7
+            return float(self.n)
+
+        def read(self):
+            if self.i >= self.n:
+                return False, None
+            self.i += 1
+            return True, np.full((2, 2, 3), (self.i - 1) % 256, dtype=np.uint8)
+
+        def release(self):
+            Cap.released += 1
+
+    counts = {"a.avi": 301, "short.avi": 5, "empty.avi": 0, "bad.avi": -1}
+    cv2 = types.ModuleType("cv2")
+    cv2.CAP_PROP_FRAME_COUNT = 7
+    cv2.VideoCapture = lambda path: Cap(path, counts[os.path.basename(path)])
+    monkeypatch.setitem(sys.modules, "cv2", cv2)
+    frames = list(read_video_frames(tmp_path / "a.avi"))
+    assert len(frames) == 300 and int(frames[0][0, 0, 0]) == 0 and int(frames[-1][0, 0, 0]) == 299 % 256
+    assert len(list(read_video_frames(str(tmp_path / "short.avi")))) == 4
+    assert list(read_video_frames(tmp_path / "empty.avi")) == []
+    assert Cap.released == 3
+    with pytest.raises(RuntimeError, match="Unable to open"):
+        list(read_video_frames(tmp_path / "bad.avi"))
+
+
+def test_deferred_consumer_consumes_in_order_when_ready_and_bounds_what_is_alive():
+    """launch_monitor.DeferredConsumer (the evaluation / inference loops): an output is post-processed and dropped as soon as its
+    event has completed - never before, never out of order - every completed launch is settled first (an aborted one healed
+    before its output is used), and more than max_pending waiting entries make the producer wait for the oldest"""
+    from objectpermanence_amd import launch_monitor as lm
+
+    class Ev:
+        def __init__(self, done=False):
+            self.done, self.waited = done, 0
+
+        def query(self):
+            return self.done
+
+        def synchronize(self):
+            self.waited += 1
+            self.done = True
+
+    class Model(torch.nn.Module):
+        pass
+
+    m = Model()
+    m._monitor = lm.LaunchMonitor()
+    m._monitor._host = torch.zeros((lm._SLOTS, 4), dtype=torch.int32)
+    healed, got = [], []
+    # a watched launch that aborted and has completed: it must be healed before the first consume
+    slot = m._monitor._free.pop()
+    m._monitor._host[slot, 0] = 1
+    m._monitor._pending.append((Ev(True), slot, lambda: healed.append("redo"), "launch"))
+    running = Ev(False)                               # ... and one still running: settle() must not wait for it
+    slot2 = m._monitor._free.pop()
+    m._monitor._pending.append((running, slot2, None, "running"))
+    d = lm.DeferredConsumer(m, lambda tag: got.append((tag, list(healed))), max_pending=3)
+    evs = [Ev(False) for _ in range(6)]
+    import warnings
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        d.add(evs[0], "a")
+        d.add(evs[1], "b")
+        assert got == []                                  # nothing is ready: nothing consumed, nobody waited
+        evs[1].done = True
+        d.drain()
+        assert got == []                                  # b is ready but a is not: order is kept
+        evs[0].done = True
+        d.drain()
+    assert got == [("a", ["redo"]), ("b", ["redo"])] and running.waited == 0 and m._monitor.pending() == 1
+    for k in range(2, 6):
+        d.add(evs[k], "cdef"[k - 2])                      # the fourth waiting entry exceeds max_pending = 3: waits for the oldest
+    assert evs[2].waited == 1 and [g[0] for g in got] == ["a", "b", "c"] and d.peak_pending == 4
+    d.drain(block=True, all_=True)
+    assert [g[0] for g in got] == list("abcdef") and all(e.done for e in evs)

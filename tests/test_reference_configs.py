@@ -1,0 +1,159 @@
+""""The JSON configs in configs/ still work unchanged" (BASELINE.json north_star), pinned to the reference's OWN files.
+
+Container-only (skipped where /root/reference is absent, like the golden regeneration test): every one of the eight
+/root/reference/configs/*.json is read as it lies and fed to the mirrored code -
+  * the five model configs build every `--model_type` through ModelsFactory.get_model, and the module's state_dict (names and
+    shapes) is the one of the reference's class built from the SAME file (models_factory.py:42-80, learned_models.py);
+  * the three run configs: the keys each mirrored driver reads are keys of the reference's file, they are the keys the
+    reference's driver reads (AST of both sides), and the drivers - called with the file's dict - get as far as their first
+    access to the (absent) data without a KeyError.
+No GPU: constructing the modules and reading configs is host logic."""
+import ast
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("OPNET_REFERENCE", "/root/reference")
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "configs")), reason="the reference is not on this machine")
+
+MODEL_FILES = {"opnet": "opnet_model_config.json", "opnet_lstm_mlp": "opnet_lstm_mlp_model_config.json",
+               "baseline_lstm": "baseline_lstm_model_config.json", "non_linear_lstm": "non_linear_lstm_model_config.json",
+               "transformer_lstm": "transformer_lstm_model_config.json"}
+
+
+def _ref_json(name):
+    with open(os.path.join(REF, "configs", name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def ref_models():
+    """the reference's learned_models / supported_models, imported with stubs for cv2 / torchvision (not on the reasoner path)"""
+    for name in ("cv2", "torchvision", "torchvision.models", "torchvision.models.detection", "torchvision.models.detection.faster_rcnn"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.models.detection.faster_rcnn"].FastRCNNPredictor = object
+    if not hasattr(np, "int"):
+        np.int = int
+    if not hasattr(np, "bool"):
+        np.bool = bool
+    sys.path.insert(0, REF)
+    try:
+        from baselines import learned_models, supported_models
+    finally:
+        sys.path.remove(REF)
+    return learned_models, supported_models
+
+
+def test_all_eight_reference_config_files_are_covered():
+    have = sorted(os.listdir(os.path.join(REF, "configs")))
+    assert have == sorted(list(MODEL_FILES.values()) + ["training_config.json", "inference_config.json", "preprocess_config.json"])
+
+
+def test_every_model_type_builds_from_the_reference_files_with_the_reference_state_dict(ref_models):
+    from objectpermanence_amd import ModelsFactory, supported_models
+    lm, ref_sup = ref_models
+    ref_cls = {"opnet": lm.OPNet, "opnet_lstm_mlp": lm.OPNetLstmMlp, "baseline_lstm": lm.BaselineLstm,
+               "non_linear_lstm": lm.NonLinearLstm, "transformer_lstm": lm.TransformerLstm}
+    # the --model_type vocabulary is the reference's (supported_models.py:1-56)
+    programmed = set(ref_sup.PROGRAMMED_MODELS)         # the detector-only trackers (out of scope), not reasoners
+    for lst in ("TRAINING_SUPPORTED_MODELS", "INFERENCE_SUPPORTED_MODELS", "TRAINING_SUPPORTED_MODELS_5_TRACKS",
+                "TRAINING_SUPPORTED_MODELS_6_TRACKS", "DOUBLE_OUTPUT_MODELS", "NO_LABELS_MODELS"):
+        assert sorted(getattr(supported_models, lst)) == sorted(set(getattr(ref_sup, lst)) - programmed), lst
+    names = sorted(set(getattr(ref_sup, "TRAINING_SUPPORTED_MODELS", [])) | set(getattr(ref_sup, "INFERENCE_SUPPORTED_MODELS", [])) | set(MODEL_FILES))
+    built = 0
+    for name in names:
+        base = name.replace("_no_labels", "")
+        if base not in MODEL_FILES:
+            continue                                     # (trackers / heuristics: not learned reasoners)
+        cfg = _ref_json(MODEL_FILES[base])
+        try:
+            mine = ModelsFactory.get_model(name, dict(cfg))
+        except AttributeError:
+            # the reference's factory does not know "opnet_no_labels" either (models_factory.py:64 spells it "opent_no_labels")
+            assert name == "opnet_no_labels"
+            mine = ModelsFactory.get_model("opent_no_labels", dict(cfg))
+        ref = ref_cls[base](dict(cfg))
+        a, b = mine.state_dict(), ref.state_dict()
+        assert list(a.keys()) == list(b.keys()), name
+        for k in a:
+            assert tuple(a[k].shape) == tuple(b[k].shape) and a[k].dtype == b[k].dtype, (name, k)
+        # ... and a checkpoint of the reference's class loads (training_main.py:28 torch.save(state_dict) -> models_factory.py:77)
+        mine.load_state_dict(ref.state_dict())
+        built += 1
+    assert built >= 8
+
+
+def _keys_read(path, names):
+    """string keys subscripted on (or tested with `in` against) the variables `names` in the source file `path`"""
+    tree = ast.parse(open(path).read())
+    keys = set()
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Subscript) and isinstance(node.value, ast.Name) and node.value.id in names:
+            sl = node.slice
+            if isinstance(sl, ast.Constant) and isinstance(sl.value, str):
+                keys.add(sl.value)
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "get" and \
+                isinstance(node.func.value, ast.Name) and node.func.value.id in names and node.args and \
+                isinstance(node.args[0], ast.Constant) and isinstance(node.args[0].value, str):
+            keys.add(node.args[0].value)
+    return keys
+
+
+DRIVERS = [  # (reference source, mirrored source, the reference's config file, keys the reference guards with `in` / only one mode reads)
+    ("baselines/training_main.py", "objectpermanence_amd/training_main.py", "training_config.json", set()),
+    ("baselines/inference_main.py", "objectpermanence_amd/inference_main.py", "inference_config.json", {"sample_file"}),
+    ("baselines/cater_setup_inference.py", "objectpermanence_amd/cater_setup_inference.py", "inference_config.json", set()),
+    ("baselines/preprocess_perception_main.py", "objectpermanence_amd/preprocess_perception_main.py", "preprocess_config.json",
+     {"sample_file", "device"}),
+]
+
+
+@pytest.mark.parametrize("ref_src,my_src,cfg_file,optional", DRIVERS)
+def test_drivers_read_exactly_the_keys_the_reference_files_hold(ref_src, my_src, cfg_file, optional):
+    names = {"config", "train_config", "inference_config", "preprocess_config"}
+    file_keys = set(_ref_json(cfg_file))
+    ref_keys = _keys_read(os.path.join(REF, ref_src), names)
+    my_keys = _keys_read(os.path.join(REPO, my_src), names)
+    if ref_src.endswith("preprocess_perception_main.py"):
+        # the reference's preprocess driver reads videos_dir through inference_main.py's helpers (get_videos_paths...)
+        ref_keys |= _keys_read(os.path.join(REF, "baselines/inference_main.py"), names) & {"videos_dir", "sample_file"}
+    # every key the mirrored driver needs exists in the reference's file (the file works unchanged) ...
+    assert my_keys - optional <= file_keys, sorted(my_keys - optional - file_keys)
+    # ... and the mirror reads no key the reference's driver does not (no new mandatory settings)
+    assert my_keys - optional <= ref_keys | optional, sorted(my_keys - ref_keys)
+
+
+class _Recording(dict):
+    def __init__(self, d):
+        super().__init__(d)
+        self.read = set()
+
+    def __getitem__(self, k):
+        self.read.add(k)
+        return super().__getitem__(k)               # KeyError = the driver wants a key the reference's file does not have
+
+
+def test_drivers_reach_their_data_with_the_reference_dicts(tmp_path, monkeypatch):
+    """the mirrored drivers called with the reference's files as they lie: each must fail at its first access to the absent DATA
+    (FileNotFoundError / a device error), never on a missing key"""
+    from objectpermanence_amd.cater_setup_inference import cater_setup_inference
+    from objectpermanence_amd.inference_main import reasoning_inference_main
+    from objectpermanence_amd.training_main import training_main
+    monkeypatch.chdir(tmp_path)                         # the files' relative paths (data/..., trained_models/...) resolve to nothing here
+    model_cfg = _ref_json(MODEL_FILES["opnet"])
+    train = _Recording(_ref_json("training_config.json"))
+    with pytest.raises((FileNotFoundError, NotADirectoryError, RuntimeError, AssertionError, OSError)) as e:
+        training_main("opnet", train, model_cfg)
+    assert not isinstance(e.value, KeyError) and train.read and train.read <= set(_ref_json("training_config.json"))
+    for fn in (reasoning_inference_main, cater_setup_inference):
+        with pytest.raises((FileNotFoundError, NotADirectoryError, RuntimeError, AssertionError, OSError)) as e:
+            fn("opnet", str(tmp_path / "out"), os.path.join(REF, "configs", "inference_config.json"),
+               os.path.join(REF, "configs", MODEL_FILES["opnet"]))
+        assert not isinstance(e.value, KeyError)
