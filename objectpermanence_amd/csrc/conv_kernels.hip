@@ -34,6 +34,9 @@ struct ConvArgs {
     // 128 x BN sums to P[z][M][Cout]; conv_splitk_reduce adds the slices in order and applies bias / residual / ReLU
     float *P;
     int ksplit, ksteps;
+#ifdef CONV_TRACE                 // tools/probes/gemm_probe.hip only: per-K-step cycle sums of wave 0 of every workgroup
+    unsigned long long *trace;    // [0] steps, [1] top -> MFMAs issued, [2] -> waits done, [3] -> next top (barrier + DMA issue)
+#endif
 };
 
 __global__ void __launch_bounds__(256) conv2d_nhwc(const ConvArgs a)
@@ -518,7 +521,17 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
     __builtin_amdgcn_s_barrier();
 
     const int fsw = (i >> 2) & 3;                       // fragment rows are 16-aligned: (row >> 2) & 3 = (i >> 2) & 3
+#ifdef CONV_TRACE
+    unsigned long long tr_t0 = 0, tr_t1 = 0, tr_t2 = 0, tr_prev2 = 0, tr_a = 0, tr_b = 0, tr_c = 0;
+    if (a.trace && tid == 0) {          // census of resident workgroups: [4] now, [5] the most seen at once
+        const unsigned long long now = atomicAdd(a.trace + 4, 1ull) + 1;
+        atomicMax(a.trace + 5, now);
+    }
+#endif
     for (int q = 0; q < nhex; ++q) {
+#ifdef CONV_TRACE
+        asm volatile("s_memtime %0" : "=s"(tr_t0));
+#endif
         const bool steady = q + NS - 1 < nhex;
         if (steady) issue(q + NS - 1);                  // into the buffer every wave finished reading at step q-1
         const float4 *As = smem + (q % NS) * STAGE_F4;
@@ -546,11 +559,29 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
             for (int y = 0; y < FN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[y].w, af[x].w, acc[x][y], 0, 0, 0);
         // stage q+1 must have landed before the barrier that lets every wave read it: in steady state NS-2 later
         // stages stay in flight; in the tail (nothing new issued) simply drain
+#ifdef CONV_TRACE
+        asm volatile("s_memtime %0" : "=s"(tr_t1));
+#endif
         if (steady) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPS * (NS - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef CONV_TRACE
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_t2), "+s"(tr_t0), "+s"(tr_t1) :: "memory");
+        if (q > 0) tr_c += tr_t0 - tr_prev2;
+        tr_a += tr_t1 - tr_t0; tr_b += tr_t2 - tr_t1; tr_prev2 = tr_t2;
+#endif
         __builtin_amdgcn_s_barrier();
     }
+#ifdef CONV_TRACE
+    if (a.trace && tid == 0) atomicAdd(a.trace + 4, ~0ull);
+    if (a.trace && tid == 0 && (blockIdx.x & 31) == 0) {
+        atomicAdd(a.trace + 0, (unsigned long long)nhex);
+        atomicAdd(a.trace + 1, tr_a); atomicAdd(a.trace + 2, tr_b); atomicAdd(a.trace + 3, tr_c);
+    }
+#endif
+#ifdef CONV_DEBUG                      // probe only: bit 8 of relu = leave without storing (what the epilogue costs)
+    if (a.relu & 256) { if (acc[0][0][0] == 12345.678f) a.Y[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
+#endif
     // epilogue: D fragment lane = (pixel column l&15, channel rows 4*(l>>4)+r)
     if (a.ksplit > 1) {                 // raw sums of this K slice (Cout % 4 == 0, dense rows: the host's split plan)
         float *P = a.P + (long)blockIdx.z * M * a.Cout;
