@@ -8,6 +8,7 @@
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include "../../objectpermanence_amd/csrc/conv_kernels.hip"
+#include "conv_persistent_variant.hip"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -48,7 +49,43 @@ int main(int argc, char **argv)
         c.trace = trace;
 #endif
         const dim3 g((unsigned)((M + 127) / 128), (s.Cout + 127) / 128, 1);
-        for (int variant = 0; variant < 4; ++variant) {    // 0: as is (3 workgroups per CU); 1: no epilogue stores; 2, 3: the same at 1 per CU
+        {   // the persistent tile loop (conv2d_nhwc_pglds): 3 workgroups per CU resident, one stage ring across tiles; checked against the launch-per-tile form
+            int per_cu = 0;
+            CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv2d_nhwc_pglds<128, 3>, 256, 0));
+            const unsigned long long nt = (unsigned long long)g.x * g.y;
+            const unsigned slots = (unsigned)per_cu * 256, gp = nt >= slots ? slots : (unsigned)((nt + 7) / 8 * 8);
+            c.relu = 1;
+            float *Y2;
+            CK(hipMalloc(&Y2, (size_t)M * s.Cout * 4));
+            conv2d_nhwc_glds<128, 3><<<g, 256>>>(c);
+            ConvArgs c2 = c; c2.Y = Y2;
+            conv2d_nhwc_pglds<128, 3><<<gp, 256>>>(c2);
+            CK(hipDeviceSynchronize());
+            std::vector<float> ya((size_t)M * s.Cout), yb((size_t)M * s.Cout);
+            CK(hipMemcpy(ya.data(), Y, ya.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(yb.data(), Y2, yb.size() * 4, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t k = 0; k < ya.size(); ++k) bad += ya[k] != yb[k];
+            for (int mode : {0, 1, 2, 3}) {       // 0 as is, 1 no stores, 2 stores spread over the K loop (wrong values), 3 as is with start skew
+                hipEvent_t e0, e1;
+                CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                const int skew = mode == 3 ? 100000 : 0;
+                c2.ksteps = skew;
+                c2.relu = mode == 1 ? 257 : mode == 2 ? 513 : 1;
+                CK(hipEventRecord(e0));
+                for (int r = 0; r < 5; ++r) conv2d_nhwc_pglds<128, 3><<<gp, 256>>>(c2);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                ms /= 5;
+                const double fl = 2.0 * M * s.Cout * K;
+                printf("%-32s persistent mode %d (%u workgroups, %d per CU, start skew %6d cycles): %8.1f us %6.1f TF (%.3f)   differing from the launch-per-tile form: %zu\n",
+                       s.name, mode, gp, per_cu, skew, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 157.3, bad);
+            }
+            CK(hipFree(Y2));
+        }
+        for (int variant = 0; variant < 2; ++variant) {    // 0: as is (3 workgroups per CU); 1: no epilogue stores; 2, 3: the same at 1 per CU
             const int pad_kb = variant >= 2 ? 40 : 0;
             const int occ = 160 / (48 + pad_kb);
             c.relu = (variant & 1) ? 257 : 1;
