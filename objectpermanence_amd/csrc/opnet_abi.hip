@@ -1314,13 +1314,6 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
     // leave most of the chip idle (measured per step, fused / split: B=96 6.72 / 7.17 ms, B=128 7.79 / 7.92, B=256 12.97 / 12.38).
     const char *mode = getenv("OPNET_BWD_MODE");          // "fused" / "split": measurement override
     const bool fused = mode ? strcmp(mode, "fused") == 0 : RB <= 4;
-    // MEASUREMENT ONLY (OPNET_WGRAD_OVERLAP_PROBE=1, tools/wgrad_overlap_probe.sh; the gradients of such a step are WRONG): the
-    // weight-gradient launches go out on a side stream BEFORE the reverse recurrence - on the histories the previous step left -
-    // so that the two run side by side: what the recurrence loses to a co-resident throughput kernel against what hiding the
-    // 0.24 ms of weight gradients would save
-    static hipStream_t probe_stream = nullptr;
-    static hipEvent_t probe_ev[2] = {nullptr, nullptr};
-    const bool overlap_probe = x4_bwd && env_int("OPNET_WGRAD_OVERLAP_PROBE", 0) != 0;
     if (x4_bwd) {
         // small batch on a whole device: the 4-clip persistent reverse recurrence (opnet_xcd4_kernels.hip)
         Xcd4BArgs x;
@@ -1329,14 +1322,6 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
         HIP_TRY(hipGetDevice(&dev));
         opnet_xcd4_init_bwd<<<256, 256, 0, st>>>(x, (const float4 *)dy, (float4 *)(w + W.dyp), (float *)(w + W.dcz),
                                                  (long)((W.dcz_end - W.dcz) / 4), B);
-        if (overlap_probe) {
-            if (!probe_ev[0]) {
-                HIP_TRY(hipStreamCreateWithFlags(&probe_stream, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&probe_ev[0], hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&probe_ev[1], hipEventDisableTiming));
-            }
-            HIP_TRY(hipEventRecord(probe_ev[0], st));
-        }
         std::lock_guard<std::mutex> lock(g_xcd_mu);
         if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
         else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
@@ -1356,16 +1341,6 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
         }
     }
     // weight gradients over the saved histories
-    if (overlap_probe) {
-        if (!probe_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&probe_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&probe_ev[0], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&probe_ev[1], hipEventDisableTiming));
-        }
-        HIP_TRY(hipStreamWaitEvent(probe_stream, probe_ev[0], 0));     // (recorded before the recurrence was enqueued, below)
-    }
-    hipStream_t st_main = st;
-    if (overlap_probe) st = probe_stream;
     WgradBatch wb;
     int njobs = 0, ntiles = 0;
     auto wgrad = [&](const float4 *P, long ps, int MQ, const float4 *Q, long qs, int NQ, float *out, int ld,
@@ -1396,11 +1371,11 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
     }
     // a forward or reverse recurrence that gave up (4-clip persistent kernels) left partial histories: every dW becomes NaN
     wb.abort = x4_batch(B, H1, H2) ? (const unsigned *)(w + W.x4status) : nullptr;
-    if (!wgrad_wave_tiles(wb.job, njobs, T, RB, (float *)(w + W.wgpart), wb.abort, st)) opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
-    if (overlap_probe) {
-        HIP_TRY(hipEventRecord(probe_ev[1], probe_stream));
-        HIP_TRY(hipStreamWaitEvent(st_main, probe_ev[1], 0));
+    if (wgrad_wave_tiles(wb.job, njobs, T, RB, (float *)(w + W.wgpart), wb.abort, st)) {
+        HIP_TRY(hipGetLastError());
+        return OPNET_OK;
     }
+    opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }
