@@ -1164,10 +1164,14 @@ def bench_infer_xcd(args, model, batches, world, rank, dev, dist):
         # launch) next to the kernel's own bytes: what the whole forward moves per launch
         pack = pmc_traffic("opnet_xcd_pack_input", cpl).get("traffic")
         compulsory = cpl * 130_800 + W_BYTES
+        # the server's torch.cat of the launch's requests (serving.ReasonerServer, concat = True) sits in the timed region too: it
+        # reads and writes every input byte once more (108 000 B per clip each way; arithmetic, not a PMC figure)
+        concat = 2 * cpl * 108_000 if per_launch > 1 else 0
         traffic["traffic_pack_kernel"] = pack
+        traffic["traffic_request_concat"] = concat
         traffic["compulsory_bytes_8d4"] = compulsory
         traffic["traffic_over_compulsory_8d4"] = round(traffic["traffic"] / compulsory, 3)
-        traffic["forward_total_over_compulsory_8d4"] = round((traffic["traffic"] + (pack or 0)) / compulsory, 3)
+        traffic["forward_total_over_compulsory_8d4"] = round((traffic["traffic"] + (pack or 0) + concat) / compulsory, 3)
     out["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                        "frac": round(tf / MFMA_F32_PEAK_TF, 4), **traffic,
                        "kernel": "opnet_xcd_forward", "launch_ms": round(kms.value / max(launches * R, 1), 4),

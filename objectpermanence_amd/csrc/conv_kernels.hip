@@ -488,21 +488,32 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
         t_dy = tap / a.KW;
         t_dx = tap - t_dy * a.KW;
     }
-    auto issue = [&](int q) {           // q: step within the slice
-        const unsigned sbase = lds0 + (unsigned)(q % NS) * (STAGE_F4 * 16);
-        const int toff = ((t_dy * a.W + t_dx) * XS + t_c0) * 4;
+    // Per-lane work of a stage issue is ONE add per DMA: the tap's masked base offset (aoff: the bounds tests and the select) is
+    // recomputed only when the tap changes - every Cin / 16 steps - and a masked offset (>= 2^31: past num_records, the DMA writes
+    // zeros) stays masked under the small per-step additions.  fp32 MFMA runs on the VALU lanes: every VALU instruction of the K
+    // loop is taken from the MFMA stream (round 5: ~20 -> 4 per step).
+    unsigned aoff[2];
+    auto tap_offsets = [&]() {
+        const int toff = ((t_dy * a.W + t_dx) * XS) * 4;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool ok = prow_ok[j] && (unsigned)(iy0[j] + t_dy) < (unsigned)a.H && (unsigned)(ix0[j] + t_dx) < (unsigned)a.W;
-            conv_glds16(rx, ok ? (unsigned)(xoff[j] + toff) : 0x80000000u, sbase + (32 * w + 16 * j) * 64);
+            aoff[j] = ok ? (unsigned)(xoff[j] + toff) : 0x80000000u;
         }
+    };
+    tap_offsets();
+    auto issue = [&](int q) {           // q: step within the slice
+        const unsigned sbase = lds0 + (unsigned)(q % NS) * (STAGE_F4 * 16);
+        const unsigned cb = (unsigned)t_c0 * 4u, wb = (unsigned)(qb + q) * 64u;      // (wave-uniform)
 #pragma unroll
-        for (int j = 0; j < WLD; ++j)
-            conv_glds16(rwt, woff[j] == 0x80000000u ? woff[j] : woff[j] + (qb + q) * 64, sbase + BM * 64 + ((BN / 4) * w + 16 * j) * 64);
+        for (int j = 0; j < 2; ++j) conv_glds16(rx, aoff[j] + cb, sbase + (32 * w + 16 * j) * 64);
+#pragma unroll
+        for (int j = 0; j < WLD; ++j) conv_glds16(rwt, woff[j] + wb, sbase + BM * 64 + ((BN / 4) * w + 16 * j) * 64);
         t_c0 += 16;
         if (t_c0 == a.Cin) {
             t_c0 = 0;
             if (++t_dx == a.KW) { t_dx = 0; ++t_dy; }
+            tap_offsets();
         }
     };
 
