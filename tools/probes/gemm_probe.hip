@@ -25,6 +25,10 @@ int main(int argc, char **argv)
         {"l2c2   16x100x136 128->128 3x3", 16, 100, 136, 128, 128, 3, 1},
         {"l4c2   16x25x34   512->512 3x3", 16, 25, 34, 512, 512, 3, 1},
         {"l3c1   16x50x68  1024->256 1x1", 16, 50, 68, 1024, 256, 1, 0},
+        {"l3c2   16x50x68   256->256 3x3", 16, 50, 68, 256, 256, 3, 1},
+        {"l3c3   16x50x68   256->1024 1x1", 16, 50, 68, 256, 1024, 1, 0},
+        {"fc6    M=16000 N=1024 K=12544 ", 1, 1, 16000, 12544, 1024, 1, 0},
+        {"p3     16x100x136 256->256 3x3", 16, 100, 136, 256, 256, 3, 1},
     };
     unsigned long long *trace;
     CK(hipMalloc(&trace, 64));
@@ -84,6 +88,23 @@ int main(int argc, char **argv)
                        s.name, mode, gp, per_cu, skew, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 157.3, bad);
             }
             CK(hipFree(Y2));
+        }
+        {   // the 128 x 64-tile form of the product kernel (4 resident per CU): twice the tiles - better rounds on mid-size layers?
+            const dim3 g64((unsigned)((M + 127) / 128), (s.Cout + 63) / 64, 1);
+            c.relu = 1;
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            conv2d_nhwc_glds<64, 3><<<g64, 256>>>(c);
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < 5; ++r) conv2d_nhwc_glds<64, 3><<<g64, 256>>>(c);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= 5;
+            const double fl = 2.0 * M * s.Cout * K;
+            printf("%-32s BN = 64 tiles (%u workgroups = %.2f rounds of 1024; BN = 128: %u = %.2f of 768): %8.1f us %6.1f TF (%.3f)\n", s.name,
+                   g64.x * g64.y, g64.x * g64.y / 1024.0, g.x * g.y, g.x * g.y / 768.0, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 157.3);
         }
         for (int variant = 0; variant < 2; ++variant) {    // 0: as is (3 workgroups per CU); 1: no epilogue stores; 2, 3: the same at 1 per CU
             const int pad_kb = variant >= 2 ? 40 : 0;
