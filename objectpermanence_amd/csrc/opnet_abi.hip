@@ -51,6 +51,22 @@ __attribute__((visibility("hidden"))) int opnet_set_error(int code, const char *
                         __FILE__, __LINE__);                                               \
     } while (0)
 
+static int env_int(const char *name, int dflt);
+
+// 128 x 64 instead of 128 x 128 tiles for the LDS-DMA kernel?  Same arithmetic per output element (one K-ordered chain per element
+// whatever the tile), so the choice is free; measured per shape on the MI355X (tools/probes/gemm_probe.hip, profiles/r5_conv_gemm_probe.txt):
+// the narrow tiles (four resident workgroups per CU, twice the tiles) win by 6-11 % on short K (K <= 512: the K = 256 token-wise
+// products, the 1 x 1 expand convs) and when the wide tiles would leave a nearly empty second round (1.0-1.4 rounds of 768: the
+// stride-16 layers of a 16-frame pass, fc6); the wide tiles win by 3-8 % on the long-K 3 x 3 layers with many or fewer-than-one rounds.
+static bool conv_prefers_bn64(const ConvArgs &c, long M)
+{
+    if (c.Cout <= 64) return true;
+    const int K = c.KH * c.KW * c.Cin;
+    const double rounds128 = (double)((M + 127) / 128) * ((c.Cout + 127) / 128) / 768.0;
+    if (K <= 512) return rounds128 >= 2.0;              // (small launches: fewer, fatter workgroups keep their K loop fed)
+    return rounds128 > 1.0 && rounds128 < 1.4;
+}
+
 // the LDS-staged conv / GEMM kernels: 128 x {128, 64} tiles; LDS-DMA staging (3 stages) needs Cin % 16 == 0
 static void launch_conv_tiled(const ConvArgs &c, long M, hipStream_t st)
 {
@@ -61,7 +77,7 @@ static void launch_conv_tiled(const ConvArgs &c, long M, hipStream_t st)
     }
     const bool al = (c.Cin & 15) == 0;
     const unsigned gx = (unsigned)((M + 127) / 128);
-    if (c.Cout > 64) {
+    if (c.Cout > 64 && !(al && env_int("OPNET_CONV_BN64", 1) && conv_prefers_bn64(c, M))) {
         const dim3 g(gx, (c.Cout + 127) / 128, 1);
         if (al) conv2d_nhwc_glds<128, 3><<<g, 256, 0, st>>>(c);
         else conv2d_nhwc_tiled<128><<<g, 256, 0, st>>>(c);
