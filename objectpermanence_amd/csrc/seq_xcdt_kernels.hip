@@ -167,11 +167,15 @@ __device__ __forceinline__ bool st_wait_flags(__amdgpu_buffer_rsrc_t rws, unsign
 // only gets VALU cycles the product wave GIVES it - an issue gap of 36 cycles (XCD_GAP) after the MFMAs of the first YM rows of a
 // phase and after the first MFMA of every ST_TAIL-th row of the rest.  YM by groups per XCD: -1 (no gap anywhere) for one group -
 // the finish runs while this wave waits for the exchange anyway.
+// Measured (tools/seqt_gap_ab.sh, kernel ms at 256 / 384 / 512 clips for MODE 1 and 128 / 192 / 256 for MODE 2): no gaps at all 2.21 / 3.36 / 4.18
+// and 3.05 / 4.35 / 5.59 against 1.71 / 2.49 / 3.24 and 2.15 / 2.94 / 3.87 with them; a gap on every 3rd row of the tail is ~1 % ahead
+// of every 2nd for MODE 1 (1.69 / 2.46 / 3.20) and behind for MODE 2; 16 leading gapped rows instead of 8 with two groups help MODE 2
+// (2.08 at 128 clips) and not MODE 1; leading gaps from three groups on help nobody.
 #ifndef ST_TAIL
-#define ST_TAIL 2
+#define ST_TAIL (MODE == 1 ? 3 : 2)
 #endif
 #ifndef ST_NY2
-#define ST_NY2 8               // two groups per XCD: the exchange is on the critical path, the finish must be quick
+#define ST_NY2 (MODE == 1 ? 8 : 16)   // two groups per XCD: the exchange is on the critical path, the finish must be quick
 #endif
 #ifndef ST_NY3
 #define ST_NY3 0
