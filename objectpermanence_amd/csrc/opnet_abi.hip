@@ -3024,7 +3024,10 @@ static int conv_split_plan(const ConvArgs &a, long M, int *ksteps)
     if (conv_fills_chip(a, M) || (a.Cin & 15) || (a.Cout & 3) || a.KP != a.KH * a.KW * a.Cin) return 1;
     if ((long)a.N * a.H * a.W * a.Cin * 4 >= (1L << 31) || (long)a.Cout * a.KP * 4 >= (1L << 31)) return 1;
     const int nhex = a.KP >> 4;
-    const long tiles = ((M + 127) / 128) * (a.Cout > 64 ? (a.Cout + 127) / 128 : (a.Cout + 63) / 64);
+    // split layers run on 128 x 64 tiles (round 5: twice the tiles = half the slices, i.e. half the partial-sum traffic and fewer
+    // K-loop prologues: the one-frame call 240 -> 246 frames/s with two in flight; OPNET_SPLIT_BN128=1 = the wide tiles of round 4)
+    const bool bn64 = a.Cout <= 64 || env_int("OPNET_SPLIT_BN128", 0) == 0;
+    const long tiles = ((M + 127) / 128) * (bn64 ? (a.Cout + 63) / 64 : (a.Cout + 127) / 128);
     long S = (640 + tiles - 1) / tiles;      // (swept on the one-frame call: 400 .. 1024 workgroups x >= 8 .. 32 steps; this is the minimum)
     if (S > nhex / 16) S = nhex / 16;
     if (S > 32) S = 32;
@@ -3086,7 +3089,7 @@ extern "C" int opdet_conv2d_ws_f32(const float *x, const float *w, const float *
         if (!workspace || workspace_bytes < need) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", workspace_bytes, need);
         a.P = (float *)workspace; a.ksplit = S; a.ksteps = ksteps;
         const unsigned gx = (unsigned)((M + 127) / 128);
-        if (Cout > 64) conv2d_nhwc_glds<128, 3><<<dim3(gx, (Cout + 127) / 128, S), 256, 0, st>>>(a);
+        if (Cout > 64 && env_int("OPNET_SPLIT_BN128", 0) != 0) conv2d_nhwc_glds<128, 3><<<dim3(gx, (Cout + 127) / 128, S), 256, 0, st>>>(a);
         else conv2d_nhwc_glds<64, 3><<<dim3(gx, (Cout + 63) / 64, S), 256, 0, st>>>(a);
         const long n4 = M * Cout / 4;
         conv_splitk_reduce<<<(unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256), 256, 0, st>>>(a.P, S, M, Cout, bias, residual, y,

@@ -65,8 +65,8 @@ def test_conv2d_tiled_matches_torch(cin, cout, k, stride, pad, h, w):
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,pad,n,h,w,slices", [
-    (512, 512, 3, 1, 1, 1, 25, 34, 18),     # layer4 3x3 of one frame: 28 tiles of 128 x 128, 288 K steps
-    (256, 256, 3, 1, 1, 1, 50, 68, 9),      # layer3 3x3: 54 tiles, 144 K steps
+    (512, 512, 3, 1, 1, 1, 25, 34, 12),     # layer4 3x3 of one frame: 56 tiles of 128 x 64, 288 K steps
+    (256, 256, 3, 1, 1, 1, 50, 68, 6),      # layer3 3x3: 108 tiles, 144 K steps
     (1024, 512, 1, 1, 0, 1, 25, 34, 4),     # 1x1, 64 K steps
     (256, 48, 3, 2, 1, 1, 50, 68, 9),       # BN = 64 tiles, stride 2, Cout % 16 != 0
     (64, 64, 1, 1, 0, 2, 20, 27, 1),        # K too short: not split (0 bytes of scratch), same entry point
@@ -96,7 +96,7 @@ def test_conv2d_split_k_matches_torch(cin, cout, k, stride, pad, n, h, w, slices
 
 
 def test_linear_rows_split_k_and_refusals():
-    """TwoMLPHead.fc6 of one frame (1000 x 12544 -> 1024): 64 tiles, 784 K steps -> 10 slices"""
+    """TwoMLPHead.fc6 of one frame (1000 x 12544 -> 1024): 128 tiles of 128 x 64, 784 K steps -> 5 slices"""
     from objectpermanence_amd import _lib
     from objectpermanence_amd.detector import _Linear
     lib = _lib.load()
@@ -104,7 +104,7 @@ def test_linear_rows_split_k_and_refusals():
     b = torch.from_numpy(synth.synth_tensor("fc6b", (1024,), 0.2))
     x = torch.from_numpy(synth.synth_tensor("fc6x", (1000, 12544), 1.0))
     fc = _Linear(wt, b, "cuda:0")
-    assert lib.opdet_conv2d_workspace_bytes(1, 1, 1000, 12544, 1024, 1, 1, 1, 0, fc.kp) == 10 * 1000 * 1024 * 4
+    assert lib.opdet_conv2d_workspace_bytes(1, 1, 1000, 12544, 1024, 1, 1, 1, 0, fc.kp) == 5 * 1000 * 1024 * 4
     y = fc.rows(x.cuda(), relu=True)
     torch.cuda.synchronize()
     ref = F.relu(x.double() @ wt.double().t() + b.double())
