@@ -109,14 +109,17 @@ static int attention_key_split(long S, int nhead, int QF)
     return best;
 }
 
-// nseg sequences of S tokens back to back, each attending to itself: every choice below (query fragments per wave, key split)
-// is made from ONE segment's shape, so a segment is computed exactly as that sequence alone would be (bit-identical); the
+// nseg sequences of S tokens back to back, each attending to itself: the key split (which changes the order of a query's sums)
+// is chosen from ONE segment's shape, so a segment is computed exactly as that sequence alone would be (bit-identical); the
 // segments only add workgroups (grid.x).  The key split's scratch covers all nseg * S rows.
 template <int HD>
 static void launch_attention_hd(const float *qkv, float *att, int S, int nseg, int E, int nhead, void *scratch,
                                 size_t scratch_bytes, hipStream_t st)
 {
     const float scale = 1.0f / sqrtf((float)HD);
+    // (two query fragments per wave once ONE segment alone leaves a workgroup per CU.  Counting all segments of a pass instead is
+    // bit-identical - which queries share a wave enters no query's arithmetic; tested in round 5 - and slower: at head size 128 the
+    // QF = 2 form needs 206 registers, one wave per SIMD: sixteen 16-clip requests per pass 16.8 ms against 15.7)
     const int QF = (long)((S + 127) / 128) * nhead >= 256 ? 2 : 1;
     const long Stot = (long)S * nseg;
     int KS = attention_key_split(S, nhead, QF);                   // from the segment's shape alone, like QF: same arithmetic as alone

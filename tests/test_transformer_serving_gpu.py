@@ -30,7 +30,9 @@ def _requests(first, n, b, T):
     return [torch.from_numpy(synth.boxes5(synth.make_batch(first + 7 * r, b, T)[0])).cuda() for r in range(n)]
 
 
-@pytest.mark.parametrize("heads,n,b,T", [(2, 16, 1, 300), (4, 16, 1, 300), (4, 5, 2, 300), (2, 7, 1, 37), (4, 3, 3, 50), (2, 33, 1, 20)])
+# (4, 8, 4, 300): eight coupled requests of four clips (S = 1 200 each)
+@pytest.mark.parametrize("heads,n,b,T", [(2, 16, 1, 300), (4, 16, 1, 300), (4, 5, 2, 300), (2, 7, 1, 37), (4, 3, 3, 50), (2, 33, 1, 20),
+                                         (4, 8, 4, 300)])
 def test_every_request_of_a_merged_pass_is_bit_identical_to_its_lone_forward(heads, n, b, T):
     cfg = dict(REAL, num_attention_heads=heads)
     m = _model(cfg)
