@@ -12,8 +12,8 @@
 //   * K image: row-major [key][hd] with the 16-byte piece index XOR-swizzled on the SOURCE side so that the fragment
 //     read "16 consecutive keys, one k-quad" is bank-conflict free; V image: plain row-major (its fragment read is 16
 //     consecutive pieces of one key);
-//   * S^T[key][query] = K_tile Q^T (A = K rows from LDS, B = Q registers), two accumulators per query fragment so
-//     the dependent-MFMA latency (40 cycles vs a 32-cycle issue) is hidden;
+//   * S^T[key][query] = K_tile Q^T (A = K rows from LDS, B = Q registers), two accumulators per query fragment that take turns
+//     with every MFMA, so the dependent-MFMA latency (40 cycles vs a 32-cycle issue) is hidden;
 //   * a lane holds 4 keys (rows 4*(l>>4)+r) of ONE query (column l&15): row max / sum = 4 registers + two shuffles;
 //   * O^T[d][query] += V_tile^T P^T with the score registers themselves as the B operand (MFMA r contracts keys
 //     {r, 4+r, 8+r, 12+r}); A = V read as float4 along d, element e -> accumulator e holding d = 64c + 4i + e.
@@ -150,10 +150,12 @@ __global__ void __launch_bounds__(256) attention_glds(const float *__restrict__ 
             const float4 kf = Kt[i * PPR + ((4 * c + kk) ^ ksw)];
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
-                sc[f][c & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[f][c].x, sc[f][c & 1], 0, 0, 0);
-                sc[f][c & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[f][c].y, sc[f][c & 1], 0, 0, 0);
-                sc[f][c & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[f][c].z, sc[f][c & 1], 0, 0, 0);
-                sc[f][c & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[f][c].w, sc[f][c & 1], 0, 0, 0);
+                // the two chains alternate with every MFMA (even / odd k of the hexadecet): back-to-back MFMAs on ONE accumulator issue
+                // 40 cycles apart (dependent latency) instead of 32
+                sc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[f][c].x, sc[f][0], 0, 0, 0);
+                sc[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[f][c].y, sc[f][1], 0, 0, 0);
+                sc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[f][c].z, sc[f][0], 0, 0, 0);
+                sc[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[f][c].w, sc[f][1], 0, 0, 0);
             }
         }
         // V fragments of this tile

@@ -2782,39 +2782,34 @@ extern "C" size_t opseq_encoder_train_scratch_bytes(long S, int E, int nhead, in
 
 /* TEST-ONLY (tests/test_siblings_train.py): the layer calls made with `seed` take their four dropout masks (device pointers,
  * one byte per element, nonzero = keep; sites 0 attention weights [nhead][S][S], 1 [S][E], 2 [S][ffn], 3 [S][E]) from these buffers
- * instead of the counter generator - how the reference's own masks are fed in.  slot 0..7; *_clear() empties the table.  Both
- * synchronise the device (constant memory is rewritten). */
+ * instead of the counter generator - how the reference's own masks are fed in.  slot 0..7; *_clear() empties the table.  The table
+ * lives on the HOST: a layer call looks its seed up when it builds its launches and hands the kernels a mask pointer (null in
+ * production) - no device state, nothing for a production kernel to scan. */
+#define ENC_TEST_MASK_SLOTS 8
+struct EncTestMasks { unsigned long long seed; const unsigned char *m[4]; bool used; };
+static EncTestMasks g_enc_test[ENC_TEST_MASK_SLOTS] = {};
+static std::mutex g_enc_test_mu;
+
 extern "C" int opseq_encoder_test_masks_set(int slot, unsigned long long seed, const unsigned char *m0, const unsigned char *m1,
                                             const unsigned char *m2, const unsigned char *m3)
 {
     if (slot < 0 || slot >= ENC_TEST_MASK_SLOTS || !m0 || !m1 || !m2 || !m3) return fail(OPNET_EINVAL, "bad test-mask slot / null mask");
-    HIP_TRY(hipDeviceSynchronize());
-    EncTestMasks e;
-    e.seed = seed; e.m[0] = m0; e.m[1] = m1; e.m[2] = m2; e.m[3] = m3;
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_enc_test), &e, sizeof(e), (size_t)slot * sizeof(e), hipMemcpyHostToDevice));
-    int n = 0;
-    HIP_TRY(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_enc_test_n), sizeof(n), 0, hipMemcpyDeviceToHost));
-    if (n < slot + 1) {
-        // slots between the old count and this one must not match by accident: give them a seed no call uses
-        for (int q = n; q < slot; ++q) {
-            EncTestMasks z;
-            z.seed = ~0ull; z.m[0] = m0; z.m[1] = m1; z.m[2] = m2; z.m[3] = m3;
-            HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_enc_test), &z, sizeof(z), (size_t)q * sizeof(z), hipMemcpyHostToDevice));
-        }
-        n = slot + 1;
-        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_enc_test_n), &n, sizeof(n), 0, hipMemcpyHostToDevice));
-    }
+    std::lock_guard<std::mutex> lock(g_enc_test_mu);
+    g_enc_test[slot] = EncTestMasks{seed, {m0, m1, m2, m3}, true};
     return OPNET_OK;
 }
 extern "C" int opseq_encoder_test_masks_clear(void)
 {
-    HIP_TRY(hipDeviceSynchronize());
-    const int n = 0;
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_enc_test_n), &n, sizeof(n), 0, hipMemcpyHostToDevice));
+    std::lock_guard<std::mutex> lock(g_enc_test_mu);
+    for (auto &e : g_enc_test) e.used = false;
     return OPNET_OK;
 }
 
-struct EncDrop { unsigned thresh; float inv_keep; unsigned long long seed; };
+struct EncDrop {
+    unsigned thresh; float inv_keep; unsigned long long seed;
+    const unsigned char *mask[4];
+    EncSite at(unsigned site) const { return EncSite{seed, mask[site & 3], site}; }
+};
 
 static EncDrop enc_drop(float p, unsigned long long seed)
 {
@@ -2822,6 +2817,11 @@ static EncDrop enc_drop(float p, unsigned long long seed)
     d.thresh = p > 0.f ? (unsigned)((double)p * 4294967296.0) : 0u;
     d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     d.seed = seed;
+    for (auto &m : d.mask) m = nullptr;
+    std::lock_guard<std::mutex> lock(g_enc_test_mu);
+    for (const auto &e : g_enc_test)
+        if (e.used && e.seed == seed)
+            for (int k = 0; k < 4; ++k) d.mask[k] = e.m[k];
     return d;
 }
 
@@ -2864,7 +2864,7 @@ extern "C" int opseq_encoder_layer_train_forward_f32(const float *z_in, float *z
             float *P = sc + SC.pc;                                       // [qn][Sp] scores -> probabilities, not kept
             gemm_nt(qkv + q0 * 3 * E + h * hd, 3 * E, qkv + E + h * hd, 3 * E, nullptr, nullptr, P, Sp, qn, (int)S, hd, 0, st);
             float *Pd = D.thresh ? sc + SC.sq0 : nullptr;
-            enc_softmax_rows<<<(unsigned)qn, 256, 0, st>>>(P, Pd, Sp, (int)S, scale, D.seed, 0u,
+            enc_softmax_rows<<<(unsigned)qn, 256, 0, st>>>(P, Pd, Sp, (int)S, scale, D.at(0u),
                                                            (unsigned long long)h * S * S + (unsigned long long)q0 * S, D.thresh, D.inv_keep,
                                                            (float2 *)(sv + SV.astat) + (size_t)h * S + q0);
             if (S > QC) gemm_nt_splitk(Pd ? Pd : P, Sp, Vt, Sp, att + q0 * E + h * hd, E, qn, hd, (int)Sp, sc + SC.sq1, st);
@@ -2874,12 +2874,12 @@ extern "C" int opseq_encoder_layer_train_forward_f32(const float *z_in, float *z
     float *e0 = sc + SC.e0;
     gemm_nt(att, E, out_w, E, out_b, nullptr, e0, E, S, E, E, 0, st);
     enc_add_drop_ln<<<(unsigned)((S + 3) / 4), 256, 0, st>>>(zs, e0, n1_w, n1_b, sv + SV.u1, (float2 *)(sv + SV.st1),
-                                                            sv + SV.x1, (int)S, E, 1e-5f, D.seed, 1u, D.thresh, D.inv_keep);
+                                                            sv + SV.x1, (int)S, E, 1e-5f, D.at(1u), D.thresh, D.inv_keep);
     gemm_nt(sv + SV.x1, E, l1_w, E, l1_b, nullptr, sv + SV.hid, ffn, S, ffn, E, 1, st);
-    if (D.thresh) enc_dropout<<<ew_grid((long)S * ffn), 256, 0, st>>>(sv + SV.hid, (long)S * ffn, D.seed, 2u, D.thresh, D.inv_keep);
+    if (D.thresh) enc_dropout<<<ew_grid((long)S * ffn), 256, 0, st>>>(sv + SV.hid, (long)S * ffn, D.at(2u), D.thresh, D.inv_keep);
     gemm_nt(sv + SV.hid, ffn, l2_w, ffn, l2_b, nullptr, e0, E, S, E, ffn, 0, st);
     enc_add_drop_ln<<<(unsigned)((S + 3) / 4), 256, 0, st>>>(sv + SV.x1, e0, n2_w, n2_b, sv + SV.u2, (float2 *)(sv + SV.st2),
-                                                            z_out, (int)S, E, 1e-5f, D.seed, 3u, D.thresh, D.inv_keep);
+                                                            z_out, (int)S, E, 1e-5f, D.at(3u), D.thresh, D.inv_keep);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }
@@ -2935,7 +2935,7 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
     // ---- norm2, dropout2, linear2, ReLU/dropout, linear1 ----
     enc_ln_bwd<<<nb_ln, 256, 0, st>>>(dz_out, sv + SV.u2, (const float2 *)(sv + SV.st2), n2_w, nullptr, e1, part, (int)S, E, 64);
     enc_colsum_final<<<dim3((E + 255) / 256, 2, 1), 256, 0, st>>>(part, g_n2_w, g_n2_b, nb_ln, E);
-    enc_dropout_copy<<<ew_grid((long)S * E), 256, 0, st>>>(e1, e0, (long)S * E, D.seed, 3u, D.thresh, D.inv_keep);   // d f
+    enc_dropout_copy<<<ew_grid((long)S * E), 256, 0, st>>>(e1, e0, (long)S * E, D.at(3u), D.thresh, D.inv_keep);   // d f
     colsum(e0, E, E, g_l2_b);
     gemm_tn(e0, E, E, hid, ffn, ffn, g_l2_w);                                               // [E][ffn]
     gemm_nt(e0, E, sc + SC.wt_l2, E, nullptr, nullptr, t0, ffn, S, ffn, E, 0, st);          // d hid
@@ -2946,7 +2946,7 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
     // ---- norm1, dropout1, out_proj ----
     enc_ln_bwd<<<nb_ln, 256, 0, st>>>(e2, sv + SV.u1, (const float2 *)(sv + SV.st1), n1_w, nullptr, e1, part, (int)S, E, 64);
     enc_colsum_final<<<dim3((E + 255) / 256, 2, 1), 256, 0, st>>>(part, g_n1_w, g_n1_b, nb_ln, E);
-    enc_dropout_copy<<<ew_grid((long)S * E), 256, 0, st>>>(e1, e0, (long)S * E, D.seed, 1u, D.thresh, D.inv_keep);   // d proj
+    enc_dropout_copy<<<ew_grid((long)S * E), 256, 0, st>>>(e1, e0, (long)S * E, D.at(1u), D.thresh, D.inv_keep);   // d proj
     colsum(e0, E, E, g_out_b);
     gemm_tn(e0, E, E, att, E, E, g_out_w);
     gemm_nt(e0, E, sc + SC.wt_out, E, nullptr, nullptr, e2, E, S, E, E, 0, st);             // d att
@@ -2968,14 +2968,14 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
             // the chunk's probabilities again: the forward's score GEMM and the last pass of its softmax (the same bits)
             gemm_nt(qkv + q0 * 3 * E + h * hd, 3 * E, qkv + E + h * hd, 3 * E, nullptr, nullptr, pc, Sp, qn, (int)S, hd, 0, st);
             const float *Pu = pc;                                        // the matrix that multiplied V in the forward
-            enc_softmax_from_stats<<<(unsigned)qn, 256, 0, st>>>(pc, D.thresh ? sq2 : nullptr, Sp, (int)S, scale, D.seed, 0u, idx0,
+            enc_softmax_from_stats<<<(unsigned)qn, 256, 0, st>>>(pc, D.thresh ? sq2 : nullptr, Sp, (int)S, scale, D.at(0u), idx0,
                                                                  D.thresh, D.inv_keep, (const float2 *)(sv + SV.astat) + (size_t)h * S + q0);
             if (D.thresh) Pu = sq2;
             const float *acc_v = q0 ? dV : nullptr, *acc_k = q0 ? dK : nullptr;               // later chunks accumulate
             transpose_to(Pu, Sp, sq1, qp, qn, (int)S, st);                                    // P^T [key][query of the chunk]
             gemm_nt(sq1, qp, dOt + q0, Sp, nullptr, acc_v, dV, 3 * E, S, hd, (int)qp, 0, st);             // dV += P^T dO
             gemm_nt(e2 + q0 * E + h * hd, E, qkv + 2 * E + h * hd, 3 * E, nullptr, nullptr, sq0, Sp, qn, (int)S, hd, 0, st);   // dP
-            enc_softmax_bwd_rows<<<(unsigned)qn, 256, 0, st>>>(pc, sq0, Sp, (int)S, scale, D.seed, 0u, idx0, D.thresh, D.inv_keep);
+            enc_softmax_bwd_rows<<<(unsigned)qn, 256, 0, st>>>(pc, sq0, Sp, (int)S, scale, D.at(0u), idx0, D.thresh, D.inv_keep);
             if (S > QC) gemm_nt_splitk(sq0, Sp, Kt, Sp, dQ + q0 * 3 * E, 3 * E, qn, hd, (int)Sp, sq1, st);   // dQ rows of the chunk
             else gemm_nt(sq0, Sp, Kt, Sp, nullptr, nullptr, dQ + q0 * 3 * E, 3 * E, qn, hd, (int)Sp, 0, st);
             transpose_to(sq0, Sp, sq1, qp, qn, (int)S, st);                                   // dS^T
