@@ -39,7 +39,7 @@ extern "C" {
 
 /* bumped whenever entry points are added or a signature changes; the Python mirror refuses a library of another version
  * (objectpermanence_amd/_lib.py) instead of failing later on a missing symbol.  4 = round 4. */
-#define OPNET_HIP_ABI_VERSION 5
+#define OPNET_HIP_ABI_VERSION 6
 int opnet_hip_abi_version(void);
 const char *opnet_last_error(void);
 
@@ -422,7 +422,27 @@ int opseq_encoder_layer_train_backward_f32(const float *dz_out, float *dz_in, co
  * AnchorGenerator(sizes = anchor_sizes[l], ratios 0.5/1/2, strides int(padded/grid)), per-level top pre_nms_top_n on
  * the logits, decode (weights 1), clip to [image_h, image_w], drop sides < min_size, per-level NMS, best
  * post_nms_top_n.  Out: proposals [post_nms_top_n, 4] xyxy (rows >= *count zero), scores (may be NULL), count
- * (DEVICE int).  Nothing is copied to the host; gh / gw / anchor_sizes are HOST arrays. */
+ * (DEVICE int).  Nothing is copied to the host; gh / gw / anchor_sizes are HOST arrays.
+ *
+ * The *_batch_* forms serve the n_images (1..64) equally sized images of one pass with ONE launch per stage (detector.py:84 is one
+ * call per frame; the frames of a video share a size): every device array gains a leading image dimension - head_out level l =
+ * [n_images, gh, gw, 16], proposals [n_images, post_nms_top_n, 4], scores [n_images, post], count [n_images]; feats level l =
+ * [n_images, fh, fw, C], rois [n_images, max_rois, 4], out [n_images, max_rois, 7, 7, C]; class_logits [n_images, max_rois, NC], ...,
+ * boxes [n_images, max_det, 4], n_det [n_images] - and the workspace is n_images blocks of the one-image size.  Each image's result
+ * is bit-identical to its own one-image call (which is the same launch with one image). */
+size_t opdet_rpn_workspace_bytes_batch(int n_images, int n_levels, const int *gh, const int *gw, const int *anchor_sizes, int padded_h,
+                                       int padded_w, int pre_nms_top_n);
+int opdet_rpn_proposals_batch_f32(const float *const *head_out, int n_images, int n_levels, const int *gh, const int *gw,
+                                  const int *anchor_sizes, int image_h, int image_w, int padded_h, int padded_w,
+                                  int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float min_size, float *proposals,
+                                  float *scores, int *count, void *workspace, size_t workspace_bytes, void *stream);
+int opdet_roi_align_batch_f32(const float *const *feats, int n_images, const int *fh, const int *fw, int C, int image_h,
+                              const float *rois, const int *count, int max_rois, float *out, void *stream);
+size_t opdet_detections_workspace_bytes_batch(int n_images, int max_rois, int num_classes);
+int opdet_detections_batch_f32(const float *class_logits, const float *box_regression, const float *proposals,
+                               const int *count, int n_images, int max_rois, int num_classes, int image_h, int image_w, int orig_h,
+                               int orig_w, float score_thresh, float nms_thresh, int max_det, float *boxes, float *scores,
+                               long long *labels, int *n_det, void *workspace, size_t workspace_bytes, void *stream);
 size_t opdet_rpn_workspace_bytes(int n_levels, const int *gh, const int *gw, const int *anchor_sizes, int padded_h,
                                  int padded_w, int pre_nms_top_n);
 int opdet_rpn_proposals_f32(const float *const *head_out, int n_levels, const int *gh, const int *gw,

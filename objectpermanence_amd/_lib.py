@@ -13,7 +13,7 @@ from . import build as _build
 _LIB = None
 
 OPNET_OK = 0
-ABI_VERSION = 5                            # include/opnet_hip.h OPNET_HIP_ABI_VERSION
+ABI_VERSION = 6                            # include/opnet_hip.h OPNET_HIP_ABI_VERSION
 NO_OFFSET = ctypes.c_size_t(-1).value      # opnet_*_status_offset: "this shape never runs a persistent kernel"
 
 
@@ -243,6 +243,18 @@ def _declare(lib):
     lib.opdet_detections_f32.restype = c_int
     lib.opdet_detections_f32.argtypes = [fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                          fp, fp, fp, fp, c_void_p, c_size_t, c_void_p]
+    lib.opdet_rpn_workspace_bytes_batch.restype = c_size_t
+    lib.opdet_rpn_workspace_bytes_batch.argtypes = [c_int, c_int, ip, ip, ip, c_int, c_int, c_int]
+    lib.opdet_rpn_proposals_batch_f32.restype = c_int
+    lib.opdet_rpn_proposals_batch_f32.argtypes = [POINTER(c_void_p), c_int, c_int, ip, ip, ip, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                  c_float, c_float, fp, fp, fp, c_void_p, c_size_t, c_void_p]
+    lib.opdet_roi_align_batch_f32.restype = c_int
+    lib.opdet_roi_align_batch_f32.argtypes = [POINTER(c_void_p), c_int, ip, ip, c_int, c_int, fp, fp, c_int, fp, c_void_p]
+    lib.opdet_detections_workspace_bytes_batch.restype = c_size_t
+    lib.opdet_detections_workspace_bytes_batch.argtypes = [c_int, c_int, c_int]
+    lib.opdet_detections_batch_f32.restype = c_int
+    lib.opdet_detections_batch_f32.argtypes = [fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
+                                               fp, fp, fp, fp, c_void_p, c_size_t, c_void_p]
     lib.opnet_encode_clips_f32.restype = c_int
     lib.opnet_encode_clips_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                            c_void_p, c_void_p]
@@ -283,7 +295,8 @@ EXPORTS = [
     "opseq_encoder_layer_train_backward_f32", "opseq_encoder_test_masks_set", "opseq_encoder_test_masks_clear",
     "opdet_conv2d_f32", "opdet_conv2d_workspace_bytes", "opdet_conv2d_ws_f32", "opdet_maxpool3x3s2_f32", "opdet_subsample2_f32", "opdet_upsample_add_f32",
     "opdet_preprocess_frame_f32", "opdet_rpn_workspace_bytes", "opdet_rpn_proposals_f32", "opdet_roi_align_f32",
-    "opdet_detections_workspace_bytes", "opdet_detections_f32", "opdet_test_sort_scratch_bytes", "opdet_test_sort_pairs",
+    "opdet_detections_workspace_bytes", "opdet_detections_f32", "opdet_rpn_workspace_bytes_batch", "opdet_rpn_proposals_batch_f32",
+    "opdet_roi_align_batch_f32", "opdet_detections_workspace_bytes_batch", "opdet_detections_batch_f32", "opdet_test_sort_scratch_bytes", "opdet_test_sort_pairs",
 ]
 
 

@@ -6,6 +6,11 @@
 // Arithmetic that feeds a discrete decision (sort keys, thresholds, IoU tests) is written with explicit
 // round-to-nearest intrinsics (no FMA contraction) so that identical inputs give identical decisions to the
 // unfused fp32 restatement in oracle/detector_oracle.py.  PARITY UNPINNED vs torchvision.
+//
+// IMAGES OF A PASS: every kernel takes an image index from its grid (blockIdx.y, or folded into blockIdx.z / .x where stated) and
+// works on that image's slice of every buffer: workspace buffers of consecutive images lie `wsb` BYTES apart (one workspace block
+// per image, same layout in each), the caller's arrays are image-major.  One launch per stage serves the whole pass; a one-image
+// call is the same launch with one image.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,8 +19,12 @@
 #define DET_ANCHORS 3           // aspect ratios per position
 #define DET_HEAD_C 16           // packed RPN head output channels: 3 objectness + 12 deltas + 1 pad
 
+// image `i` of a buffer whose per-image slices lie `bytes` apart
+template <typename T>
+__device__ __forceinline__ T *det_img(T *p, size_t bytes, int i) { return (T *)((char *)p + (size_t)i * bytes); }
+
 struct RpnLevels {
-    const float *head[DET_MAX_LEVELS];   // [gh, gw, 16] fp32 NHWC
+    const float *head[DET_MAX_LEVELS];   // [n_images][gh, gw, 16] fp32 NHWC
     int gh[DET_MAX_LEVELS], gw[DET_MAX_LEVELS];
     int sh[DET_MAX_LEVELS], sw[DET_MAX_LEVELS];   // integer strides int(padded / grid)
     int off[DET_MAX_LEVELS + 1];         // anchor offsets of the levels in the flat key array
@@ -34,15 +43,17 @@ __device__ __forceinline__ unsigned det_orderable(float f)
 // ---- RPN ------------------------------------------------------------------------------------------
 // keys: (level << 32) | ~orderable(objectness)  -> one ascending radix sort groups the levels and orders
 // each by descending objectness; the sort is stable, so ties keep anchor order (position-major, anchor-minor)
-__global__ void __launch_bounds__(256) rpn_make_keys(const RpnLevels L, unsigned long long *keys, unsigned *vals)
+__global__ void __launch_bounds__(256) rpn_make_keys(const RpnLevels L, unsigned long long *keys, unsigned *vals, size_t wsb)
 {
     const int total = L.off[L.n_levels];
+    const int img = blockIdx.y;
+    keys = det_img(keys, wsb, img); vals = det_img(vals, wsb, img);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         int l = 0;
         while (l + 1 < L.n_levels && i >= L.off[l + 1]) ++l;
         const int idx = i - L.off[l];
         const int pos = idx / DET_ANCHORS, a = idx - pos * DET_ANCHORS;
-        const float obj = L.head[l][(long)pos * DET_HEAD_C + a];
+        const float obj = L.head[l][((long)img * L.gh[l] * L.gw[l] + pos) * DET_HEAD_C + a];
         keys[i] = ((unsigned long long)l << 32) | (unsigned)(~det_orderable(obj));
         vals[i] = (unsigned)idx;
     }
@@ -71,18 +82,22 @@ __device__ __forceinline__ float4 det_clip(float4 b, float width, float height)
 // ckeys = ~orderable(score) (0xffffffff for dropped candidates: they sort last), cvals = candidate index
 __global__ void __launch_bounds__(256) rpn_decode_topk(const RpnLevels L, const unsigned *sorted_vals, float4 *cbox,
                                                        float *cscore, unsigned *ckeys, unsigned *cvals,
-                                                       int *n_valid, float img_w, float img_h, float min_size, float clipv)
+                                                       int *n_valid, float img_w, float img_h, float min_size, float clipv,
+                                                       size_t wsb)
 {
     const int total = L.coff[L.n_levels];
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= total) return;
+    const int img = blockIdx.y;
+    sorted_vals = det_img(sorted_vals, wsb, img); cbox = det_img(cbox, wsb, img); cscore = det_img(cscore, wsb, img);
+    ckeys = det_img(ckeys, wsb, img); cvals = det_img(cvals, wsb, img); n_valid = det_img(n_valid, wsb, img);
     int l = 0;
     while (l + 1 < L.n_levels && c >= L.coff[l + 1]) ++l;
     const int r = c - L.coff[l];
     const int idx = (int)sorted_vals[L.off[l] + r];
     const int pos = idx / DET_ANCHORS, a = idx - pos * DET_ANCHORS;
     const int y = pos / L.gw[l], x = pos - y * L.gw[l];
-    const float *o = L.head[l] + (long)pos * DET_HEAD_C;
+    const float *o = L.head[l] + ((long)img * L.gh[l] * L.gw[l] + pos) * DET_HEAD_C;
     const float fx = __fmul_rn((float)x, (float)L.sw[l]), fy = __fmul_rn((float)y, (float)L.sh[l]);
     const float4 anchor = make_float4(__fadd_rn(fx, L.base[l][a][0]), __fadd_rn(fy, L.base[l][a][1]),
                                       __fadd_rn(fx, L.base[l][a][2]), __fadd_rn(fy, L.base[l][a][3]));
@@ -99,8 +114,12 @@ __global__ void __launch_bounds__(256) rpn_decode_topk(const RpnLevels L, const 
 
 __global__ void __launch_bounds__(256) det_gather_sorted(const unsigned *order, const float4 *cbox, const int *cgroup,
                                                          const float *cscore, float4 *sbox, int *sgroup, float *sscore,
-                                                         const int *n_valid, int cap)
+                                                         const int *n_valid, int cap, size_t wsb)
 {
+    const int img = blockIdx.y;
+    order = det_img(order, wsb, img); cbox = det_img(cbox, wsb, img); cgroup = det_img(cgroup, wsb, img);
+    cscore = det_img(cscore, wsb, img); sbox = det_img(sbox, wsb, img); sgroup = det_img(sgroup, wsb, img);
+    sscore = det_img(sscore, wsb, img); n_valid = det_img(n_valid, wsb, img);
     const int n = min(*n_valid, cap);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const unsigned c = order[i];
@@ -139,47 +158,64 @@ __device__ __forceinline__ unsigned long long det_resolve_chunk(unsigned long lo
 
 // suppression bits of box i against boxes j > i of the same group, 64 columns per word; only the upper
 // triangle of 64x64 blocks is produced (and read).  IoU test is the strict ">" of torchvision's CUDA kernel.
+// The number of boxes is only known on the device: gridDim.x workgroups per image walk the (row block, column block) pairs of the
+// upper triangle that exist (a grid sized for the capacity would be ~44 000 workgroups per image, nearly all of them empty).
 __global__ void __launch_bounds__(64) nms_mask(const float4 *sbox, const int *sgroup, const int *n_valid, int cap,
-                                               float thresh, unsigned long long *mask, int nw)
+                                               float thresh, unsigned long long *mask, int nw, size_t wsb)
 {
+    const int img = blockIdx.y;
+    sbox = det_img(sbox, wsb, img); sgroup = det_img(sgroup, wsb, img); n_valid = det_img(n_valid, wsb, img);
+    mask = det_img(mask, wsb, img);
     const int n = min(*n_valid, cap);
-    const int rb = blockIdx.y, cb = blockIdx.x;
-    if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+    const int nbv = (n + 63) >> 6;
+    const int npairs = nbv * (nbv + 1) / 2;
     __shared__ float4 cbx[64];
     __shared__ int cg[64];
     const int tid = threadIdx.x;
-    const int j0 = cb * 64;
-    if (j0 + tid < n) {
-        cbx[tid] = sbox[j0 + tid];
-        cg[tid] = sgroup[j0 + tid];
+    for (int pidx = blockIdx.x; pidx < npairs; pidx += gridDim.x) {
+        // row block rb starts at pair rb * nbv - rb (rb - 1) / 2 of the row-major upper triangle
+        int rb = (int)(((float)(2 * nbv + 1) - sqrtf((float)(2 * nbv + 1) * (float)(2 * nbv + 1) - 8.0f * (float)pidx)) * 0.5f);
+        rb = max(0, min(rb, nbv - 1));
+        while (rb > 0 && rb * nbv - rb * (rb - 1) / 2 > pidx) --rb;
+        while (rb + 1 < nbv && (rb + 1) * nbv - (rb + 1) * rb / 2 <= pidx) ++rb;
+        const int cb = rb + pidx - (rb * nbv - rb * (rb - 1) / 2);
+        const int j0 = cb * 64;
+        __syncthreads();
+        if (j0 + tid < n) {
+            cbx[tid] = sbox[j0 + tid];
+            cg[tid] = sgroup[j0 + tid];
+        }
+        __syncthreads();
+        const int i = rb * 64 + tid;
+        if (i >= n) continue;
+        const float4 b = sbox[i];
+        const int g = sgroup[i];
+        const float area = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
+        unsigned long long bits = 0;
+        const int lim = min(64, n - j0);
+        for (int t = 0; t < lim; ++t) {
+            if (j0 + t <= i || cg[t] != g) continue;
+            const float4 o = cbx[t];
+            const float iw = fmaxf(__fsub_rn(fminf(b.z, o.z), fmaxf(b.x, o.x)), 0.f);
+            const float ih = fmaxf(__fsub_rn(fminf(b.w, o.w), fmaxf(b.y, o.y)), 0.f);
+            const float inter = __fmul_rn(iw, ih);
+            const float oarea = __fmul_rn(__fsub_rn(o.z, o.x), __fsub_rn(o.w, o.y));
+            const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area, oarea), inter));
+            if (iou > thresh) bits |= 1ull << t;
+        }
+        mask[(size_t)i * nw + cb] = bits;
     }
-    __syncthreads();
-    const int i = rb * 64 + tid;
-    if (i >= n) return;
-    const float4 b = sbox[i];
-    const int g = sgroup[i];
-    const float area = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
-    unsigned long long bits = 0;
-    const int lim = min(64, n - j0);
-    for (int t = 0; t < lim; ++t) {
-        if (j0 + t <= i || cg[t] != g) continue;
-        const float4 o = cbx[t];
-        const float iw = fmaxf(__fsub_rn(fminf(b.z, o.z), fmaxf(b.x, o.x)), 0.f);
-        const float ih = fmaxf(__fsub_rn(fminf(b.w, o.w), fmaxf(b.y, o.y)), 0.f);
-        const float inter = __fmul_rn(iw, ih);
-        const float oarea = __fmul_rn(__fsub_rn(o.z, o.x), __fsub_rn(o.w, o.y));
-        const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area, oarea), inter));
-        if (iou > thresh) bits |= 1ull << t;
-    }
-    mask[(size_t)i * nw + cb] = bits;
 }
 
 // greedy pass over the sorted boxes, one workgroup: thread w owns word w of the "suppressed" bit vector.
 // Per chunk of 64 boxes the owner of the chunk's word resolves the in-chunk dependencies from the diagonal
 // mask block, then every later word ORs in the rows of the boxes that were kept.  Stops at max_keep.
 __global__ void __launch_bounds__(512) nms_scan(const unsigned long long *mask, int nw, const int *n_valid, int cap,
-                                                 int max_keep, int *kept, int *n_kept)
+                                                 int max_keep, int *kept, int *n_kept, size_t wsb)
 {
+    const int img = blockIdx.x;
+    mask = det_img(mask, wsb, img); n_valid = det_img(n_valid, wsb, img); kept = det_img(kept, wsb, img);
+    n_kept = det_img(n_kept, wsb, img);
     __shared__ unsigned long long chunk_rem;
     __shared__ unsigned long long keepbits;
     __shared__ int kept_total;
@@ -235,9 +271,10 @@ __global__ void __launch_bounds__(512) nms_scan(const unsigned long long *mask, 
 // masks (<= pre_nms_top_n^2 / 2 pairs per level instead of one 4.7k x 4.7k triangle) and one wave per level for
 // the greedy pass.  Boxes dropped for size carry key 0xffffffff and start out suppressed.
 __global__ void __launch_bounds__(64) rpn_nms_mask(const RpnLevels L, const float4 *cbox, const unsigned *ckeys,
-                                                   float thresh, unsigned long long *mask, int nw)
+                                                   float thresh, unsigned long long *mask, int nw, size_t wsb)
 {
-    const int l = blockIdx.z;
+    const int img = blockIdx.z / L.n_levels, l = blockIdx.z - img * L.n_levels;
+    cbox = det_img(cbox, wsb, img); ckeys = det_img(ckeys, wsb, img); mask = det_img(mask, wsb, img);
     const int c0 = L.coff[l], n = L.coff[l + 1] - c0;
     const int rb = blockIdx.y, cb = blockIdx.x;
     if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
@@ -273,9 +310,11 @@ __global__ void __launch_bounds__(64) rpn_nms_mask(const RpnLevels L, const floa
 // one wave per level (needs n_l <= 64 * 64); lane w owns word w of the level's suppressed vector.  Writes the
 // final sort key of every candidate: ~orderable(score) if kept, 0xffffffff otherwise, and counts the kept.
 __global__ void __launch_bounds__(64) rpn_nms_scan(const RpnLevels L, const unsigned long long *mask, int nw,
-                                                   const unsigned *ckeys, int max_keep, unsigned *fkeys, int *n_kept)
+                                                   const unsigned *ckeys, int max_keep, unsigned *fkeys, int *n_kept, size_t wsb)
 {
-    const int l = blockIdx.x, tid = threadIdx.x;
+    const int l = blockIdx.x, tid = threadIdx.x, img = blockIdx.y;
+    mask = det_img(mask, wsb, img); ckeys = det_img(ckeys, wsb, img); fkeys = det_img(fkeys, wsb, img);
+    n_kept = det_img(n_kept, wsb, img);
     const int c0 = L.coff[l], n = L.coff[l + 1] - c0;
     const int nwords = (n + 63) >> 6;
     unsigned long long rem = 0;
@@ -315,8 +354,13 @@ __global__ void __launch_bounds__(64) rpn_nms_scan(const RpnLevels L, const unsi
 
 __global__ void __launch_bounds__(256) rpn_emit_sorted(const unsigned *order, const int *n_kept, int max_out,
                                                        const float4 *cbox, const float *cscore, float4 *proposals,
-                                                       float *scores, int *count)
+                                                       float *scores, int *count, size_t wsb)
 {
+    const int img = blockIdx.y;
+    order = det_img(order, wsb, img); n_kept = det_img(n_kept, wsb, img); cbox = det_img(cbox, wsb, img);
+    cscore = det_img(cscore, wsb, img);
+    proposals += (long)img * max_out; count += img;
+    if (scores) scores += (long)img * max_out;
     const int n = min(*n_kept, max_out);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < max_out; i += gridDim.x * 256) {
         proposals[i] = i < n ? cbox[order[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -325,9 +369,22 @@ __global__ void __launch_bounds__(256) rpn_emit_sorted(const unsigned *order, co
     if (blockIdx.x == 0 && threadIdx.x == 0) *count = n;
 }
 
+// per image: `nzero` counters zeroed, `nfill` words set to 0xffffffff (the keys of candidates no scan visits)
+__global__ void __launch_bounds__(256) det_stage_init(int *counters, int nzero, unsigned *fill, int nfill, size_t wsb)
+{
+    const int img = blockIdx.y;
+    counters = det_img(counters, wsb, img);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nzero) counters[i] = 0;
+    if (fill) {
+        fill = det_img(fill, wsb, img);
+        for (int q = i; q < nfill; q += gridDim.x * 256) fill[q] = 0xffffffffu;
+    }
+}
+
 // ---- MultiScaleRoIAlign ---------------------------------------------------------------------------
 struct RoiLevels {
-    const float *feat[4];    // [fh, fw, C] fp32 NHWC
+    const float *feat[4];    // [n_images][fh, fw, C] fp32 NHWC
     int fh[4], fw[4];
     float scale[4];
     int C;
@@ -350,14 +407,15 @@ __device__ __forceinline__ float4 roi_sample(const float4 *f, int H, int W, int 
                        w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z, w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
 }
 
-// one workgroup per roi; thread = (bin group, float4 channel group); out [max_rois, 7, 7, C], rows >= count zero
+// one workgroup per (roi, image); thread = (bin group, float4 channel group); out [n_images][max_rois, 7, 7, C], rows >= count zero
 __global__ void __launch_bounds__(256) roi_align_levels(const RoiLevels L, const float4 *rois, const int *count,
                                                         float4 *out)
 {
-    const int r = blockIdx.x;
+    const int r = blockIdx.x, img = blockIdx.y;
     const int C4 = L.C >> 2;
     const int tid = threadIdx.x;
-    float4 *o = out + (long)r * 49 * C4;
+    float4 *o = out + ((long)img * gridDim.x + r) * 49 * C4;
+    rois += (long)img * gridDim.x; count += img;
     if (r >= *count) {
         for (int i = tid; i < 49 * C4; i += 256) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
@@ -370,7 +428,7 @@ __global__ void __launch_bounds__(256) roi_align_levels(const RoiLevels L, const
     const int l = (int)t - 2;
     const float sc = L.scale[l];
     const int H = L.fh[l], W = L.fw[l];
-    const float4 *f = (const float4 *)L.feat[l];
+    const float4 *f = (const float4 *)L.feat[l] + (long)img * H * W * C4;
     const float x0 = b.x * sc, y0 = b.y * sc;
     const float rw = fmaxf(b.z * sc - x0, 1.f), rh = fmaxf(b.w * sc - y0, 1.f);
     const float bw = rw / 7.f, bh = rh / 7.f;
@@ -401,11 +459,14 @@ __global__ void __launch_bounds__(256) det_score_boxes(const float *logits, cons
                                                        const int *count, int NC, float img_w, float img_h,
                                                        float score_thresh, float min_size, float clipv, float4 *cbox,
                                                        int *cgroup, float *cscore, unsigned *ckeys, unsigned *cvals,
-                                                       int *n_valid)
+                                                       int *n_valid, size_t wsb)
 {
     __shared__ float red[256];
-    const int r = blockIdx.x, tid = threadIdx.x;
+    const int r = blockIdx.x, tid = threadIdx.x, img = blockIdx.y;
     const int ncand = NC - 1;
+    logits += (long)img * gridDim.x * NC; reg += (long)img * gridDim.x * NC * 4; rois += (long)img * gridDim.x; count += img;
+    cbox = det_img(cbox, wsb, img); cgroup = det_img(cgroup, wsb, img); cscore = det_img(cscore, wsb, img);
+    ckeys = det_img(ckeys, wsb, img); cvals = det_img(cvals, wsb, img); n_valid = det_img(n_valid, wsb, img);
     const bool live = r < *count;
     const float *z = logits + (long)r * NC;
     float m = -INFINITY;
@@ -447,8 +508,12 @@ __global__ void __launch_bounds__(256) det_score_boxes(const float *logits, cons
 
 __global__ void __launch_bounds__(128) det_emit(const int *kept, const int *n_kept, int max_det, const float4 *sbox,
                                                 const int *sgroup, const float *sscore, float ratio_w, float ratio_h,
-                                                float4 *boxes, float *scores, long long *labels, int *n_det)
+                                                float4 *boxes, float *scores, long long *labels, int *n_det, size_t wsb)
 {
+    const int img = blockIdx.x;
+    kept = det_img(kept, wsb, img); n_kept = det_img(n_kept, wsb, img); sbox = det_img(sbox, wsb, img);
+    sgroup = det_img(sgroup, wsb, img); sscore = det_img(sscore, wsb, img);
+    boxes += (long)img * max_det; scores += (long)img * max_det; labels += (long)img * max_det; n_det += img;
     const int n = min(*n_kept, max_det);
     for (int i = threadIdx.x; i < max_det; i += 128) {
         if (i < n) {

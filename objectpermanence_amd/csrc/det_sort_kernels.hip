@@ -15,12 +15,18 @@
 // (A one-launch form - the same two phases around grid-wide barriers, pairs exchanged with write-through stores - was built and
 // measured at 92 us against 91 us for this one at the RPN's size: no gain to pay for its need of co-resident workgroups)
 // Sorts of up to 8 192 4-byte-key pairs (the ~4 700 RPN survivors) run in ONE workgroup of 16 waves with both copies in LDS.
+// SEGMENTS: every launch sorts gridDim.y (rs_sort_small: gridDim.x) independent arrays of the same length n - the images of a detector
+// pass - whose buffers (and histograms) lie `seg` BYTES apart: one launch per stage for the whole pass instead of one per image.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define RS_TILE 2048
 #define RS_SMALL_MAX 8192
+
+// segment `i` of a buffer whose segments lie `bytes` apart
+template <typename T>
+__device__ __forceinline__ T *rs_seg(T *p, size_t bytes, int i) { return (T *)((char *)p + (size_t)i * bytes); }
 
 // lanes of this wave whose digit equals mine (me included)
 template <int RB>
@@ -199,31 +205,36 @@ __device__ __forceinline__ unsigned rs_pass_mask(int bits, int shift, int RB)
 
 // a pass = these two launches of one workgroup per tile
 template <typename K, int RB>
-__global__ void __launch_bounds__(256) rs_pass_count(const K *ka, const unsigned *va, long n, int bits, int shift, unsigned *hist)
+__global__ void __launch_bounds__(256) rs_pass_count(const K *ka, const unsigned *va, long n, int bits, int shift, unsigned *hist, size_t seg)
 {
     __shared__ unsigned base[1 << RB];
     K k[8];
     unsigned v[8];
+    ka = rs_seg(ka, seg, blockIdx.y); va = rs_seg(va, seg, blockIdx.y); hist = rs_seg(hist, seg, blockIdx.y);
     rs_phase_count<K, RB>(ka, va, n, (int)blockIdx.x, shift, rs_pass_mask(bits, shift, RB), hist, base, k, v);
 }
 
 template <typename K, int RB>
 __global__ void __launch_bounds__(256) rs_pass_scatter(const K *ka, const unsigned *va, K *kb, unsigned *vb, long n, int bits, int shift,
-                                                       const unsigned *hist)
+                                                       const unsigned *hist, size_t seg)
 {
     constexpr int NB = 1 << RB;
     __shared__ unsigned base[NB];
     __shared__ unsigned wcount[4 * NB];
     K k[8];
     unsigned v[8];
+    ka = rs_seg(ka, seg, blockIdx.y); va = rs_seg(va, seg, blockIdx.y); hist = rs_seg(hist, seg, blockIdx.y);
+    kb = rs_seg(kb, seg, blockIdx.y); vb = rs_seg(vb, seg, blockIdx.y);
     rs_load_span<K>(ka, va, (long)blockIdx.x * RS_TILE, n, 8, k, v);
     rs_phase_scatter<K, RB>(k, v, kb, vb, n, (int)blockIdx.x, (int)gridDim.x, shift, rs_pass_mask(bits, shift, RB), hist, base, wcount);
 }
 
 // n <= RS_SMALL_MAX pairs of 4-byte keys, every pass in one workgroup of 16 waves, both copies in LDS; result to kout / vout
 __global__ void __launch_bounds__(1024) rs_sort_small(const unsigned *__restrict__ kin, const unsigned *__restrict__ vin,
-                                                      unsigned *__restrict__ kout, unsigned *__restrict__ vout, int n, int bits)
+                                                      unsigned *__restrict__ kout, unsigned *__restrict__ vout, int n, int bits, size_t seg)
 {
+    kin = rs_seg(kin, seg, blockIdx.x); vin = rs_seg(vin, seg, blockIdx.x);
+    kout = rs_seg(kout, seg, blockIdx.x); vout = rs_seg(vout, seg, blockIdx.x);
     extern __shared__ unsigned rs_lds[];
     unsigned *ka = rs_lds, *kb = ka + RS_SMALL_MAX, *va = kb + RS_SMALL_MAX, *vb = va + RS_SMALL_MAX;
     __shared__ unsigned base[256];

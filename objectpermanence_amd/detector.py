@@ -118,7 +118,6 @@ class FasterRCNNHeads:
         self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms_thresh = pre_nms_top_n, post_nms_top_n, rpn_nms_thresh
         self.score_thresh, self.nms_thresh, self.detections_per_img = score_thresh, nms_thresh, detections_per_img
         self._ws: Dict[tuple, torch.Tensor] = {}
-        self._side = None
 
     def _workspace(self, key, nbytes: int, what: str) -> torch.Tensor:
         if nbytes == 0:
@@ -133,47 +132,54 @@ class FasterRCNNHeads:
         return [self.rpn_out(self.rpn_conv(f, relu=True), relu=False) for f in feats.values()]
 
     def proposals(self, head_outs: List[torch.Tensor], image_size, padded_size):
-        """RegionProposalNetwork.filter_proposals for ONE image: -> (proposals [post,4], scores [post], count [1] int32)"""
+        """RegionProposalNetwork.filter_proposals for the n equally sized images of head_outs ([n, h, w, 16] per level), one launch per
+        stage: -> (proposals [n, post, 4], scores [n, post], count [n] int32)"""
         lib = _lib.load()
         dev = self.device
         nl = len(head_outs)
+        n = int(head_outs[0].shape[0])
         IntArr, PtrArr = ctypes.c_int * nl, ctypes.c_void_p * nl
         for h in head_outs:
-            if h.shape[0] != 1 or h.shape[3] != 16 or not h.is_contiguous():
-                raise ValueError("head outputs must be contiguous [1, h, w, 16]")
+            if h.shape[0] != n or h.shape[3] != 16 or not h.is_contiguous():
+                raise ValueError("head outputs must be contiguous [n, h, w, 16]")
         gh, gw = IntArr(*[int(h.shape[1]) for h in head_outs]), IntArr(*[int(h.shape[2]) for h in head_outs])
         sizes = IntArr(*self.ANCHOR_SIZES[:nl])
         ptrs = PtrArr(*[h.data_ptr() for h in head_outs])
         ph, pw = int(padded_size[0]), int(padded_size[1])
-        key = ("rpn", tuple(gh), tuple(gw), ph, pw)
-        ws = self._workspace(key, lib.opdet_rpn_workspace_bytes(nl, gh, gw, sizes, ph, pw, self.pre_nms_top_n),
-                             "opdet_rpn_workspace_bytes")
-        props = torch.empty((self.post_nms_top_n, 4), dtype=torch.float32, device=dev)
-        scores = torch.empty((self.post_nms_top_n,), dtype=torch.float32, device=dev)
-        count = torch.empty((1,), dtype=torch.int32, device=dev)
+        key = ("rpn", n, tuple(gh), tuple(gw), ph, pw)
+        ws = self._workspace(key, lib.opdet_rpn_workspace_bytes_batch(n, nl, gh, gw, sizes, ph, pw, self.pre_nms_top_n),
+                             "opdet_rpn_workspace_bytes_batch")
+        props = torch.empty((n, self.post_nms_top_n, 4), dtype=torch.float32, device=dev)
+        scores = torch.empty((n, self.post_nms_top_n), dtype=torch.float32, device=dev)
+        count = torch.empty((n,), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.opdet_rpn_proposals_f32(ptrs, nl, gh, gw, sizes, int(image_size[0]), int(image_size[1]), ph, pw,
-                                             self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms_thresh, 1e-3,
-                                             props.data_ptr(), scores.data_ptr(), count.data_ptr(), ws.data_ptr(),
-                                             ws.numel(), _stream(dev))
-        _lib.check(rc, "opdet_rpn_proposals_f32")
+            rc = lib.opdet_rpn_proposals_batch_f32(ptrs, n, nl, gh, gw, sizes, int(image_size[0]), int(image_size[1]), ph, pw,
+                                                   self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms_thresh, 1e-3,
+                                                   props.data_ptr(), scores.data_ptr(), count.data_ptr(), ws.data_ptr(),
+                                                   ws.numel(), _stream(dev))
+        _lib.check(rc, "opdet_rpn_proposals_batch_f32")
         return props, scores, count
 
     def roi_align(self, feats: List[torch.Tensor], props: torch.Tensor, count: torch.Tensor, image_size,
                   out: torch.Tensor = None) -> torch.Tensor:
-        """MultiScaleRoIAlign on maps "0".."3" ([1,h,w,C] each) -> [R, 7, 7, C]"""
+        """MultiScaleRoIAlign on maps "0".."3" ([n, h, w, C] each) with props [n, R, 4], count [n] -> [n * R, 7, 7, C]"""
         lib = _lib.load()
         IntArr, PtrArr = ctypes.c_int * 4, ctypes.c_void_p * 4
+        n = int(feats[0].shape[0])
+        if props.dim() == 2:
+            props = props[None]
+        if props.dim() != 3 or props.shape[0] != n or count.numel() != n or any(f.shape[0] != n or not f.is_contiguous() for f in feats[:4]):
+            raise ValueError("roi_align: maps [n, h, w, C], props [n, R, 4], count [n]")
         fh, fw = IntArr(*[int(f.shape[1]) for f in feats[:4]]), IntArr(*[int(f.shape[2]) for f in feats[:4]])
         ptrs = PtrArr(*[f.data_ptr() for f in feats[:4]])
         c = int(feats[0].shape[3])
-        r = int(props.shape[0])
+        r = int(props.shape[1])
         if out is None:
-            out = torch.empty((r, 7, 7, c), dtype=torch.float32, device=props.device)
+            out = torch.empty((n * r, 7, 7, c), dtype=torch.float32, device=props.device)
         with torch.cuda.device(props.device):
-            rc = lib.opdet_roi_align_f32(ptrs, fh, fw, c, int(image_size[0]), props.data_ptr(), count.data_ptr(), r,
-                                         out.data_ptr(), _stream(props.device))
-        _lib.check(rc, "opdet_roi_align_f32")
+            rc = lib.opdet_roi_align_batch_f32(ptrs, n, fh, fw, c, int(image_size[0]), props.data_ptr(), count.data_ptr(), r,
+                                               out.data_ptr(), _stream(props.device))
+        _lib.check(rc, "opdet_roi_align_batch_f32")
         return out
 
     def box_heads(self, pooled: torch.Tensor):
@@ -182,67 +188,59 @@ class FasterRCNNHeads:
         return self.cls_score.rows(x, relu=False), self.bbox_pred.rows(x, relu=False)
 
     def detections(self, class_logits, box_regression, props, count, image_size, original_size):
+        """RoIHeads.postprocess_detections + rescale for n images: class_logits [n * R, NC], box_regression [n * R, 4 NC], props
+        [n, R, 4], count [n] -> boxes [n, md, 4], scores [n, md], labels [n, md] int64, n_det [n] int32"""
         lib = _lib.load()
         dev = props.device
-        r, nc, md = int(props.shape[0]), self.num_classes, self.detections_per_img
-        ws = self._workspace(("det", r, nc), lib.opdet_detections_workspace_bytes(r, nc), "opdet_detections_workspace_bytes")
-        boxes = torch.empty((md, 4), dtype=torch.float32, device=dev)
-        scores = torch.empty((md,), dtype=torch.float32, device=dev)
-        labels = torch.empty((md,), dtype=torch.int64, device=dev)
-        n_det = torch.empty((1,), dtype=torch.int32, device=dev)
+        if props.dim() == 2:
+            props = props[None]
+        n, r, nc, md = int(props.shape[0]), int(props.shape[1]), self.num_classes, self.detections_per_img
+        if class_logits.shape[0] != n * r or not class_logits.is_contiguous() or not box_regression.is_contiguous():
+            raise ValueError("detections: class_logits / box_regression must be contiguous with n * R rows")
+        ws = self._workspace(("det", n, r, nc), lib.opdet_detections_workspace_bytes_batch(n, r, nc),
+                             "opdet_detections_workspace_bytes_batch")
+        boxes = torch.empty((n, md, 4), dtype=torch.float32, device=dev)
+        scores = torch.empty((n, md), dtype=torch.float32, device=dev)
+        labels = torch.empty((n, md), dtype=torch.int64, device=dev)
+        n_det = torch.empty((n,), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.opdet_detections_f32(class_logits.data_ptr(), box_regression.data_ptr(), props.data_ptr(),
-                                          count.data_ptr(), r, nc, int(image_size[0]), int(image_size[1]),
-                                          int(original_size[0]), int(original_size[1]), self.score_thresh, self.nms_thresh,
-                                          md, boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(), n_det.data_ptr(),
-                                          ws.data_ptr(), ws.numel(), _stream(dev))
-        _lib.check(rc, "opdet_detections_f32")
+            rc = lib.opdet_detections_batch_f32(class_logits.data_ptr(), box_regression.data_ptr(), props.data_ptr(),
+                                                count.data_ptr(), n, r, nc, int(image_size[0]), int(image_size[1]),
+                                                int(original_size[0]), int(original_size[1]), self.score_thresh,
+                                                self.nms_thresh, md, boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(),
+                                                n_det.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev))
+        _lib.check(rc, "opdet_detections_batch_f32")
         return boxes, scores, labels, n_det
 
     def forward_images(self, feats: "OrderedDict[str, torch.Tensor]", image_sizes, padded_size, original_sizes):
-        """feats: the five maps of n images ([n,h,w,256]).  The dense stages (RPN head, TwoMLPHead, predictors) run once
-        over the whole batch - the deep levels and the 1000-row GEMMs of one image cannot fill 256 CUs - the
-        proposal / RoIAlign / detection stages per image.  -> list of padded (boxes, scores, labels, n_det)"""
+        """feats: the five maps of n images ([n,h,w,256]).  Every stage - the dense ones (RPN head, TwoMLPHead, predictors) and the
+        selection ones (proposals, RoIAlign, detections) - is launched ONCE for all the images of a run that share (resized size,
+        original size): the frames of a video do, so a pass is one run (reference detector.py:84 calls the model per frame).
+        -> list of padded (boxes [md,4], scores [md], labels [md], n_det [1]) per image"""
         n = int(next(iter(feats.values())).shape[0])
         head = self.rpn_head(feats)
         maps = list(feats.values())
         r = self.post_nms_top_n
-        pooled = torch.empty((n * r, 7, 7, int(maps[0].shape[3])), dtype=torch.float32, device=self.device)
-        # the per-image stages are ~45 small launches that leave most of the chip idle: images are independent, so
-        # they go round-robin over a few side streams (each with its own workspaces) and overlap one another
-        cur = torch.cuda.current_stream(self.device)
-        if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.device) for _ in range(4)]
-        sides = self._side[:max(1, min(len(self._side), n))]
-        props = [None] * n
-
-        def fork():
-            for st in sides:
-                st.wait_stream(cur)
-
-        def join():
-            for st in sides:
-                cur.wait_stream(st)
-
-        fork()
+        sizes = [(tuple(int(v) for v in image_sizes[i]), tuple(int(v) for v in original_sizes[i])) for i in range(n)]
+        runs = []           # maximal runs of consecutive images with one geometry
         for i in range(n):
-            with torch.cuda.stream(sides[i % len(sides)]):
-                p, _, count = self.proposals([h[i:i + 1] for h in head], image_sizes[i], padded_size)
-                self.roi_align([m[i:i + 1] for m in maps], p, count, image_sizes[i], out=pooled[i * r:(i + 1) * r])
-                p.record_stream(cur); count.record_stream(cur)
-                props[i] = (p, count)
-        join()
+            if runs and sizes[runs[-1][0]] == sizes[i]:
+                runs[-1][1] = i + 1
+            else:
+                runs.append([i, i + 1])
+        whole = len(runs) == 1
+        pooled = torch.empty((n * r, 7, 7, int(maps[0].shape[3])), dtype=torch.float32, device=self.device)
+        props = []
+        for a, b in runs:
+            p, _, count = self.proposals(head if whole else [h[a:b] for h in head], image_sizes[a], padded_size)
+            self.roi_align(maps if whole else [m[a:b] for m in maps], p, count, image_sizes[a], out=pooled[a * r:b * r])
+            props.append((p, count))
         cls, reg = self.box_heads(pooled)
         outs = [None] * n
-        fork()
-        for i in range(n):
-            with torch.cuda.stream(sides[i % len(sides)]):
-                o = self.detections(cls[i * r:(i + 1) * r], reg[i * r:(i + 1) * r], props[i][0], props[i][1], image_sizes[i],
-                                    original_sizes[i])
-                for t in o:
-                    t.record_stream(cur)
-                outs[i] = o
-        join()
+        for (a, b), (p, count) in zip(runs, props):
+            boxes, scores, labels, n_det = self.detections(cls[a * r:b * r], reg[a * r:b * r], p, count, image_sizes[a], original_sizes[a])
+            for i in range(a, b):
+                outs[i] = (boxes[i - a], scores[i - a], labels[i - a], n_det[i - a:i - a + 1])
         return outs
 
 
@@ -359,7 +357,7 @@ class CaterObjectDetector(object):
         self.heads = FasterRCNNHeads(state_dict, device=compute_device, num_classes=self.num_classes)
 
     def backbone_features(self, frame: np.ndarray, compute_device: torch.device) -> "OrderedDict[str, torch.Tensor]":
-        x = preprocess_frame(frame, compute_device)
+        x = preprocess_frame(frame, compute_device, self.min_size, self.max_size)
         with torch.cuda.device(x.device):
             return self.backbone.forward_nhwc(x)
 
@@ -367,14 +365,14 @@ class CaterObjectDetector(object):
         """Several frames of a clip in ONE backbone pass ([n,240,320,3] uint8): the reference runs the detector on
         one frame per call (detector.py:80, preprocess_perception_main.py:28-41); the deep 25x34 / 50x68 maps of a
         single frame cannot fill 256 CUs, 16 frames per pass reach ~0.43 of the fp32 MFMA peak."""
-        x = torch.cat([preprocess_frame(f, compute_device) for f in frames], dim=0)
+        x = torch.cat([preprocess_frame(f, compute_device, self.min_size, self.max_size) for f in frames], dim=0)
         with torch.cuda.device(x.device):
             return self.backbone.forward_nhwc(x)
 
     MAX_FRAMES_PER_PASS = 32      # keeps every activation under the 2 GiB the conv kernel's 32-bit offsets address
 
     def _enqueue(self, frames, compute_device):
-        """everything of one pass enqueued on the current stream (and the heads' side streams); no host sync"""
+        """everything of one pass enqueued on the current stream; no host sync"""
         if self.backbone is None:
             raise RuntimeError("load_model() first")
         if len({f.shape for f in frames}) != 1:
@@ -421,7 +419,7 @@ class CaterObjectDetector(object):
         return self._detect([frame], compute_device)
 
     def detect_batch(self, frames, compute_device: torch.device) -> List[Dict[str, torch.Tensor]]:
-        """several frames of a clip in ONE pass of the dense stages (fills the chip); the
-        proposal / RoI / detection stages stay per image; one host sync at the end.  Same results as frame by frame
+        """several frames of a clip in ONE pass: every stage, dense or selection, is one launch over the frames of the pass (DESIGN.md
+        section 11); one host sync at the end.  Same results as frame by frame
         (the reference calls the detector on one frame at a time, preprocess_perception_main.py:28-41)."""
         return self._detect(list(frames), compute_device)
