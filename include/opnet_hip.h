@@ -374,6 +374,12 @@ size_t opdet_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int 
 int opdet_conv2d_ws_f32(const float *x, const float *w, const float *bias, const float *residual, float *y, int N, int H, int W,
                         int Cin, int Cout, int KH, int KW, int stride, int pad, int KP, int relu, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* FeaturePyramidNetwork's top-down step:  y = conv(x) + bias + nearest_upsample(top), top [N, TH, TW, Cout] (F.interpolate to the conv's
+ * output size); the addition rides in the conv kernel's epilogue where the shape allows, else conv + in-place upsample_add - the same
+ * fp32 operations in the same order.  workspace as for opdet_conv2d_ws_f32. */
+int opdet_conv2d_up_f32(const float *x, const float *w, const float *bias, const float *top, float *y, int N, int H, int W,
+                        int Cin, int Cout, int KH, int KW, int stride, int pad, int KP, int TH, int TW, void *workspace,
+                        size_t workspace_bytes, void *stream);
 int opdet_maxpool3x3s2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
 int opdet_subsample2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
 int opdet_upsample_add_f32(const float *lateral, const float *top, float *y, int N, int H, int W, int C,

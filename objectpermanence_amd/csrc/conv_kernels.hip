@@ -34,6 +34,9 @@ struct ConvArgs {
     // 128 x BN sums to P[z][M][Cout]; conv_splitk_reduce adds the slices in order and applies bias / residual / ReLU
     float *P;
     int ksplit, ksteps;
+    // conv2d_nhwc_glds only, RH > 0: R is a COARSER map [N][RH][RW][Cout] added nearest-upsampled (F.interpolate to the output's size):
+    // the FPN's top-down step  lateral(x) + upsample(top)  in the lateral conv's own epilogue (FeaturePyramidNetwork.forward)
+    int RH, RW;
 #ifdef CONV_TRACE                 // tools/probes/gemm_probe.hip only: per-K-step cycle sums of wave 0 of every workgroup
     unsigned long long *trace;    // [0] steps, [1] top -> MFMAs issued, [2] -> waits done, [3] -> next top (barrier + DMA issue)
 #endif
@@ -116,23 +119,31 @@ __global__ void __launch_bounds__(256) conv2d_nhwc(const ConvArgs a)
         }
 }
 
+// C % 4 == 0 (the host checks): one float4 of channels per thread
 __global__ void __launch_bounds__(256) maxpool3x3s2(const float *__restrict__ X, float *__restrict__ Y, int N,
                                                     int H, int W, int C, int OH, int OW)
 {
-    const long n_out = (long)N * OH * OW * C;
+    const int C4 = C >> 2;
+    const long n_out = (long)N * OH * OW * C4;
+    const float4 *X4 = (const float4 *)X;
     for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n_out; idx += (long)gridDim.x * 256) {
-        const int c = idx % C;
-        long t = idx / C;
+        const int c = idx % C4;
+        long t = idx / C4;
         const int ox = t % OW; t /= OW;
         const int oy = t % OH;
         const int n = t / OH;
-        float m = -INFINITY;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
         for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int y = oy * 2 - 1 + dy, x = ox * 2 - 1 + dx;
-                if (y >= 0 && y < H && x >= 0 && x < W) m = fmaxf(m, X[(((long)n * H + y) * W + x) * C + c]);
+                if (y >= 0 && y < H && x >= 0 && x < W) {
+                    const float4 v = X4[(((long)n * H + y) * W + x) * C4 + c];
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                }
             }
-        Y[idx] = m;
+        ((float4 *)Y)[idx] = m;
     }
 }
 
@@ -416,6 +427,18 @@ __device__ __forceinline__ void conv_glds16(conv_u32x4 rsrc, unsigned voff, unsi
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
 }
 
+// row of the residual operand that output row pp adds: pp itself, or its nearest-neighbour source row in a coarser map
+__device__ __forceinline__ long conv_rrow(const ConvArgs &a, long pp)
+{
+    if (a.RH == 0) return pp;
+    const int ox = (int)(pp % a.OW);
+    const long t = pp / a.OW;
+    const int oy = (int)(t % a.OH);
+    const long n = t / a.OH;
+    const int ty = min((int)(((long)oy * a.RH) / a.OH), a.RH - 1), tx = min((int)(((long)ox * a.RW) / a.OW), a.RW - 1);
+    return (n * a.RH + ty) * a.RW + tx;
+}
+
 template <int BN, int NS>
 __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
 {
@@ -523,6 +546,10 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
 #pragma unroll
         for (int y = 0; y < FN; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // (Measured and not adopted, round 5: fetching the residual operand of the short-K expanding 1 x 1 convs HERE, ahead of the first
+    // stage - the narrow tile has the 32 registers - instead of in the epilogue.  It made them 13 - 35 % SLOWER (layer1 conv3 645 ->
+    // 870 us, layer2 391 -> 512, layer3 293 -> 343): the first MFMA then waits for 32 KB of residual behind the 12 KB stage, and the
+    // other two resident workgroups were already covering the epilogue's latency.)
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0)
         if (s0 < nhex) issue(s0);
@@ -624,7 +651,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
                     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
                 }
                 if (a.R) {
-                    const float4 r = *(const float4 *)(a.R + pp * YS + co);
+                    const float4 r = *(const float4 *)(a.R + conv_rrow(a, pp) * YS + co);
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }
                 if (a.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
@@ -634,7 +661,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
                 for (int r = 0; r < 4; ++r) {
                     if (co + r >= a.Cout) break;
                     float v = acc[x][y][r] + (a.bias ? a.bias[co + r] : 0.f);
-                    if (a.R) v += a.R[pp * YS + co + r];
+                    if (a.R) v += a.R[conv_rrow(a, pp) * YS + co + r];
                     if (a.relu) v = fmaxf(v, 0.f);
                     a.Y[pp * YS + co + r] = v;
                 }

@@ -3102,11 +3102,51 @@ extern "C" int opdet_conv2d_ws_f32(const float *x, const float *w, const float *
     return OPNET_OK;
 }
 
+// does launch_conv() run this shape on conv2d_nhwc_glds (the only kernel that honours ConvArgs.RH / RW)?
+static bool conv_uses_glds(const ConvArgs &a, long M)
+{
+    const long tiles = ((M + 127) / 128) * (a.Cout > 64 ? (a.Cout + 127) / 128 : (a.Cout + 63) / 64);
+    if (!(conv_fills_chip(a, M) || (!(a.Cin & 15) && tiles >= 100))) return false;
+    if ((long)a.N * a.H * a.W * a.Cin * 4 >= (1L << 31) || (long)a.Cout * a.KP * 4 >= (1L << 31)) return false;
+    return (a.Cin & 15) == 0;
+}
+
+/* FeaturePyramidNetwork's top-down step in one call:  y = conv(x) + bias + nearest_upsample(top)  with top [N, TH, TW, Cout] and y the
+ * conv's [N, OH, OW, Cout] (F.interpolate(top, size = (OH, OW), mode "nearest"): source index floor(dst * T / O)).  Where the shape runs on
+ * the LDS-DMA kernel un-split, the addition happens in that kernel's epilogue (one pass over y instead of three); otherwise the conv
+ * is followed by the in-place upsample_add launch.  Same fp32 operations in the same order either way. */
+extern "C" int opdet_conv2d_up_f32(const float *x, const float *w, const float *bias, const float *top, float *y, int N, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, int stride, int pad, int KP, int TH, int TW, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    if (!x || !w || !y || !top) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(x) || !aligned16(w) || !aligned16(y) || !aligned16(workspace) || !aligned16(bias) || !aligned16(top))
+        return fail(OPNET_EINVAL, "x / w / y / bias / top / workspace must be 16-byte aligned");
+    if (TH <= 0 || TW <= 0) return fail(OPNET_ESHAPE, "bad top map size");
+    ConvArgs a;
+    if (int rc = conv_args(&a, x, w, bias, nullptr, y, N, H, W, Cin, Cout, KH, KW, stride, pad, KP, 0)) return rc;
+    const long M = (long)N * a.OH * a.OW;
+    int ksteps;
+    hipStream_t st = (hipStream_t)stream;
+    if (conv_split_plan(a, M, &ksteps) <= 1 && conv_uses_glds(a, M) && (Cout & 3) == 0) {
+        a.R = top; a.RH = TH; a.RW = TW;
+        launch_conv(a, M, st);
+        HIP_TRY(hipGetLastError());
+        return OPNET_OK;
+    }
+    if (int rc = opdet_conv2d_ws_f32(x, w, bias, nullptr, y, N, H, W, Cin, Cout, KH, KW, stride, pad, KP, 0, workspace, workspace_bytes, stream))
+        return rc;
+    upsample_add<<<ew_blocks(M * Cout), 256, 0, st>>>(y, top, y, N, a.OH, a.OW, Cout, TH, TW);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
 extern "C" int opdet_maxpool3x3s2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream)
 {
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(OPNET_EINVAL, "bad argument");
+    if ((C & 3) || !aligned16(x) || !aligned16(y)) return fail(OPNET_EINVAL, "maxpool: C %% 4 == 0, x / y 16-byte aligned");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    maxpool3x3s2<<<ew_blocks((long)N * OH * OW * C), 256, 0, (hipStream_t)stream>>>(x, y, N, H, W, C, OH, OW);
+    maxpool3x3s2<<<ew_blocks((long)N * OH * OW * (C / 4)), 256, 0, (hipStream_t)stream>>>(x, y, N, H, W, C, OH, OW);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

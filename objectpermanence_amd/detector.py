@@ -71,6 +71,25 @@ class _Conv:
         _lib.check(rc, "opdet_conv2d_ws_f32")
         return y
 
+    def plus_upsampled(self, x: torch.Tensor, top: torch.Tensor) -> torch.Tensor:
+        """conv(x) + bias + F.interpolate(top, size=conv's, mode="nearest"): FeaturePyramidNetwork's top-down step in one call"""
+        lib = _lib.load()
+        n, h, w, c = x.shape
+        assert c == self.cin and top.shape[0] == n and top.shape[3] == self.cout and top.is_contiguous()
+        oh = (h + 2 * self.pad - self.kh) // self.stride + 1
+        ow = (w + 2 * self.pad - self.kw) // self.stride + 1
+        y = torch.empty((n, oh, ow, self.cout), dtype=torch.float32, device=x.device)
+        shape = (n, h, w, c, self.cout, self.kh, self.kw, self.stride, self.pad, self.kp)
+        nws = self._ws_bytes.get(shape)
+        if nws is None:
+            nws = self._ws_bytes[shape] = int(lib.opdet_conv2d_workspace_bytes(*shape))
+        ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+        rc = lib.opdet_conv2d_up_f32(x.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), top.data_ptr(), y.data_ptr(), *shape,
+                                     int(top.shape[1]), int(top.shape[2]), None if ws is None else ws.data_ptr(), nws,
+                                     _stream(x.device))
+        _lib.check(rc, "opdet_conv2d_up_f32")
+        return y
+
 
 class _Linear(_Conv):
     """nn.Linear as a 1x1 "conv" over a row of R pixels: x [R, K] -> [R, out]"""
@@ -287,12 +306,8 @@ class ResNet50FPNBackbone:
         last = self.inner[3](feats[3], relu=False)
         results = [self.outer[3](last, relu=False)]
         for i in (2, 1, 0):
-            lat = self.inner[i](feats[i], relu=False)
-            n, h, w, c = lat.shape
-            merged = torch.empty_like(lat)
-            _lib.check(lib.opdet_upsample_add_f32(lat.data_ptr(), last.data_ptr(), merged.data_ptr(), n, h, w, c,
-                                                  last.shape[1], last.shape[2], st), "opdet_upsample_add_f32")
-            last = merged
+            # lateral conv + nearest-upsampled coarser level, added in the conv's epilogue (FeaturePyramidNetwork.forward)
+            last = self.inner[i].plus_upsampled(feats[i], last)
             results.insert(0, self.outer[i](last, relu=False))
         top = results[-1]
         n, h, w, c = top.shape

@@ -95,6 +95,35 @@ def test_conv2d_split_k_matches_torch(cin, cout, k, stride, pad, n, h, w, slices
         assert (got - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,n,h,w,th,tw", [
+    (256, 256, 2, 128, 130, 64, 65),      # the LDS-DMA kernel un-split: the addition rides in the conv's epilogue (narrow tile: prefetched)
+    (512, 256, 1, 100, 136, 50, 68),      # one frame's P3 lateral: 107 tiles x 4
+    (1024, 256, 1, 50, 68, 25, 34),       # one frame's P4 lateral: split K -> conv + in-place upsample_add
+    (32, 40, 1, 23, 31, 12, 16),          # tiny: the un-staged kernel -> conv + in-place upsample_add; odd sizes (floor(dst * T / O))
+])
+def test_lateral_conv_plus_upsampled_top(cin, cout, n, h, w, th, tw):
+    """FeaturePyramidNetwork's top-down step in one call = lateral conv, then F.interpolate(top, nearest) added: bit for bit the two
+    launches it replaces (same fp32 operations in the same order), and torch's fp64 within rounding."""
+    from objectpermanence_amd import _lib
+    from objectpermanence_amd.detector import _Conv
+    sd = {"w": synth.synth_tensor(f"lw{cin}{cout}", (cout, cin, 1, 1), float(np.sqrt(6.0 / cin))), "b": synth.synth_tensor("lb", (cout,), 0.2)}
+    x = torch.from_numpy(synth.synth_tensor("lx", (n, cin, h, w), 1.0))
+    top = torch.from_numpy(synth.synth_tensor("lt", (n, cout, th, tw), 1.0))
+    conv = _Conv(sd, "w", bias="b")
+    xd, td = _nhwc(x).cuda(), _nhwc(top).cuda().contiguous()
+    got = conv.plus_upsampled(xd, td)
+    lat = conv(xd, relu=False)
+    two = torch.empty_like(lat)
+    _lib.check(_lib.load().opdet_upsample_add_f32(lat.data_ptr(), td.data_ptr(), two.data_ptr(), n, h, w, cout, th, tw,
+                                                  torch.cuda.current_stream().cuda_stream), "opdet_upsample_add_f32")
+    torch.cuda.synchronize()
+    assert torch.equal(got, two)
+    ref = F.conv2d(x.double(), torch.from_numpy(sd["w"]).double(), torch.from_numpy(sd["b"]).double()) + \
+        F.interpolate(top.double(), size=(h, w), mode="nearest")
+    g = got.cpu().permute(0, 3, 1, 2).double()
+    assert (g - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max())
+
+
 def test_linear_rows_split_k_and_refusals():
     """TwoMLPHead.fc6 of one frame (1000 x 12544 -> 1024): 128 tiles of 128 x 64, 784 K steps -> 5 slices"""
     from objectpermanence_amd import _lib
