@@ -336,9 +336,30 @@ def detector_flops_per_frame(h=800, w=1088, rois=1000, classes=193):
     return total
 
 
+def _passes_in_flight():
+    from objectpermanence_amd.detector import PASSES_IN_FLIGHT
+    return max(1, int(os.environ.get("OPDET_IN_FLIGHT", str(PASSES_IN_FLIGHT))))
+
+
+def _detector_passes(det, frames, dev, streams):
+    """run(n): n passes over `frames`, len(streams) of them enqueued at a time on alternating streams (as
+    preprocess_perception_main runs a video); returns the last pass's detections"""
+    def run(n):
+        waiting, out = [], None
+        for k in range(n):
+            with torch.cuda.stream(streams[k % len(streams)]):
+                waiting.append(det.detect_batch_async(frames, dev))
+            if len(waiting) >= len(streams):
+                out = waiting.pop(0)()
+        while waiting:
+            out = waiting.pop(0)()
+        return out
+    return run
+
+
 def detector_block(dev, nf=16, passes=3):
     """BASELINE.json config 4's front-end next to the headline (outside the timed region; `--mode detect` is the full
-    measurement): `passes` calls of CaterObjectDetector.detect_batch on `nf` 240x320 frames, two passes in flight.
+    measurement): `passes` calls of CaterObjectDetector.detect_batch on `nf` 240x320 frames, PASSES_IN_FLIGHT passes in flight.
     Parity of this stage is UNPINNED (no torchvision in the image: DESIGN.md section 11)."""
     from objectpermanence_amd.detector import CaterObjectDetector
     from synthdata import detector as sd
@@ -347,17 +368,9 @@ def detector_block(dev, nf=16, passes=3):
     det = CaterObjectDetector(None)
     det.load_state_dict(params, dev)
     frames = [f for f in np.random.default_rng(0).integers(0, 256, size=(nf, 240, 320, 3), dtype=np.uint8)]
-    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(_passes_in_flight())]
 
-    def run(n):
-        prev, out = None, None
-        for k in range(n):
-            with torch.cuda.stream(streams[k % 2]):
-                h = det.detect_batch_async(frames, dev)
-            if prev is not None:
-                out = prev()
-            prev = h
-        return prev() if prev is not None else out
+    run = _detector_passes(det, frames, dev, streams)
 
     run(2)
     torch.cuda.synchronize(dev)
@@ -396,19 +409,11 @@ def bench_detect(args, world, rank, dev, dist):
     det.load_state_dict(params, dev)
     nf = args.batch
     frames = [f for f in np.random.default_rng(rank).integers(0, 256, size=(nf, 240, 320, 3), dtype=np.uint8)]
-    # two passes in flight on alternating streams, as preprocess_perception_main runs a video: the per-image selection
+    # PASSES_IN_FLIGHT passes enqueued at a time on alternating streams, as preprocess_perception_main runs a video: the
     # kernels of pass k overlap the conv GEMMs of pass k+1
-    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(_passes_in_flight())]
 
-    def run(n):
-        prev, out = None, None
-        for k in range(n):
-            with torch.cuda.stream(streams[k % 2]):
-                h = det.detect_batch_async(frames, dev)
-            if prev is not None:
-                out = prev()
-            prev = h
-        return prev() if prev is not None else out
+    run = _detector_passes(det, frames, dev, streams)
 
     out = run(max(2, args.warmup))
     torch.cuda.synchronize(dev)

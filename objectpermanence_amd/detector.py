@@ -24,6 +24,11 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 _LAYERS = (3, 4, 6, 3)
 
 
+# passes a caller keeps enqueued at once on alternating streams (preprocess_perception_main, bench.py): the partial last round of one
+# pass's conv launches is filled by the next pass's workgroups
+PASSES_IN_FLIGHT = 3
+
+
 def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 

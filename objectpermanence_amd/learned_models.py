@@ -1137,6 +1137,12 @@ class TransformerLstm(AbstractCaterModel):
         n_t = min(n_tok, max(1, int(lib.opseq_xcdt_max_batch(T, r.L, r.KX, r.H)) // b))
         return n_t if n_t * b >= r.XCDT_MIN_BATCH and n_t > n_exact else n_exact
 
+    def pass_engine(self, n_seg: int, b: int, T: int, exact: bool = False) -> str:
+        """the stacked LSTM's engine for a pass of n_seg requests of b clips x T frames ("t" / "x" / "c", _LstmStackRunner.engine):
+        the lone request's when exact (or alone), else the whole pass's"""
+        lone = self._runner.engine(b, T)
+        return lone if (exact or n_seg == 1) else self._runner.engine(n_seg * b, T)
+
     def _forward_eval(self, x: torch.Tensor, n_seg: int, exact: bool = False) -> torch.Tensor:
         if n_seg > 1 and n_seg > self.max_requests_per_pass(int(x.shape[0]) // n_seg, int(x.shape[1]), exact):
             raise ValueError(f"{n_seg} requests of {int(x.shape[0]) // n_seg} clips x {int(x.shape[1])} frames exceed one pass "

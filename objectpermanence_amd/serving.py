@@ -16,6 +16,9 @@ persistent launch runs the stacked LSTM over all their clips - each request's re
 A pass is ~0.55 ms of encoder launches followed by the 0.67 ms persistent stacked-LSTM launch, which leaves the matrix pipes 83 %
 idle: such a server therefore issues its passes on TWO side streams in turn, so that one pass's encoder runs under the other's
 recurrence (persistent launches themselves are serialised per device inside the library): 13.8 k -> 17.4 k clips/s, same bits.
+A pass in the THROUGHPUT form (>= 64 clips: the 16-clip persistent launch at 0.8 matrix-pipe busy, large GEMM tiles) has no such
+idle time to fill - a second pass's GEMM workgroups on the same CUs only slow the recurrence's critical path: measured 25.7 k
+clips/s with two passes in flight against 28.2 k one after the other at 256 requests per pass - so those passes share ONE side stream.
 """
 from __future__ import annotations
 
@@ -73,6 +76,7 @@ class ReasonerServer:
         self.exact = bool(exact)
         self._queue: List[Tuple[torch.Tensor, PendingResult]] = []
         self._pending = 0
+        self._pass_limit = {}        # (b, T) of a request -> clips one pass takes (segmented models)
         # optional callable run on the host right before the forward is enqueued (after the requests were concatenated): a
         # data-parallel caller makes the launch wait for its previous collective here - a persistent launch needs every CU of
         # the device, and an RCCL kernel that holds a few of them while it waits for a slower rank would stall it
@@ -96,17 +100,26 @@ class ReasonerServer:
         self._pending += h.n_clips
         limit = self.max_clips
         if self.segmented:           # as many requests as one pass takes (exact: and returns bit-identical to their lone forwards)
-            limit = min(limit, self.model.max_requests_per_pass(int(boxes.shape[0]), int(boxes.shape[1]), self.exact) * int(boxes.shape[0]))
+            key = (int(boxes.shape[0]), int(boxes.shape[1]))
+            per_pass = self._pass_limit.get(key)
+            if per_pass is None:
+                per_pass = self._pass_limit[key] = self.model.max_requests_per_pass(key[0], key[1], self.exact) * key[0]
+            limit = min(limit, per_pass)
         if self._pending >= limit:
             self.flush()
         return h
 
-    def _side_stream(self, device: torch.device):
-        """the side stream of the next pass (round robin), or None: one stream asked for / not a GPU"""
+    def _side_stream(self, device: torch.device, queue=None):
+        """the side stream of the next pass (round robin; always the first one for a pass in the throughput form: module docstring),
+        or None: one stream asked for / not a GPU"""
         if self._n_streams <= 1 or device.type != "cuda":
             return None
         if self._device != device:
             self._device, self._side = device, [torch.cuda.Stream(device=device) for _ in range(self._n_streams)]
+        if self.segmented and queue and not self.exact and hasattr(self.model, "pass_engine"):
+            b, T = int(queue[0][0].shape[0]), int(queue[0][0].shape[1])
+            if self.model.pass_engine(len(queue), b, T, False) == "t":
+                return self._side[0]
         return self._side[self.forwards % len(self._side)]
 
     def _forward(self, queue):
@@ -131,7 +144,7 @@ class ReasonerServer:
         queue, self._queue, self._pending = self._queue, [], 0
         event = None
         try:
-            side = self._side_stream(queue[0][0].device)
+            side = self._side_stream(queue[0][0].device, queue)
             if side is None:
                 out = self._forward(queue)
             else:
