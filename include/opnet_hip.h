@@ -434,7 +434,9 @@ int opseq_encoder_layer_train_backward_f32(const float *dz_out, float *dz_in, co
  * call per frame; the frames of a video share a size): every device array gains a leading image dimension - head_out level l =
  * [n_images, gh, gw, 16], proposals [n_images, post_nms_top_n, 4], scores [n_images, post], count [n_images]; feats level l =
  * [n_images, fh, fw, C], rois [n_images, max_rois, 4], out [n_images, max_rois, 7, 7, C]; class_logits [n_images, max_rois, NC], ...,
- * boxes [n_images, max_det, 4], n_det [n_images] - and the workspace is n_images blocks of the one-image size.  Each image's result
+ * boxes [n_images, max_det, 4], n_det [n_images] - and the workspace is n_images blocks of the one-image size.  logits_stride /
+ * reg_stride: floats between consecutive rois' rows of class_logits / box_regression (0 = dense: NC / 4 NC) - the two predictors
+ * run as ONE product whose output row holds both.  Each image's result
  * is bit-identical to its own one-image call (which is the same launch with one image). */
 size_t opdet_rpn_workspace_bytes_batch(int n_images, int n_levels, const int *gh, const int *gw, const int *anchor_sizes, int padded_h,
                                        int padded_w, int pre_nms_top_n);
@@ -446,9 +448,10 @@ int opdet_roi_align_batch_f32(const float *const *feats, int n_images, const int
                               const float *rois, const int *count, int max_rois, float *out, void *stream);
 size_t opdet_detections_workspace_bytes_batch(int n_images, int max_rois, int num_classes);
 int opdet_detections_batch_f32(const float *class_logits, const float *box_regression, const float *proposals,
-                               const int *count, int n_images, int max_rois, int num_classes, int image_h, int image_w, int orig_h,
-                               int orig_w, float score_thresh, float nms_thresh, int max_det, float *boxes, float *scores,
-                               long long *labels, int *n_det, void *workspace, size_t workspace_bytes, void *stream);
+                               const int *count, int n_images, int max_rois, int num_classes, int logits_stride, int reg_stride,
+                               int image_h, int image_w, int orig_h, int orig_w, float score_thresh, float nms_thresh, int max_det,
+                               float *boxes, float *scores, long long *labels, int *n_det, void *workspace, size_t workspace_bytes,
+                               void *stream);
 size_t opdet_rpn_workspace_bytes(int n_levels, const int *gh, const int *gw, const int *anchor_sizes, int padded_h,
                                  int padded_w, int pre_nms_top_n);
 int opdet_rpn_proposals_f32(const float *const *head_out, int n_levels, const int *gh, const int *gw,

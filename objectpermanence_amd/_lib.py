@@ -255,7 +255,7 @@ def _declare(lib):
     lib.opdet_detections_workspace_bytes_batch.restype = c_size_t
     lib.opdet_detections_workspace_bytes_batch.argtypes = [c_int, c_int, c_int]
     lib.opdet_detections_batch_f32.restype = c_int
-    lib.opdet_detections_batch_f32.argtypes = [fp, fp, fp, fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
+    lib.opdet_detections_batch_f32.argtypes = [fp, fp, fp, fp] + [c_int] * 9 + [c_float, c_float, c_int,
                                                fp, fp, fp, fp, c_void_p, c_size_t, c_void_p]
     lib.opnet_encode_clips_f32.restype = c_int
     lib.opnet_encode_clips_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,

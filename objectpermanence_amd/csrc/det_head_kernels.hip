@@ -459,16 +459,16 @@ __global__ void __launch_bounds__(256) det_score_boxes(const float *logits, cons
                                                        const int *count, int NC, float img_w, float img_h,
                                                        float score_thresh, float min_size, float clipv, float4 *cbox,
                                                        int *cgroup, float *cscore, unsigned *ckeys, unsigned *cvals,
-                                                       int *n_valid, size_t wsb)
+                                                       int *n_valid, size_t wsb, int ls, int rs)
 {
     __shared__ float red[256];
     const int r = blockIdx.x, tid = threadIdx.x, img = blockIdx.y;
     const int ncand = NC - 1;
-    logits += (long)img * gridDim.x * NC; reg += (long)img * gridDim.x * NC * 4; rois += (long)img * gridDim.x; count += img;
+    logits += (long)img * gridDim.x * ls; reg += (long)img * gridDim.x * rs; rois += (long)img * gridDim.x; count += img;   // ls, rs: row strides
     cbox = det_img(cbox, wsb, img); cgroup = det_img(cgroup, wsb, img); cscore = det_img(cscore, wsb, img);
     ckeys = det_img(ckeys, wsb, img); cvals = det_img(cvals, wsb, img); n_valid = det_img(n_valid, wsb, img);
     const bool live = r < *count;
-    const float *z = logits + (long)r * NC;
+    const float *z = logits + (long)r * ls;
     float m = -INFINITY;
     for (int c = tid; c < NC; c += 256) m = fmaxf(m, z[c]);
     red[tid] = m;
@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(256) det_score_boxes(const float *logits, cons
     for (int c = 1 + tid; c < NC; c += 256) {
         const long id = (long)r * ncand + (c - 1);
         const float score = __fdiv_rn(expf(z[c] - m), sum);
-        const float *d = reg + ((long)r * NC + c) * 4;
+        const float *d = reg + (long)r * rs + c * 4;
         float4 b = det_decode(box, __fdiv_rn(d[0], 10.f), __fdiv_rn(d[1], 10.f), __fdiv_rn(d[2], 5.f),
                               __fdiv_rn(d[3], 5.f), clipv);
         b = det_clip(b, img_w, img_h);

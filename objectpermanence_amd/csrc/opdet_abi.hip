@@ -314,11 +314,14 @@ extern "C" size_t opdet_detections_workspace_bytes(int max_rois, int num_classes
 }
 
 extern "C" int opdet_detections_batch_f32(const float *class_logits, const float *box_regression, const float *proposals,
-                                          const int *count, int n_images, int max_rois, int num_classes, int image_h, int image_w,
-                                          int orig_h, int orig_w, float score_thresh, float nms_thresh, int max_det,
-                                          float *boxes, float *scores, long long *labels, int *n_det, void *workspace,
-                                          size_t workspace_bytes, void *stream)
+                                          const int *count, int n_images, int max_rois, int num_classes, int logits_stride,
+                                          int reg_stride, int image_h, int image_w, int orig_h, int orig_w, float score_thresh,
+                                          float nms_thresh, int max_det, float *boxes, float *scores, long long *labels, int *n_det,
+                                          void *workspace, size_t workspace_bytes, void *stream)
 {
+    if (logits_stride == 0) logits_stride = num_classes;
+    if (reg_stride == 0) reg_stride = 4 * num_classes;
+    if (logits_stride < num_classes || reg_stride < 4 * num_classes) return fail(OPNET_ESHAPE, "row strides shorter than the rows");
     if (n_images < 1 || n_images > DET_MAX_IMAGES) return fail(OPNET_ESHAPE, "1..%d images per call", DET_MAX_IMAGES);
     if (!class_logits || !box_regression || !proposals || !count || !boxes || !scores || !labels || !n_det || !workspace)
         return fail(OPNET_EINVAL, "null pointer");
@@ -349,7 +352,7 @@ extern "C" int opdet_detections_batch_f32(const float *class_logits, const float
     det_stage_init<<<dim3(1, ni), 256, 0, st>>>(n_valid, 1, nullptr, 0, wsb);
     det_score_boxes<<<dim3(max_rois, ni), 256, 0, st>>>(class_logits, box_regression, (const float4 *)proposals, count, num_classes,
                                                        (float)image_w, (float)image_h, score_thresh, 1e-2f, kBoxClip, cbox, cgroup,
-                                                       cscore, ck_in, cv_in, n_valid, wsb);
+                                                       cscore, ck_in, cv_in, n_valid, wsb, logits_stride, reg_stride);
     const unsigned *cv_sorted = sort_pairs<unsigned>(ck_in, cv_in, ck_out, cv_out, c, 32, tmp, st, n_images, wsb) ? cv_out : cv_in;
     det_gather_sorted<<<dim3((unsigned)((P.cap + 255) / 256), ni), 256, 0, st>>>(cv_sorted, cbox, cgroup, cscore, nb.sbox, nb.sgroup,
                                                                                 nb.sscore, n_valid, P.cap, wsb);
@@ -368,7 +371,7 @@ extern "C" int opdet_detections_f32(const float *class_logits, const float *box_
                                     float *boxes, float *scores, long long *labels, int *n_det, void *workspace,
                                     size_t workspace_bytes, void *stream)
 {
-    return opdet_detections_batch_f32(class_logits, box_regression, proposals, count, 1, max_rois, num_classes, image_h, image_w, orig_h,
+    return opdet_detections_batch_f32(class_logits, box_regression, proposals, count, 1, max_rois, num_classes, 0, 0, image_h, image_w, orig_h,
                                       orig_w, score_thresh, nms_thresh, max_det, boxes, scores, labels, n_det, workspace, workspace_bytes,
                                       stream);
 }

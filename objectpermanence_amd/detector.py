@@ -134,11 +134,18 @@ class FasterRCNNHeads:
         w6 = w6.view(-1, c, 7, 7).permute(0, 2, 3, 1).reshape(w6.shape[0], -1)
         self.fc6 = _Linear(w6, sd["roi_heads.box_head.fc6.bias"], device)
         self.fc7 = _Linear(sd["roi_heads.box_head.fc7.weight"], sd["roi_heads.box_head.fc7.bias"], device)
-        self.cls_score = _Linear(sd["roi_heads.box_predictor.cls_score.weight"], sd["roi_heads.box_predictor.cls_score.bias"], device)
-        self.bbox_pred = _Linear(sd["roi_heads.box_predictor.bbox_pred.weight"], sd["roi_heads.box_predictor.bbox_pred.bias"], device)
-        self.num_classes = num_classes
-        if self.cls_score.cout != num_classes or self.bbox_pred.cout != 4 * num_classes:
+        # FastRCNNPredictor's two Linears (cls_score NC, bbox_pred 4 NC) as ONE product: output row = [scores | pad to a multiple of
+        # 4 | deltas]; the detections stage reads the two parts through row strides
+        wc, wb = sd["roi_heads.box_predictor.cls_score.weight"], sd["roi_heads.box_predictor.bbox_pred.weight"]
+        if wc.shape[0] != num_classes or wb.shape[0] != 4 * num_classes:
             raise ValueError("box predictor shape does not match num_classes")
+        self._reg_col = (num_classes + 3) // 4 * 4
+        w = torch.zeros((self._reg_col + 4 * num_classes, wc.shape[1]))
+        b = torch.zeros(self._reg_col + 4 * num_classes)
+        w[:num_classes], w[self._reg_col:] = wc, wb
+        b[:num_classes], b[self._reg_col:] = sd["roi_heads.box_predictor.cls_score.bias"], sd["roi_heads.box_predictor.bbox_pred.bias"]
+        self.predictor = _Linear(w, b, device)
+        self.num_classes = num_classes
         self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms_thresh = pre_nms_top_n, post_nms_top_n, rpn_nms_thresh
         self.score_thresh, self.nms_thresh, self.detections_per_img = score_thresh, nms_thresh, detections_per_img
         self._ws: Dict[tuple, torch.Tensor] = {}
@@ -207,9 +214,10 @@ class FasterRCNNHeads:
         return out
 
     def box_heads(self, pooled: torch.Tensor):
-        """TwoMLPHead + FastRCNNPredictor -> (class_logits [R, NC], box_regression [R, 4 NC])"""
+        """TwoMLPHead + FastRCNNPredictor -> (class_logits [R, NC], box_regression [R, 4 NC]): two column ranges of one product"""
         x = self.fc7.rows(self.fc6.rows(pooled.view(pooled.shape[0], -1), relu=True), relu=True)
-        return self.cls_score.rows(x, relu=False), self.bbox_pred.rows(x, relu=False)
+        both = self.predictor.rows(x, relu=False)
+        return both[:, :self.num_classes], both[:, self._reg_col:]
 
     def detections(self, class_logits, box_regression, props, count, image_size, original_size):
         """RoIHeads.postprocess_detections + rescale for n images: class_logits [n * R, NC], box_regression [n * R, 4 NC], props
@@ -219,8 +227,8 @@ class FasterRCNNHeads:
         if props.dim() == 2:
             props = props[None]
         n, r, nc, md = int(props.shape[0]), int(props.shape[1]), self.num_classes, self.detections_per_img
-        if class_logits.shape[0] != n * r or not class_logits.is_contiguous() or not box_regression.is_contiguous():
-            raise ValueError("detections: class_logits / box_regression must be contiguous with n * R rows")
+        if class_logits.shape[0] != n * r or box_regression.shape[0] != n * r or class_logits.stride(1) != 1 or box_regression.stride(1) != 1:
+            raise ValueError("detections: class_logits / box_regression must have n * R rows of unit-stride columns")
         ws = self._workspace(("det", n, r, nc), lib.opdet_detections_workspace_bytes_batch(n, r, nc),
                              "opdet_detections_workspace_bytes_batch")
         boxes = torch.empty((n, md, 4), dtype=torch.float32, device=dev)
@@ -229,7 +237,8 @@ class FasterRCNNHeads:
         n_det = torch.empty((n,), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             rc = lib.opdet_detections_batch_f32(class_logits.data_ptr(), box_regression.data_ptr(), props.data_ptr(),
-                                                count.data_ptr(), n, r, nc, int(image_size[0]), int(image_size[1]),
+                                                count.data_ptr(), n, r, nc, int(class_logits.stride(0)), int(box_regression.stride(0)),
+                                                int(image_size[0]), int(image_size[1]),
                                                 int(original_size[0]), int(original_size[1]), self.score_thresh,
                                                 self.nms_thresh, md, boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(),
                                                 n_det.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev))
