@@ -439,7 +439,10 @@ __device__ __forceinline__ long conv_rrow(const ConvArgs &a, long pp)
     return (n * a.RH + ty) * a.RW + tx;
 }
 
-template <int BN, int NS>
+// C4 = true: Cin == 4 (the stem: 7 x 7 over the 4-channel frame).  A k-quad is then ONE TAP's four channels - still one aligned 16-B
+// run in memory - so the same DMA stages it; only the source walk differs: the lane's quad position selects the tap (4 q + quad of
+// stage q), each lane advances its own (dy, dx) by four taps per stage, taps past KH x KW are masked (their weights are zero padding).
+template <int BN, int NS, bool C4 = false>
 __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
 {
     constexpr int BM = 128;
@@ -491,7 +494,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
         const int nimg = tq / a.OH;
         iy0[j] = oy * a.stride - a.pad;
         ix0[j] = ox * a.stride - a.pad;
-        xoff[j] = (int)(((((long)nimg * a.H + iy0[j]) * a.W + ix0[j]) * XS + 4 * lkq) * 4);
+        xoff[j] = (int)(((((long)nimg * a.H + iy0[j]) * a.W + ix0[j]) * XS + (C4 ? 0 : 4 * lkq)) * 4);
     }
     unsigned woff[WLD];
 #pragma unroll
@@ -524,10 +527,24 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
             aoff[j] = ok ? (unsigned)(xoff[j] + toff) : 0x80000000u;
         }
     };
-    tap_offsets();
+    if constexpr (!C4) tap_offsets();
+    int l_dy = (qb * 4 + lkq) / a.KW, l_dx = (qb * 4 + lkq) - l_dy * a.KW;      // C4: this lane's tap of the next stage to issue
     auto issue = [&](int q) {           // q: step within the slice
         const unsigned sbase = lds0 + (unsigned)(q % NS) * (STAGE_F4 * 16);
         const unsigned cb = (unsigned)t_c0 * 4u, wb = (unsigned)(qb + q) * 64u;      // (wave-uniform)
+        if constexpr (C4) {
+            const int toff = (l_dy * a.W + l_dx) * 16;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool ok = prow_ok[j] && l_dy < a.KH && (unsigned)(iy0[j] + l_dy) < (unsigned)a.H && (unsigned)(ix0[j] + l_dx) < (unsigned)a.W;
+                conv_glds16(rx, ok ? (unsigned)(xoff[j] + toff) : 0x80000000u, sbase + (32 * w + 16 * j) * 64);
+            }
+#pragma unroll
+            for (int j = 0; j < WLD; ++j) conv_glds16(rwt, woff[j] + wb, sbase + BM * 64 + ((BN / 4) * w + 16 * j) * 64);
+            l_dx += 4;
+            while (l_dx >= a.KW) { l_dx -= a.KW; ++l_dy; }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) conv_glds16(rx, aoff[j] + cb, sbase + (32 * w + 16 * j) * 64);
 #pragma unroll

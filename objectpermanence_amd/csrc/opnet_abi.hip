@@ -79,6 +79,10 @@ static void launch_conv_tiled(const ConvArgs &c, long M, hipStream_t st)
     }
     const bool al = (c.Cin & 15) == 0;
     const unsigned gx = (unsigned)((M + 127) / 128);
+    if (c.Cin == 4 && c.XS == 0 && c.KW >= 4 && c.ksplit <= 1) {     // the stem: a tap per k-quad through the same LDS-DMA stages
+        conv2d_nhwc_glds<64, 3, true><<<dim3(gx, (c.Cout + 63) / 64, 1), 256, 0, st>>>(c);
+        return;
+    }
     if (c.Cout > 64 && !(al && env_int("OPNET_CONV_BN64", 1) && conv_prefers_bn64(c, M))) {
         const dim3 g(gx, (c.Cout + 127) / 128, 1);
         if (al) conv2d_nhwc_glds<128, 3><<<g, 256, 0, st>>>(c);
