@@ -380,6 +380,15 @@ int opdet_conv2d_ws_f32(const float *x, const float *w, const float *bias, const
 int opdet_conv2d_up_f32(const float *x, const float *w, const float *bias, const float *top, float *y, int N, int H, int W,
                         int Cin, int Cout, int KH, int KW, int stride, int pad, int KP, int TH, int TW, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* conv3 and the downsample branch of a stage's first bottleneck as ONE product (torchvision Bottleneck.forward:
+ * relu(bn3(conv3(out)) + downsample(x))): y = act(W[:, :Cin] . x + W[:, Cin:] . x2[every stride2-th pixel] + bias); both 1 x 1; x [N, H, W, Cin],
+ * x2 [N, H2, W2, Cin2] with (H2 - 1) / stride2 + 1 == H, w [Cout][Cin + Cin2], bias = the two folded biases added.  Cin, Cin2 multiples of
+ * 16, Cout of 4.  _workspace_bytes: scratch of the K split (0: none), -1 (and OPNET_ESHAPE from the call) when the shape is not one the
+ * LDS-DMA kernel runs - the caller then runs the two convs (opdet_conv2d_ws_f32 with the residual). */
+long long opdet_conv2d_dual_workspace_bytes(int N, int H, int W, int Cin, int H2, int W2, int Cin2, int stride2, int Cout);
+int opdet_conv2d_dual_f32(const float *x, const float *x2, const float *w, const float *bias, float *y, int N, int H, int W,
+                          int Cin, int H2, int W2, int Cin2, int stride2, int Cout, int relu, void *workspace,
+                          size_t workspace_bytes, void *stream);
 int opdet_maxpool3x3s2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
 int opdet_subsample2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream);
 int opdet_upsample_add_f32(const float *lateral, const float *top, float *y, int N, int H, int W, int C,

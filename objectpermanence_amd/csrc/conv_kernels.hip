@@ -37,6 +37,11 @@ struct ConvArgs {
     // conv2d_nhwc_glds only, RH > 0: R is a COARSER map [N][RH][RW][Cout] added nearest-upsampled (F.interpolate to the output's size):
     // the FPN's top-down step  lateral(x) + upsample(top)  in the lateral conv's own epilogue (FeaturePyramidNetwork.forward)
     int RH, RW;
+    // conv2d_nhwc_glds only, X2 != null (1 x 1, stride 1, pad 0 on X): a SECOND 1 x 1 source [N][H2][W2][Cin2] sampled at stride2 joins
+    // the same K loop - k < Cin from X, Cin <= k < Cin + Cin2 from X2, weights [Cout][Cin + Cin2]: conv3 and the downsample branch of a
+    // stage's first bottleneck as ONE product (relu(bn3(conv3(out)) + bn_d(downsample(x))), torchvision Bottleneck.forward)
+    const float *X2;
+    int Cin2, H2, W2, stride2;
 #ifdef CONV_TRACE                 // tools/probes/gemm_probe.hip only: per-K-step cycle sums of wave 0 of every workgroup
     unsigned long long *trace;    // [0] steps, [1] top -> MFMAs issued, [2] -> waits done, [3] -> next top (barrier + DMA issue)
 #endif
@@ -502,6 +507,24 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
         const int r = n0 + (BN / 4) * w + 16 * j + lr;
         woff[j] = r < a.Cout ? (unsigned)(((long)r * WS + 4 * lkq) * 4) : 0x80000000u;
     }
+    // second source (dual product): its descriptor and this lane's row offsets
+    conv_u32x4 rx2 = rx;
+    unsigned aoff2[2] = {0x80000000u, 0x80000000u};
+    if (!C4 && a.X2) {
+        const unsigned long long b2 = (unsigned long long)a.X2;
+        rx2.x = (unsigned)b2; rx2.y = (unsigned)(b2 >> 32);
+        rx2.z = (unsigned)((long)a.N * a.H2 * a.W2 * a.Cin2 * 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            long p = m0 + 32 * w + 16 * j + lr;
+            if (p >= M) continue;
+            const int ox = p % a.OW;
+            const long tq = p / a.OW;
+            const int oy = tq % a.OH;
+            const long nimg = tq / a.OH;
+            aoff2[j] = (unsigned)((((nimg * a.H2 + (long)oy * a.stride2) * a.W2 + (long)ox * a.stride2) * a.Cin2 + 4 * lkq) * 4);
+        }
+    }
 
     // K steps of this workgroup: all of them, or slice blockIdx.z of a split
     const int nhex_all = a.KP >> 4;
@@ -545,8 +568,14 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
             while (l_dx >= a.KW) { l_dx -= a.KW; ++l_dy; }
             return;
         }
+        if (a.X2 && (qb + q) * 16 >= a.Cin) {            // (wave-uniform) the second source's channels (qb + q) * 16 - Cin ..
+            const unsigned cb2 = (unsigned)((qb + q) * 16 - a.Cin) * 4u;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) conv_glds16(rx, aoff[j] + cb, sbase + (32 * w + 16 * j) * 64);
+            for (int j = 0; j < 2; ++j) conv_glds16(rx2, aoff2[j] + cb2, sbase + (32 * w + 16 * j) * 64);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) conv_glds16(rx, aoff[j] + cb, sbase + (32 * w + 16 * j) * 64);
+        }
 #pragma unroll
         for (int j = 0; j < WLD; ++j) conv_glds16(rwt, woff[j] + wb, sbase + BM * 64 + ((BN / 4) * w + 16 * j) * 64);
         t_c0 += 16;

@@ -3147,6 +3147,77 @@ extern "C" int opdet_conv2d_up_f32(const float *x, const float *w, const float *
     return OPNET_OK;
 }
 
+/* conv3 and the downsample branch of a stage's first bottleneck as ONE product (torchvision Bottleneck.forward:
+ * relu(bn3(conv3(out)) + downsample(x))):  y = act(W[:, :Cin] . x + W[:, Cin:] . x2[sampled at stride2] + bias), both 1 x 1, x [N, H, W, Cin]
+ * at stride 1, x2 [N, H2, W2, Cin2] with (H2 - 1) / stride2 + 1 == H (same for W), w [Cout][Cin + Cin2], bias = the two folded biases
+ * added.  Saves writing the downsample's output and reading it back as the residual.  Cin, Cin2 multiples of 16 and the shape on the
+ * LDS-DMA kernel (un-split or K-split: _dual_workspace_bytes); otherwise OPNET_ESHAPE - the caller then runs the two convs. */
+static int conv_dual_args(ConvArgs *a, const float *x, const float *x2, const float *w, const float *bias, float *y, int N, int H, int W,
+                          int Cin, int H2, int W2, int Cin2, int stride2, int Cout, int relu)
+{
+    if (stride2 <= 0 || Cin2 <= 0 || (Cin & 15) || (Cin2 & 15)) return fail(OPNET_ESHAPE, "dual conv: Cin, Cin2 multiples of 16");
+    if (H2 <= 0 || W2 <= 0 || (H2 - 1) / stride2 + 1 != H || (W2 - 1) / stride2 + 1 != W)
+        return fail(OPNET_ESHAPE, "dual conv: the second source sampled at stride %d does not give %d x %d", stride2, H, W);
+    if (int rc = conv_args(a, x, w, bias, nullptr, y, N, H, W, Cin, Cout, 1, 1, 1, 0, Cin + Cin2, relu)) return rc;
+    if ((long)N * H2 * W2 * Cin2 * 4 >= (1L << 31)) return fail(OPNET_ESHAPE, "dual conv: second source of 2 GiB or more");
+    a->X2 = x2; a->Cin2 = Cin2; a->H2 = H2; a->W2 = W2; a->stride2 = stride2;
+    return OPNET_OK;
+}
+
+// K-split plan of a dual product: conv_split_plan() with the K of both sources (it tests KP == KH KW Cin)
+static int conv_dual_split_plan(const ConvArgs &a, long M, int *ksteps)
+{
+    ConvArgs t = a;
+    t.Cin = a.Cin + a.Cin2;
+    t.X2 = nullptr;
+    return conv_split_plan(t, M, ksteps);
+}
+
+extern "C" long long opdet_conv2d_dual_workspace_bytes(int N, int H, int W, int Cin, int H2, int W2, int Cin2, int stride2, int Cout)
+{
+    ConvArgs a;
+    if (conv_dual_args(&a, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, H2, W2, Cin2, stride2, Cout, 0)) return -1;
+    const long M = (long)N * H * W;
+    ConvArgs t = a;
+    t.Cin = Cin + Cin2;
+    if (!conv_uses_glds(t, M)) { fail(OPNET_ESHAPE, "dual conv: shape does not run on the LDS-DMA kernel"); return -1; }
+    int ksteps;
+    const int S = conv_dual_split_plan(a, M, &ksteps);
+    return S > 1 ? (long long)S * M * Cout * 4 : 0;
+}
+
+extern "C" int opdet_conv2d_dual_f32(const float *x, const float *x2, const float *w, const float *bias, float *y, int N, int H, int W,
+                                     int Cin, int H2, int W2, int Cin2, int stride2, int Cout, int relu, void *workspace,
+                                     size_t workspace_bytes, void *stream)
+{
+    if (!x || !x2 || !w || !y) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(x) || !aligned16(x2) || !aligned16(w) || !aligned16(y) || !aligned16(workspace) || !aligned16(bias))
+        return fail(OPNET_EINVAL, "x / x2 / w / y / bias / workspace must be 16-byte aligned");
+    ConvArgs a;
+    if (int rc = conv_dual_args(&a, x, x2, w, bias, y, N, H, W, Cin, H2, W2, Cin2, stride2, Cout, relu)) return rc;
+    const long M = (long)N * H * W;
+    ConvArgs t = a;
+    t.Cin = Cin + Cin2;
+    if (!conv_uses_glds(t, M)) return fail(OPNET_ESHAPE, "dual conv: shape does not run on the LDS-DMA kernel");
+    int ksteps;
+    const int S = conv_dual_split_plan(a, M, &ksteps);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned gx = (unsigned)((M + 127) / 128);
+    if (S <= 1) {
+        if (Cout > 64 && !conv_prefers_bn64(t, M)) conv2d_nhwc_glds<128, 3><<<dim3(gx, (Cout + 127) / 128, 1), 256, 0, st>>>(a);
+        else conv2d_nhwc_glds<64, 3><<<dim3(gx, (Cout + 63) / 64, 1), 256, 0, st>>>(a);
+    } else {
+        const size_t need = (size_t)S * M * Cout * 4;
+        if (!workspace || workspace_bytes < need) return fail(OPNET_EWORKSPACE, "workspace %zu B < %zu B", workspace_bytes, need);
+        a.P = (float *)workspace; a.ksplit = S; a.ksteps = ksteps;
+        conv2d_nhwc_glds<64, 3><<<dim3(gx, (Cout + 63) / 64, S), 256, 0, st>>>(a);
+        const long n4 = M * Cout / 4;
+        conv_splitk_reduce<<<(unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256), 256, 0, st>>>(a.P, S, M, Cout, bias, nullptr, y, relu);
+    }
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
 extern "C" int opdet_maxpool3x3s2_f32(const float *x, float *y, int N, int H, int W, int C, void *stream)
 {
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(OPNET_EINVAL, "bad argument");

@@ -96,6 +96,38 @@ class _Conv:
         return y
 
 
+class _DualConv:
+    """conv3 + downsample of a stage's first bottleneck (both 1 x 1, FrozenBN folded) as ONE product over the concatenated K:
+    relu(conv3(out) + downsample(x)) without the downsample's output ever being written.  Shapes the LDS-DMA kernel does not run
+    (tiny maps) go through the two convs."""
+
+    def __init__(self, c3: _Conv, ds: _Conv):
+        assert (c3.kh, c3.kw, ds.kh, ds.kw, c3.stride, c3.pad, ds.pad) == (1, 1, 1, 1, 1, 0, 0) and c3.cout == ds.cout
+        self.c3, self.ds = c3, ds
+        self.ok = c3.cin % 16 == 0 and ds.cin % 16 == 0 and c3.cout % 4 == 0
+        if self.ok:
+            self.w = torch.cat([c3.w[:, :c3.cin], ds.w[:, :ds.cin]], dim=1).contiguous()
+            self.b = (c3.b + ds.b).contiguous()
+        self._ws_bytes: Dict[tuple, int] = {}
+
+    def __call__(self, out: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        c3, ds = self.c3, self.ds
+        n, h, w, _ = out.shape
+        shape = (n, h, w, c3.cin, int(x.shape[1]), int(x.shape[2]), ds.cin, ds.stride, c3.cout)
+        lib = _lib.load()
+        nws = self._ws_bytes.get(shape)
+        if nws is None:
+            nws = self._ws_bytes[shape] = int(lib.opdet_conv2d_dual_workspace_bytes(*shape)) if self.ok else -1
+        if nws < 0:
+            return c3(out, relu=True, residual=ds(x, relu=False))
+        y = torch.empty((n, h, w, c3.cout), dtype=torch.float32, device=out.device)
+        ws = torch.empty(nws, dtype=torch.uint8, device=out.device) if nws else None
+        rc = lib.opdet_conv2d_dual_f32(out.data_ptr(), x.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), y.data_ptr(), *shape, 1,
+                                       None if ws is None else ws.data_ptr(), nws, _stream(out.device))
+        _lib.check(rc, "opdet_conv2d_dual_f32")
+        return y
+
+
 class _Linear(_Conv):
     """nn.Linear as a 1x1 "conv" over a row of R pixels: x [R, K] -> [R, out]"""
 
@@ -295,7 +327,7 @@ class ResNet50FPNBackbone:
                 c2 = mk(p + ".conv2.weight", bn=p + ".bn2", stride=stride, pad=1)     # stride on the 3x3 ("v1.5")
                 c3 = mk(p + ".conv3.weight", bn=p + ".bn3")
                 ds = mk(p + ".downsample.0.weight", bn=p + ".downsample.1", stride=stride) if blk == 0 else None
-                layer.append((c1, c2, c3, ds))
+                layer.append((c1, c2, c3, ds if ds is None else _DualConv(c3, ds)))
             self.blocks.append(layer)
         f = "backbone.fpn."
         self.inner = [mk(f + f"inner_blocks.{i}.weight", bias=f + f"inner_blocks.{i}.bias") for i in range(4)]
@@ -313,9 +345,9 @@ class ResNet50FPNBackbone:
         feats = []
         for layer in self.blocks:
             for c1, c2, c3, ds in layer:
-                idt = x if ds is None else ds(x, relu=False)
                 out = c2(c1(x, relu=True), relu=True)
-                x = c3(out, relu=True, residual=idt)          # relu(bn3(conv3) + identity) fused in the epilogue
+                # relu(bn3(conv3) + identity) in the epilogue; a stage's first block: conv3 and the downsample branch as one product
+                x = c3(out, relu=True, residual=x) if ds is None else ds(out, x)
             feats.append(x)
         last = self.inner[3](feats[3], relu=False)
         results = [self.outer[3](last, relu=False)]

@@ -124,6 +124,44 @@ def test_lateral_conv_plus_upsampled_top(cin, cout, n, h, w, th, tw):
     assert (g - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max())
 
 
+@pytest.mark.parametrize("c3in,dsin,cout,stride,n,h,w,path", [
+    (64, 64, 256, 1, 2, 128, 130, "one"),        # layer1-like: both sources at stride 1, narrow tiles, ragged M
+    (128, 256, 512, 2, 2, 100, 136, "one"),      # layer2-like: the second source every other pixel
+    (256, 512, 1024, 2, 1, 50, 68, "split"),     # one frame's layer3: K split, the slice boundary inside / across the sources
+    (512, 1024, 2048, 2, 1, 25, 34, "split"),    # one frame's layer4
+    (64, 64, 256, 1, 1, 9, 11, "two"),           # too few tiles for the LDS-DMA kernel: the two convs
+])
+def test_conv3_plus_downsample_as_one_product(c3in, dsin, cout, stride, n, h, w, path):
+    """relu(conv3(out) + downsample(x)) of a stage's first bottleneck as ONE product over the concatenated K (opdet_conv2d_dual_f32)
+    against torch fp64 and against the two launches it replaces (same math, another summation order: rounding apart)."""
+    from objectpermanence_amd import _lib
+    from objectpermanence_amd.detector import _Conv, _DualConv
+    sd = {"w3": synth.synth_tensor(f"d3{c3in}{cout}", (cout, c3in, 1, 1), float(np.sqrt(3.0 / c3in))), "b3": synth.synth_tensor("db3", (cout,), 0.2),
+          "wd": synth.synth_tensor(f"dd{dsin}{cout}", (cout, dsin, 1, 1), float(np.sqrt(3.0 / dsin))), "bd": synth.synth_tensor("dbd", (cout,), 0.2)}
+    out = torch.from_numpy(synth.synth_tensor("dout", (n, c3in, h, w), 1.0))
+    hx, wx = (h - 1) * stride + 1 + (stride - 1), (w - 1) * stride + 1          # (an even height at stride 2, an odd width)
+    x = torch.from_numpy(synth.synth_tensor("dx", (n, dsin, hx, wx), 1.0))
+    assert (hx - 1) // stride + 1 == h and (wx - 1) // stride + 1 == w
+    c3, ds = _Conv(sd, "w3", bias="b3"), _Conv(sd, "wd", bias="bd", stride=stride)
+    dual = _DualConv(c3, ds)
+    od, xd = _nhwc(out).cuda(), _nhwc(x).cuda()
+    nws = _lib.load().opdet_conv2d_dual_workspace_bytes(n, h, w, c3in, hx, wx, dsin, stride, cout)
+    assert {"one": nws == 0, "split": nws > 0, "two": nws < 0}[path]
+    got = dual(od, xd)
+    again = dual(od, xd)
+    two = c3(od, relu=True, residual=ds(xd, relu=False))
+    torch.cuda.synchronize()
+    assert torch.equal(got, again)
+    ref = F.relu(F.conv2d(out.double(), torch.from_numpy(sd["w3"]).double(), torch.from_numpy(sd["b3"]).double()) +
+                 F.conv2d(x.double(), torch.from_numpy(sd["wd"]).double(), torch.from_numpy(sd["bd"]).double(), stride=stride))
+    g = got.cpu().permute(0, 3, 1, 2).double()
+    assert g.shape == ref.shape
+    assert (g - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max())
+    assert (got - two).abs().max() < 2e-5 * max(1.0, float(two.abs().max()))
+    if path == "two":
+        assert torch.equal(got, two)
+
+
 def test_linear_rows_split_k_and_refusals():
     """TwoMLPHead.fc6 of one frame (1000 x 12544 -> 1024): 128 tiles of 128 x 64, 784 K steps -> 5 slices"""
     from objectpermanence_amd import _lib
