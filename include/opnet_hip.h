@@ -39,7 +39,7 @@ extern "C" {
 
 /* bumped whenever entry points are added or a signature changes; the Python mirror refuses a library of another version
  * (objectpermanence_amd/_lib.py) instead of failing later on a missing symbol.  4 = round 4. */
-#define OPNET_HIP_ABI_VERSION 6
+#define OPNET_HIP_ABI_VERSION 7
 int opnet_hip_abi_version(void);
 const char *opnet_last_error(void);
 
@@ -356,6 +356,14 @@ int opseq_encoder_layer_batched_f32(float *z, const float *in_w, const float *in
                                       const float *l2_b, const float *n1_w, const float *n1_b, const float *n2_w,
                                       const float *n2_b, void *workspace, size_t workspace_bytes, long S, int n_seg,
                                       int E, int nhead, int ffn, void *stream);
+
+/* The feed-forward block of that layer as ONE kernel (csrc/ffn_kernels.hip): y [M,E] = relu(x linear1^T + b1) linear2^T + b2
+ * (learned_models.py:166-171 via nn.TransformerEncoderLayer.forward: linear2(dropout(relu(linear1(src)))), eval), the [M,ffn]
+ * activations kept in LDS.  Bit-identical to the two token-wise products of opseq_encoder_layer_batched_f32, which calls it when
+ * the shape fits (E == 256, ffn a multiple of 128, x below 2 GiB; OPSEQ_FFN_FUSED=0 keeps the two products).  No workspace. */
+int opseq_ffn_fused_supported(long M, int E, int ffn);
+int opseq_ffn_fused_f32(const float *x, const float *l1_w, const float *l1_b, const float *l2_w, const float *l2_b,
+                        float *y, long M, int E, int ffn, void *stream);
 
 /* ---- detector backbone primitives (torchvision fasterrcnn_resnet50_fpn built at
  *      object_detection/models.py:6-20, called at baselines/detector.py:71-86).  fp32, NHWC.  The

@@ -8,6 +8,7 @@
 #include "seq_xcd_kernels.hip"
 #include "seq_xcdt_kernels.hip"
 #include "conv_kernels.hip"
+#include "ffn_kernels.hip"
 #include "attn_kernels.hip"
 #include "enc_train_kernels.hip"
 
@@ -2548,6 +2549,41 @@ extern "C" int opseq_attention_f32(const float *qkv, float *out, long S, int E, 
     return OPNET_OK;
 }
 
+/* linear1 -> ReLU -> linear2 as ONE kernel (csrc/ffn_kernels.hip): y [M][E] = relu(x W1^T + b1) W2^T + b2, bit-identical to the two
+ * products on conv2d_nhwc_glds.  E == 256, ffn a multiple of 128, x / y / weights 16-byte aligned, x below 2 GiB. */
+static bool ffn_fused_shape(long M, int E, int ffn)
+{
+    return E == 256 && ffn > 0 && (ffn & 127) == 0 && M > 0 && M * (long)E * 4 < (1L << 31) && (long)ffn * E * 4 < (1L << 31);
+}
+
+static int launch_ffn_fused(const float *x, const float *w1, const float *b1, const float *w2, const float *b2, float *y, long M,
+                            int ffn, hipStream_t st)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const int cus = xcd_device_cus(dev);
+    if (cus <= 0) return fail(OPNET_EHIP, "no CU count for device %d", dev);
+    FfnArgs a = {};
+    a.X = x; a.W1 = w1; a.b1 = b1; a.W2 = w2; a.b2 = b2; a.Y = y; a.M = (int)M; a.F = ffn; a.m_begin = 0;
+    unsigned grid = 0;
+    ffn_w8_plan(M, cus, &a, &grid);
+    ffn_fused_w8<<<grid, 512, 0, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+extern "C" int opseq_ffn_fused_supported(long M, int E, int ffn) { return ffn_fused_shape(M, E, ffn) ? 1 : 0; }
+
+extern "C" int opseq_ffn_fused_f32(const float *x, const float *l1_w, const float *l1_b, const float *l2_w, const float *l2_b,
+                                   float *y, long M, int E, int ffn, void *stream)
+{
+    if (!x || !l1_w || !l1_b || !l2_w || !l2_b || !y) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(l1_w) || !aligned16(l2_w) || !aligned16(l1_b) || !aligned16(l2_b))
+        return fail(OPNET_EINVAL, "x / y / weights / biases must be 16-byte aligned");
+    if (!ffn_fused_shape(M, E, ffn)) return fail(OPNET_ESHAPE, "fused feed-forward: M=%ld E=%d ffn=%d (E == 256, ffn %% 128 == 0, x < 2 GiB)", M, E, ffn);
+    return launch_ffn_fused(x, l1_w, l1_b, l2_w, l2_b, y, M, ffn, (hipStream_t)stream);
+}
+
 /* one post-LN nn.TransformerEncoderLayer (eval), in place on z [nseg * S][E]: nseg independent sequences of S tokens each.
  * Token-wise stages (the four products, the two layer norms) run over all nseg * S rows at once; attention stays inside a
  * sequence.  EVERY kernel choice is made from ONE sequence's shape (S), never from nseg * S, and every kernel computes an
@@ -2608,8 +2644,14 @@ static int encoder_layer(float *z, const float *in_w, const float *in_b, const f
     }
     gemm(att, out_w, out_b, proj, E, E, 0);
     add_layernorm<<<(M + 3) / 4, 256, 0, st>>>(z, proj, n1_w, n1_b, z1, M, E, 1e-5f);
-    gemm(z1, l1_w, l1_b, hid, ffn, E, 1);
-    gemm(hid, l2_w, l2_b, proj, E, ffn, 0);
+    // the throughput form runs the feed-forward block as one kernel (csrc/ffn_kernels.hip: the [M][ffn] activations never leave the
+    // CU; the same bits as the two products below); the exact form keeps the lone request's K-split products
+    if (batched && ffn_fused_shape(M, E, ffn) && aligned16(l1_b) && aligned16(l2_b) && env_int("OPSEQ_FFN_FUSED", 1)) {
+        if (int rc = launch_ffn_fused(z1, l1_w, l1_b, l2_w, l2_b, proj, M, ffn, st)) return rc;
+    } else {
+        gemm(z1, l1_w, l1_b, hid, ffn, E, 1);
+        gemm(hid, l2_w, l2_b, proj, E, ffn, 0);
+    }
     add_layernorm<<<(M + 3) / 4, 256, 0, st>>>(z1, proj, n2_w, n2_b, z, M, E, 1e-5f);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
