@@ -272,3 +272,137 @@ static inline void ffn_w8_plan(long M, int cus, FfnArgs *a, unsigned *grid)
     a->tail_frags = frags;
     *grid = (unsigned)(a->n_full + (rem + 16L * frags - 1) / (16L * frags));
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same tile for ONE product with K = 256:  Y[m][n] = act(X[m][:] . W[n][:] + b[n]),  N a multiple of 128 (the encoder's input
+// projection, N = 768, and the hoisted layer-0 input product of the stacked LSTM, N = 2 048; learned_models.py:166-172, 184-192).
+// The workgroup's 64 token rows are read from memory ONCE (conv2d_nhwc_glds re-stages them for each of its N / 64 column tiles),
+// wave w owns output columns 128 c + 16 w .. + 15 of every 128-column chunk c and streams their weight rows through a private
+// four-stage ring; no barrier after the token rows have landed.  Same fragments and K order as conv2d_nhwc_glds: the same bits.
+// The chunk's 64 x 16 results per wave are stored as they finish (16 tokens x 64 B per instruction); the counted waits of the
+// following steps cover those stores too (a store can only make a wait longer, never let a stage be read early).
+// ------------------------------------------------------------------------------------------------
+struct Gemm256Args {
+    const float *X;    // [M][256]
+    const float *W;    // [N][256]
+    const float *b;    // [N] or null
+    float *Y;          // [M][N]
+    int M, N, relu;
+    int n_full, tail_frags;      // the tile plan (ffn_w8_plan)
+};
+
+constexpr int G256_LDS_F4 = 16 * 256 + 8 * 4 * 64;      // token rows + eight private rings of four 1-KB stages: 96 KB
+
+template <int FMX>
+__device__ __forceinline__ void gemm256_tile_w8(const Gemm256Args &a, float4 *smem, const long m0)
+{
+    constexpr int E = 256, NC = 128, K1 = E / 16, NS = 4, D = NS - 1;
+    constexpr int SLICE_F4 = 64 * 4, RSTAGE_F4 = 16 * 4;
+    static_assert(K1 % NS == 0, "a chunk's first stage must land in ring slot 0");
+    static_assert(K1 * SLICE_F4 + 8 * NS * RSTAGE_F4 == G256_LDS_F4, "LDS layout");
+    float4 *const Xs = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kk = lane >> 4;
+    const int fsw = (i >> 2) & 3;
+    const int nchunk = a.N / NC;
+    float4 *const ring = smem + K1 * SLICE_F4 + w * (NS * RSTAGE_F4);
+
+    conv_u32x4 rx, rw;
+    {
+        const unsigned long long bx = (unsigned long long)a.X, bw = (unsigned long long)a.W;
+        rx.x = (unsigned)bx; rx.y = (unsigned)(bx >> 32); rx.z = (unsigned)((long)a.M * E * 4); rx.w = 0x00020000u;
+        rw.x = (unsigned)bw; rw.y = (unsigned)(bw >> 32); rw.z = (unsigned)((long)a.N * E * 4); rw.w = 0x00020000u;
+    }
+    const unsigned lds_x = (unsigned)(unsigned long long)(const void *)Xs;
+    const unsigned lds_ring = (unsigned)(unsigned long long)(const void *)ring;
+    const int lkq = (lane & 3) ^ ((lane >> 4) & 3), lr = lane >> 2;
+    if ((w & 3) < FMX) {
+        const long row = m0 + 16 * (w & 3) + lr;
+        const unsigned off = row < a.M ? (unsigned)((row * E + 4 * lkq) * 4) : 0x80000000u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = 8 * (w >> 2) + j;
+            conv_glds16(rx, off + (unsigned)q * 64u, lds_x + (unsigned)(q * SLICE_F4 + 16 * (w & 3) * 4) * 16u);
+        }
+    }
+    const unsigned offw = (unsigned)(((16 * w + lr) * E + 4 * lkq) * 4);
+    auto issue = [&](int ch, int r) {      // k-step r of chunk ch into ring slot r % NS (one instruction)
+        conv_glds16(rw, offw + (unsigned)r * 64u + (unsigned)ch * (NC * E * 4), lds_ring + (unsigned)(r % NS) * (RSTAGE_F4 * 16));
+    };
+    const int frag = i * 4 + (kk ^ fsw);
+
+#pragma unroll
+    for (int r = 0; r < D; ++r) issue(0, r);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D - 1) : "memory");      // token rows + stage 0
+    __builtin_amdgcn_s_barrier();
+    float4 xa[FMX], wa;
+#pragma unroll
+    for (int x = 0; x < FMX; ++x) xa[x] = Xs[x * 64 + frag];
+    wa = ring[frag];
+
+    for (int c = 0; c < nchunk; ++c) {
+        const bool last = c + 1 == nchunk;
+        f32x4 bq = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a.b) {
+            const float *p = a.b + c * NC + 16 * w + 4 * kk;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq) : "v"(p) : "memory");
+        }
+        f32x4 acc[FMX];
+#pragma unroll
+        for (int x = 0; x < FMX; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < K1; ++q) {
+            const bool more = !(last && q + D >= K1);
+            if (more) { if (q + D < K1) issue(c, q + D); else issue(c + 1, q + D - K1); }
+#pragma unroll
+            for (int x = 0; x < FMX; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, xa[x].x, acc[x], 0, 0, 0);
+            // stage q + 1 landed when only the D - 1 stages behind it are in flight (fewer at the very end)
+            if (q == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(bq) : "n"(D - 1) : "memory");
+            else if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D - 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            float4 xn[FMX], wn;
+            if (q + 1 < K1) {
+#pragma unroll
+                for (int x = 0; x < FMX; ++x) xn[x] = Xs[(q + 1) * SLICE_F4 + x * 64 + frag];
+                wn = ring[((q + 1) % NS) * RSTAGE_F4 + frag];
+            } else if (!last) {
+#pragma unroll
+                for (int x = 0; x < FMX; ++x) xn[x] = Xs[x * 64 + frag];
+                wn = ring[frag];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int x = 0; x < FMX; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, xa[x].y, acc[x], 0, 0, 0);
+#pragma unroll
+            for (int x = 0; x < FMX; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, xa[x].z, acc[x], 0, 0, 0);
+#pragma unroll
+            for (int x = 0; x < FMX; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, xa[x].w, acc[x], 0, 0, 0);
+            if (q + 1 < K1 || !last) {
+#pragma unroll
+                for (int x = 0; x < FMX; ++x) xa[x] = xn[x];
+                wa = wn;
+            }
+        }
+        // lane = token i of fragment x, output columns 128 c + 16 w + 4 kk .. + 3
+#pragma unroll
+        for (int x = 0; x < FMX; ++x) {
+            const long row = m0 + x * 16 + i;
+            float4 v = make_float4(acc[x][0] + bq[0], acc[x][1] + bq[1], acc[x][2] + bq[2], acc[x][3] + bq[3]);
+            if (a.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            if (row < a.M) *(float4 *)(a.Y + row * a.N + c * NC + 16 * w + 4 * kk) = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(512, 1) gemm_k256_w8(const Gemm256Args a)
+{
+    __shared__ __attribute__((aligned(1024))) float4 smem[G256_LDS_F4];
+    const int b = (int)blockIdx.x;
+    if (b < a.n_full) { gemm256_tile_w8<4>(a, smem, (long)b * 64); return; }
+    const long m0 = (long)a.n_full * 64 + (long)(b - a.n_full) * 16 * a.tail_frags;
+    if (a.tail_frags == 3) gemm256_tile_w8<3>(a, smem, m0);
+    else if (a.tail_frags == 2) gemm256_tile_w8<2>(a, smem, m0);
+    else if (a.tail_frags == 1) gemm256_tile_w8<1>(a, smem, m0);
+    else gemm256_tile_w8<4>(a, smem, m0);
+}

@@ -86,10 +86,11 @@ def test_encoder_layer_with_the_fused_block_against_the_two_products(heads, n_se
     z0 = rnd(n_seg * S, E)
     ws = torch.empty(lib.opseq_encoder_workspace_bytes(n_seg * S, E, heads, FFN) // 4, device="cuda")
     out = {}
-    old = os.environ.get("OPSEQ_FFN_FUSED")
+    old = os.environ.get("OPSEQ_FFN_FUSED"), os.environ.get("OPSEQ_GEMM_W8")
     try:
         for flag in ("0", "1"):
-            os.environ["OPSEQ_FFN_FUSED"] = flag
+            # ... and the layer's other K = 256 products (input / output projection) on gemm_k256_w8 from 8 192 rows on: the same bits again
+            os.environ["OPSEQ_FFN_FUSED"] = os.environ["OPSEQ_GEMM_W8"] = flag
             z = z0.clone()
             rc = lib.opseq_encoder_layer_batched_f32(z.data_ptr(), *(t.data_ptr() for t in (in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b,
                                                                                           n1_w, n1_b, n2_w, n2_b)),
@@ -98,10 +99,11 @@ def test_encoder_layer_with_the_fused_block_against_the_two_products(heads, n_se
             torch.cuda.synchronize()
             out[flag] = z
     finally:
-        if old is None:
-            os.environ.pop("OPSEQ_FFN_FUSED", None)
-        else:
-            os.environ["OPSEQ_FFN_FUSED"] = old
+        for name, v in zip(("OPSEQ_FFN_FUSED", "OPSEQ_GEMM_W8"), old):
+            if v is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = v
     assert torch.isfinite(out["1"]).all() and not torch.equal(out["1"], z0)
     if ((n_seg * S + 63) // 64) * 4 >= 256:
         assert torch.equal(out["0"], out["1"])
@@ -123,3 +125,31 @@ def test_a_served_throughput_pass_still_matches_its_lone_forwards():
         alone = torch.cat([m(x[r:r + 1]) for r in (0, 17, 47)])
     torch.cuda.synchronize()
     assert np.abs((merged[[0, 17, 47]] - alone).cpu().numpy()).max() < 1e-5
+
+
+def test_a_throughput_pass_is_the_same_bits_with_and_without_the_resident_token_kernels():
+    """transformer_lstm, 48 one-clip requests of 300 frames in one throughput pass (14 400 token rows): the encoder's products and the
+    hoisted layer-0 input product of the stacked LSTM on gemm_k256_w8 / ffn_fused_w8, or all of them on conv2d_nhwc_glds"""
+    from objectpermanence_amd import ModelsFactory
+    from oracle import synth
+    cfg = {"boxes_features_dim": 256, "num_attention_heads": 4, "num_attention_layers": 2, "num_lstm_layers": 2, "lstm_hidden_dim": 512}
+    m = ModelsFactory.get_model("transformer_lstm", cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.transformer_lstm_synth_params(cfg).items()})
+    m = m.eval().to("cuda:0")
+    x = torch.from_numpy(synth.boxes5(synth.make_batch(3, 48, 300)[0])).cuda()
+    old = os.environ.get("OPSEQ_FFN_FUSED"), os.environ.get("OPSEQ_GEMM_W8")
+    out = {}
+    try:
+        for flag in ("0", "1"):
+            os.environ["OPSEQ_FFN_FUSED"] = os.environ["OPSEQ_GEMM_W8"] = flag
+            with torch.no_grad():
+                out[flag] = m.forward_segments(x, 48, exact=False).clone()
+            torch.cuda.synchronize()
+    finally:
+        for name, v in zip(("OPSEQ_FFN_FUSED", "OPSEQ_GEMM_W8"), old):
+            if v is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = v
+    assert m._runner._monitor.verify() == 0
+    assert torch.isfinite(out["1"]).all() and torch.equal(out["0"], out["1"])

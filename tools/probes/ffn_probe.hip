@@ -112,5 +112,45 @@ int main(int argc, char **argv)
         printf("\n");
         CK(hipFree(X)); CK(hipFree(W1)); CK(hipFree(b1)); CK(hipFree(W2)); CK(hipFree(b2)); CK(hipFree(H)); CK(hipFree(Y0)); CK(hipFree(Y1));
     }
+    // ---- the single K = 256 product (gemm_k256_w8) against conv2d_nhwc_glds<64, 3> / <128, 3> ----
+    const int Ns[] = {768, 2048, 256};
+    for (int N : Ns)
+        for (int M : {300, 19200, 76800, 76817, 153600}) {
+            float *X, *W, *b, *Y0, *Y1;
+            CK(hipMalloc(&X, (size_t)M * E * 4)); CK(hipMalloc(&W, (size_t)N * E * 4)); CK(hipMalloc(&b, N * 4));
+            CK(hipMalloc(&Y0, (size_t)M * N * 4)); CK(hipMalloc(&Y1, (size_t)M * N * 4));
+            srand(M + N);
+            fill(X, (size_t)M * E, 1.f); fill(W, (size_t)N * E, 0.06f); fill(b, N, 0.1f);
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            auto timeit = [&](auto fn) {
+                std::vector<float> ts;
+                for (int r = 0; r < 7; ++r) {
+                    CK(hipEventRecord(e0)); fn(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms);
+                }
+                std::sort(ts.begin(), ts.end());
+                return ts[ts.size() / 2];
+            };
+            const float t_n = timeit([&] { gemm(X, W, b, Y0, M, N, E, 1, true); });
+            const float t_w = timeit([&] { gemm(X, W, b, Y0, M, N, E, 1, false); });
+            Gemm256Args g = {X, W, b, Y1, M, N, 1, 0, 0};
+            FfnArgs plan = {};
+            unsigned grid;
+            ffn_w8_plan(M, 256, &plan, &grid);
+            g.n_full = plan.n_full; g.tail_frags = plan.tail_frags;
+            CK(hipMemset(Y1, 0xff, (size_t)M * N * 4));
+            const float t_g = timeit([&] { gemm_k256_w8<<<grid, 512>>>(g); });
+            CK(hipGetLastError()); CK(hipDeviceSynchronize());
+            std::vector<float> y0((size_t)M * N), y1((size_t)M * N);
+            CK(hipMemcpy(y0.data(), Y0, y0.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(y1.data(), Y1, y1.size() * 4, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t k = 0; k < y0.size(); ++k) bad += memcmp(&y0[k], &y1[k], 4) != 0;
+            const double gf = 2.0 * M * E * N * 1e-9;
+            printf("K = 256 product M = %6d N = %4d: 128 x 64 tiles %.3f ms (%.1f TF), 128 x 128 tiles %.3f ms (%.1f TF) | gemm_k256_w8 %.3f ms (%.1f TF) %s\n", M, N,
+                   t_n, gf / t_n, t_w, gf / t_w, t_g, gf / t_g, bad ? "DIFFERENT" : "bit-identical");
+            CK(hipFree(X)); CK(hipFree(W)); CK(hipFree(b)); CK(hipFree(Y0)); CK(hipFree(Y1));
+        }
     return 0;
 }
