@@ -1053,6 +1053,46 @@ def other_batches(model, boxes, dev):
     return {"reference_batch_sizes": res}
 
 
+def shader_clock_probe(model, batches, n_clips, dev, lib):
+    """The shader clock the persistent forward actually ran at: ONE extra launch of the timed region's shape with the kernel's
+    in-kernel stamps on (opnet_xcd_set_trace: s_memtime of block 0 at the top of every phase; a tick is a shader cycle) between HIP
+    events around the kernel (opnet_xcd_profile).  The chip clocks to its power budget (MI355X_MICROARCH.md, DVFS): a dense fp32 MFMA
+    stream does not sustain the 2.4 GHz that `roofline.peak` is quoted at, and `frac` against the peak AT THE MEASURED CLOCK is what the
+    kernel's own cycles achieve.  Outside the timed region; a traced launch is a few % slower than an untraced one and is only used
+    for the clock."""
+    from objectpermanence_amd import _lib
+    try:
+        x = torch.cat([batches[i % len(batches)] for i in range((n_clips + batches[0].shape[0] - 1) // batches[0].shape[0])])[:n_clips].contiguous()
+        T = int(x.shape[1])
+        ng = (n_clips + 127) // 128
+        tr = torch.zeros((T + 4) * ng * 8, dtype=torch.int64, device=dev)
+        with torch.no_grad():
+            model(x)                                   # the shape's workspace exists, the clock has ramped
+            torch.cuda.synchronize(dev)
+            kms, nl = ctypes.c_double(0.0), ctypes.c_int(0)
+            lib.opnet_xcd_profile(1)
+            lib.opnet_xcd_profile_read(ctypes.byref(kms), ctypes.byref(nl))      # (drain)
+            lib.opnet_xcd_set_trace(tr.data_ptr())
+            model(x)
+            torch.cuda.synchronize(dev)
+            lib.opnet_xcd_set_trace(None)
+            _lib.check(lib.opnet_xcd_profile_read(ctypes.byref(kms), ctypes.byref(nl)), "opnet_xcd_profile_read")
+            lib.opnet_xcd_profile(0)
+        if model.verify_launches() or nl.value != 1 or kms.value <= 0:
+            return None
+        t0 = tr.cpu().numpy().reshape(-1, 8)[:, 0]
+        t0 = t0[t0 != 0]
+        if len(t0) < 8:
+            return None
+        ticks = float(t0[-1] - t0[0]) * len(t0) / (len(t0) - 1)      # the stamps bracket all phases but the last
+        ghz = ticks / (kms.value * 1e6)
+        return {"effective_ghz": round(ghz, 3), "nominal_ghz": 2.4, "phases_stamped": int(len(t0)), "traced_launch_ms": round(kms.value, 4),
+                "method": "s_memtime stamps of block 0 over one extra traced launch of this shape / its HIP-event time (a tick = a shader cycle; "
+                          "the kernel's prologue, ~0.5 % of the launch, is counted as phases)"}
+    except Exception as e:      # the probe is context, never a reason to lose the line
+        return {"error": str(e)[:200]}
+
+
 def bench_infer_xcd(args, model, batches, world, rank, dev, dist):
     """Request batching into the per-XCD persistent forward: every step submits its batch to a ReasonerServer, which runs
     `per_launch` pending batches as one launch; the post-process (and, N > 1, the all-gather of the int32 predictions) runs
@@ -1184,6 +1224,11 @@ def bench_infer_xcd(args, model, batches, world, rank, dev, dist):
                        "kernel": "opnet_xcd_forward", "launch_ms": round(kms.value / max(launches * R, 1), 4),
                        "launches": launches, "alg_flop_per_launch": int(clips * FLOP_PER_CLIP / max(launches, 1)),
                        "timing": "HIP events around every launch of the kernel on its stream (opnet_xcd_profile)"}
+    clk = shader_clock_probe(model, batches, cpl, dev, lib)
+    if clk:
+        if clk.get("effective_ghz"):
+            clk["frac_of_peak_at_this_clock"] = round(tf / (MFMA_F32_PEAK_TF * clk["effective_ghz"] / clk["nominal_ghz"]), 4)
+        out["roofline"]["shader_clock"] = clk
     out["roofline_hbm_model"] = {"bound": "hbm", "achieved": round(model_bytes / kernel_s / 1e9, 1), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(model_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                                  "note": "SURVEY.md 8-d4 streaming-model bytes of the same clips (weights once per time step per "
