@@ -71,7 +71,8 @@ def test_shapes_outside_the_kernel_are_refused():
     assert rc == -2                                                # OPNET_ESHAPE
 
 
-@pytest.mark.parametrize("heads,n_seg,S", [(4, 40, 300), (2, 14, 300), (4, 70, 300), (2, 7, 300), (4, 3, 50)])
+# (rows -> tail tiles of the single products: 12 000 -> 48 tokens, 21 000 -> 32, 19 400 -> 16 after one full round, 4 200 / 2 100 / 150: conv tiles)
+@pytest.mark.parametrize("heads,n_seg,S", [(4, 40, 300), (2, 14, 300), (4, 70, 300), (4, 388, 50), (2, 7, 300), (4, 3, 50)])
 def test_encoder_layer_with_the_fused_block_against_the_two_products(heads, n_seg, S):
     """opseq_encoder_layer_batched_f32 with and without the fused kernel: the same words in z wherever the two products run in the
     ascending-K order of conv2d_nhwc_glds / gemm_bias_act (4 033 rows and more); below that linear2 is a K-split product
