@@ -62,6 +62,8 @@ PY
 bash tools/detector_layer_times.sh > $O/detlayers.log 2>&1; cp $R/gpurun_out/detlayers/conv_dispatches.txt $O/detector_conv_dispatches.txt
 bash tools/detector_one_frame_trace.sh > $O/det1.log 2>&1; cp $R/gpurun_out/det1/one_frame_kernels.txt $O/detector_one_frame_kernels.txt
 python tools/transformer_serving_time.py 4 > $O/transformer_serving_time.txt 2>&1
+python tools/transformer_pass_kernels.py 256 4 > $O/transformer_pass_kernels_256.txt 2>&1
+[ -x tools/probes/ffn_probe ] && timeout 300 tools/probes/ffn_probe > $O/ffn_probe.txt 2>&1
 python tools/transformer_server_host_time.py 256 > $O/transformer_server_host_time.txt 2>&1
 for d in 1 2 3 4; do echo "passes in flight: $d"; OPDET_IN_FLIGHT=$d python bench.py --mode detect --no-cpu-baseline --steps 12 --warmup 4 2>/dev/null | tail -1 | cut -c1-260; OPDET_IN_FLIGHT=$d python bench.py --mode detect --batch 1 --steps 60 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-260; done > $O/detector_passes_in_flight.txt 2>&1
 # keep only the small artefacts
