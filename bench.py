@@ -492,7 +492,7 @@ STACK_KERNELS = {"x": ("seqx", "seqx_forward<64, 2> (4-clip groups: the latency 
 def _read_profile(lib):
     from objectpermanence_amd import _lib
     prof = {}
-    for tag, name in ((1, "seqx"), (2, "attn"), (3, "seqt")):
+    for tag, name in ((1, "seqx"), (2, "attn"), (3, "seqt"), (4, "ffn")):
         kms, nl = ctypes.c_double(0.0), ctypes.c_int(0)
         _lib.check(lib.opnet_kernel_profile_read(tag, ctypes.byref(kms), ctypes.byref(nl)), "opnet_kernel_profile_read")
         prof[name] = (kms.value, nl.value)
@@ -725,6 +725,16 @@ def bench_transformer(args, world, rank, dev, dist):
                                       "frac": round(tfa / MFMA_F32_PEAK_TF, 4), "kernel": "attention_glds (one call = the segments of "
                                       "all requests of a pass)", "call_ms": round(attn_ms, 4), "calls": prof["attn"][1],
                                       "alg_flop_per_call": int(req_per_launch * attn_flop)}
+    if prof.get("ffn", (0, 0))[1] > 0:
+        # linear1 -> ReLU -> linear2 of an encoder layer as one kernel (csrc/ffn_kernels.hip): 2 x 2 x E x FFN flop per token
+        ffn_ms = prof["ffn"][0] / prof["ffn"][1]
+        ffn_flop = req_per_launch * B * T_FRAMES * 4 * E * FFN_TX
+        tff = ffn_flop / (ffn_ms * 1e-3) / 1e12
+        line["roofline_feed_forward"] = {"bound": "mfma", "achieved": round(tff, 3), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                         "frac": round(tff / MFMA_F32_PEAK_TF, 4), "kernel": "ffn_fused_w8 (one launch = the feed-forward block of one "
+                                         "encoder layer over all token rows of a pass; the [rows][2048] activations stay in LDS)",
+                                         "launch_ms": round(ffn_ms, 4), "launches": prof["ffn"][1], "alg_flop_per_launch": int(ffn_flop),
+                                         **pmc_mfma_busy("ffn_fused_w8")}
     # coupled minibatches (the reference's training / evaluation call: ONE sequence of S = b x 300): one forward each
     extra = {}
     for b in (16, 32):

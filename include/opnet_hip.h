@@ -102,7 +102,8 @@ int opnet_xcd_forward_multi_f32(const float *const *boxes, const int *counts, in
 int opnet_xcd_profile(int enable);
 int opnet_xcd_profile_read(double *kernel_ms_total, int *launches);
 /* the same for the other profiled kernels while opnet_xcd_profile(1) is on: tag 0 = opnet_xcd_forward, 1 = seqx_forward (the
- * persistent stacked LSTM), 2 = the attention kernel(s) of an encoder layer's attention call */
+ * persistent stacked LSTM), 2 = the attention kernel(s) of an encoder layer's attention call, 3 = seqt_forward, 4 = the fused
+ * feed-forward kernel of an encoder layer */
 int opnet_kernel_profile_read(int tag, double *kernel_ms_total, int *launches);
 /* tools: device buffer of >= (T+1) * ceil(B/128) * 8 uint64 receiving s_memtime stamps of block 0 (NULL = off) */
 void opnet_xcd_set_trace(void *device_buffer);

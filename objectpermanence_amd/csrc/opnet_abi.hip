@@ -403,7 +403,8 @@ static int g_xcd_cus[64] = {};
 #define PROF_SEQX 1
 #define PROF_ATTN 2
 #define PROF_SEQT 3
-#define PROF_TAGS 4
+#define PROF_FFN 4          // the fused feed-forward kernel of an encoder layer (csrc/ffn_kernels.hip)
+#define PROF_TAGS 5
 typedef std::pair<hipEvent_t, hipEvent_t> ProfPair;
 static bool g_xcd_prof = false;
 static std::vector<ProfPair> g_prof_ev[PROF_TAGS];
@@ -2674,7 +2675,10 @@ static int encoder_layer(float *z, const float *in_w, const float *in_b, const f
     // the throughput form runs the feed-forward block as one kernel (csrc/ffn_kernels.hip: the [M][ffn] activations never leave the
     // CU; the same bits as the two products below); the exact form keeps the lone request's K-split products
     if (batched && ffn_fused_shape(M, E, ffn) && aligned16(l1_b) && aligned16(l2_b) && env_int("OPSEQ_FFN_FUSED", 1)) {
+        ProfPair pe{};
+        const bool prof = prof_begin(st, &pe);
         if (int rc = launch_ffn_fused(z1, l1_w, l1_b, l2_w, l2_b, proj, M, ffn, st)) return rc;
+        if (prof) prof_end(PROF_FFN, st, pe);
     } else {
         gemm(z1, l1_w, l1_b, hid, ffn, E, 1);
         gemm(hid, l2_w, l2_b, proj, E, ffn, 0);
