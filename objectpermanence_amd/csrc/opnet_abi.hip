@@ -2553,8 +2553,25 @@ extern "C" int opseq_attention_f32(const float *qkv, float *out, long S, int E, 
 
 /* linear1 -> ReLU -> linear2 as ONE kernel (csrc/ffn_kernels.hip): y [M][E] = relu(x W1^T + b1) W2^T + b2, bit-identical to the two
  * products on conv2d_nhwc_glds.  E == 256, ffn a multiple of 128, x / y / weights 16-byte aligned, x below 2 GiB. */
+// the eight-wave tiles of csrc/ffn_kernels.hip need 144 KB of LDS in one workgroup (gfx950: 160 KB per CU)
+static bool w8_device_ok()
+{
+    static std::atomic<int> cached[64];          // 0 = unknown, 1 = yes, 2 = no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    int c = cached[dev].load();
+    if (c == 0) {
+        int lds = 0;
+        c = (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
+             (size_t)lds >= (size_t)FFN_W8_LDS_F4 * sizeof(float4)) ? 1 : 2;
+        cached[dev].store(c);
+    }
+    return c == 1;
+}
+
 static bool ffn_fused_shape(long M, int E, int ffn)
 {
+    if (!w8_device_ok()) return false;
     return E == 256 && ffn > 0 && (ffn & 127) == 0 && M > 0 && M * (long)E * 4 < (1L << 31) && (long)ffn * E * 4 < (1L << 31);
 }
 
@@ -2581,7 +2598,7 @@ static int launch_gemm_k256(const ConvArgs &c, long M, hipStream_t st)
     const bool plain = c.KH == 1 && c.KW == 1 && c.stride == 1 && c.pad == 0 && !c.R && !c.X2 && c.ksplit <= 1 && c.XS == 0 && c.WS == 0 &&
                        c.YS == 0 && c.RH == 0 && c.N == 1 && c.H == 1;
     if (plain && c.Cin == 256 && c.KP == 256 && (c.Cout & 127) == 0 && M >= 8192 && M * 256L * 4 < (1L << 31) &&
-        (!c.bias || aligned16(c.bias)) && aligned16(c.X) && aligned16(c.Wt) && aligned16(c.Y) && env_int("OPSEQ_GEMM_W8", 1)) {
+        (!c.bias || aligned16(c.bias)) && aligned16(c.X) && aligned16(c.Wt) && aligned16(c.Y) && env_int("OPSEQ_GEMM_W8", 1) && w8_device_ok()) {
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
         const int cus = xcd_device_cus(dev);
