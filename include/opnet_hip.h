@@ -363,6 +363,9 @@ int opseq_encoder_layer_batched_f32(float *z, const float *in_w, const float *in
  * activations kept in LDS.  Bit-identical to the two token-wise products of opseq_encoder_layer_batched_f32, which calls it when
  * the shape fits (E == 256, ffn a multiple of 128, x below 2 GiB; OPSEQ_FFN_FUSED=0 keeps the two products).  No workspace. */
 int opseq_ffn_fused_supported(long M, int E, int ffn);
+/* host logic only: the tile plan of those kernels for M rows on `cus` compute units - workgroups 0 .. n_full - 1 own 64 rows each, the
+ * other grid - n_full workgroups 16 * tail_frags rows each (what full rounds of 64-row tiles leave, cut evenly over the CUs) */
+int opseq_ffn_fused_plan(long M, int cus, int *n_full, int *tail_frags, unsigned *grid);
 int opseq_ffn_fused_f32(const float *x, const float *l1_w, const float *l1_b, const float *l2_w, const float *l2_b,
                         float *y, long M, int E, int ffn, void *stream);
 

@@ -217,6 +217,8 @@ def _declare(lib):
                                                     c_void_p]
     lib.opseq_ffn_fused_supported.restype = c_int
     lib.opseq_ffn_fused_supported.argtypes = [ctypes.c_long, c_int, c_int]
+    lib.opseq_ffn_fused_plan.restype = c_int
+    lib.opseq_ffn_fused_plan.argtypes = [ctypes.c_long, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_uint)]
     lib.opseq_ffn_fused_f32.restype = c_int
     lib.opseq_ffn_fused_f32.argtypes = [fp] * 6 + [ctypes.c_long, c_int, c_int, c_void_p]
     lib.opdet_conv2d_f32.restype = c_int
@@ -300,7 +302,7 @@ EXPORTS = [
     "opseq_lstm_stack_train_pack_weights_f32", "opseq_lstm_stack_train_forward_f32",
     "opseq_lstm_stack_train_backward_f32",
     "opseq_encoder_workspace_bytes",
-    "opseq_encoder_layer_f32", "opseq_encoder_layer_segmented_f32", "opseq_encoder_layer_batched_f32", "opseq_ffn_fused_supported", "opseq_ffn_fused_f32", "opseq_attention_f32", "opseq_attention_workspace_bytes",
+    "opseq_encoder_layer_f32", "opseq_encoder_layer_segmented_f32", "opseq_encoder_layer_batched_f32", "opseq_ffn_fused_supported", "opseq_ffn_fused_plan", "opseq_ffn_fused_f32", "opseq_attention_f32", "opseq_attention_workspace_bytes",
     "opseq_encoder_train_saved_bytes", "opseq_encoder_train_scratch_bytes", "opseq_encoder_layer_train_forward_f32",
     "opseq_encoder_layer_train_backward_f32", "opseq_encoder_test_masks_set", "opseq_encoder_test_masks_clear",
     "opdet_conv2d_f32", "opdet_conv2d_workspace_bytes", "opdet_conv2d_ws_f32", "opdet_conv2d_up_f32", "opdet_conv2d_dual_workspace_bytes", "opdet_conv2d_dual_f32", "opdet_maxpool3x3s2_f32", "opdet_subsample2_f32", "opdet_upsample_add_f32",

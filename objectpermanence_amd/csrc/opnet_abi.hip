@@ -2618,6 +2618,18 @@ static int launch_gemm_k256(const ConvArgs &c, long M, hipStream_t st)
 
 extern "C" int opseq_ffn_fused_supported(long M, int E, int ffn) { return ffn_fused_shape(M, E, ffn) ? 1 : 0; }
 
+/* host logic only (no device call): the tile plan ffn_fused_w8 / gemm_k256_w8 run M token rows with on `cus` compute units -
+ * workgroups 0 .. n_full - 1 own 64 rows each, the remaining grid - n_full workgroups 16 * tail_frags rows each */
+extern "C" int opseq_ffn_fused_plan(long M, int cus, int *n_full, int *tail_frags, unsigned *grid)
+{
+    if (M <= 0 || cus <= 0 || !n_full || !tail_frags || !grid) return fail(OPNET_EINVAL, "bad plan request");
+    FfnArgs a = {};
+    ffn_w8_plan(M, cus, &a, grid);
+    *n_full = a.n_full;
+    *tail_frags = a.tail_frags;
+    return OPNET_OK;
+}
+
 extern "C" int opseq_ffn_fused_f32(const float *x, const float *l1_w, const float *l1_b, const float *l2_w, const float *l2_b,
                                    float *y, long M, int E, int ffn, void *stream)
 {

@@ -63,6 +63,28 @@ def test_size_queries_and_validation_without_gpu():
     assert lib.opnet_postprocess_iou(None, None, None, None, None, 1, 1, None) == -1
 
 
+def test_tile_plan_of_the_resident_token_kernels_covers_every_row_once():
+    """csrc/ffn_kernels.hip (the encoder's feed-forward block of learned_models.py:166-171 as one kernel): full rounds of 64-row tiles
+    over the CUs, the rest cut into equal tiles of 16 / 32 / 48 / 64 rows - host logic, no device call"""
+    lib = _lib()
+    rng = np.random.default_rng(7)
+    cases = [(1, 256), (15, 256), (64, 256), (300, 256), (16384, 256), (16385, 256), (76800, 256), (153600, 256), (76800, 304), (5000, 8)]
+    cases += [(int(m), int(c)) for m, c in zip(rng.integers(1, 400000, 200), rng.choice([8, 32, 64, 128, 256, 304], 200))]
+    for M, cus in cases:
+        n_full, frags, grid = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_uint(0)
+        assert lib.opseq_ffn_fused_plan(M, cus, ctypes.byref(n_full), ctypes.byref(frags), ctypes.byref(grid)) == 0
+        n_full, frags, grid = n_full.value, frags.value, grid.value
+        assert 1 <= frags <= 4 and n_full % cus == 0 and n_full * 64 <= M
+        tail = grid - n_full
+        rem = M - n_full * 64
+        assert rem < 64 * cus                                   # the tail is less than one full round
+        assert tail * 16 * frags >= rem and (tail == 0) == (rem == 0)
+        if tail:
+            assert (tail - 1) * 16 * frags < rem                # no empty workgroup
+            assert tail <= cus or frags == 4                    # one tail tile per CU unless a CU's share exceeds a full tile
+    assert lib.opseq_ffn_fused_plan(0, 256, None, None, None) == -1
+
+
 def test_module_mirrors_reference_interface():
     from objectpermanence_amd import ModelsFactory, supported_models
     cfg = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
