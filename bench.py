@@ -391,6 +391,8 @@ def detector_block(dev, nf=16, passes=6):
     return {"detector": {
         "workload": f"Faster-RCNN R50-FPN (193 classes) eval on 240x320 frames -> 800x1066, {nf} frames per pass, synthetic weights",
         "frames_per_s": round(nf * passes / dt, 1), "ms_per_pass": round(dt / passes * 1e3, 2),
+        # config 4 end to end: a clip is 300 frames through this detector (the reasoner then costs ~7 us per clip: the headline)
+        "clips_per_s_end_to_end_300_frames": round(nf * passes / dt / 300.0, 3),
         "single_frame_call": {"ms": round(single * 1e3, 2), "frames_per_s": round(1.0 / single, 1)},
         "kernel": "conv2d_nhwc_glds (dominant; all dense launches of a pass over the whole-pass time incl. selection stages)",
         "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
