@@ -50,6 +50,17 @@ def test_fused_block_against_the_torch_statement(M):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err      # fp32 sums over 256 and 2 048 terms against fp64
 
 
+@pytest.mark.parametrize("ffn,M", [(128, 200), (128, 20000), (384, 777), (1024, 16384 + 33), (4096, 5000)])
+def test_other_hidden_widths(ffn, M):
+    """one chunk of 128 hidden units (the ring's first and last chunk at once), three, eight, thirty-two"""
+    w1, b1, w2, b2 = _weights(ffn + M, ffn)
+    x = torch.randn(M, E, generator=torch.Generator().manual_seed(M)).cuda()
+    y = _fused(x, w1, b1, w2, b2)
+    ref = torch.relu(x.double() @ w1.double().T + b1.double()) @ w2.double().T + b2.double()
+    assert torch.isfinite(y).all()
+    assert (y.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_rows_do_not_depend_on_where_they_sit():
     """a token row's result is the same bits alone, inside a short tile, inside a 64-token tile and inside a tail tile"""
     w1, b1, w2, b2 = _weights(3)
