@@ -70,6 +70,25 @@ def test_rows_do_not_depend_on_where_they_sit():
         assert torch.equal(_fused(x[lo:hi].contiguous(), w1, b1, w2, b2), y[lo:hi]), (lo, hi)
 
 
+def test_two_streams_at_once_give_the_sequential_results():
+    """two launches on two streams share the chip tile by tile (one 144-KB workgroup per CU): each still returns its own result"""
+    binding, lib = _lib()
+    w1, b1, w2, b2 = _weights(9)
+    xs = [torch.randn(m, E, generator=torch.Generator().manual_seed(m)).cuda() for m in (30000, 20011)]
+    ref = [_fused(x, w1, b1, w2, b2) for x in xs]
+    streams = [torch.cuda.Stream() for _ in xs]
+    for rep in range(3):
+        ys = [torch.full_like(x, float("nan")) for x in xs]
+        torch.cuda.synchronize()
+        for x, y, st in zip(xs, ys, streams):
+            rc = lib.opseq_ffn_fused_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), y.data_ptr(),
+                                         x.shape[0], E, FFN, st.cuda_stream)
+            binding.check(rc, "opseq_ffn_fused_f32")
+        torch.cuda.synchronize()
+        for y, r in zip(ys, ref):
+            assert torch.equal(y, r)
+
+
 def test_shapes_outside_the_kernel_are_refused():
     binding, lib = _lib()
     assert lib.opseq_ffn_fused_supported(300, 256, 2048) == 1
