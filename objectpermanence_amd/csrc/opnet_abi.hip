@@ -7,6 +7,7 @@
 #include "seq_kernels.hip"
 #include "seq_xcd_kernels.hip"
 #include "seq_xcdt_kernels.hip"
+#include "seq_xcd_bwd_kernels.hip"
 #include "conv_kernels.hip"
 #include "ffn_kernels.hip"
 #include "attn_kernels.hip"
@@ -2141,7 +2142,7 @@ extern "C" int opseq_xcdt_forward_f32(const float *x, const float *packed, const
     return OPNET_OK;
 }
 
-struct StackTrainPacked { size_t fwd_total, whh_t[SEQ_MAX_LAYERS], wih_t[SEQ_MAX_LAYERS], whead, wih0_t, seqx, total; };
+struct StackTrainPacked { size_t fwd_total, whh_t[SEQ_MAX_LAYERS], wih_t[SEQ_MAX_LAYERS], whead, wih0_t, seqx, seqxb, total; };
 
 static StackTrainPacked stack_train_packed_layout(int L, int KX, int H)
 {
@@ -2157,6 +2158,9 @@ static StackTrainPacked stack_train_packed_layout(int L, int KX, int H)
     o = align_up(o, 64);
     P.seqx = o;                                    // register image of the persistent forward (seq_xcd_kernels.hip)
     if (seqx_dims(L, KX, H)) o += seqx_packed_layout(L, seqx_nxq0(KX, H)).total;
+    o = align_up(o, 64);
+    P.seqxb = o;                                   // register image of the persistent reverse recurrence (seq_xcd_bwd_kernels.hip)
+    if (seqx_dims(L, KX, H)) o += seqxb_packed_layout(L).total;
     P.total = o;
     return P;
 }
@@ -2164,7 +2168,8 @@ static StackTrainPacked stack_train_packed_layout(int L, int KX, int H)
 struct StackTrainWs {
     size_t xp, state, hall[SEQ_MAX_LAYERS], call[SEQ_MAX_LAYERS], state_end, g[SEQ_MAX_LAYERS], ystage, dyp,
         rpart[SEQ_MAX_LAYERS], dxpart[SEQ_MAX_LAYERS], dcz, dc[SEQ_MAX_LAYERS], dcz_end, darows, wgpart,
-        sx_status, sx_hl[2], sx_hc[2], total;      // sx_*: exchange histories + status words of the persistent forward
+        sx_status, sx_hl[2], sx_hc[2],             // sx_*: exchange histories + status words of the persistent forward
+        sxb_ring[2], sxb_dxring, sxb_dxh, total;   // sxb_*: exchange rings of the persistent reverse recurrence
 };
 static bool seqx_train_shape(int B, int L, int KX, int H) { return seqx_dims(L, KX, H) && B <= opseq_xcd_max_batch(L); }
 
@@ -2202,6 +2207,15 @@ static StackTrainWs stack_train_ws_layout(int B, int T, int L, int KX, int H)
             W.sx_hl[l] = o; o += NGT * (TT + 1) * 8192;
             W.sx_hc[l] = o; if (l + 1 < L) o += NGT * (TT + 1) * 8192;
         }
+    }
+    // the persistent reverse recurrence: a ring of partial dh rows per layer (+ the top layer's partials of the lower layer's dh);
+    // their sums for the lower layer's XCD reuse the forward's cross-XCD history (sx_hc[0]: idle once the forward is over)
+    for (int l = 0; l < 2; ++l) W.sxb_ring[l] = o;
+    W.sxb_dxring = o; W.sxb_dxh = W.sx_hc[0];
+    if (seqx_train_shape(B, L, KX, H)) {
+        const size_t NGT = (B + 3) / 4, ring = NGT * SXB_SLOTS * 32 * 32 * 256;
+        for (int l = 0; l < L; ++l) { W.sxb_ring[l] = o; o += ring; }
+        if (L == 2) { W.sxb_dxring = o; o += ring; }
     }
     W.total = align_up(o, 256);
     return W;
@@ -2263,6 +2277,8 @@ extern "C" int opseq_lstm_stack_train_pack_weights_f32(const float *const *w_ih,
     if (seqx_dims(L, KX, H))
         seqx_pack<<<2048, 256, 0, st>>>(packed + P.seqx, w_ih[0], w_hh[0], L == 2 ? w_ih[1] : nullptr, L == 2 ? w_hh[1] : nullptr, L,
                                         seqx_nxq0(KX, H), KX);
+    if (seqx_dims(L, KX, H))
+        seqxb_pack<<<2048, 256, 0, st>>>(packed + P.seqxb, w_hh[0], L == 2 ? w_hh[1] : nullptr, L == 2 ? w_ih[1] : nullptr, w_head, L);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }
@@ -2423,12 +2439,47 @@ extern "C" int opseq_lstm_stack_train_backward_f32(const float *dy, const float 
     hipStream_t st = (hipStream_t)stream;
     opnet_pack_dy<<<256, 256, 0, st>>>((const float4 *)dy, (float4 *)(w + W.dyp), (float *)(w + W.dcz),
                                         (long)((W.dcz_end - W.dcz) / 4), B, T, RB);
-    const int per = 4 * (H / 16);
-    const dim3 ggemm((2 * L - 1) * per, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
-    const dim3 gcell(L * (H / 8), RB, 1);
-    for (int n = 0; n < T + L - 1; ++n) {
-        stack_bwd_cell<<<gcell, 256, 0, st>>>(b, n);
-        stack_bwd_gemm<<<ggemm, OPNET_THREADS, 0, st>>>(b, n);
+    // the whole reverse recurrence as ONE persistent launch (seq_xcd_bwd_kernels.hip) for the shapes whose forward runs as one
+    // (OPSEQ_XCD_BWD=0 keeps the launch chain: two launches per reverse step)
+    const bool use_sxb = seqx_train_shape(B, L, KX, H) && opseq_xcd_supported(L, KX, H) && W.total < ((size_t)1 << 31) &&
+                         env_int("OPSEQ_XCD_BWD", 1) != 0;
+    unsigned *sxb_status = nullptr;
+    if (use_sxb) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        SeqXBArgs sb;
+        memset(&sb, 0, sizeof(sb));
+        sb.B = B; sb.T = T; sb.L = L; sb.NGT = (B + 3) / 4; sb.RB = RB;
+        sb.pk = packed + TP.seqxb;
+        sb.ws = w;
+        for (int l = 0; l < 2; ++l) {
+            sb.g_off[l] = (unsigned)W.g[l < L ? l : 0]; sb.c_off[l] = (unsigned)W.call[l < L ? l : 0];
+            sb.ring_off[l] = (unsigned)W.sxb_ring[l];
+        }
+        sb.dy_off = (unsigned)W.dyp; sb.dxring_off = (unsigned)W.sxb_dxring; sb.dxh_off = (unsigned)W.sxb_dxh;
+        sb.status = sxb_status = (unsigned *)(w + W.sx_status);
+        sb.force_safe = env_int("OPNET_XCD_SAFE", 0);
+        sb.debug = env_int("OPSEQ_XCD_DEBUG", 0);
+        seqxb_init<<<512, 256, 0, st>>>(sb);
+        {
+            std::lock_guard<std::mutex> lock(g_xcd_mu);
+            if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
+            else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
+            ProfPair pe{};
+            const bool prof = prof_begin(st, &pe);
+            if (L == 1) seqx_backward<1><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sb);
+            else seqx_backward<2><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sb);
+            if (prof) prof_end(PROF_SEQX, st, pe);
+            HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
+        }
+    } else {
+        const int per = 4 * (H / 16);
+        const dim3 ggemm((2 * L - 1) * per, RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
+        const dim3 gcell(L * (H / 8), RB, 1);
+        for (int n = 0; n < T + L - 1; ++n) {
+            stack_bwd_cell<<<gcell, 256, 0, st>>>(b, n);
+            stack_bwd_gemm<<<ggemm, OPNET_THREADS, 0, st>>>(b, n);
+        }
     }
     // weight gradients over the saved histories (same merged GEMM launch as OPNet's)
     const long hs = (long)(H / 4) * 32;
@@ -2468,9 +2519,9 @@ extern "C" int opseq_lstm_stack_train_backward_f32(const float *dy, const float 
                 wb.job[j].tiles_m = 1;
             }
         }
-        wb.abort = nullptr;       // (the stack's recurrences are launch chains: nothing can give up)
+        wb.abort = sxb_status;    // (null on the launch chain: nothing can give up there)
         const int nj = (int)(jobs.size() - j0 < OPNET_WGRAD_JOBS ? jobs.size() - j0 : OPNET_WGRAD_JOBS);
-        if (!wgrad_wave_tiles(wb.job, nj, T, RB, (float *)(w + W.wgpart), nullptr, st))
+        if (!wgrad_wave_tiles(wb.job, nj, T, RB, (float *)(w + W.wgpart), sxb_status, st))
             opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
     }
     if (dx0) {

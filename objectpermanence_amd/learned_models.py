@@ -628,6 +628,12 @@ class _StackTrainFunction(torch.autograd.Function):
                                                          None if dx is None else dx.data_ptr(), B, T, L, KX, H,
                                                          _stream_ptr(dev))
         _lib.check(rc, "opseq_lstm_stack_train_backward_f32")
+        # the persistent reverse recurrence (csrc/seq_xcd_bwd_kernels.hip) raises the same status words as the forward when it gives
+        # up (its gradients are then NaN and the guarded optimiser leaves the weights alone)
+        off = lib.opseq_lstm_stack_train_status_offset(B, T, L, KX, H)
+        if off != _lib.NO_OFFSET and lib.opseq_xcd_supported(L, KX, H):
+            with torch.cuda.device(dev):
+                runner._monitor.watch(runner.tws, off, runner._note_training_abort, "seqx_backward (training)")
         return (None, dx) + tuple(grads)
 
 

