@@ -71,6 +71,28 @@ static void gemm_nt_ks(const float *X, long XS, const float *Wt, long WS, float 
 }
 static const size_t kGemmSplitMax = 16;
 
+// Y = act(X W^T + bias (+ R)) for a SHORT sequence (a handful of 128-row tiles) and a long K: the same split, with the epilogue in
+// the reduce.  Dense output rows (YS = N).  A one-clip training step (S = 300) had eleven such launches of 6 workgroups walking
+// K = 256 .. 2048 alone: 90 us each.
+static void gemm_nt_small(const float *X, long XS, const float *Wt, long WS, const float *bias, const float *R, float *Y, long M, int N,
+                          int K, int relu, float *part, size_t part_floats, hipStream_t st)
+{
+    const long tiles = ((M + 127) / 128) * ((N + 63) / 64);
+    int ks = (N & 3) || tiles >= 128 ? 1 : gemm_split_slices(M, N, K);
+    while (ks > 1 && (size_t)ks * M * N > part_floats) --ks;
+    if (ks <= 1) { gemm_nt(X, XS, Wt, WS, bias, R, Y, N, M, N, K, relu, st); return; }
+    ConvArgs c = {};
+    c.X = X; c.Wt = Wt; c.Y = Y;
+    c.N = 1; c.H = 1; c.W = (int)M; c.Cin = K; c.Cout = N; c.KH = 1; c.KW = 1; c.stride = 1; c.pad = 0;
+    c.OH = 1; c.OW = (int)M; c.KP = K;
+    c.XS = (int)XS; c.WS = (int)WS; c.YS = N;
+    const int nhex = K >> 4, per = (nhex + ks - 1) / ks;
+    c.P = part; c.ksteps = per; c.ksplit = (nhex + per - 1) / per;
+    conv2d_nhwc_glds<64, 3><<<dim3((unsigned)((M + 127) / 128), (N + 63) / 64, c.ksplit), 256, 0, st>>>(c);
+    const long n4 = M * N / 4;
+    conv_splitk_reduce<<<(unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256), 256, 0, st>>>(part, c.ksplit, M, N, bias, R, Y, relu);
+}
+
 // ---- flash training attention (attn_train_kernels.hip) ---------------------------------------------------------------------
 // head sizes the LDS-DMA tiles are built for; anything else (and OPSEQ_ATTN_FLASH=0) keeps the chunked GEMM form below
 static bool attn_flash_shape(long S, int E, int nhead)
@@ -289,6 +311,7 @@ extern "C" int opseq_encoder_layer_train_forward_f32(const float *z_in, float *z
     const EncSaved SV = enc_saved_layout(S, E, nhead, ffn);
     const EncScratch SC = enc_scratch_layout(S, E, nhead, ffn);
     if (saved_bytes < SV.total * 4 || scratch_bytes < SC.total * 4) return fail(OPNET_EWORKSPACE, "saved / scratch buffer too small");
+    const size_t wgp_floats = SC.total - SC.wgp;
     hipStream_t st = (hipStream_t)stream;
     float *sv = (float *)saved, *sc = (float *)scratch;
     const int hd = E / nhead;
@@ -343,7 +366,7 @@ extern "C" int opseq_encoder_layer_train_forward_f32(const float *z_in, float *z
                                                             sv + SV.x1, (int)S, E, 1e-5f, D.at(1u), D.thresh, D.inv_keep);
     gemm_nt(sv + SV.x1, E, l1_w, E, l1_b, nullptr, sv + SV.hid, ffn, S, ffn, E, 1, st);
     if (D.thresh) enc_dropout<<<ew_grid((long)S * ffn), 256, 0, st>>>(sv + SV.hid, (long)S * ffn, D.at(2u), D.thresh, D.inv_keep);
-    gemm_nt(sv + SV.hid, ffn, l2_w, ffn, l2_b, nullptr, e0, E, S, E, ffn, 0, st);
+    gemm_nt_small(sv + SV.hid, ffn, l2_w, ffn, l2_b, nullptr, e0, S, E, ffn, 0, sc + SC.wgp, wgp_floats, st);
     enc_add_drop_ln<<<(unsigned)((S + 3) / 4), 256, 0, st>>>(sv + SV.x1, e0, n2_w, n2_b, sv + SV.u2, (float2 *)(sv + SV.st2),
                                                             z_out, (int)S, E, 1e-5f, D.at(3u), D.thresh, D.inv_keep);
     HIP_TRY(hipGetLastError());
@@ -371,6 +394,7 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
     const EncSaved SV = enc_saved_layout(S, E, nhead, ffn);
     const EncScratch SC = enc_scratch_layout(S, E, nhead, ffn);
     if (saved_bytes < SV.total * 4 || scratch_bytes < SC.total * 4) return fail(OPNET_EWORKSPACE, "saved / scratch buffer too small");
+    const size_t wgp_floats = SC.total - SC.wgp;
     hipStream_t st = (hipStream_t)stream;
     const float *sv = (const float *)saved;
     float *sc = (float *)scratch;
@@ -381,9 +405,15 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
     const float *zs = sv + SV.z_in, *qkv = sv + SV.qkv, *att = sv + SV.att, *hid = sv + SV.hid, *x1 = sv + SV.x1;
     float *e0 = sc + SC.e0, *e1 = sc + SC.e1, *e2 = sc + SC.e2, *t0 = sc + SC.t0, *tA = sc + SC.tA, *tB = sc + SC.tB;
     float *dqkv = sc + SC.dqkv, *part = sc + SC.part, *sq0 = sc + SC.sq0, *sq1 = sc + SC.sq1;
-    const int nb_ln = (int)((S + 63) / 64), nb_cs = (int)((S + 255) / 256);
+    // LayerNorm backward: rows per workgroup as few as the partial-sum buffer ((S + 63) / 64 x 2 x wide floats) allows - 64 rows a
+    // workgroup left a one-clip step with 5 workgroups walking 16 rows per wave (37 us a launch)
+    const long wide_ = ffn > 3 * E ? ffn : 3 * E;
+    long nb_cap = ((S + 63) / 64) * (wide_ / E);
+    if (nb_cap > 2048) nb_cap = 2048;
+    const int ln_rows = (int)(((S + nb_cap - 1) / nb_cap + 3) / 4 * 4);
+    const int nb_ln = (int)((S + ln_rows - 1) / ln_rows), nb_cs = (int)((S + 63) / 64);
     auto colsum = [&](const float *X, long ld, int N, float *out) {
-        enc_colsum_part<<<dim3((N + 255) / 256, nb_cs, 1), 256, 0, st>>>(X, ld, part, (int)S, N, 256);
+        enc_colsum_part<<<dim3((N + 255) / 256, nb_cs, 1), 256, 0, st>>>(X, ld, part, (int)S, N, 64);
         enc_colsum_final<<<dim3((N + 255) / 256, 1, 1), 256, 0, st>>>(part, out, out, nb_cs, N);
     };
     // dW[n][k] = sum_s A[s][n] B[s][k]  (A [S][N], B [S][K])
@@ -399,7 +429,7 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
     transpose_to(l2_w, ffn, sc + SC.wt_l2, E, E, ffn, st);           // [ffn][E]
 
     // ---- norm2, dropout2, linear2, ReLU/dropout, linear1 ----
-    enc_ln_bwd<<<nb_ln, 256, 0, st>>>(dz_out, sv + SV.u2, (const float2 *)(sv + SV.st2), n2_w, nullptr, e1, part, (int)S, E, 64);
+    enc_ln_bwd<<<nb_ln, 256, 0, st>>>(dz_out, sv + SV.u2, (const float2 *)(sv + SV.st2), n2_w, nullptr, e1, part, (int)S, E, ln_rows);
     enc_colsum_final<<<dim3((E + 255) / 256, 2, 1), 256, 0, st>>>(part, g_n2_w, g_n2_b, nb_ln, E);
     enc_dropout_copy<<<ew_grid((long)S * E), 256, 0, st>>>(e1, e0, (long)S * E, D.at(3u), D.thresh, D.inv_keep);   // d f
     colsum(e0, E, E, g_l2_b);
@@ -408,9 +438,9 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
     enc_relu_drop_bwd<<<ew_grid((long)S * ffn), 256, 0, st>>>(t0, hid, (long)S * ffn, D.inv_keep);
     colsum(t0, ffn, ffn, g_l1_b);
     gemm_tn(t0, ffn, ffn, x1, E, E, g_l1_w);                                                // [ffn][E]
-    gemm_nt(t0, ffn, sc + SC.wt_l1, ffn, nullptr, e1, e2, E, S, E, ffn, 0, st);             // d x1 = d pre W1 + d u2
+    gemm_nt_small(t0, ffn, sc + SC.wt_l1, ffn, nullptr, e1, e2, S, E, ffn, 0, sc + SC.wgp, wgp_floats, st);   // d x1 = d pre W1 + d u2
     // ---- norm1, dropout1, out_proj ----
-    enc_ln_bwd<<<nb_ln, 256, 0, st>>>(e2, sv + SV.u1, (const float2 *)(sv + SV.st1), n1_w, nullptr, e1, part, (int)S, E, 64);
+    enc_ln_bwd<<<nb_ln, 256, 0, st>>>(e2, sv + SV.u1, (const float2 *)(sv + SV.st1), n1_w, nullptr, e1, part, (int)S, E, ln_rows);
     enc_colsum_final<<<dim3((E + 255) / 256, 2, 1), 256, 0, st>>>(part, g_n1_w, g_n1_b, nb_ln, E);
     enc_dropout_copy<<<ew_grid((long)S * E), 256, 0, st>>>(e1, e0, (long)S * E, D.at(1u), D.thresh, D.inv_keep);   // d proj
     colsum(e0, E, E, g_out_b);
@@ -489,7 +519,7 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
     // ---- in_proj ----
     colsum(dqkv, 3 * E, 3 * E, g_in_b);
     gemm_tn(dqkv, 3 * E, 3 * E, zs, E, E, g_in_w);                                          // [3E][E]
-    gemm_nt(dqkv, 3 * E, sc + SC.wt_in, 3 * E, nullptr, e1, dz_in, E, S, E, 3 * E, 0, st);  // + d u1 (residual)
+    gemm_nt_small(dqkv, 3 * E, sc + SC.wt_in, 3 * E, nullptr, e1, dz_in, S, E, 3 * E, 0, sc + SC.wgp, wgp_floats, st);  // + d u1 (residual)
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

@@ -1236,7 +1236,7 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
 // wave job fits ONE round of the SIMDs and big (4 units of work per step) and small (1) end together.  `partial`: WG2_MAX_WAVES x
 // WG2_PART_F floats of workspace.  false = not applicable (OPNET_WGRAD2=0, or a slice beyond a buffer descriptor's 2 GiB): the caller
 // runs opnet_wgrad.
-static bool wgrad_wave_tiles(const WgradArgs *jobs, int njobs, int T, int RB, float *partial, const unsigned *abort, hipStream_t st)
+static bool wgrad_wave_tiles(const WgradArgs *jobs, int njobs, int T, int RB, int B, float *partial, const unsigned *abort, hipStream_t st)
 {
     if (env_int("OPNET_WGRAD2", 1) == 0 || njobs < 1 || njobs > OPNET_WGRAD_JOBS || !partial) return false;
     Wg2Batch tb;
@@ -1290,6 +1290,9 @@ static bool wgrad_wave_tiles(const WgradArgs *jobs, int njobs, int T, int RB, fl
     tb.njobs = njobs; tb.nwaves = nw;
     tb.partial = partial;
     tb.abort = abort;
+    // one ragged row block: the clip groups past the batch hold zeros in every operand (histories zeroed, da = 0 where dy = 0)
+    tb.ncg = 8;
+    if (RB == 1 && env_int("OPNET_WGRAD_NCG", 1) != 0) tb.ncg = B <= 4 ? 1 : B <= 8 ? 2 : B <= 16 ? 4 : 8;
     opnet_wgrad_tiles<<<(nw + 3) / 4, 256, 0, st>>>(tb);
     opnet_wgrad_reduce<<<1024, 256, 0, st>>>(tb);
     return true;
@@ -1401,7 +1404,7 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
     }
     // a forward or reverse recurrence that gave up (4-clip persistent kernels) left partial histories: every dW becomes NaN
     wb.abort = x4_batch(B, H1, H2) ? (const unsigned *)(w + W.x4status) : nullptr;
-    if (wgrad_wave_tiles(wb.job, njobs, T, RB, (float *)(w + W.wgpart), wb.abort, st)) {
+    if (wgrad_wave_tiles(wb.job, njobs, T, RB, B, (float *)(w + W.wgpart), wb.abort, st)) {
         HIP_TRY(hipGetLastError());
         return OPNET_OK;
     }
@@ -2521,7 +2524,7 @@ extern "C" int opseq_lstm_stack_train_backward_f32(const float *dy, const float 
         }
         wb.abort = sxb_status;    // (null on the launch chain: nothing can give up there)
         const int nj = (int)(jobs.size() - j0 < OPNET_WGRAD_JOBS ? jobs.size() - j0 : OPNET_WGRAD_JOBS);
-        if (!wgrad_wave_tiles(wb.job, nj, T, RB, (float *)(w + W.wgpart), sxb_status, st))
+        if (!wgrad_wave_tiles(wb.job, nj, T, RB, B, (float *)(w + W.wgpart), sxb_status, st))
             opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
     }
     if (dx0) {

@@ -687,12 +687,14 @@ struct Wg2Job {
 struct Wg2Batch {
     Wg2Job job[OPNET_WGRAD_JOBS];
     int njobs, nwaves;
+    int ncg;                   // clip groups (of 4) per row block that can hold a clip: 8, or 1 / 2 / 4 for one ragged row block - the
+                               // groups past the batch are all zeros in every operand, adding them changes no sum
     float *partial;            // [wave job][16 384 floats] (small jobs use the first 4 096)
     const unsigned *abort;
 };
 #define WG2_PART_F 16384
 
-template <int GA, int GB>
+template <int GA, int GB, int NCG>
 __device__ __forceinline__ void wg2_tile(const float4 *P, long p_stride, int MQ, const float4 *Q, long q_stride, int NQ, int mq0, int nq0,
                                          long it0, long it1, float *__restrict__ part)
 {
@@ -724,8 +726,9 @@ __device__ __forceinline__ void wg2_tile(const float4 *P, long p_stride, int MQ,
                     acc[a][b][x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     asm volatile("" : "+a"(acc[a][b][x][y]));
                 }
-    // ring of four clip groups, three ahead: slot = clip group & 3 (eight clip groups per step: static indices).  Past the slice's
-    // last step the ring re-reads that step (never used).
+    // ring of four clip groups, three ahead.  The (step, clip group) items of the slice are walked in spans of U = max(NCG, 4) items, so
+    // that slot = item & 3 and the clip group = item % NCG are static indices.  Past the slice's last step the ring re-reads that
+    // step (never used).
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 ra[4][GA], rb[4][GB];
     auto fetch = [&](int st, int cg, int slot) {
@@ -735,12 +738,15 @@ __device__ __forceinline__ void wg2_tile(const float4 *P, long p_stride, int MQ,
 #pragma unroll
         for (int b = 0; b < GB; ++b) rb[slot][b] = __builtin_amdgcn_raw_buffer_load_b128(rq, vb[b], so * qs + cg * 64, 0);
     };
-    if (nst > 0) { fetch(0, 0, 0); fetch(0, 1, 1); fetch(0, 2, 2); }
-    for (int st = 0; st < nst; ++st) {
+    constexpr int U = NCG < 4 ? 4 : NCG, SPU = U / NCG;          // items and steps per span
+    const int total = nst * NCG;
+    if (nst > 0) { fetch(0 / NCG, 0 % NCG, 0); fetch(1 / NCG, 1 % NCG, 1); fetch(2 / NCG, 2 % NCG, 2); }
+    for (int s0 = 0, st0 = 0; s0 < total; s0 += U, st0 += SPU) {
 #pragma unroll
-        for (int cg = 0; cg < 8; ++cg) {
-            fetch(st + ((cg + 3) >> 3), (cg + 3) & 7, (cg + 3) & 3);
-            const int sl = cg & 3;
+        for (int u = 0; u < U; ++u) {
+            if (NCG < 4 && s0 + u >= total) break;               // (a ragged last span: only when a step is less than a span)
+            fetch(st0 + (u + 3) / NCG, (u + 3) % NCG, (u + 3) & 3);
+            const int sl = u & 3;
 #pragma unroll
             for (int a = 0; a < GA; ++a) {
                 const float ae[4] = {__uint_as_float(ra[sl][a][0]), __uint_as_float(ra[sl][a][1]), __uint_as_float(ra[sl][a][2]), __uint_as_float(ra[sl][a][3])};
@@ -790,8 +796,14 @@ __global__ void __launch_bounds__(256, 1) opnet_wgrad_tiles(const Wg2Batch batch
     const float4 *P = J.g.P, *Q = J.g.Q;
     const long p_stride = J.g.p_stride, q_stride = J.g.q_stride;
     const int MQ = J.g.MQ, NQ = J.g.NQ;
-    if (J.big) wg2_tile<2, 2>(P, p_stride, MQ, Q, q_stride, NQ, tm * 32, tn * 32, it0, it1, part);
-    else wg2_tile<1, 1>(P, p_stride, MQ, Q, q_stride, NQ, tm * 16, tn * 16, it0, it1, part);
+    const int ncg = __builtin_amdgcn_readfirstlane(batch.ncg);
+#define WG2_RUN(NCG) do { if (J.big) wg2_tile<2, 2, NCG>(P, p_stride, MQ, Q, q_stride, NQ, tm * 32, tn * 32, it0, it1, part); \
+                          else wg2_tile<1, 1, NCG>(P, p_stride, MQ, Q, q_stride, NQ, tm * 16, tn * 16, it0, it1, part); } while (0)
+    if (ncg == 8) WG2_RUN(8);
+    else if (ncg == 4) WG2_RUN(4);
+    else if (ncg == 2) WG2_RUN(2);
+    else WG2_RUN(1);
+#undef WG2_RUN
 }
 
 // one thread per accumulator quad (tile, a, b, x, y, lane): the slices of the tile in slice order, then the four rows of the quad
