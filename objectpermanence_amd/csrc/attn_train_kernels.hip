@@ -280,8 +280,12 @@ struct AttBwdArgs {
 
 // DKV = false: rows a = queries, rows b = keys, acc0 = dQ.  DKV = true: rows a = keys, rows b = queries, acc0 = dK, acc1 = dV.
 // AF = 16-row stationary fragments per wave (the tile reads and the barrier are shared by them).
-template <int HD, bool DKV, int AF>
-__global__ void __launch_bounds__(256) attention_bwd(const AttBwdArgs a)
+// DROP = 0: no dropout; 1: multipliers from the counter generator; 2: from the test-only mask table (a.ds.mask) - a template
+// parameter so that the per-score code carries no branch on it (the first version: 13 scalar branches per tile).
+// Two waves per SIMD (256 registers): the LDS fragments travel through two-deep register rings instead of all at once
+// (the first version of the dK / dV pass needed 278 registers: one wave per SIMD, 0.53 of the fp32 MFMA peak against 0.61 for dQ).
+template <int HD, bool DKV, int AF, int DROP>
+__global__ void __launch_bounds__(256, 2) attention_bwd(const AttBwdArgs a)
 {
     constexpr int NS = 3, PPR = HD / 4, NHEX = HD / 16, NC = (HD + 63) / 64, TI = HD / 16, LPS = (2 * TI + 3) / 4, TILE_F4 = 16 * PPR;
     __shared__ __attribute__((aligned(1024))) float4 smem[NS * 2 * TILE_F4];
@@ -352,7 +356,14 @@ __global__ void __launch_bounds__(256) attention_bwd(const AttBwdArgs a)
                 acc0[f][c][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if constexpr (DKV) acc1[f][c][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+    // dropout: element (q, k) of head h has index h S^2 + q S + k.  Per tile one 64-bit base for this lane's first streaming row,
+    // per element two 64-bit additions: idx = base + off[f] + r * rstep
     const unsigned long long SS = (unsigned long long)S, idx_h = (unsigned long long)head * SS * SS;
+    const unsigned long long rstep = DKV ? SS : 1ull;
+    unsigned long long ioff[AF];
+#pragma unroll
+    for (int f = 0; f < AF; ++f) ioff[f] = DKV ? (unsigned long long)arow[f] : (unsigned long long)arow[f] * SS;
+    const unsigned key = DROP == 1 ? enc_key(a.ds.seed, a.ds.site) : 0u;
 
     const int nall = (S + 15) >> 4;
     const int per = (nall + (int)gridDim.z - 1) / (int)gridDim.z;
@@ -377,14 +388,22 @@ __global__ void __launch_bounds__(256) attention_bwd(const AttBwdArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) stb[r] = st4h[min(b0 + 4 * kk + r, S - 1)];
         }
-        // ---- the two score-shaped products: four independent accumulator chains per stationary fragment ----
+        // ---- the two score-shaped products: four independent accumulator chains per stationary fragment; the tile's k-quads
+        //      through a two-deep register ring ----
         f32x4 sc[AF][2], dp[AF][2];
 #pragma unroll
         for (int f = 0; f < AF; ++f) sc[f][0] = sc[f][1] = dp[f][0] = dp[f][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 kfr[2], vfr[2];
+        kfr[0] = Y0[i * PPR + (kk ^ ksw)];
+        vfr[0] = Y1[i * PPR + (kk ^ ksw)];
 #pragma unroll
         for (int c = 0; c < NHEX; ++c) {
-            const float4 kf = Y0[i * PPR + ((4 * c + kk) ^ ksw)];
-            const float4 vf = Y1[i * PPR + ((4 * c + kk) ^ ksw)];
+            if (c + 1 < NHEX) {
+                kfr[(c + 1) & 1] = Y0[i * PPR + ((4 * (c + 1) + kk) ^ ksw)];
+                vfr[(c + 1) & 1] = Y1[i * PPR + ((4 * (c + 1) + kk) ^ ksw)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 kf = kfr[c & 1], vf = vfr[c & 1];
 #pragma unroll
             for (int f = 0; f < AF; ++f) {
                 sc[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, x0f[f][c].x, sc[f][0], 0, 0, 0);
@@ -396,54 +415,65 @@ __global__ void __launch_bounds__(256) attention_bwd(const AttBwdArgs a)
                 sc[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, x0f[f][c].w, sc[f][1], 0, 0, 0);
                 dp[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, x1f[f][c].w, dp[f][1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- the tiles read row-wise (A operands of the accumulating products): row 4 kk + r, pieces 16 c + i, un-swizzled ----
-        float4 y0v[4][NC], y1v[DKV ? 4 : 1][NC];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        // ---- the tiles read row-wise (A operands of the accumulating products): row 4 kk + r, pieces 16 c + i, un-swizzled; row r + 1
+        //      is fetched under row r's products, row 0 under the elementwise part ----
+        float4 y0r[2][NC], y1r[DKV ? 2 : 1][NC];
+        auto rowread = [&](int r, int slot) {
             const int row = 4 * kk + r, rsw = att_kswz<HD>(row);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const bool on = 16 * c + i < PPR;
-                y0v[r][c] = on ? Y0[row * PPR + ((16 * c + i) ^ rsw)] : make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (DKV) y1v[r][c] = on ? Y1[row * PPR + ((16 * c + i) ^ rsw)] : make_float4(0.f, 0.f, 0.f, 0.f);
+                y0r[slot][c] = on ? Y0[row * PPR + ((16 * c + i) ^ rsw)] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (DKV) y1r[slot][c] = on ? Y1[row * PPR + ((16 * c + i) ^ rsw)] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        }
+        };
+        rowread(0, 0);
         // ---- elementwise: P, Pd, dS of this lane's 4 streaming rows x AF stationary rows ----
+        float dsv[AF][4], pdv[AF][4];
+        const unsigned long long ibase = idx_h + (unsigned long long)(b0 + 4 * kk) * rstep;
 #pragma unroll
         for (int f = 0; f < AF; ++f) {
-            float dsv[4], pdv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int b = b0 + 4 * kk + r;
                 const float4 st = DKV ? stb[r] : sta[f];
                 const float s = sc[f][0][r] + sc[f][1][r];
                 const float p = b < S ? __expf(s - st.x) * st.y : 0.f;
-                float dpv = dp[f][0][r] + dp[f][1][r];
+                const float dpv = dp[f][0][r] + dp[f][1][r];
                 float keep = 1.0f;
-                if (a.thresh) {
-                    const unsigned long long q = DKV ? (unsigned long long)min(b, S - 1) : (unsigned long long)arow[f];
-                    const unsigned long long k = DKV ? (unsigned long long)arow[f] : (unsigned long long)min(b, S - 1);
-                    keep = enc_keep(a.ds, idx_h + q * SS + k, a.thresh, a.inv_keep);
+                if constexpr (DROP != 0) {
+                    const unsigned long long idx = ibase + ioff[f] + (unsigned long long)r * rstep;
+                    if constexpr (DROP == 1) keep = enc_hash_keyed(key, idx) >= a.thresh ? a.inv_keep : 0.0f;
+                    else keep = (b < S && a.ds.mask[idx]) ? a.inv_keep : 0.0f;
                 }
-                pdv[r] = p * keep;
-                dsv[r] = p * (dpv * keep - st.z);
+                pdv[f][r] = p * keep;
+                dsv[f][r] = p * (dpv * keep - st.z);
             }
+        }
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
+        for (int r = 0; r < 4; ++r) {
+            if (r + 1 < 4) rowread(r + 1, (r + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc0[f][c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0v[r][c].x, dsv[r], acc0[f][c][0], 0, 0, 0);
-                    acc0[f][c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0v[r][c].y, dsv[r], acc0[f][c][1], 0, 0, 0);
-                    acc0[f][c][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0v[r][c].z, dsv[r], acc0[f][c][2], 0, 0, 0);
-                    acc0[f][c][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0v[r][c].w, dsv[r], acc0[f][c][3], 0, 0, 0);
+            for (int f = 0; f < AF; ++f)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float4 y0 = y0r[r & 1][c];
+                    acc0[f][c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0.x, dsv[f][r], acc0[f][c][0], 0, 0, 0);
+                    acc0[f][c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0.y, dsv[f][r], acc0[f][c][1], 0, 0, 0);
+                    acc0[f][c][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0.z, dsv[f][r], acc0[f][c][2], 0, 0, 0);
+                    acc0[f][c][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(y0.w, dsv[f][r], acc0[f][c][3], 0, 0, 0);
                     if constexpr (DKV) {
-                        acc1[f][c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1v[r][c].x, pdv[r], acc1[f][c][0], 0, 0, 0);
-                        acc1[f][c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1v[r][c].y, pdv[r], acc1[f][c][1], 0, 0, 0);
-                        acc1[f][c][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1v[r][c].z, pdv[r], acc1[f][c][2], 0, 0, 0);
-                        acc1[f][c][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1v[r][c].w, pdv[r], acc1[f][c][3], 0, 0, 0);
+                        const float4 y1 = y1r[r & 1][c];
+                        acc1[f][c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1.x, pdv[f][r], acc1[f][c][0], 0, 0, 0);
+                        acc1[f][c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1.y, pdv[f][r], acc1[f][c][1], 0, 0, 0);
+                        acc1[f][c][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1.z, pdv[f][r], acc1[f][c][2], 0, 0, 0);
+                        acc1[f][c][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(y1.w, pdv[f][r], acc1[f][c][3], 0, 0, 0);
                     }
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (steady) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPS * (NS - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

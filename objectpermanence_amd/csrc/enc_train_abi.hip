@@ -129,19 +129,26 @@ static void launch_attn_train_fwd(const AttTrainFwdArgs &a, int nhead, int KS, h
 {
     attention_train_fwd<HD><<<dim3((unsigned)((a.S + 63) / 64), nhead, KS), 256, 0, st>>>(a);
 }
-template <int HD>
-static void launch_attn_bwd(const AttBwdArgs &a, bool dkv, int AF, int nhead, int ZS, hipStream_t st)
+template <int HD, int DROP>
+static void launch_attn_bwd_d(const AttBwdArgs &a, bool dkv, int AF, int nhead, int ZS, hipStream_t st)
 {
     const dim3 g((unsigned)((a.S + 64 * AF - 1) / (64 * AF)), nhead, ZS);
     if constexpr (HD <= 64) {
         if (AF == 2) {
-            if (dkv) attention_bwd<HD, true, 2><<<g, 256, 0, st>>>(a);
-            else attention_bwd<HD, false, 2><<<g, 256, 0, st>>>(a);
+            if (dkv) attention_bwd<HD, true, 2, DROP><<<g, 256, 0, st>>>(a);
+            else attention_bwd<HD, false, 2, DROP><<<g, 256, 0, st>>>(a);
             return;
         }
     }
-    if (dkv) attention_bwd<HD, true, 1><<<g, 256, 0, st>>>(a);
-    else attention_bwd<HD, false, 1><<<g, 256, 0, st>>>(a);
+    if (dkv) attention_bwd<HD, true, 1, DROP><<<g, 256, 0, st>>>(a);
+    else attention_bwd<HD, false, 1, DROP><<<g, 256, 0, st>>>(a);
+}
+template <int HD>
+static void launch_attn_bwd(const AttBwdArgs &a, bool dkv, int AF, int nhead, int ZS, hipStream_t st)
+{
+    if (a.thresh == 0u) launch_attn_bwd_d<HD, 0>(a, dkv, AF, nhead, ZS, st);
+    else if (a.ds.mask) launch_attn_bwd_d<HD, 2>(a, dkv, AF, nhead, ZS, st);       // (tests: the reference's recorded masks)
+    else launch_attn_bwd_d<HD, 1>(a, dkv, AF, nhead, ZS, st);
 }
 
 static void transpose_to(const float *src, long sld, float *dst, long dld, long R, int C, hipStream_t st)
@@ -466,7 +473,7 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
         for (int pass = 0; pass < 2; ++pass) {
             const int NOUT = pass ? 2 : 1;
             int zmax = (int)(SC.tAB / ((size_t)NOUT * S * E));
-            if (zmax > 4) zmax = 4;
+            if (zmax > 8) zmax = 8;
             const int ZS = attn_sweep_split(W, (S + 15) / 16, zmax);
             if (pass == 0) {
                 ba.x0 = qkv; ba.ldx0 = 3 * E; ba.x1 = e2; ba.ldx1 = E;

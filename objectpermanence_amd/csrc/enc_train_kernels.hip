@@ -13,12 +13,29 @@
 
 #define ENC_LN_MAX_PER_LANE 8     // E <= 512
 
-__device__ __forceinline__ unsigned enc_hash(unsigned long long seed, unsigned site, unsigned long long idx)
+// 32 bits per (seed, site, element).  The key (seed, site) goes through a 64-bit splitmix finaliser - wave-uniform, loop-invariant:
+// scalar instructions, once per kernel - and the element index through one multiply, the key, and the two multiply / xor-shift
+// rounds of the "lowbias32" integer hash: ~12 VALU instructions per element (the first version put the element through the 64-bit
+// finaliser too: ~35, and the flash attention kernels draw one multiplier per score - a fifth of their non-MFMA instructions)
+__device__ __forceinline__ unsigned enc_key(unsigned long long seed, unsigned site)
 {
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((unsigned long long)site << 56);
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)site + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+__device__ __forceinline__ unsigned enc_hash_keyed(unsigned key, unsigned long long idx)
+{
+    unsigned x = ((unsigned)idx * 0x9E3779B1u) ^ key;
+    x += (unsigned)(idx >> 32) * 0x85EBCA77u;
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned enc_hash(unsigned long long seed, unsigned site, unsigned long long idx)
+{
+    return enc_hash_keyed(enc_key(seed, site), idx);
 }
 
 // One dropout site of one layer call: the generator's key (seed, site) - or, TEST-ONLY, a mask buffer (one byte per element, nonzero =
