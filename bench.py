@@ -109,13 +109,63 @@ def accuracy_block(dev):
     boxes, labels = synth.make_batch(int(g["first"]), int(g["n"]), T_FRAMES)
     with torch.no_grad():
         y, _ = m(torch.from_numpy(boxes).to(dev))
-    _, _, iou = metrics.postprocess_and_iou(y, torch.from_numpy(labels).to(dev))
+    pred_px, _, iou = metrics.postprocess_and_iou(y, torch.from_numpy(labels).to(dev))
     miou, map50 = metrics.mean_iou_and_map(iou)
+    # the int32 pixel boxes (inference_main.py:219) against the reference's for the same weights and clips
+    mism = int((pred_px.cpu().numpy() != g["pred_px"]).sum())
     return {"accuracy": {"weights": "OPNet trained on MI355X by this repo's training path (tools/train_synthetic.py), fp16-rounded",
                          "clips": int(g["n"]), "mean_iou": round(miou, 6), "map_0.5": round(map50, 6),
+                         "int_pixel_mismatches": mism, "int_pixel_components": int(g["pred_px"].size),
                          "reference_mean_iou": round(float(g["video_mean_iou"].mean()), 6),
                          "reference_map_0.5": round(float(g["video_map50"].mean()), 6),
                          "max_abs_dy_vs_reference": float(np.abs(y.cpu().numpy() - g["y"]).max())}}
+
+
+def inference_from_files_block(n_clips=4096, threads=12):
+    """What a user of the inference driver gets (outside the timed region): `n_clips` synthetic <video>.pkl + <video>_bb.json on
+    local disk -> reasoning_inference_main (native clip-file reader into pinned buffers, ReasonerServer, int32 post-process, IoU)
+    at the reference's 12 workers (configs/inference_config.json: num_workers 12, batch_size 16).  cold: first pass after the page
+    cache was dropped (null when this process may not drop it); warm: the best of the three passes after it (every pass listed)."""
+    import pickle
+    import tempfile
+    from objectpermanence_amd.inference_main import reasoning_inference_main
+    from synthdata import opnet as synth
+    with tempfile.TemporaryDirectory() as tmp:
+        sdir, ldir = os.path.join(tmp, "s"), os.path.join(tmp, "l")
+        os.mkdir(sdir)
+        os.mkdir(ldir)
+        raws = [synth.make_raw_video(i, "plain") for i in range(32)]
+        for k in range(n_clips):
+            bb, lab, gt = raws[k % 32]
+            with open(os.path.join(sdir, f"v{k:05d}.pkl"), "wb") as f:
+                pickle.dump({"bb": bb, "labels": lab}, f, pickle.HIGHEST_PROTOCOL)
+            with open(os.path.join(ldir, f"v{k:05d}_bb.json"), "w") as f:
+                json.dump(gt, f)
+        torch.save({k: torch.from_numpy(v) for k, v in synth.opnet_synth_params(CFG).items()}, os.path.join(tmp, "opnet.pth"))
+        json.dump(CFG, open(os.path.join(tmp, "model.json"), "w"))
+        json.dump({"batch_size": 16, "num_workers": threads, "device": "cuda:0", "model_path": os.path.join(tmp, "opnet.pth"),
+                   "videos_dir": "unused", "sample_dir": sdir, "labels_dir": ldir}, open(os.path.join(tmp, "infer.json"), "w"))
+        dropped = False
+        try:
+            os.sync()
+            with open("/proc/sys/vm/drop_caches", "w") as f:
+                f.write("3\n")
+            dropped = True
+        except OSError:
+            pass
+        rates = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            res = reasoning_inference_main("opnet", os.path.join(tmp, "out"), os.path.join(tmp, "infer.json"),
+                                           os.path.join(tmp, "model.json"), write_files=False)
+            rates.append((n_clips / (time.perf_counter() - t0), res["timing"]["steady_clips_per_s"]))
+    return {"inference_from_files": {"clips": n_clips, "threads": threads, "batch_size": 16,
+                                     "clips_per_s_cold": round(rates[0][0], 1) if dropped else None,
+                                     "clips_per_s_warm": round(max(r[0] for r in rates[1:]), 1),
+                                     "steady_clips_per_s_warm": round(max(r[1] for r in rates[1:]), 1),
+                                     "clips_per_s_by_pass": [round(r[0], 1) for r in rates],
+                                     "what": "python -m objectpermanence_amd reasoning_inference from .pkl / _bb.json files on local disk, whole call "
+                                             "(start-up included) and its steady state; the headline `value` is the model call alone with inputs in HBM"}}
 
 
 def parse():
@@ -125,6 +175,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=None,
                     help="clips per GPU per step (default 32, the BASELINE configs); frames per pass for --mode detect (default 16)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="--mode train: clips per step over ALL GPUs (BASELINE.json config 5 says 256): per-rank batch = global / N, "
+                         "the line says \"scaling\": \"strong\" (default: --batch clips per GPU, weak scaling)")
     ap.add_argument("--engine", choices=["xcd", "chain"], default="xcd",
                     help="xcd = request batching into the per-XCD persistent forward (default); chain = one hipGraph of "
                          "step launches per batch on S streams (round 1)")
@@ -271,8 +324,11 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "repeats": max(1, args.repeats), "value_is": "median over the repeats of the timed region",
             "value_min": round(world * B * args.steps / t_max, 1), "value_max": round(world * B * args.steps / t_min, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"opnet training (BASELINE.json config {5 if world > 1 else 2}), batch={B} clips/GPU x 300 "
+            "higher_is_better": True, "scaling": "strong" if args.global_batch is not None else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"opnet training (BASELINE.json config {5 if world > 1 or args.global_batch is not None else 2}), "
+                                   + (f"global batch {args.global_batch} clips fixed over the GPUs, " if args.global_batch is not None else "")
+                                   + f"batch={B} clips/GPU x 300 "
                                    f"frames x 15 slots (10 objects), {args.loss} bbox loss, Adam lr 1e-3"
                                    + (f", data parallel over {world} GPUs: one RCCL all-reduce of the flat {W_BYTES + 16} B gradient "
                                       "bucket per step on a side stream" if world > 1 else ""),
@@ -607,6 +663,104 @@ def transformer_block(dev, heads=4, n_exact=16, n_tp=256):
     return {"transformer_step": out}
 
 
+def _train_step_ms(name, model, x, y, dev, lib, warm=3, reps=9):
+    """median ms of train_step (forward + L1 + backward + Adam) by HIP events + the profiled kernels' time of ONE step"""
+    from objectpermanence_amd import FusedAdam
+    from objectpermanence_amd.training import step_aborted, train_step
+    opt = FusedAdam(model.parameters(), lr=1e-4)
+    for _ in range(warm):
+        train_step(name, model, opt, x, y)
+    torch.cuda.synchronize(dev)
+    times = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        loss = train_step(name, model, opt, x, y)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        times.append(e0.elapsed_time(e1))
+    lib.opnet_xcd_profile(1)
+    train_step(name, model, opt, x, y)
+    torch.cuda.synchronize(dev)
+    prof = {}
+    for tag, key in ((1, "seqx_forward"), (7, "seqx_backward"), (5, "attention_forward"), (6, "attention_backward")):
+        kms, nl = ctypes.c_double(0.0), ctypes.c_int(0)
+        lib.opnet_kernel_profile_read(tag, ctypes.byref(kms), ctypes.byref(nl))
+        prof[key] = (kms.value, nl.value)
+    lib.opnet_xcd_profile(0)
+    if step_aborted(model):
+        raise SystemExit("bench: a persistent launch of a sibling training step aborted")
+    return sorted(times)[len(times) // 2], float(loss), prof
+
+
+def siblings_training_block(dev, heads=2):
+    """Training steps of the stacked-LSTM reasoners next to the headline (outside the timed region): transformer_lstm (BASELINE.json
+    config 3's model; `heads` = configs/transformer_lstm_config.json's 2) and baseline_lstm at the batches 1, the reference's 16
+    (configs/training_config.json) and 32.  One step = forward + L1 + backward + Adam (training_main.py:183-217), dropout 0.1 live
+    in the encoder.  FLOP per step counted from the model (forward: SURVEY.md 8-d4; backward: twice the forward, + the attention
+    backward's recomputed score and dP tiles: 7 instead of 4 products of S^2 E MACs per layer)."""
+    from objectpermanence_amd import ModelsFactory, _lib
+    from synthdata import opnet as synth
+    lib = _lib.load()
+    base_b, base_l = synth.make_batch(7000, 32, T_FRAMES)
+    xb = torch.from_numpy(synth.boxes5(base_b)).to(dev)
+    yb = torch.from_numpy(base_l).to(dev)
+    # ---- transformer_lstm ----
+    tx = {"workload": f"transformer_lstm (d_model 256, {heads} heads, 2 encoder layers, 2 x LSTM 512) training step: forward + L1 + "
+                      "backward + Adam, dropout 0.1; one minibatch = ONE sequence of B x 300 tokens (the reference's sequence-first encoder)",
+          "batches": {}}
+    for B in (1, 16, 32):
+        S = B * T_FRAMES
+        torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+        held = torch.cuda.memory_allocated(dev)          # (what the earlier blocks of this process still hold)
+        model, _ = _transformer_model(heads, dev)        # a fresh model per batch size: its workspaces are this batch's
+        model.train(True)
+        ms, loss, prof = _train_step_ms("transformer_lstm", model, xb[:B].contiguous(), yb[:B].contiguous(), dev, lib)
+        tok = 2 * S * (E_TX * 3 * E_TX + E_TX * E_TX + 2 * E_TX * FFN_TX) * 2           # token-wise products, both layers (flop)
+        att_u = 2 * S * S * E_TX                                                        # one S x S x E product over all heads (flop)
+        fwd = tok + 2 * 2 * att_u + B * TX_STACK_FLOP
+        bwd = 2 * tok + 2 * 7 * att_u + 2 * B * TX_STACK_FLOP
+        a_f, a_b = prof["attention_forward"], prof["attention_backward"]
+        blk = {"ms_per_step": round(ms, 3), "clips_per_s": round(B / ms * 1e3, 1), "tokens": S, "loss": round(loss, 5),
+               "flop_per_step": int(fwd + bwd),
+               "mfma_frac": round((fwd + bwd) / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+               "kernel_ms": {k: round(v[0], 4) for k, v in prof.items()}, "kernel_launches": {k: v[1] for k, v in prof.items()},
+               "peak_device_bytes": int(torch.cuda.max_memory_allocated(dev) - held)}
+        if a_b[0] > 0:      # the dominant kernels: the attention backward passes of the two layers (prep + dQ pass + dK / dV pass)
+            tf = 2 * 7 * att_u / (a_b[0] * 1e-3) / 1e12
+            blk["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+                               "kernel": "attention_bwd<128, false> (dQ) + attention_bwd<128, true> (dK, dV) of both layers, HIP events around "
+                                         "each layer's launches", "alg_flop": int(2 * 7 * att_u)}
+            blk["attention_forward_mfma_frac"] = round(2 * 2 * att_u / (a_f[0] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if a_f[0] > 0 else None
+        tx["batches"][str(B)] = blk
+        del model
+    # ---- baseline_lstm ----
+    cfg = {"videos_hidden_dim": 512}
+    bl = ModelsFactory.get_model("baseline_lstm", cfg)
+    bl.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.baseline_lstm_synth_params(cfg).items()})
+    bl.to(dev).train(True)
+    bflop = 2 * T_FRAMES * 4 * H_TX * (80 + H_TX)
+    bs = {"workload": "baseline_lstm (LSTM 75 -> 512 + Linear 512 -> 4) training step: forward + L1 + backward + Adam", "batches": {}}
+    for B in (1, 16, 32):
+        ms, loss, prof = _train_step_ms("baseline_lstm", bl, xb[:B].contiguous(), yb[:B].contiguous(), dev, lib)
+        f, b_ = prof["seqx_forward"], prof["seqx_backward"]
+        blk = {"ms_per_step": round(ms, 3), "clips_per_s": round(B / ms * 1e3, 1), "loss": round(loss, 5),
+               "flop_per_step": int(3 * B * bflop), "mfma_frac": round(3 * B * bflop / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+               "kernel_ms": {"seqx_forward": round(f[0], 4), "seqx_backward": round(b_[0], 4)}}
+        if b_[0] > 0:
+            # the reverse recurrence: W_hh^T da per step = 2 x 4H x H flop per clip; latency-bound by construction (one 4-clip group
+            # per XCD, 300 dependent steps with an exchange between the XCD's 32 CUs each)
+            tf = B * 2 * T_FRAMES * 4 * H_TX * H_TX / (b_[0] * 1e-3) / 1e12
+            blk["roofline"] = {"bound": "mfma", "achieved": round(tf, 3), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": round(tf / MFMA_F32_PEAK_TF, 5), "kernel": "seqx_backward<1> (one persistent launch per backward)",
+                               "us_per_reverse_step": round(b_[0] * 1e3 / T_FRAMES, 3)}
+        bs["batches"][str(B)] = blk
+    return {"transformer_training": tx, "baseline_lstm_training": bs}
+
+
 def bench_transformer(args, world, rank, dev, dist):
     """BASELINE.json config 3: transformer_lstm (d_model 256, `--heads` heads, 2 encoder layers, 2 LSTM layers of 512).  One step
     = one REQUEST of `--batch` clips (default ONE clip: seq_len S = 300 - the reference's sequence-first encoder attends over
@@ -783,7 +937,7 @@ def launch_ranks(args) -> int:
     return subprocess.call(cmd)
 
 
-def launcher_selftest(world, rank, mode="infer", batch=32):
+def launcher_selftest(world, rank, mode="infer", batch=32, strong=False):
     """rendezvous + one collective on gloo: what `--gpus N` has to get right before any GPU work (CPU test).  --mode train
     additionally runs config 5's exchange - the flat OPNet gradient bucket (1 421 056 floats + the guard slot) through
     parallel.GradBucket.all_reduce, weighted n_local / n_global - on CPU tensors, and reports the line's config block."""
@@ -808,6 +962,7 @@ def launcher_selftest(world, rank, mode="infer", batch=32):
         assert bucket.flat.numel() == W_BYTES // 4 and torch.allclose(bucket.flat, torch.full_like(bucket.flat, want))
         assert float(bucket.guard[0]) == 1.0 and float(bucket.guard[1]) == 0.0    # every rank sees that SOME rank aborted
         out.update({"mode": "train", "grad_bucket_floats": int(bucket.flat.numel()), "guard_after_allreduce": float(bucket.guard[0]),
+                    "scaling": "strong" if strong else "weak", "batch_per_gpu": batch,
                     "config": {"global_batch": world * batch, "parallelism": f"dp{world}"}})
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -824,7 +979,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if args.launcher_selftest:
-        return launcher_selftest(world, rank, args.mode, args.batch or 32)
+        if args.global_batch is not None and args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} GPUs")
+        return launcher_selftest(world, rank, args.mode, args.global_batch // world if args.global_batch is not None else (args.batch or 32),
+                                 strong=args.global_batch is not None)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     quiet_stdout()
@@ -860,6 +1018,12 @@ def main():
     from objectpermanence_amd import ModelsFactory
     from synthdata import opnet as synth
 
+    if args.global_batch is not None:
+        if args.mode != "train":
+            raise SystemExit("--global-batch is a --mode train option (BASELINE.json config 5)")
+        if args.global_batch <= 0 or args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} GPUs")
+        args.batch = args.global_batch // world
     args.batch = args.batch or 32
     B = args.batch
     params = synth.opnet_synth_params(CFG)
@@ -903,7 +1067,10 @@ def main():
         out.update(other_batches(model, boxes, dev))
         out.update(training_block(params, boxes, labels, dev))
         out.update(transformer_block(dev))
+        out.update(siblings_training_block(dev))
         out.update(detector_block(dev))
+        if world == 1:
+            out.update(inference_from_files_block())
         if world == 1 and not args.no_cpu_baseline:
             cb, y_cpu = cpu_baseline(boxes_np, params, args.cpu_seconds)
             out["cpu_baseline"] = cb
@@ -1214,6 +1381,8 @@ def bench_infer_xcd(args, model, batches, world, rank, dev, dist):
                 f"({per_launch * B} clips) as one per-XCD persistent forward",
                 {"engine": "xcd", "batches_per_launch": per_launch, "launches": launches,
                  "distinct_clips_per_timed_region": min(nd, args.steps) * B}, spread=(t_min, t_max))
+    out["value_is"] = (f"median over the repeats of the timed region; a repeat is {launches} persistent launch(es) of {clips // max(launches, 1)} "
+                       "clips (about 5 ms of GPU time): the spread value_min..value_max is the spread over single launches")
     if proof is not None:
         out["collective"] = proof
     cpl = clips // max(launches, 1)

@@ -103,7 +103,8 @@ int opnet_xcd_profile(int enable);
 int opnet_xcd_profile_read(double *kernel_ms_total, int *launches);
 /* the same for the other profiled kernels while opnet_xcd_profile(1) is on: tag 0 = opnet_xcd_forward, 1 = seqx_forward (the
  * persistent stacked LSTM), 2 = the attention kernel(s) of an encoder layer's attention call, 3 = seqt_forward, 4 = the fused
- * feed-forward kernel of an encoder layer */
+ * feed-forward kernel of an encoder layer, 5 / 6 = the flash attention launches of an encoder layer's TRAINING forward / backward
+ * (csrc/attn_train_kernels.hip), 7 = seqx_backward (the stacked LSTM's reverse recurrence as one launch) */
 int opnet_kernel_profile_read(int tag, double *kernel_ms_total, int *launches);
 /* tools: device buffer of >= (T+1) * ceil(B/128) * 8 uint64 receiving s_memtime stamps of block 0 (NULL = off) */
 void opnet_xcd_set_trace(void *device_buffer);

@@ -36,6 +36,7 @@ def get_classes_predictions(predictions: np.ndarray) -> List[int]:
     return get_class_predictions(p[:, 0] * 2 / W_FRAME - 1, p[:, 1] * 2 / H_FRAME - 1, nrows=3, ncols=3).tolist()
 
 
+@parallel.bounded_host_threads
 def cater_setup_inference(model_name: str, results_dir: str, inference_config_path: str, model_config_path: str) -> pd.DataFrame:
     with open(inference_config_path, "rb") as f:
         config: Dict[str, str] = json.load(f)

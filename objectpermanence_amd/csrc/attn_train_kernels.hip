@@ -50,8 +50,9 @@ struct AttTrainFwdArgs {
 
 // QF = 1 form of attention_glds with the two things training needs: the dropout multiplier on the probabilities that multiply V
 // (the row sum stays the sum of the UNdropped exponentials) and the softmax statistics written out.
-template <int HD>
-__global__ void __launch_bounds__(256) attention_train_fwd(const AttTrainFwdArgs a)
+// DROP = 0: no dropout; 1: counter generator; 2: test-only mask table (as in attention_bwd below)
+template <int HD, int DROP>
+__global__ void __launch_bounds__(256, 2) attention_train_fwd(const AttTrainFwdArgs a)
 {
     constexpr int NS = 3, PPR = HD / 4, NHEX = HD / 16, NC = (HD + 63) / 64, TI = HD / 16, LPS = (2 * TI + 3) / 4, TILE_F4 = 16 * PPR;
     __shared__ __attribute__((aligned(1024))) float4 smem[NS * 2 * TILE_F4];
@@ -111,6 +112,7 @@ __global__ void __launch_bounds__(256) attention_train_fwd(const AttTrainFwdArgs
         for (int e = 0; e < 4; ++e) o[c][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
     const unsigned long long idx_q = ((unsigned long long)head * S + (unsigned long long)qi) * (unsigned long long)S;
+    const unsigned dkey = DROP == 1 ? enc_key(a.ds.seed, a.ds.site) : 0u;
 
     const int nall = (S + 15) >> 4;
     const int per = (nall + (int)gridDim.z - 1) / (int)gridDim.z;
@@ -166,11 +168,13 @@ __global__ void __launch_bounds__(256) attention_train_fwd(const AttTrainFwdArgs
         ps += __shfl_xor(ps, 32);
         l_run = l_run * alpha + ps;
         m_run = m_new;
-        if (a.thresh) {
+        if constexpr (DROP != 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + 4 * kk + r;
-                if (key < S) p[r] *= enc_keep(a.ds, idx_q + (unsigned long long)key, a.thresh, a.inv_keep);
+                const unsigned long long idx = idx_q + (unsigned long long)key;
+                if constexpr (DROP == 1) p[r] *= enc_hash_keyed(dkey, idx) >= a.thresh ? a.inv_keep : 0.0f;
+                else p[r] *= (key < S && a.ds.mask[idx]) ? a.inv_keep : 0.0f;      // (keys past S: p = 0 already)
             }
         }
         const bool rescale = __any(alpha != 1.0f);

@@ -127,7 +127,10 @@ static int attn_sweep_split(long W, long ntiles, int zmax)
 template <int HD>
 static void launch_attn_train_fwd(const AttTrainFwdArgs &a, int nhead, int KS, hipStream_t st)
 {
-    attention_train_fwd<HD><<<dim3((unsigned)((a.S + 63) / 64), nhead, KS), 256, 0, st>>>(a);
+    const dim3 g((unsigned)((a.S + 63) / 64), nhead, KS);
+    if (a.thresh == 0u) attention_train_fwd<HD, 0><<<g, 256, 0, st>>>(a);
+    else if (a.ds.mask) attention_train_fwd<HD, 2><<<g, 256, 0, st>>>(a);
+    else attention_train_fwd<HD, 1><<<g, 256, 0, st>>>(a);
 }
 template <int HD, int DROP>
 static void launch_attn_bwd_d(const AttBwdArgs &a, bool dkv, int AF, int nhead, int ZS, hipStream_t st)
@@ -333,10 +336,12 @@ extern "C" int opseq_encoder_layer_train_forward_f32(const float *z_in, float *z
     if (flash) {
         // all heads in ONE launch, the scores in registers (attn_train_kernels.hip); a key split when the workgroup count is a
         // small non-multiple of the CU count (partials in tA / tB, idle in the forward)
+        ProfPair pe{};
+        const bool prof = prof_begin(st, &pe);
         AttTrainFwdArgs fa = {};
         fa.qkv = qkv; fa.att = att; fa.stats = (float2 *)(sv + SV.astat);
         fa.S = (int)S; fa.E = E; fa.scale = scale; fa.ds = D.at(0u); fa.thresh = D.thresh; fa.inv_keep = D.inv_keep;
-        int KS = attn_sweep_split(((S + 63) / 64) * nhead, (S + 15) / 16, 4);
+        int KS = attn_sweep_split(((S + 63) / 64) * nhead, (S + 15) / 16, 8);
         while (KS > 1 && (size_t)KS * S * E + (size_t)KS * S * nhead * 2 > SC.tAB) --KS;
         fa.opart = sc + SC.tA;
         fa.ml = (float2 *)(sc + SC.tA + (size_t)KS * S * E);
@@ -351,6 +356,7 @@ extern "C" int opseq_encoder_layer_train_forward_f32(const float *z_in, float *z
             attention_train_merge<<<(unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), 256, 0, st>>>(fa.opart, fa.ml, att, fa.stats,
                                                                                                            (int)S, E, nhead, KS);
         }
+        if (prof) prof_end(PROF_ATTN_TF, st, pe);
     }
     for (int h = 0; h < nhead && !flash; ++h) {
         float *Vt = sc + SC.hT;
@@ -416,7 +422,7 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
     // workgroup left a one-clip step with 5 workgroups walking 16 rows per wave (37 us a launch)
     const long wide_ = ffn > 3 * E ? ffn : 3 * E;
     long nb_cap = ((S + 63) / 64) * (wide_ / E);
-    if (nb_cap > 2048) nb_cap = 2048;
+    if (nb_cap > 256) nb_cap = 256;                  // (enc_colsum_final walks the workgroups' partial sums one by one)
     const int ln_rows = (int)(((S + nb_cap - 1) / nb_cap + 3) / 4 * 4);
     const int nb_ln = (int)((S + ln_rows - 1) / ln_rows), nb_cs = (int)((S + 63) / 64);
     auto colsum = [&](const float *X, long ld, int N, float *out) {
@@ -463,6 +469,8 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
     if (flash) {
         // two launches for all heads: the query-stationary pass (dQ) and the key-stationary pass (dK, dV), each recomputing its score
         // and dP tiles in registers from q, k, v, dO and the forward's row statistics (attn_train_kernels.hip)
+        ProfPair pe{};
+        const bool prof = prof_begin(st, &pe);
         float4 *st4 = (float4 *)(sc + SC.st4);
         attention_bwd_prep<<<(unsigned)((S * nhead + 3) / 4), 256, 0, st>>>(e2, att, (const float2 *)(sv + SV.astat), st4, (int)S, E, nhead);
         AttBwdArgs ba = {};
@@ -496,6 +504,7 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
                                                                                                               ba.out1, 3 * E, S, E);
             }
         }
+        if (prof) prof_end(PROF_ATTN_TB, st, pe);
     }
     for (int h = 0; h < nhead && !flash; ++h) {
         transpose_to(e2 + h * hd, E, dOt, Sp, S, hd, st);                                     // dO^T [hd][query]

@@ -406,7 +406,10 @@ static int g_xcd_cus[64] = {};
 #define PROF_ATTN 2
 #define PROF_SEQT 3
 #define PROF_FFN 4          // the fused feed-forward kernel of an encoder layer (csrc/ffn_kernels.hip)
-#define PROF_TAGS 5
+#define PROF_ATTN_TF 5      // training attention, forward: attention_train_fwd (+ merge) of one layer call (csrc/attn_train_kernels.hip)
+#define PROF_ATTN_TB 6      // training attention, backward: prep + the dQ pass + the dK / dV pass (+ reduces) of one layer call
+#define PROF_SEQXB 7        // seqx_backward: the stacked LSTM's reverse recurrence as one launch (csrc/seq_xcd_bwd_kernels.hip)
+#define PROF_TAGS 8
 typedef std::pair<hipEvent_t, hipEvent_t> ProfPair;
 static bool g_xcd_prof = false;
 static std::vector<ProfPair> g_prof_ev[PROF_TAGS];
@@ -2472,7 +2475,7 @@ extern "C" int opseq_lstm_stack_train_backward_f32(const float *dy, const float 
             const bool prof = prof_begin(st, &pe);
             if (L == 1) seqx_backward<1><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sb);
             else seqx_backward<2><<<XCD_COUNT * XCD_CUS, 256, 0, st>>>(sb);
-            if (prof) prof_end(PROF_SEQX, st, pe);
+            if (prof) prof_end(PROF_SEQXB, st, pe);
             HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
         }
     } else {

@@ -22,13 +22,14 @@
 // values per lane by the cell wave.  The chunks travel through rings of 4 steps whose words hold a sentinel until published
 // ("the data is the flag", re-armed two steps on: opnet_xcd4_kernels.hip has the safety argument).
 // L = 2: the top layer's XCD also multiplies W_ih1^T (AccVGPR operands) by its da into partial dh rows of the LOWER layer,
-// reduces them among its own CUs (waves 2, 3 gather beside waves 0, 1; wave 1 finishes the sum a phase later, off the
-// recurrence's critical chain) and writes the 256 B per CU and step into a FULL-history buffer for the lower layer's XCD: every
+// reduces them among its own CUs (waves 2, 3 gather beside waves 0, 1, one phase late; wave 1 finishes the sum a phase after
+// that, off the recurrence's critical chain) and writes the 256 B per CU and step into a FULL-history buffer for the lower layer's XCD: every
 // word written once per launch, so the two layers are a pipeline without flow control, as in the forward.
 // Phase (group gi, n), t = T - 1 - n:
 //   A. wave 0: dh = sum of the 32 chunks + upstream -> cell backward -> da -> LDS and the gate history; barrier
 //   B. every wave: its 128 output rows x the CU's 64 gate rows (128 MFMAs; + 128 for W_ih1^T) -> the owners' chunks
-//   C. waves 0, 1: the next phase's chunks (sentinel-polled); top of L = 2, waves 2, 3: this step's lower-layer chunks; barrier
+//   C. waves 0, 1: the next phase's chunks (sentinel-polled); top of L = 2, waves 2, 3: the PREVIOUS phase's lower-layer chunks
+//      (published a phase ago: with two or more groups per XCD pair nothing in a phase waits for that phase's products); barrier
 // Every poll is bounded (XCD_SPIN_LIMIT): an abort raises status[0] (sticky: the optimiser's guard and the weight-gradient
 // launch see it, the gradients are NaN), every poller leaves.
 // (included by opnet_abi.hip after seq_xcd_kernels.hip, opnet_xcd4_kernels.hip and opnet_train_kernels.hip: it uses their helpers)
@@ -201,8 +202,11 @@ __global__ void __launch_bounds__(256) seqx_backward(const SeqXBArgs a)
     fetch(0, 0, cg, cdy, cct, ccp);
     ask_dx(0, 0);
 
-    int gi = 0, n = 0, gprev = 0, nprev = -1;
-    for (int p = 0; p <= nph; ++p) {
+    // (top of L = 2) the lower layer's dh lags the recurrence: the chunks of phase p are gathered in phase p + 1 - they were published a
+    // phase ago, so with two or more groups per XCD pair no gather of a phase waits for this phase's products - and summed and
+    // handed over in phase p + 2
+    int gi = 0, n = 0, g1 = 0, n1 = -1, g2 = 0, n2 = -1;       // (g1, n1): the previous phase, (g2, n2): the one before
+    for (int p = 0; p <= nph + 1; ++p) {
         const bool work = p < nph;
         const int buf = p & 1;
         const int G = gi * NPAIR + pr, t = T - 1 - n;
@@ -211,8 +215,8 @@ __global__ void __launch_bounds__(256) seqx_backward(const SeqXBArgs a)
         const bool more = p + 1 < nph;
         bool ok = true;
         if (work && more) fetch(gn, nn, ng_, ndy, nct, ncp);
-        // ================================ A. the cell of this phase (wave 0); top of L = 2, wave 1: the lower layer's dh of the
-        //                                     PREVIOUS phase's step (its chunks were summed four by four at the end of that phase)
+        // ================================ A. the cell of this phase (wave 0); top of L = 2, wave 1: the lower layer's dh of the phase
+        //                                     before the previous one (its chunks were summed four by four at the end of the last phase)
         if (w == 0 && work) {
             float rec = 0.f;
             if (n > 0) {
@@ -247,16 +251,17 @@ __global__ void __launch_bounds__(256) seqx_backward(const SeqXBArgs a)
             const int rb = (4 * G) >> 5, cl = ((4 * G) & 31) + j;
             ((float4 *)(a.ws + g_mine))[(((size_t)t * RB + rb) * SX_H + 16 * c + b) * 32 + cl] = da;
         }
-        if (w == 1 && dxon && nprev >= 0) {
-            const float *prp = (const float *)&sDX[buf][0][0] + ((b >> 2) * 4 + j) * 4 + (b & 3);
+        if (w == 1 && dxon && n2 >= 0) {
+            const float *prp = (const float *)&sDX[buf ^ 1][0][0] + ((b >> 2) * 4 + j) * 4 + (b & 3);
             float r0 = 0.f, r1 = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) { r0 += prp[q * 64]; r1 += prp[256 + q * 64]; }
-            const int Gp = gprev * NPAIR + pr, tp = T - 1 - nprev;
+            const int Gp = g2 * NPAIR + pr, tp = T - 1 - n2;
             xcd_store4(rws, lane4, a.dxh_off + ((unsigned)(Gp * T + tp) * 32 + c) * 256, r0 + r1, false);   // write-through: read on another XCD
         }
-        if (!work) break;
+        if (p > nph) break;
         if (!ok) XCD_LDS_ST(sAbort, 1);
+        if (work) {
         __syncthreads();                        // barrier 1: the CU's da of the phase is in LDS
         // ================================ B. products: the CU's 64 gate rows x its da -> partial dh rows of every unit =========
         {
@@ -287,25 +292,26 @@ __global__ void __launch_bounds__(256) seqx_backward(const SeqXBArgs a)
             // lane (block bb = b, clip j) holds rows 4 b .. 4 b + 3 of its row set = one float4 of the owner's chunk:
             //   row 128 w + 64 set + 4 b + i -> owner 8 w + 4 set + (b >> 2), unit quad b & 3
             const unsigned vo = (((b >> 2) * 32) * 16 + (b & 3) * 4 + j) * 16;           // owner stride: 32 producers x 16 float4
-            const unsigned slot = (unsigned)(G * SXB_SLOTS + (t & 3)), rearm = (unsigned)(G * SXB_SLOTS + ((t + 2) & 3));
-            if (t > 0) {                        // (the products of da_0 would feed dh_{-1})
+            const unsigned slot = (unsigned)(G * SXB_SLOTS + (t & 3));
+            if (t > 0) {                        // (the products of da_0 would feed dh_{-1}); re-armed two steps on
                 const sx_f32x4 d2a = (e2a[0] + e2a[1]) + (e2a[2] + e2a[3]), d2b = (e2b[0] + e2b[1]) + (e2b[2] + e2b[3]);
                 const unsigned so = ring_mine + ((slot * 32 + 8 * w) * 32 + c) * 256;
-                const unsigned sr = ring_mine + ((rearm * 32 + 8 * w) * 32 + c) * 256;
+                const unsigned sr = ring_mine + (((unsigned)(G * SXB_SLOTS + ((t + 2) & 3)) * 32 + 8 * w) * 32 + c) * 256;
                 xcd_store16(rws, vo, so, make_float4(d2a[0], d2a[1], d2a[2], d2a[3]), local);
                 xcd_store16(rws, vo, so + 4 * 32 * 256, make_float4(d2b[0], d2b[1], d2b[2], d2b[3]), local);
                 xcd_store16(rws, vo, sr, sentf, local);
                 xcd_store16(rws, vo, sr + 4 * 32 * 256, sentf, local);
             }
-            if (dxon) {
+            if (dxon) {                         // re-armed THREE steps on: its readers gather a phase late
                 const sx_f32x4 d2a = (f2a[0] + f2a[1]) + (f2a[2] + f2a[3]), d2b = (f2b[0] + f2b[1]) + (f2b[2] + f2b[3]);
                 const unsigned so = a.dxring_off + ((slot * 32 + 8 * w) * 32 + c) * 256;
-                const unsigned sr = a.dxring_off + ((rearm * 32 + 8 * w) * 32 + c) * 256;
+                const unsigned sr = a.dxring_off + (((unsigned)(G * SXB_SLOTS + ((t + 3) & 3)) * 32 + 8 * w) * 32 + c) * 256;
                 xcd_store16(rws, vo, so, make_float4(d2a[0], d2a[1], d2a[2], d2a[3]), local);
                 xcd_store16(rws, vo, so + 4 * 32 * 256, make_float4(d2b[0], d2b[1], d2b[2], d2b[3]), local);
                 xcd_store16(rws, vo, sr, sentf, local);
                 xcd_store16(rws, vo, sr + 4 * 32 * 256, sentf, local);
             }
+        }
         }
         // ================================ C. the next phase's inputs =========================================================
         if (w < 2) {
@@ -314,9 +320,10 @@ __global__ void __launch_bounds__(256) seqx_backward(const SeqXBArgs a)
                 const unsigned src = ring_mine + ((Gn * SXB_SLOTS + ((T - nn) & 3)) * 32 + c) * 8192 + w * 4096;
                 if (!x4_gather_sum4(rws, lane16, src, true, &sR[buf ^ 1][w][lane], a.status, p)) ok = false;
             }
-        } else if (dxon) {
-            const unsigned src = a.dxring_off + (((unsigned)G * SXB_SLOTS + (t & 3)) * 32 + c) * 8192 + (w - 2) * 4096;
-            if (!x4_gather_sum4(rws, lane16, src, true, &sDX[buf ^ 1][w - 2][lane], a.status, p)) ok = false;
+        } else if (dxon && n1 >= 0) {
+            const unsigned G1 = (unsigned)(g1 * NPAIR + pr);
+            const unsigned src = a.dxring_off + ((G1 * SXB_SLOTS + ((T - 1 - n1) & 3)) * 32 + c) * 8192 + (w - 2) * 4096;
+            if (!x4_gather_sum4(rws, lane16, src, true, &sDX[buf][w - 2][lane], a.status, p)) ok = false;
         }
         if (more) ask_dx(gn, nn);
         if (!ok) XCD_LDS_ST(sAbort, 1);
@@ -324,7 +331,8 @@ __global__ void __launch_bounds__(256) seqx_backward(const SeqXBArgs a)
         __syncthreads();                        // barrier 2: the next phase's chunks have landed
         if (abort_seen) return;
         abort_seen = XCD_LDS_LD(sAbort);
-        gprev = gi; nprev = n;
+        g2 = g1; n2 = n1;
+        g1 = gi; n1 = work ? n : -1;
         gi = gn; n = nn;
         cg = ng_; cdy = ndy; cct = nct; ccp = ncp;
     }

@@ -46,6 +46,7 @@ def write_bb_predictions_to_file(video_name: str, results_dir: str, predictions)
     return str(path)
 
 
+@parallel.bounded_host_threads
 def reasoning_inference_main(model_name: str, results_dir: str, inference_config_path: str, model_config_path: str,
                              write_files: bool = True) -> Dict[str, object]:
     with open(inference_config_path, "rb") as f:

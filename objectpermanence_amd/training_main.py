@@ -122,6 +122,7 @@ def training_batches(model_name: str, n_items: int, batch_size: int, world: int,
     return steps
 
 
+@parallel.bounded_host_threads
 def training_main(model_name: str, train_config: Dict[str, Any], model_config: Dict[str, int]) -> Dict[str, Any]:
     # the JSON's device (training_main.py:144) - or cuda:LOCAL_RANK when this process is one rank of a torchrun job
     device = parallel.resolve_device(train_config["device"])

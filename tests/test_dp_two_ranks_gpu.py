@@ -157,7 +157,7 @@ def test_training_entry_point_at_world_size_two_checkpoints_the_single_process_w
         assert float((a[k].float() - b[k].float()).abs().max()) <= 1e-4, k
 
 
-@pytest.mark.parametrize("mode_args", [["--engine", "chain"], ["--mode", "train"]])
+@pytest.mark.parametrize("mode_args", [["--engine", "chain"], ["--mode", "train"], ["--mode", "train", "--global-batch", "8"]])
 def test_bench_as_two_ranks_prints_one_line_from_rank_zero(tmp_path, mode_args):
     """the driver's `--gpus N` command, rehearsed at N = 2 on the one GPU (gloo, launch-chain engines): the barrier / max-over-ranks
     timing, the periodic all-gather of predictions (inference) or the bucket all-reduce (training) run, rank 0 prints exactly one JSON
@@ -173,7 +173,11 @@ def test_bench_as_two_ranks_prints_one_line_from_rank_zero(tmp_path, mode_args):
     out0, out1 = res[0][0].decode().strip(), res[1][0].decode().strip()
     assert out1 == "" and len(out0.splitlines()) == 1
     line = json.loads(out0)
-    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2"
+    if "--global-batch" in mode_args:       # BASELINE.json config 5 at its FIXED global batch: per-rank batch = global / N
+        assert line["scaling"] == "strong" and line["config"]["global_batch"] == 8 and "batch=4 clips/GPU" in line["config"]["workload"]
+    else:
+        assert line["scaling"] == "weak"
     assert line["value"] > 0 and line["steps"] == 3 and line["warmup"] == 1
     # the line answers "did the collective see N ranks" itself
     assert line["collective"]["backend"] == "gloo" and line["collective"]["ranks_seen"] == line["collective"]["world_size"] == 2

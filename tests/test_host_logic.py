@@ -285,7 +285,13 @@ def test_bench_train_mode_launches_ranks_and_reduces_the_gradient_bucket():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["mode"] == "train" and out["grad_bucket_floats"] == 1_421_056 and out["guard_after_allreduce"] == 1.0
-    assert out["config"] == {"global_batch": 64, "parallelism": "dp2"}
+    assert out["config"] == {"global_batch": 64, "parallelism": "dp2"} and out["scaling"] == "weak"
+    # config 5 at its fixed global batch: 256 clips over the ranks, "strong"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--mode", "train", "--global-batch", "256",
+                        "--launcher-selftest"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"] == {"global_batch": 256, "parallelism": "dp2"} and out["scaling"] == "strong" and out["batch_per_gpu"] == 128
 
 
 def test_bench_refuses_more_gpus_than_the_node_has():
