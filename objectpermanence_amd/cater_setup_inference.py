@@ -60,7 +60,10 @@ def cater_setup_inference(model_name: str, results_dir: str, inference_config_pa
     # every minibatch is a request to the server (clip-independent reasoners: concatenated into one persistent launch;
     # transformer_lstm*: merged as segments); of each output only the LAST frame is kept (:77) - 16 B per clip - as soon as its
     # forward is seen complete and clean; one host copy at the end instead of a .cpu() per minibatch
-    server = ReasonerServer(model, model_name)
+    # evaluation is deterministic per call in the reference: a request's result must not depend on what else shares its pass.  The
+    # throughput form of the segmented models (transformer_lstm*: large-tile GEMMs, 16-clip LSTM groups - results equal to rounding
+    # only) is an explicit choice: "exact_serving": false in the inference config
+    server = ReasonerServer(model, model_name, exact=bool(config.get("exact_serving", True)))
     names: List[str] = []
     last: List[torch.Tensor] = []
 

@@ -2733,7 +2733,7 @@ static int encoder_layer(float *z, const float *in_w, const float *in_b, const f
     // chip: another K order, results agree with the lone forward to rounding)
     const int Ms = batched ? M : (int)S;
     // C[M][N] = act(A[M][K] W[N][K]^T + b) = a 1x1 "convolution" over M pixels: the LDS-staged tiled kernel
-    auto gemm = [&](const float *A, const float *Wt, const float *b, float *C, int N, int K, int act) {
+    auto gemm = [&](const float *A, const float *Wt, const float *b, float *C, int N, int K, int act) -> int {
         if ((long)((Ms + 127) / 128) * ((N + 127) / 128) < 256) {   // too few 128-tiles to fill the chip
             // ... and with fewer than 256 64-tiles (one clip: S = 300) even those leave CUs idle behind long serial K walks:
             // 32 x 32 tiles with K split over the workgroup's waves
@@ -2741,23 +2741,24 @@ static int encoder_layer(float *z, const float *in_w, const float *in_b, const f
                 gemm_bias_act_ks<<<dim3((M + 31) / 32, (N + 31) / 32, 1), 256, 0, st>>>(A, Wt, b, C, M, N, K, act);
             else
                 gemm_bias_act<<<dim3((M + 63) / 64, (N + 63) / 64, 1), 256, 0, st>>>(A, Wt, b, C, M, N, K, act);
-            return;
+            return OPNET_OK;
         }
         ConvArgs c = {};
         c.X = A; c.Wt = Wt; c.bias = b; c.R = nullptr; c.Y = C;
         c.N = 1; c.H = 1; c.W = M; c.Cin = K; c.Cout = N; c.KH = 1; c.KW = 1; c.stride = 1; c.pad = 0;
         c.OH = 1; c.OW = M; c.KP = K; c.relu = act;
-        if (batched) (void)launch_gemm_k256(c, M, st);      // (K = 256 products of a throughput pass: the resident-token tile, same bits)
-        else launch_conv_tiled(c, M, st);
+        if (batched) return launch_gemm_k256(c, M, st);     // (K = 256 products of a throughput pass: the resident-token tile, same bits)
+        launch_conv_tiled(c, M, st);
+        return OPNET_OK;
     };
-    gemm(z, in_w, in_b, qkv, 3 * E, E, 0);
+    if (int rc = gemm(z, in_w, in_b, qkv, 3 * E, E, 0)) return rc;
     {
         ProfPair pe{};
         const bool prof = prof_begin(st, &pe);
         launch_attention(qkv, att, (int)S, nseg, E, nhead, hd, hid, (size_t)St * ffn * sizeof(float), st);   // hid is free until the FFN
         if (prof) prof_end(PROF_ATTN, st, pe);
     }
-    gemm(att, out_w, out_b, proj, E, E, 0);
+    if (int rc = gemm(att, out_w, out_b, proj, E, E, 0)) return rc;
     add_layernorm<<<(M + 3) / 4, 256, 0, st>>>(z, proj, n1_w, n1_b, z1, M, E, 1e-5f);
     // the throughput form runs the feed-forward block as one kernel (csrc/ffn_kernels.hip: the [M][ffn] activations never leave the
     // CU; the same bits as the two products below); the exact form keeps the lone request's K-split products
@@ -2767,8 +2768,8 @@ static int encoder_layer(float *z, const float *in_w, const float *in_b, const f
         if (int rc = launch_ffn_fused(z1, l1_w, l1_b, l2_w, l2_b, proj, M, ffn, st)) return rc;
         if (prof) prof_end(PROF_FFN, st, pe);
     } else {
-        gemm(z1, l1_w, l1_b, hid, ffn, E, 1);
-        gemm(hid, l2_w, l2_b, proj, E, ffn, 0);
+        if (int rc = gemm(z1, l1_w, l1_b, hid, ffn, E, 1)) return rc;
+        if (int rc = gemm(hid, l2_w, l2_b, proj, E, ffn, 0)) return rc;
     }
     add_layernorm<<<(M + 3) / 4, 256, 0, st>>>(z1, proj, n2_w, n2_b, z, M, E, 1e-5f);
     HIP_TRY(hipGetLastError());

@@ -200,14 +200,26 @@ class ClipFileError(ValueError):
 _refusal_warned = False
 
 
+# Refusals that only say "a plain numeric array in a layout the native reader was not built for": the reference's pickle.load reads
+# such a file, and handing it to pickle.load is as safe as the file's numeric content.
+_BENIGN_REFUSALS = ("big-endian arrays are not read", "only C-contiguous arrays are read")
+
+
 def refused_by_native_reader(err: "ClipFileError") -> None:
-    """The restricted native reader refuses what it was not built for (a pkl rewritten by another numpy / pickle path, a
-    Fortran-ordered or big-endian array, object dtype ...) - the reference's pickle.load reads all of these.  By default the
-    caller falls back to pickle.load + encode for that minibatch and this warns once; OPNET_NATIVE_STRICT=1 (untrusted inputs:
-    nothing but the restricted reader may touch the files) makes the refusal final."""
+    """The restricted native reader refuses what it was not built for.  pickle.load executes what a file tells it to, and the files the
+    safe reader rejects as malformed or unexpected (an opcode outside the subset, a global other than numpy's ndarray / dtype
+    reconstruction, a REDUCE of something else, object dtypes ...) are exactly the ones that must NOT reach it - so a refusal is
+    final, with two exceptions: the benign layout refusals above (Fortran order, big-endian: plain numeric arrays
+    written by another numpy / platform) fall back to pickle.load + encode for that minibatch with one warning, and
+    OPNET_NATIVE_FALLBACK=1 opts in to that fallback for EVERY refusal (trusted files in a format this reader does not know).
+    OPNET_NATIVE_STRICT=1 makes every refusal final, the benign ones included."""
     global _refusal_warned
     if os.environ.get("OPNET_NATIVE_STRICT", "0") == "1":
         raise err
+    benign = any(m in str(err) for m in _BENIGN_REFUSALS)
+    if not benign and os.environ.get("OPNET_NATIVE_FALLBACK", "0") != "1":
+        raise ClipFileError(f"{err} - the file is NOT handed to pickle.load (set OPNET_NATIVE_FALLBACK=1 to read files you trust "
+                            "with pickle.load instead)") from err
     if not _refusal_warned:
         _refusal_warned = True
         import warnings

@@ -77,7 +77,10 @@ def reasoning_inference_main(model_name: str, results_dir: str, inference_config
     # every DataLoader minibatch is one request.  Clip-independent reasoners: pending requests are concatenated into one
     # forward; transformer_lstm* (attention couples the clips of a minibatch): merged as SEGMENTS - each minibatch still attends
     # only to itself, exactly the reference's per-minibatch call (serving.py)
-    server = ReasonerServer(model, model_name)
+    # evaluation is deterministic per call in the reference: a request's result must not depend on what else shares its pass.  The
+    # throughput form of the segmented models (transformer_lstm*: large-tile GEMMs, 16-clip LSTM groups - results equal to rounding
+    # only) is an explicit choice: "exact_serving": false in the inference config
+    server = ReasonerServer(model, model_name, exact=bool(config.get("exact_serving", True)))
 
     names: List[str] = []
     preds, ious = [], []

@@ -865,6 +865,12 @@ class _LstmStackRunner:
         if engine == "t":
             return self._run_xcdt(x, ws_list, head)
         if engine == "x":
+            # a caller may ask for the lone request's 4-clip engine on a merged pass that is larger than one such launch carries
+            # (OPSEQ_XCDT_MIN_BATCH raised above opseq_xcd_max_batch: ADVICE round 5): clips are independent in the stack, so the
+            # pass runs as several launches of whole 4-clip groups - every clip as in its lone forward
+            cap = int(_lib.load().opseq_xcd_max_batch(self.L))
+            if int(x.shape[0]) > cap:
+                return torch.cat([self._run_xcd(x[i:i + cap].contiguous(), ws_list, head) for i in range(0, int(x.shape[0]), cap)])
             return self._run_xcd(x, ws_list, head)
         return self._run_chain(x, ws_list, head)
 

@@ -87,13 +87,15 @@ def init_from_env(backend: Optional[str] = None) -> Launch:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if "MASTER_PORT" not in os.environ:
         if world > 1:
-            raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: start the ranks with torch.distributed.run (or export MASTER_ADDR / "
-                               "MASTER_PORT)")
-        # a forced group of one: any free port (a fixed one would collide between two such runs on one box)
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            # launchers that export only RANK / WORLD_SIZE / MASTER_ADDR (srun, mpirun wrappers): one deterministic default that every
+            # rank derives alike (README: export MASTER_PORT to run two such jobs on one node)
+            os.environ["MASTER_PORT"] = "29541"
+        else:
+            # a forced group of one: any free port (a fixed one would collide between two such runs on one box)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     # OPNET_DIST_BACKEND=gloo: several ranks on ONE device (RCCL refuses that) - how a box with a single GPU runs world size 2
     # (tests/test_dp_two_ranks_gpu.py); gloo moves device tensors through the host
     backend = backend or os.environ.get("OPNET_DIST_BACKEND") or ("nccl" if has_gpu else "gloo")
@@ -114,9 +116,23 @@ def shutdown(launch: Optional[Launch] = None, failed: bool = False) -> None:
         if failed:
             try:                             # (nccl: tears the communicator down without waiting for its peers; a no-op elsewhere)
                 from torch.distributed.distributed_c10d import _abort_process_group
-                _abort_process_group()
-            except Exception:
-                pass
+            except ImportError:
+                _abort_process_group = None
+            aborted = False
+            if _abort_process_group is not None:
+                try:
+                    _abort_process_group()
+                    aborted = True
+                except Exception:
+                    pass
+            if not aborted and dist.get_backend() == "nccl":
+                # a torch build without the (private) abort: the communicator cannot be torn down without its peers, and its teardown at
+                # interpreter exit would block on them - leave at once; the exception that brought us here has been printed by the caller
+                import sys
+                import traceback
+                traceback.print_exc()
+                sys.stderr.flush()
+                os._exit(1)
         else:
             try:
                 dist.barrier()

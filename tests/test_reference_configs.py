@@ -108,8 +108,9 @@ def _keys_read(path, names):
 
 DRIVERS = [  # (reference source, mirrored source, the reference's config file, keys the reference guards with `in` / only one mode reads)
     ("baselines/training_main.py", "objectpermanence_amd/training_main.py", "training_config.json", set()),
-    ("baselines/inference_main.py", "objectpermanence_amd/inference_main.py", "inference_config.json", {"sample_file"}),
-    ("baselines/cater_setup_inference.py", "objectpermanence_amd/cater_setup_inference.py", "inference_config.json", set()),
+    # ("exact_serving": an OPTIONAL key of this build, read with .get(..., True): absent from the reference's files, which run unchanged)
+    ("baselines/inference_main.py", "objectpermanence_amd/inference_main.py", "inference_config.json", {"sample_file", "exact_serving"}),
+    ("baselines/cater_setup_inference.py", "objectpermanence_amd/cater_setup_inference.py", "inference_config.json", {"exact_serving"}),
     ("baselines/preprocess_perception_main.py", "objectpermanence_amd/preprocess_perception_main.py", "preprocess_config.json",
      {"sample_file", "device"}),
 ]
