@@ -280,9 +280,11 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
     comm_ms = sum(a.elapsed_time(b) for a, b in comm_events) / max(len(comm_events), 1) if comm_events else None
     if rank == 0:
         from objectpermanence_amd import _lib
-        persistent = (B <= int(os.environ.get("OPNET_XCD4_MAX_B", "32")) and os.environ.get("OPNET_XCD4", "1") != "0"
-                      and bool(_lib.load().opnet_xcd_supported(CFG["object_to_track_hidden_dim"], CFG["videos_hidden_dim"])))
-        engine = "xcd4" if persistent else "chain"
+        x4_ok = (os.environ.get("OPNET_XCD4", "1") != "0"
+                 and bool(_lib.load().opnet_xcd_supported(CFG["object_to_track_hidden_dim"], CFG["videos_hidden_dim"])))
+        persistent = x4_ok and B <= int(os.environ.get("OPNET_XCD4_MAX_B", "32"))
+        fwd_persistent = x4_ok and B <= int(os.environ.get("OPNET_XCD4_MAX_B", os.environ.get("OPNET_XCD4_FWD_MAX_B", "96")))
+        engine = "xcd4" if persistent else ("xcd4 forward + chain backward" if fwd_persistent else "chain")
         kernels = ("opnet_xcd4_forward + opnet_xcd4_backward (the whole recurrence as ONE persistent launch each, 4-clip groups "
                    "per XCD, weights resident in registers) + opnet_wgrad" if persistent else
                    "opnet_step + opnet_bwd_fused (the 2 launches of a time step; opnet_bwd_gemm + opnet_bwd_cell above 128 clips) "

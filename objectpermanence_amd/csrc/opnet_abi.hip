@@ -1134,10 +1134,15 @@ extern "C" int opnet_xcd4_forward_f32(const float *boxes, const float *packed, f
 // Does the training step of this batch run on the 4-clip persistent kernels?  Reference hidden sizes, a whole device (8 XCDs
 // x 32 CUs), at most OPNET_XCD4_MAX_B clips (default 32: one group per XCD - larger batches serialise their row blocks and
 // the launch chain's wide step wins again), OPNET_XCD4 = 0 switches it off.
-static bool x4_use(int B, int T, int H1, int H2)
+// (Round 6: forward and reverse recurrence are routed separately.  Both kernels read and write the launch chain's own history
+// layouts, so a step may run its forward on the persistent kernel and its backward on the chain.  With two or three row blocks per
+// XCD the persistent FORWARD still wins - 64 clips 1.31 against 1.78 ms, 96 clips 2.01 against 2.66 - while the reverse recurrence,
+// whose phase is longer, loses from 33 clips on: 64 clips 2.32 against 2.22 ms.  OPNET_XCD4_MAX_B sets both limits.)
+static bool x4_use(int B, int T, int H1, int H2, bool forward = false)
 {
     if (!x4_batch(B, H1, H2) || !x4_on()) return false;
-    if (B > env_int("OPNET_XCD4_MAX_B", 32)) return false;
+    const int cap = getenv("OPNET_XCD4_MAX_B") ? env_int("OPNET_XCD4_MAX_B", 32) : (forward ? env_int("OPNET_XCD4_FWD_MAX_B", 96) : 32);
+    if (B > cap) return false;
     if (train_workspace_layout(B, T, H1, H2).total >= ((size_t)1 << 31)) return false;   // one buffer descriptor
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
@@ -1201,7 +1206,7 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
     const TrainWorkspaceLayout W = train_workspace_layout(B, T, H1, H2);
     hipStream_t st = (hipStream_t)stream;
     OpnetIO *dio = (OpnetIO *)((char *)workspace + W.io);
-    if (x4_use(B, T, H1, H2)) {
+    if (x4_use(B, T, H1, H2, true)) {
         // small batch on a whole device: the 4-clip persistent step (opnet_xcd4_kernels.hip) writes the same histories.  Three
         // launches per forward: prologue (device-side io, input pack, rings), the recurrence, output head + copies to the caller
         Xcd4Args x;
