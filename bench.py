@@ -284,11 +284,16 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
                  and bool(_lib.load().opnet_xcd_supported(CFG["object_to_track_hidden_dim"], CFG["videos_hidden_dim"])))
         persistent = x4_ok and B <= int(os.environ.get("OPNET_XCD4_MAX_B", "32"))
         fwd_persistent = x4_ok and B <= int(os.environ.get("OPNET_XCD4_MAX_B", os.environ.get("OPNET_XCD4_FWD_MAX_B", "96")))
-        engine = "xcd4" if persistent else ("xcd4 forward + chain backward" if fwd_persistent else "chain")
+        fwd16 = (x4_ok and not fwd_persistent and os.environ.get("OPNET_XCD_TRAIN", "1") != "0" and 96 < B <= 1024
+                 and B >= int(os.environ.get("OPNET_XCD_TRAIN_MIN_B", "97")))
+        engine = ("xcd4" if persistent else "xcd4 forward + chain backward" if fwd_persistent
+                  else "xcd (16-clip persistent) forward + chain backward" if fwd16 else "chain")
         kernels = ("opnet_xcd4_forward + opnet_xcd4_backward (the whole recurrence as ONE persistent launch each, 4-clip groups "
                    "per XCD, weights resident in registers) + opnet_wgrad" if persistent else
-                   "opnet_step + opnet_bwd_fused (the 2 launches of a time step; opnet_bwd_gemm + opnet_bwd_cell above 128 clips) "
-                   "+ opnet_wgrad")
+                   "opnet_xcd_forward<.., true> (ONE persistent launch of 16-clip groups writing the histories) + opnet_bwd_gemm + "
+                   "opnet_bwd_cell (two launches per reverse step) + opnet_wgrad" if fwd16 else
+                   "opnet_step / opnet_xcd4_forward + opnet_bwd_fused (one launch per reverse step; opnet_bwd_gemm + opnet_bwd_cell above "
+                   "128 clips) + opnet_wgrad")
         # algorithmic bytes of one training step under the per-time-step streaming model: the
         # forward streams the weights once per step and moves each clip's state (+ the saved history: gates 4x, h, c per
         # unit), the backward streams W_hh^T / W_ih2^T / the heads once per reverse step and reads the history back

@@ -10,6 +10,12 @@
 static void gemm_nt(const float *X, long XS, const float *Wt, long WS, const float *bias, const float *R, float *Y, long YS,
                     long M, int N, int K, int relu, hipStream_t st)
 {
+    // a SHORT sequence (one clip: S = 300 rows = 3 tiles of 128) leaves a dense product with a handful of workgroups walking K alone:
+    // the inference path's 32 x 32 tiles with K split over the workgroup's waves (gemm_bias_act_ks) - 35 -> ~10 us a launch
+    if (!R && XS == K && WS == K && YS == N && (K & 63) == 0 && ((M + 63) / 64) * ((N + 63) / 64) < 256 && env_int("OPSEQ_GEMM_KS", 1)) {
+        gemm_bias_act_ks<<<dim3((unsigned)((M + 31) / 32), (N + 31) / 32, 1), 256, 0, st>>>(X, Wt, bias, Y, (int)M, N, K, relu);
+        return;
+    }
     ConvArgs c = {};
     c.X = X; c.Wt = Wt; c.bias = bias; c.R = R; c.Y = Y;
     c.N = 1; c.H = 1; c.W = (int)M; c.Cin = K; c.Cout = N; c.KH = 1; c.KW = 1; c.stride = 1; c.pad = 0;

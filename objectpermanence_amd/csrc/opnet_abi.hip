@@ -768,12 +768,16 @@ static TrainPackedLayout train_packed_layout(int H1, int H2)
 
 struct TrainWorkspaceLayout {  // offsets in bytes
     size_t io, xp, state, h1all, c1all, h2all, c2all, state_end, x2all, g1, g2, psave, ystage, lgstage,
-        dyp, dlall, dhpart2, dhpart1, dx2part, dcz, dc2, dc1, dcz_end, l1part, x4h1x, x4h2x, x4status, x4da1x, x4da2x, x4dfx, wgpart, total;
+        dyp, dlall, dhpart2, dhpart1, dx2part, dcz, dc2, dc1, dcz_end, l1part, x4h1x, x4h2x, x4status, x4da1x, x4da2x, x4dfx, wgpart,
+        xcdws, total;       // xcdws: workspace of the 16-clip persistent forward when it carries the training forward (section 9f)
 };
 #define WG2_MAX_WAVES 1024      // one round of the chip's SIMDs (opnet_wgrad_tiles)
 
 // the 4-clip persistent step carries up to X4_NGMAX row blocks; its exchange buffers exist only for such batches
 static bool x4_batch(int B, int H1, int H2) { return x4_dims(H1, H2) && (B + 31) / 32 <= X4_NGMAX; }
+// batches whose TRAINING forward may run as the 16-clip persistent launch (opnet_xcd_forward<HO, true>): above the 4-clip forward's
+// range, one launch's worth of clips
+static bool xcdt_batch(int B, int H1, int H2) { return x4_dims(H1, H2) && B > 96 && B <= XCD_MAX_B; }
 
 static TrainWorkspaceLayout train_workspace_layout(int B, int T, int H1, int H2)
 {
@@ -814,8 +818,18 @@ static TrainWorkspaceLayout train_workspace_layout(int B, int T, int H1, int H2)
     L.x4dfx = o;   o += NG * X4_SLOTS * 4096;
     o = align_up(o, 4096);
     L.wgpart = o;  o += (size_t)WG2_MAX_WAVES * WG2_PART_F * 4;     // partial tiles of the weight-gradient waves (64 MB)
+    o = align_up(o, 4096);
+    L.xcdws = o;   if (xcdt_batch(B, H1, H2)) o += xcd_workspace_layout(B, T).total;
     L.total = align_up(o, 256);
     return L;
+}
+// the status words of a training step's persistent launches (abort code, block, phase, ...): the 4-clip kernels' where they exist,
+// else the 16-clip forward's; (size_t)-1: this batch never runs a persistent launch
+static size_t train_status_offset(const TrainWorkspaceLayout &W, int B, int T, int H1, int H2)
+{
+    if (x4_batch(B, H1, H2)) return W.x4status;
+    if (xcdt_batch(B, H1, H2)) return W.xcdws + xcd_workspace_layout(B, T).status;
+    return (size_t)-1;
 }
 
 extern "C" size_t opnet_train_packed_weights_bytes(int H1, int H2)
@@ -1044,8 +1058,8 @@ extern "C" size_t opnet_xcd4_status_offset(int B, int T, int H1, int H2)
 }
 extern "C" size_t opnet_train_status_offset(int B, int T, int H1, int H2)
 {
-    if (check_dims(B, T, H1, H2) || !x4_batch(B, H1, H2)) return (size_t)-1;
-    return train_workspace_layout(B, T, H1, H2).x4status;
+    if (check_dims(B, T, H1, H2)) return (size_t)-1;
+    return train_status_offset(train_workspace_layout(B, T, H1, H2), B, T, H1, H2);
 }
 extern "C" size_t opnet_xcd4_packed_weights_bytes(int H1, int H2)
 {
@@ -1149,6 +1163,18 @@ static bool x4_use(int B, int T, int H1, int H2, bool forward = false)
     return xcd_device_cus(dev) >= XCD_COUNT * XCD_CUS;
 }
 
+// Does the training forward of this batch run as the 16-clip persistent launch?  (OPNET_XCD_TRAIN=0 keeps the chain; the switch of
+// the 4-clip kernels - thrown by the host after an aborted launch - covers it too.)
+static bool xcdt_use(int B, int T, int H1, int H2)
+{
+    if (!xcdt_batch(B, H1, H2) || !x4_on() || env_int("OPNET_XCD_TRAIN", 1) == 0) return false;
+    if (B < env_int("OPNET_XCD_TRAIN_MIN_B", 97)) return false;
+    if (train_workspace_layout(B, T, H1, H2).total >= ((size_t)1 << 31)) return false;   // one buffer descriptor, 32-bit offsets
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    return xcd_device_cus(dev) >= XCD_COUNT * XCD_CUS;
+}
+
 static int make_x4_args(Xcd4Args *x, const float *packed, void *ws, int B, int T, int H1, int H2)
 {
     const TrainWorkspaceLayout W = train_workspace_layout(B, T, H1, H2);
@@ -1228,9 +1254,70 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
     opnet_set_io<<<1, 1, 0, st>>>(dio, io);
     opnet_pack_input<<<dim3(T, a.RB), 256, 0, st>>>(dio);
     if (int rc = train_chain_layouts(packed, st)) return rc;
-    // the status words of the 4-clip kernels are sticky from the forward to the weight-gradient launch and the optimiser's
+    if (xcdt_use(B, T, H1, H2)) {
+        // 97+ clips: the forward as ONE persistent launch of 16-clip groups (opnet_xcd_forward<HO, true>, section 9f) whose finish
+        // waves write the chain's histories beside the exchange; the chain's packed input (above) is what the backward reads
+        const XcdWorkspaceLayout L = xcd_workspace_layout(B, T);
+        char *w = (char *)workspace;
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        XcdArgs xa;
+        memset(&xa, 0, sizeof(xa));
+        xa.B = B; xa.T = T; xa.NGT = L.NGT;
+        xa.packed = packed;                     // (the inference image comes first in the training image)
+        xa.xp = (const float4 *)(w + W.xcdws + L.xp);
+        xa.h1h = (float4 *)(w + W.xcdws + L.h1h);
+        xa.h2h = (float4 *)(w + W.xcdws + L.h2h);
+        xa.fbh = (float4 *)(w + W.xcdws + L.fbh);
+        xa.flags = (unsigned *)(w + W.xcdws + L.flags);
+        xa.status = (unsigned *)(w + train_status_offset(W, B, T, H1, H2));
+        xa.logits = logits;
+        xa.ws = w;
+        xa.xp_off = (unsigned)(W.xcdws + L.xp); xa.h1_off = (unsigned)(W.xcdws + L.h1h); xa.h2_off = (unsigned)(W.xcdws + L.h2h);
+        xa.fb_off = (unsigned)(W.xcdws + L.fbh); xa.flags_off = (unsigned)(W.xcdws + L.flags);
+        xa.status_off = (unsigned)train_status_offset(W, B, T, H1, H2);
+        xa.ring = L.ring; xa.yp_off = (unsigned)(W.xcdws + L.yp); xa.y = y;
+        xa.trace = nullptr;
+        xa.force_safe = env_int("OPNET_XCD_SAFE", 0);
+        xa.debug = env_int("OPNET_XCD_DEBUG", 0);
+        xa.tr_h1 = (unsigned)W.h1all; xa.tr_c1 = (unsigned)W.c1all; xa.tr_h2 = (unsigned)W.h2all; xa.tr_c2 = (unsigned)W.c2all;
+        xa.tr_g1 = (unsigned)W.g1; xa.tr_g2 = (unsigned)W.g2; xa.tr_ps = (unsigned)W.psave; xa.tr_x2 = (unsigned)W.x2all;
+        xa.RB = a.RB;
+        XcdSources src;
+        memset(&src, 0, sizeof(src));
+        src.p[0] = boxes; src.start[0] = 0; src.start[1] = B; src.n = 1;
+        // a row block whose second 16-clip group does not exist keeps whatever the workspace held in its gate histories: zeros there
+        // (0 x NaN would poison the gradients; h / c of those clips are zeroed with the state above)
+        if (L.NGT * 16 < a.RB * 32) {
+            HIP_TRY(hipMemsetAsync(w + W.g1, 0, (size_t)T * a.RB * (size_t)H1 * 32 * 16, st));
+            HIP_TRY(hipMemsetAsync(w + W.g2, 0, (size_t)T * a.RB * (size_t)H2 * 32 * 16, st));
+            HIP_TRY(hipMemsetAsync(w + W.psave, 0, (size_t)T * a.RB * 128 * 16, st));
+            HIP_TRY(hipMemsetAsync(w + W.x2all, 0, (size_t)T * a.RB * 64 * 16, st));
+        }
+        std::lock_guard<std::mutex> lock(g_xcd_mu);
+        opnet_xcd_pack_input<<<dim3(T + 2, L.NGT), 384, 0, st>>>(src, xa);
+        if (!g_xcd_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_xcd_done[dev], hipEventDisableTiming));
+        else HIP_TRY(hipStreamWaitEvent(st, g_xcd_done[dev], 0));
+        ProfPair pe{};
+        const bool prof = prof_begin(st, &pe);
+        if (L.ho) opnet_xcd_forward<true, true><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(xa);
+        else opnet_xcd_forward<false, true><<<XCD_COUNT * XCD_CUS, 512, 0, st>>>(xa);
+        if (prof) prof_end(PROF_XCD, st, pe);
+        HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
+        if (xa.ring && L.ho) {
+            opnet_xcd_y_poison<<<64, 256, 0, st>>>(xa, y);
+        } else if (xa.ring) {
+            const long ny = (long)L.NGT * T * 16;
+            opnet_xcd_y_reduce<<<(unsigned)((ny + 255) / 256 > 2048 ? 2048 : (ny + 255) / 256), 256, 0, st>>>(xa, y);
+        } else {
+            opnet_xcd_out_head<<<dim3(T, L.NGT), 256, 0, st>>>(xa, y);
+        }
+        HIP_TRY(hipGetLastError());
+        return OPNET_OK;
+    }
+    // the status words of the persistent kernels are sticky from the forward to the weight-gradient launch and the optimiser's
     // guard: a forward on the launch chain has to say "nothing aborted" itself
-    if (x4_batch(B, H1, H2)) HIP_TRY(hipMemsetAsync((char *)workspace + W.x4status, 0, 32, st));
+    if (train_status_offset(W, B, T, H1, H2) != (size_t)-1) HIP_TRY(hipMemsetAsync((char *)workspace + train_status_offset(W, B, T, H1, H2), 0, 32, st));
     const dim3 grid = step_grid(a);
     const opnet_step_fn stepk = step_kernel(a);
     for (int s = 0; s < T + 3; ++s) stepk<<<grid, step_threads(a), 0, st>>>(a, s);
@@ -1411,7 +1498,7 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
         wb.job[j].tiles_m = 1;
     }
     // a forward or reverse recurrence that gave up (4-clip persistent kernels) left partial histories: every dW becomes NaN
-    wb.abort = x4_batch(B, H1, H2) ? (const unsigned *)(w + W.x4status) : nullptr;
+    wb.abort = train_status_offset(W, B, T, H1, H2) != (size_t)-1 ? (const unsigned *)(w + train_status_offset(W, B, T, H1, H2)) : nullptr;
     if (wgrad_wave_tiles(wb.job, njobs, T, RB, B, (float *)(w + W.wgpart), wb.abort, st)) {
         HIP_TRY(hipGetLastError());
         return OPNET_OK;

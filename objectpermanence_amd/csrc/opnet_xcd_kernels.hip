@@ -86,6 +86,11 @@ struct XcdArgs {
     int force_safe;            // 1: always use the placement-independent write-through protocol (tests)
     int debug;                 // tools only (wrong results): bit 0 no poll/gather, 1 no head, 2 no cells, 3 no publish, 4 no x fetch
     unsigned long long *trace; // optional [phases][8] s_memtime stamps of block 0 (product wave 0: 0-1, finish wave 4: 2-7), or null
+    // TRAIN instantiation (the training forward of 97+ clips, opnet_train_forward_f32): byte offsets in ws of the launch chain's
+    // history buffers (train_workspace_layout: slot t + 1 of h / c = step t; row blocks of 32 clips = two 16-clip groups), which the
+    // finish waves fill beside the exchange so that the chain's reverse recurrence and the weight-gradient launch run on them
+    unsigned tr_h1, tr_c1, tr_h2, tr_c2, tr_g1, tr_g2, tr_ps, tr_x2;
+    int RB;
 };
 
 __host__ __device__ inline void xcd_groups(int NGT, int x, int *g0, int *ng)
@@ -117,6 +122,17 @@ __device__ __forceinline__ void xcd_store16(__amdgpu_buffer_rsrc_t r, unsigned v
     u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
     if (local) __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
     else __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 16);
+}
+// plain history stores (nobody reads them inside the launch): lane offset + wave-uniform scalar offset through the descriptor
+__device__ __forceinline__ void xcd_st4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v)
+{
+    xcd_u32x4 u;
+    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+}
+__device__ __forceinline__ void xcd_st1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
 __device__ __forceinline__ void xcd_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v, bool local)
 {
@@ -391,7 +407,7 @@ __host__ __device__ inline int xcd_y_cu(int s, int gi) { return (s + 11 * gi + 1
 
 #define XH_F4 (3 * 64)         // sHAND per product wave: LSTM2 gates | LSTM1 partial | head partial
 
-template <bool HO>
+template <bool HO, bool TRAIN = false>
 __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
 {
     __shared__ __attribute__((aligned(1024))) float4 sbuf[2][XB_F4];
@@ -802,6 +818,15 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
             }
             xa = make_float4(fbv[0], fbv[1], fbv[2], fbv[3]);
             xb = make_float4(fbv[4], fbv[5], 0.f, 0.f);
+          if (TRAIN && (HO || (c == ((s - 1) & (XCD_CUS - 1)) && w == 0))) {
+            // the step's slot probabilities [4 slot quads][32 clips] and frames_boxes [2 k-quads][32 clips] in the chain's layouts
+            const unsigned trb = (unsigned)(s - 1) * (unsigned)a.RB + (gg >> 1), half = (gg & 1u) * 256u;
+            xcd_st4(rws, (u * 32 + n) * 16, a.tr_ps + trb * 2048 + half, make_float4(pr[0], pr[1], pr[2], pr[3]));
+            if (u == 0) {
+                xcd_st4(rws, n * 16, a.tr_x2 + trb * 1024 + half, xa);
+                xcd_st4(rws, n * 16, a.tr_x2 + trb * 1024 + 512 + half, xb);
+            }
+          }
           if (HO) {
             // every lane now holds the clip's six values: lane (n, u) stores features u and u + 4 (6, 7 = padding zeros) of
             // slot s (= frames_boxes[s-1]) as [feature][clip]
@@ -832,13 +857,21 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
                 }
             }
             float cc = sC2[gi][w][lane];
-            const float h = lstm_cell(g[0], g[1], g[2], g[3], &cc);
+            float4 gs;
+            const float h = TRAIN ? lstm_cell_g(g[0], g[1], g[2], g[3], &cc, &gs) : lstm_cell(g[0], g[1], g[2], g[3], &cc);
             sC2[gi][w][lane] = cc;
             sTR[w][0][n * 4 + u] = h;
             XCD_WAVE_LDS_SYNC();
             if (lane < 16) {
                 const float4 hv = *(const float4 *)&sTR[w][0][lane * 4];
                 xcd_store16(rws, lane16, a.h2_off + (((gg * NS + ((unsigned)(HO ? s - 1 : s) & smask)) * (XCD_H2 / 4) + t2) * 16) * 16, hv, local);
+                if (TRAIN)      // h2[t] in the chain's history: [slot t + 1][row block][unit quad][32 clips] float4
+                    xcd_st4(rws, lane16, a.tr_h2 + ((((unsigned)(HO ? s - 1 : s) * (unsigned)a.RB + (gg >> 1)) * (XCD_H2 / 4) + t2) * 32 + (gg & 1u) * 16) * 16, hv);
+            }
+            if (TRAIN) {        // gates (post-activation) of step t and c[t] (slot t + 1): lane (clip n, unit 4 t2 + u)
+                const unsigned tstep = (unsigned)(HO ? s - 2 : s - 1), half = (gg & 1u) * 16;
+                xcd_st4(rws, (u * 32 + n) * 16, a.tr_g2 + (((tstep * (unsigned)a.RB + (gg >> 1)) * XCD_H2 + 4 * t2) * 32 + half) * 16, gs);
+                xcd_st1(rws, (u * 32 + n) * 4, a.tr_c2 + ((((tstep + 1) * (unsigned)a.RB + (gg >> 1)) * XCD_H2 + 4 * t2) * 32 + half) * 4, cc);
             }
             if ((cf & XCD_CF_RING) && !HO)   // this lane's terms of y = W_out h2: four products, summed by the CU's last-arriving wave (no shuffles
                                  // here: every VALU instruction of a finish wave is paid for by the MFMA stream of its SIMD)
@@ -848,13 +881,22 @@ __global__ void __launch_bounds__(512, 2) opnet_xcd_forward(const XcdArgs a)
         if ((wq & 1) && s < T && alive && !(cf & XCD_CF_DBG4)) {
             const float4 lo = H[(w - 1) * XH_F4 + 64], hi = H[w * XH_F4 + 64];
             float cc = sC1[gi][w >> 1][lane];
-            const float h = lstm_cell(lo.x + hi.x, lo.y + hi.y, lo.z + hi.z, lo.w + hi.w, &cc);
+            float4 gs;
+            const float h = TRAIN ? lstm_cell_g(lo.x + hi.x, lo.y + hi.y, lo.z + hi.z, lo.w + hi.w, &cc, &gs)
+                                  : lstm_cell(lo.x + hi.x, lo.y + hi.y, lo.z + hi.z, lo.w + hi.w, &cc);
             sC1[gi][w >> 1][lane] = cc;
             sTR[w][1][n * 4 + u] = h;
             XCD_WAVE_LDS_SYNC();
             if (lane < 16) {
                 const float4 hv = *(const float4 *)&sTR[w][1][lane * 4];
                 xcd_store16(rws, lane16, a.h1_off + (((gg * NS + ((unsigned)(s + 1) & smask)) * (XCD_H1 / 4) + t1) * 16) * 16, hv, local);
+                if (TRAIN)
+                    xcd_st4(rws, lane16, a.tr_h1 + ((((unsigned)(s + 1) * (unsigned)a.RB + (gg >> 1)) * (XCD_H1 / 4) + t1) * 32 + (gg & 1u) * 16) * 16, hv);
+            }
+            if (TRAIN) {
+                const unsigned half = (gg & 1u) * 16;
+                xcd_st4(rws, (u * 32 + n) * 16, a.tr_g1 + ((((unsigned)s * (unsigned)a.RB + (gg >> 1)) * XCD_H1 + 4 * t1) * 32 + half) * 16, gs);
+                xcd_st1(rws, (u * 32 + n) * 4, a.tr_c1 + ((((unsigned)(s + 1) * (unsigned)a.RB + (gg >> 1)) * XCD_H1 + 4 * t1) * 32 + half) * 4, cc);
             }
         }
         if (tracer) XCD_KARG(unsigned long long *, trace)[(long)fp * 8 + 5] = clock64();

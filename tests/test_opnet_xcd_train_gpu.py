@@ -1,0 +1,47 @@
+"""OPNet training steps of 97+ clips: the forward as ONE persistent launch of 16-clip groups whose finish waves write the launch
+chain's histories (opnet_xcd_forward<HO, true>) against the launch chain's training forward (OPNET_XCD_TRAIN=0,
+pinned to the reference's autograd in tests/test_train_gpu.py): y, logits, loss and all six gradients - the reverse recurrence and
+the weight-gradient launch run on the histories either forward left."""
+import numpy as np
+import pytest
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+CFG = {"object_to_track_pred_dim": 15, "object_to_track_hidden_dim": 256, "videos_hidden_dim": 512}
+
+
+def _step(B, T):
+    import torch
+    from objectpermanence_amd import ModelsFactory, l1_mean
+    b, l = synth.make_batch(11, min(B, 24), T)
+    reps = (B + b.shape[0] - 1) // b.shape[0]
+    boxes = torch.from_numpy(np.tile(b, (reps, 1, 1, 1))[:B].copy()).cuda()
+    labels = torch.from_numpy(np.tile(l, (reps, 1, 1))[:B].copy()).cuda()
+    m = ModelsFactory.get_model("opnet", CFG)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.opnet_synth_params(CFG).items()})
+    m.to("cuda:0").train(True)
+    y, logits = m(boxes)
+    loss = l1_mean(y, labels)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert not m.training_step_aborted()
+    return (float(loss.detach()), y.detach().cpu().numpy(), logits.detach().cpu().numpy(),
+            {k: p.grad.cpu().numpy() for k, p in m.named_parameters()})
+
+
+@pytest.mark.parametrize("B,T", [(97, 5), (128, 9), (144, 4), (200, 7), (256, 3), (400, 3)])
+def test_persistent_16_clip_training_forward_matches_the_launch_chain(monkeypatch, B, T):
+    """97 .. 400 clips: one and two groups per XCD (every-CU head), three and more (head-once form), an odd number of 16-clip
+    groups (a row block with one group), ragged last groups"""
+    monkeypatch.setenv("OPNET_XCD_TRAIN", "0")
+    l_ref, y_ref, lg_ref, g_ref = _step(B, T)
+    monkeypatch.setenv("OPNET_XCD_TRAIN", "1")
+    l, y, lg, g = _step(B, T)
+    assert np.abs(y - y_ref).max() < 2e-5 and np.abs(lg - lg_ref).max() < 1e-4
+    assert l == pytest.approx(l_ref, abs=2e-6)
+    for k in g_ref:
+        assert np.isfinite(g[k]).all(), k
+        assert np.abs(g[k] - g_ref[k]).max() <= 1e-4 * max(1e-3, np.abs(g_ref[k]).max()), k
+    l2, y2, lg2, g2 = _step(B, T)
+    assert np.array_equal(y2, y) and all(np.array_equal(g2[k], g[k]) for k in g), "run to run"

@@ -5,7 +5,7 @@ import numpy as np, torch
 from objectpermanence_amd import ModelsFactory, FusedAdam
 from objectpermanence_amd.training import train_step
 from oracle import synth
-cfg = {"boxes_features_dim": 256, "num_attention_heads": 2, "num_attention_layers": 2, "num_lstm_layers": 2, "lstm_hidden_dim": 512}
+cfg = {"boxes_features_dim": 256, "num_attention_heads": int(os.environ.get("HEADS", "2")), "num_attention_layers": 2, "num_lstm_layers": 2, "lstm_hidden_dim": 512}
 for B in [int(a) for a in sys.argv[1:]] or [1, 8, 32]:
     m = ModelsFactory.get_model("transformer_lstm", cfg)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.transformer_lstm_synth_params(cfg).items()})
