@@ -362,15 +362,27 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
         emit(line)
 
 
-def detector_flops_per_frame(h=800, w=1088, rois=1000, classes=193):
+def detector_flops_per_frame(h=800, w=1088, rois=1000, classes=193, frames_per_pass=None):
     """algorithmic FLOPs of one eval-mode fasterrcnn_resnet50_fpn call at the padded size: every conv / linear of the
-    backbone, FPN, RPN head and box heads, 2 * M * N * K each"""
-    total = 0
+    backbone, FPN, RPN head and box heads, 2 * M * N * K each.  frames_per_pass given: returns
+    (algorithmic, executed, layers) - the stride-1 3 x 3 convs that the product runs as Winograd F(2 x 2, 3 x 3) at that pass size
+    (objectpermanence_amd.detector._Conv._winograd) issue 1 / 2.25 of their direct-form MACs on the matrix pipe."""
+    total, executed, wino_layers = 0, 0, 0
+    if frames_per_pass is not None:
+        from objectpermanence_amd.detector import _Conv
+        wino_on = os.environ.get("OPDET_WINOGRAD", "1") != "0"
 
     def conv(hh, ww, cin, cout, k, s, p):
-        nonlocal total
+        nonlocal total, executed, wino_layers
         oh, ow = (hh + 2 * p - k) // s + 1, (ww + 2 * p - k) // s + 1
-        total += 2 * oh * ow * cout * k * k * cin
+        fl = 2 * oh * ow * cout * k * k * cin
+        total += fl
+        if (frames_per_pass is not None and wino_on and k == 3 and s == 1 and cin % 16 == 0 and cin >= _Conv.WINO_MIN_CIN
+                and frames_per_pass * ((hh + 1) // 2) * ((ww + 1) // 2) >= _Conv.WINO_MIN_TILES):
+            executed += fl / 2.25
+            wino_layers += 1
+        else:
+            executed += fl
         return oh, ow
 
     hh, ww = conv(h, w, 3, 64, 7, 2, 3)
@@ -395,8 +407,10 @@ def detector_flops_per_frame(h=800, w=1088, rois=1000, classes=193):
     for fh, fw in levels:
         conv(fh, fw, 256, 256, 3, 1, 1)
         conv(fh, fw, 256, 15, 1, 1, 0)
-    total += 2 * rois * (12544 * 1024 + 1024 * 1024 + 1024 * classes * 5)
-    return total
+    head = 2 * rois * (12544 * 1024 + 1024 * 1024 + 1024 * classes * 5)
+    total += head
+    executed += head
+    return total if frames_per_pass is None else (total, executed, wino_layers)
 
 
 def _passes_in_flight():
@@ -449,7 +463,7 @@ def detector_block(dev, nf=16, passes=6):
         det.detect_batch(one, dev)
     torch.cuda.synchronize(dev)
     single = (time.perf_counter() - t2) / 10
-    fl = detector_flops_per_frame()
+    fl, fl_exec, n_wino = detector_flops_per_frame(frames_per_pass=nf)
     tf = fl * nf * passes / dt / 1e12
     return {"detector": {
         "workload": f"Faster-RCNN R50-FPN (193 classes) eval on 240x320 frames -> 800x1066, {nf} frames per pass, synthetic weights",
@@ -459,7 +473,12 @@ def detector_block(dev, nf=16, passes=6):
         "single_frame_call": {"ms": round(single * 1e3, 2), "frames_per_s": round(1.0 / single, 1)},
         "kernel": "conv2d_nhwc_glds (dominant; all dense launches of a pass over the whole-pass time incl. selection stages)",
         "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": round(tf / MFMA_F32_PEAK_TF, 4), "gflop_per_frame": round(fl / 1e9, 1)},
+                     "frac": round(tf / MFMA_F32_PEAK_TF, 4), "gflop_per_frame": round(fl / 1e9, 1),
+                     # frac counts the DIRECT convolution's flops (the algorithm's); the matrix pipe issued fewer:
+                     "executed_gflop_per_frame": round(fl_exec / 1e9, 1), "executed_frac": round(tf * fl_exec / fl / MFMA_F32_PEAK_TF, 4)},
+        "winograd": {"layers_per_frame": n_wino, "form": "F(2 x 2, 3 x 3), fp32, stride-1 3 x 3 convs with >= 256 input channels",
+                     "max_rel_error_vs_direct_conv": "2.2e-6 of max|y| (tools/probes/winograd_probe.hip); detections compared with the "
+                                                     "oracle's in tests/test_detector_gpu.py as before", "switch": "OPDET_WINOGRAD=0"},
         "parity": "unpinned (checked against the build-authored oracle/detector_oracle.py only)",
         "detections_per_frame": [len(o["scores"]) for o in out][:4], "block_seconds": round(time.perf_counter() - t0, 1)}}
 
@@ -497,7 +516,7 @@ def bench_detect(args, world, rank, dev, dist):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank == 0:
-        fl = detector_flops_per_frame()
+        fl, fl_exec, n_wino = detector_flops_per_frame(frames_per_pass=nf)
         tf = fl * nf * args.steps / elapsed / 1e12
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -516,7 +535,12 @@ def bench_detect(args, world, rank, dev, dist):
             "roofline": {"bound": "mfma", "achieved": round(tf / world, 2), "peak": 157.3, "unit": "TFLOP/s",
                          "frac": round(tf / world / 157.3, 4), "traffic": None,
                          "kernel": "all dense launches of a pass (conv2d_nhwc_glds dominates); whole-step time incl. selection stages",
-                         "gflop_per_frame": round(fl / 1e9, 1)},
+                         "gflop_per_frame": round(fl / 1e9, 1),
+                         # frac counts the DIRECT convolution's flops (the algorithm's); with Winograd layers the pipe issued fewer:
+                         "executed_gflop_per_frame": round(fl_exec / 1e9, 1), "executed_frac": round(tf / world * fl_exec / fl / 157.3, 4)},
+            "winograd": {"layers_per_frame": n_wino, "form": "F(2 x 2, 3 x 3), fp32; results within 2.2e-6 of max|y| of the direct conv",
+                         "switch": "OPDET_WINOGRAD=0"},
+            "parity": "unpinned (checked against the build-authored oracle/detector_oracle.py only)",
             "cpu_baseline": cpu,
             "detections_per_frame": [len(o["scores"]) for o in out][:4]})
     if dist is not None:

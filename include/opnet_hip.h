@@ -39,7 +39,7 @@ extern "C" {
 
 /* bumped whenever entry points are added or a signature changes; the Python mirror refuses a library of another version
  * (objectpermanence_amd/_lib.py) instead of failing later on a missing symbol.  4 = round 4. */
-#define OPNET_HIP_ABI_VERSION 7
+#define OPNET_HIP_ABI_VERSION 8
 int opnet_hip_abi_version(void);
 const char *opnet_last_error(void);
 
@@ -387,6 +387,18 @@ size_t opdet_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int 
 int opdet_conv2d_ws_f32(const float *x, const float *w, const float *bias, const float *residual, float *y, int N, int H, int W,
                         int Cin, int Cout, int KH, int KW, int stride, int pad, int KP, int relu, void *workspace,
                         size_t workspace_bytes, void *stream);
+
+/* Winograd F(2 x 2, 3 x 3) form of a stride-1, pad-1 3 x 3 convolution (csrc/wino_kernels.hip; replaces the same torchvision conv2d call
+ * as opdet_conv2d_f32 for the FPN output convs / RPN head conv / deep bottleneck conv2 of reference object_detection/models.py:6-20; cuDNN,
+ * which the reference ran on, picks Winograd for these layers itself).  u: the transformed weights [16][Cout][Cin] made ONCE per weight set
+ * by opdet_wino_weights_f32 from the packed weight w [Cout][KP] of opdet_conv2d_f32; workspace: opdet_conv2d_wino_workspace_bytes (the 16
+ * position planes of the transformed input and of the products; capped by OPDET_WINO_WS_MB, larger passes run in chunks of images).
+ * Cin % 16 == 0, Cout % 4 == 0; results agree with opdet_conv2d_f32 to ~2e-6 of max|y| (another summation order). */
+size_t opdet_wino_weights_bytes(int Cin, int Cout);
+int opdet_wino_weights_f32(const float *w, float *u, int Cin, int Cout, int KP, void *stream);
+size_t opdet_conv2d_wino_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int opdet_conv2d_wino_f32(const float *x, const float *u, const float *bias, float *y, int N, int H, int W, int Cin, int Cout, int relu,
+                          void *workspace, size_t workspace_bytes, void *stream);
 /* FeaturePyramidNetwork's top-down step:  y = conv(x) + bias + nearest_upsample(top), top [N, TH, TW, Cout] (F.interpolate to the conv's
  * output size); the addition rides in the conv kernel's epilogue where the shape allows, else conv + in-place upsample_add - the same
  * fp32 operations in the same order.  workspace as for opdet_conv2d_ws_f32. */

@@ -13,7 +13,7 @@ from . import build as _build
 _LIB = None
 
 OPNET_OK = 0
-ABI_VERSION = 7                            # include/opnet_hip.h OPNET_HIP_ABI_VERSION
+ABI_VERSION = 8                            # include/opnet_hip.h OPNET_HIP_ABI_VERSION
 NO_OFFSET = ctypes.c_size_t(-1).value      # opnet_*_status_offset: "this shape never runs a persistent kernel"
 
 
@@ -233,6 +233,14 @@ def _declare(lib):
     lib.opdet_conv2d_up_f32.argtypes = [fp, fp, fp, fp, fp] + [c_int] * 12 + [c_void_p, c_size_t, c_void_p]
     lib.opdet_conv2d_ws_f32.restype = c_int
     lib.opdet_conv2d_ws_f32.argtypes = [fp, fp, fp, fp, fp] + [c_int] * 11 + [c_void_p, c_size_t, c_void_p]
+    lib.opdet_wino_weights_bytes.restype = c_size_t
+    lib.opdet_wino_weights_bytes.argtypes = [c_int, c_int]
+    lib.opdet_wino_weights_f32.restype = c_int
+    lib.opdet_wino_weights_f32.argtypes = [fp, fp, c_int, c_int, c_int, c_void_p]
+    lib.opdet_conv2d_wino_workspace_bytes.restype = c_size_t
+    lib.opdet_conv2d_wino_workspace_bytes.argtypes = [c_int] * 5
+    lib.opdet_conv2d_wino_f32.restype = c_int
+    lib.opdet_conv2d_wino_f32.argtypes = [fp, fp, fp, fp] + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]
     lib.opdet_maxpool3x3s2_f32.restype = c_int
     lib.opdet_maxpool3x3s2_f32.argtypes = [fp, fp, c_int, c_int, c_int, c_int, c_void_p]
     lib.opdet_subsample2_f32.restype = c_int
@@ -305,7 +313,7 @@ EXPORTS = [
     "opseq_encoder_layer_f32", "opseq_encoder_layer_segmented_f32", "opseq_encoder_layer_batched_f32", "opseq_ffn_fused_supported", "opseq_ffn_fused_plan", "opseq_ffn_fused_f32", "opseq_attention_f32", "opseq_attention_workspace_bytes",
     "opseq_encoder_train_saved_bytes", "opseq_encoder_train_scratch_bytes", "opseq_encoder_layer_train_forward_f32",
     "opseq_encoder_layer_train_backward_f32", "opseq_encoder_test_masks_set", "opseq_encoder_test_masks_clear",
-    "opdet_conv2d_f32", "opdet_conv2d_workspace_bytes", "opdet_conv2d_ws_f32", "opdet_conv2d_up_f32", "opdet_conv2d_dual_workspace_bytes", "opdet_conv2d_dual_f32", "opdet_maxpool3x3s2_f32", "opdet_subsample2_f32", "opdet_upsample_add_f32",
+    "opdet_conv2d_f32", "opdet_conv2d_workspace_bytes", "opdet_conv2d_ws_f32", "opdet_wino_weights_bytes", "opdet_wino_weights_f32", "opdet_conv2d_wino_workspace_bytes", "opdet_conv2d_wino_f32", "opdet_conv2d_up_f32", "opdet_conv2d_dual_workspace_bytes", "opdet_conv2d_dual_f32", "opdet_maxpool3x3s2_f32", "opdet_subsample2_f32", "opdet_upsample_add_f32",
     "opdet_preprocess_frame_f32", "opdet_rpn_workspace_bytes", "opdet_rpn_proposals_f32", "opdet_roi_align_f32",
     "opdet_detections_workspace_bytes", "opdet_detections_f32", "opdet_rpn_workspace_bytes_batch", "opdet_rpn_proposals_batch_f32",
     "opdet_roi_align_batch_f32", "opdet_detections_workspace_bytes_batch", "opdet_detections_batch_f32", "opdet_test_sort_scratch_bytes", "opdet_test_sort_pairs",

@@ -42,6 +42,9 @@ struct ConvArgs {
     // stage's first bottleneck as ONE product (relu(bn3(conv3(out)) + bn_d(downsample(x))), torchvision Bottleneck.forward)
     const float *X2;
     int Cin2, H2, W2, stride2;
+    // conv2d_nhwc_glds only, ksplit <= 1 and gridDim.z > 1: a BATCH of independent products of one shape - workgroup z works on
+    // X + z * bsx, Wt + z * bsw, Y + z * bsy (floats): the 16 tile positions of a Winograd layer in one launch (csrc/wino_kernels.hip)
+    long bsx, bsw, bsy;
 #ifdef CONV_TRACE                 // tools/probes/gemm_probe.hip only: per-K-step cycle sums of wave 0 of every workgroup
     unsigned long long *trace;    // [0] steps, [1] top -> MFMAs issued, [2] -> waits done, [3] -> next top (barrier + DMA issue)
 #endif
@@ -473,9 +476,10 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
     const long m0 = (long)(lin / gridDim.y) * BM;
     const int n0 = (lin % gridDim.y) * BN;
 
+    const long bz = a.ksplit > 1 ? 0 : (long)blockIdx.z;     // batch index (0 for every launch that is not a batch)
     conv_u32x4 rx, rwt;
     {
-        const unsigned long long bx = (unsigned long long)a.X, bw = (unsigned long long)a.Wt;
+        const unsigned long long bx = (unsigned long long)(a.X + bz * a.bsx), bw = (unsigned long long)(a.Wt + bz * a.bsw);
         rx.x = (unsigned)bx; rx.y = (unsigned)(bx >> 32);
         rx.z = (unsigned)((long)a.N * a.H * a.W * XS * 4); rx.w = 0x00020000u;
         rwt.x = (unsigned)bw; rwt.y = (unsigned)(bw >> 32);
@@ -682,6 +686,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
         return;
     }
     const bool vec = (a.Cout & 3) == 0 && (YS & 3) == 0;
+    float *const Yb = a.Y + bz * a.bsy;
 #pragma unroll
     for (int x = 0; x < FM; ++x) {
         const long pp = m0 + wm * (FM * 16) + x * 16 + i;
@@ -701,7 +706,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }
                 if (a.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                *(float4 *)(a.Y + pp * YS + co) = v;
+                *(float4 *)(Yb + pp * YS + co) = v;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -709,7 +714,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_glds(const ConvArgs a)
                     float v = acc[x][y][r] + (a.bias ? a.bias[co + r] : 0.f);
                     if (a.R) v += a.R[conv_rrow(a, pp) * YS + co + r];
                     if (a.relu) v = fmaxf(v, 0.f);
-                    a.Y[pp * YS + co + r] = v;
+                    Yb[pp * YS + co + r] = v;
                 }
             }
         }

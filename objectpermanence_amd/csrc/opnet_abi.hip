@@ -9,6 +9,7 @@
 #include "seq_xcdt_kernels.hip"
 #include "seq_xcd_bwd_kernels.hip"
 #include "conv_kernels.hip"
+#include "wino_kernels.hip"
 #include "ffn_kernels.hip"
 #include "attn_kernels.hip"
 #include "enc_train_kernels.hip"
@@ -3013,6 +3014,72 @@ extern "C" int opdet_conv2d_ws_f32(const float *x, const float *w, const float *
         const long n4 = M * Cout / 4;
         conv_splitk_reduce<<<(unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256), 256, 0, st>>>(a.P, S, M, Cout, bias, residual, y,
                                                                                                     relu);
+    }
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
+// ---- Winograd F(2 x 2, 3 x 3) for stride-1 3 x 3 convs (csrc/wino_kernels.hip) ------------------------------------------------
+// workspace: the 16 position planes of the transformed input and of the products for a chunk of images; a pass whose planes exceed
+// OPDET_WINO_WS_MB (default 1024) runs in chunks of whole images
+static int wino_chunk_images(int N, int H, int W, int Cin, int Cout)
+{
+    const size_t per = (size_t)16 * ((H + 1) / 2) * ((W + 1) / 2) * (size_t)(Cin + Cout) * 4;
+    const size_t cap = (size_t)env_int("OPDET_WINO_WS_MB", 1024) << 20;
+    long n = (long)(cap / (per ? per : 1));
+    // (one GEMM batch addresses a position plane through a 2 GiB buffer descriptor)
+    const long lim_x = ((1L << 31) - 1) / ((long)((H + 1) / 2) * ((W + 1) / 2) * (Cin > Cout ? Cin : Cout) * 4);
+    if (n > lim_x) n = lim_x;
+    if (n > N) n = N;
+    return n < 1 ? 1 : (int)n;
+}
+static int check_wino(int N, int H, int W, int Cin, int Cout)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 15) || (Cout & 3))
+        return fail(OPNET_ESHAPE, "Winograd conv: Cin must be a multiple of 16 and Cout of 4");
+    return OPNET_OK;
+}
+extern "C" size_t opdet_wino_weights_bytes(int Cin, int Cout) { return (size_t)16 * Cin * Cout * 4; }
+/* the transformed weights U [16][Cout][Cin] of a 3 x 3 conv from its packed weight w [Cout][KP] (k = (ky * 3 + kx) * Cin + ci); once per weight set */
+extern "C" int opdet_wino_weights_f32(const float *w, float *u, int Cin, int Cout, int KP, void *stream)
+{
+    if (!w || !u) return fail(OPNET_EINVAL, "null pointer");
+    if (KP < 9 * Cin) return fail(OPNET_ESHAPE, "KP=%d < 9 * Cin", KP);
+    const long n = (long)Cin * Cout;
+    wino_weights<<<(unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, u, Cin, Cout, KP);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+extern "C" size_t opdet_conv2d_wino_workspace_bytes(int N, int H, int W, int Cin, int Cout)
+{
+    if (check_wino(N, H, W, Cin, Cout)) return 0;
+    const int nc = wino_chunk_images(N, H, W, Cin, Cout);
+    return (size_t)16 * nc * ((H + 1) / 2) * ((W + 1) / 2) * (size_t)(Cin + Cout) * 4;
+}
+/* y [N, H, W, Cout] = act(conv3x3(x [N, H, W, Cin], stride 1, pad 1) + bias) through Winograd F(2 x 2, 3 x 3): u from opdet_wino_weights_f32 */
+extern "C" int opdet_conv2d_wino_f32(const float *x, const float *u, const float *bias, float *y, int N, int H, int W, int Cin, int Cout,
+                                     int relu, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_wino(N, H, W, Cin, Cout)) return rc;
+    if (!x || !u || !y || !workspace) return fail(OPNET_EINVAL, "null pointer");
+    if (!aligned16(x) || !aligned16(u) || !aligned16(y) || !aligned16(workspace) || !aligned16(bias))
+        return fail(OPNET_EINVAL, "x / u / y / bias / workspace must be 16-byte aligned");
+    if (workspace_bytes < opdet_conv2d_wino_workspace_bytes(N, H, W, Cin, Cout)) return fail(OPNET_EWORKSPACE, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nc = wino_chunk_images(N, H, W, Cin, Cout);
+    const long tiles_img = (long)((H + 1) / 2) * ((W + 1) / 2);
+    float *V = (float *)workspace, *Mm = V + (size_t)16 * nc * tiles_img * Cin;
+    for (int n0 = 0; n0 < N; n0 += nc) {
+        const int nimg = N - n0 < nc ? N - n0 : nc;
+        const long NT = nimg * tiles_img;
+        const long ni = NT * (Cin / 4), no = NT * (Cout / 4);
+        wino_input<<<(unsigned)((ni + 255) / 256 > 16384 ? 16384 : (ni + 255) / 256), 256, 0, st>>>(x, V, n0, nimg, H, W, Cin);
+        ConvArgs g = {};
+        g.X = V; g.Wt = u; g.Y = Mm;
+        g.N = 1; g.H = 1; g.W = (int)NT; g.Cin = Cin; g.Cout = Cout; g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0; g.OH = 1; g.OW = (int)NT; g.KP = Cin;
+        g.bsx = NT * Cin; g.bsw = (long)Cout * Cin; g.bsy = NT * Cout;
+        conv2d_nhwc_glds<64, 3><<<dim3((unsigned)((NT + 127) / 128), (Cout + 63) / 64, 16), 256, 0, st>>>(g);
+        wino_output<<<(unsigned)((no + 255) / 256 > 16384 ? 16384 : (no + 255) / 256), 256, 0, st>>>(Mm, bias, y, n0, nimg, H, W, Cout, relu);
     }
     HIP_TRY(hipGetLastError());
     return OPNET_OK;

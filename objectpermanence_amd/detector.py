@@ -11,6 +11,7 @@ detector.  ``CaterObjectDetector.__call__`` returns what detector.py:84 returns:
 from __future__ import annotations
 
 import ctypes
+import os
 from collections import OrderedDict
 from typing import Dict, List, Tuple
 
@@ -31,6 +32,9 @@ PASSES_IN_FLIGHT = 3
 
 def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
+
+
+_WINO_WS: Dict[tuple, torch.Tensor] = {}       # (device, stream) -> workspace of the Winograd convs enqueued on that stream
 
 
 class _Conv:
@@ -57,11 +61,51 @@ class _Conv:
         self.b = b.contiguous().to(device)
         self.cin, self.cout, self.kh, self.kw, self.stride, self.pad = cin_p, cout, kh, kw, stride, pad
         self._ws_bytes: Dict[tuple, int] = {}
+        self._u = None                  # Winograd-transformed weights [16][Cout][Cin], made on first use
+
+    # Winograd F(2 x 2, 3 x 3) (csrc/wino_kernels.hip) for the stride-1 3 x 3 convs with >= WINO_MIN_CIN input channels and at least
+    # WINO_MIN_TILES 2 x 2 output tiles in the call: 2.25 x fewer MACs against 4 x the activation traffic - measured 1.26 x on the
+    # P2-level 256 -> 256 conv of a 16-frame pass, results within 2.2e-6 of max|y| of the direct conv (profiles/r6_winograd_probe.txt).
+    # OPDET_WINOGRAD=0 keeps every conv direct.
+    WINO_MIN_CIN = int(os.environ.get("OPDET_WINO_MIN_CIN", "256"))
+    WINO_MIN_TILES = int(os.environ.get("OPDET_WINO_MIN_TILES", "200"))
+
+    def _winograd(self, n: int, h: int, w: int, residual) -> bool:
+        return (os.environ.get("OPDET_WINOGRAD", "1") != "0" and residual is None and self.kh == 3 and self.kw == 3 and self.stride == 1
+                and self.pad == 1 and self.cin % 16 == 0 and self.cout % 4 == 0 and self.cin >= self.WINO_MIN_CIN
+                and n * ((h + 1) // 2) * ((w + 1) // 2) >= self.WINO_MIN_TILES)
+
+    def _call_winograd(self, x: torch.Tensor, relu: bool) -> torch.Tensor:
+        lib = _lib.load()
+        n, h, w, c = x.shape
+        st = _stream(x.device)
+        if self._u is None or self._u.device != x.device:
+            self._u = torch.empty(int(lib.opdet_wino_weights_bytes(c, self.cout)) // 4, dtype=torch.float32, device=x.device)
+            _lib.check(lib.opdet_wino_weights_f32(self.w.data_ptr(), self._u.data_ptr(), c, self.cout, self.kp, st), "opdet_wino_weights_f32")
+        y = torch.empty((n, h, w, self.cout), dtype=torch.float32, device=x.device)
+        key = ("wino", n, h, w)
+        nws = self._ws_bytes.get(key)
+        if nws is None:
+            nws = self._ws_bytes[key] = int(lib.opdet_conv2d_wino_workspace_bytes(n, h, w, c, self.cout))
+        # ONE grow-only workspace per (device, stream): the Winograd convs of a stream run one after the other, and fresh multi-GB
+        # blocks from the caching allocator inside a pass stall it (measured: 220 against 380 frames/s when three passes in flight
+        # each allocated theirs in the timed region)
+        wkey = (x.device, st)
+        ws = _WINO_WS.get(wkey)
+        if ws is None or ws.numel() < nws:
+            _WINO_WS.pop(wkey, None)
+            ws = _WINO_WS[wkey] = torch.empty(nws, dtype=torch.uint8, device=x.device)
+        rc = lib.opdet_conv2d_wino_f32(x.data_ptr(), self._u.data_ptr(), self.b.data_ptr(), y.data_ptr(), n, h, w, c, self.cout, int(relu),
+                                       ws.data_ptr(), ws.numel(), st)
+        _lib.check(rc, "opdet_conv2d_wino_f32")
+        return y
 
     def __call__(self, x: torch.Tensor, relu: bool, residual: torch.Tensor = None) -> torch.Tensor:
         lib = _lib.load()
         n, h, w, c = x.shape
         assert c == self.cin, (c, self.cin)
+        if self._winograd(n, h, w, residual):
+            return self._call_winograd(x, relu)
         oh = (h + 2 * self.pad - self.kh) // self.stride + 1
         ow = (w + 2 * self.pad - self.kw) // self.stride + 1
         y = torch.empty((n, oh, ow, self.cout), dtype=torch.float32, device=x.device)

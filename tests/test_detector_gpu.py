@@ -38,6 +38,39 @@ def test_conv2d_matches_torch(cin, cout, k, stride, pad, h, w):
     assert (got - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,n,h,w,relu,ws_mb", [
+    (256, 256, 2, 50, 68, True, 8192),       # an FPN / RPN-head shape, even map
+    (256, 256, 3, 25, 34, False, 8192),      # odd height: the last tile row is half outside the map
+    (512, 512, 2, 13, 17, True, 8192),       # layer4's conv2, odd both ways
+    (256, 128, 5, 20, 27, True, 4),          # workspace capped to 4 MB: the pass runs in chunks of images
+    (64, 64, 2, 40, 36, True, 8192),         # (below the product's channel threshold: forced here)
+])
+def test_conv2d_winograd_matches_torch_and_the_direct_conv(monkeypatch, cin, cout, n, h, w, relu, ws_mb):
+    """Winograd F(2 x 2, 3 x 3) form of the stride-1 3 x 3 convs (csrc/wino_kernels.hip): against torch's fp64 conv2d to the tolerance of
+    the direct kernel's tests, and against the direct kernel itself to 1e-5 of max|y| (the bar the probe was held to)"""
+    from objectpermanence_amd.detector import _Conv
+    sd = {"w": synth.synth_tensor(f"ww{cin}{cout}", (cout, cin, 3, 3), float(np.sqrt(6.0 / (cin * 9)))),
+          "b": synth.synth_tensor("wb", (cout,), 0.2)}
+    x = torch.from_numpy(synth.synth_tensor("wx", (n, cin, h, w), 1.0))
+    conv = _Conv(sd, "w", bias="b", stride=1, pad=1)
+    monkeypatch.setenv("OPDET_WINO_WS_MB", str(ws_mb))
+    monkeypatch.setattr(_Conv, "WINO_MIN_CIN", 16)
+    monkeypatch.setattr(_Conv, "WINO_MIN_TILES", 0)
+    assert conv._winograd(n, h, w, None)
+    y = conv(_nhwc(x).cuda(), relu=relu)
+    monkeypatch.setenv("OPDET_WINOGRAD", "0")
+    assert not conv._winograd(n, h, w, None)
+    y_direct = conv(_nhwc(x).cuda(), relu=relu)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.double(), torch.from_numpy(sd["w"]).double(), torch.from_numpy(sd["b"]).double(), stride=1, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    got = y.cpu().permute(0, 3, 1, 2).double()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max())
+    assert (y - y_direct).abs().max().item() <= 1e-5 * max(1.0, y_direct.abs().max().item())
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [
     (32, 80, 3, 1, 1, 128, 130),     # >= 256 pixel tiles: the LDS-staged kernels (BN = 128), ragged M
     (64, 48, 1, 1, 0, 131, 127),     # BN = 64
