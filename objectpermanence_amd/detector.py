@@ -11,6 +11,7 @@ detector.  ``CaterObjectDetector.__call__`` returns what detector.py:84 returns:
 from __future__ import annotations
 
 import ctypes
+import collections
 import os
 from collections import OrderedDict
 from typing import Dict, List, Tuple
@@ -34,7 +35,10 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-_WINO_WS: Dict[tuple, torch.Tensor] = {}       # (device, stream) -> workspace of the Winograd convs enqueued on that stream
+# (device, stream) -> workspace of the Winograd convs enqueued on that stream, most recently used last; at most _WINO_WS_MAX of them
+# are kept (a workspace is allocated on the stream it is used on, so dropping one is stream-ordered like any torch free)
+_WINO_WS: "collections.OrderedDict[tuple, torch.Tensor]" = collections.OrderedDict()
+_WINO_WS_MAX = max(1, int(os.environ.get("OPDET_WINO_WS_STREAMS", "4")))
 
 
 class _Conv:
@@ -94,7 +98,11 @@ class _Conv:
         ws = _WINO_WS.get(wkey)
         if ws is None or ws.numel() < nws:
             _WINO_WS.pop(wkey, None)
+            while len(_WINO_WS) >= _WINO_WS_MAX:
+                _WINO_WS.popitem(last=False)
             ws = _WINO_WS[wkey] = torch.empty(nws, dtype=torch.uint8, device=x.device)
+        else:
+            _WINO_WS.move_to_end(wkey)
         rc = lib.opdet_conv2d_wino_f32(x.data_ptr(), self._u.data_ptr(), self.b.data_ptr(), y.data_ptr(), n, h, w, c, self.cout, int(relu),
                                        ws.data_ptr(), ws.numel(), st)
         _lib.check(rc, "opdet_conv2d_wino_f32")

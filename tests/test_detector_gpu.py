@@ -71,6 +71,25 @@ def test_conv2d_winograd_matches_torch_and_the_direct_conv(monkeypatch, cin, cou
     assert (y - y_direct).abs().max().item() <= 1e-5 * max(1.0, y_direct.abs().max().item())
 
 
+def test_winograd_workspaces_are_bounded_over_streams():
+    """one workspace per stream the convs are enqueued on, at most OPDET_WINO_WS_STREAMS (4) of them kept: a session that
+    goes through many streams does not hold a workspace for each"""
+    from objectpermanence_amd import detector
+    from objectpermanence_amd.detector import _Conv
+    sd = {"w": synth.synth_tensor("wsw", (256, 256, 3, 3), 0.03), "b": synth.synth_tensor("wsb", (256,), 0.2)}
+    x = _nhwc(torch.from_numpy(synth.synth_tensor("wsx", (1, 256, 40, 48), 1.0))).cuda()
+    conv = _Conv(sd, "w", bias="b", stride=1, pad=1)
+    ref = conv(x, relu=True)
+    torch.cuda.synchronize()
+    for _ in range(7):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            y = conv(x, relu=True)
+        st.synchronize()
+        assert torch.equal(y, ref)
+    assert len(detector._WINO_WS) <= detector._WINO_WS_MAX
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [
     (32, 80, 3, 1, 1, 128, 130),     # >= 256 pixel tiles: the LDS-staged kernels (BN = 128), ragged M
     (64, 48, 1, 1, 0, 131, 127),     # BN = 64

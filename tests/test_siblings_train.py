@@ -247,6 +247,7 @@ def test_long_sequence_training_step_runs_in_bounded_memory():
     cfg = {"boxes_features_dim": 256, "num_attention_heads": 2, "num_attention_layers": 1, "num_lstm_layers": 1,
            "lstm_hidden_dim": 512}
     boxes, labels = synth.make_batch(0, 4, 300)
+    held = torch.cuda.memory_allocated()          # what earlier tests of the session still hold is not this step's
     x = torch.from_numpy(np.tile(synth.boxes5(boxes), (32, 1, 1, 1))).cuda()
     lab = torch.from_numpy(np.tile(labels, (32, 1, 1))).cuda()
     m = ModelsFactory.get_model("transformer_lstm", cfg)
@@ -258,7 +259,7 @@ def test_long_sequence_training_step_runs_in_bounded_memory():
     torch.cuda.synchronize()
     assert np.isfinite(float(loss.detach()))
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
-    assert torch.cuda.max_memory_allocated() < 6 * 2 ** 30
+    assert torch.cuda.max_memory_allocated() - held < 6 * 2 ** 30
 
 
 # ---- TransformerLstm's TRAIN mode at the reference's dropout 0.1 -------------------------------------
