@@ -286,14 +286,17 @@ def bench_train(args, model, boxes, labels, world, rank, dev, dist, params):
         fwd_persistent = x4_ok and B <= int(os.environ.get("OPNET_XCD4_MAX_B", os.environ.get("OPNET_XCD4_FWD_MAX_B", "96")))
         fwd16 = (x4_ok and not fwd_persistent and os.environ.get("OPNET_XCD_TRAIN", "1") != "0" and 96 < B <= 1024
                  and B >= int(os.environ.get("OPNET_XCD_TRAIN_MIN_B", "97")))
-        engine = ("xcd4" if persistent else "xcd4 forward + chain backward" if fwd_persistent
-                  else "xcd (16-clip persistent) forward + chain backward" if fwd16 else "chain")
+        rbs = (B + 31) // 32
+        nsl = int(os.environ.get("OPNET_BWD_SLICES", "-1"))
+        nsl = min(4, rbs, (1 if rbs < 2 else 3 if rbs in (5, 6) else 4 if rbs > 12 else 2) if nsl < 0 else max(nsl, 1))
+        bwd = "chain backward" if nsl < 2 or os.environ.get("OPNET_BWD_MODE") else f"backward as {nsl} chains over slices of the batch, side by side"
+        engine = ("xcd4" if persistent else f"xcd4 forward + {bwd}" if fwd_persistent
+                  else f"xcd (16-clip persistent) forward + {bwd}" if fwd16 else "chain")
         kernels = ("opnet_xcd4_forward + opnet_xcd4_backward (the whole recurrence as ONE persistent launch each, 4-clip groups "
                    "per XCD, weights resident in registers) + opnet_wgrad" if persistent else
-                   "opnet_xcd_forward<.., true> (ONE persistent launch of 16-clip groups writing the histories) + opnet_bwd_gemm + "
-                   "opnet_bwd_cell (two launches per reverse step) + opnet_wgrad" if fwd16 else
-                   "opnet_step / opnet_xcd4_forward + opnet_bwd_fused (one launch per reverse step; opnet_bwd_gemm + opnet_bwd_cell above "
-                   "128 clips) + opnet_wgrad")
+                   "opnet_xcd_forward<.., true> (ONE persistent launch of 16-clip groups writing the histories) + opnet_bwd_fused "
+                   "(one launch per reverse step and slice of the batch, the slices' chains on separate streams) + opnet_wgrad" if fwd16 else
+                   "opnet_step / opnet_xcd4_forward + opnet_bwd_fused (one launch per reverse step and slice of the batch) + opnet_wgrad")
         # algorithmic bytes of one training step under the per-time-step streaming model: the
         # forward streams the weights once per step and moves each clip's state (+ the saved history: gates 4x, h, c per
         # unit), the backward streams W_hh^T / W_ih2^T / the heads once per reverse step and reads the history back

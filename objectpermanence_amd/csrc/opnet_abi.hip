@@ -397,6 +397,13 @@ extern "C" void opnet_xcd_set_trace(void *device_buffer) { g_xcd_trace = (unsign
 // the callers use.
 static std::mutex g_xcd_mu;
 static hipEvent_t g_xcd_done[64] = {};
+// side streams of the sliced reverse recurrence (opnet_train_backward_f32), per device, created on first use
+#define BWD_MAX_SLICES 4
+struct BwdSide {
+    hipStream_t s[BWD_MAX_SLICES - 1];
+    hipEvent_t fork, join[BWD_MAX_SLICES - 1];
+};
+static BwdSide g_bwd_side[64] = {};
 static int g_xcd_cus[64] = {};
 
 // Measurement (bench.py): with profiling on, every launch of a profiled kernel (tag 0: opnet_xcd_forward, 1: seqx_forward,
@@ -974,6 +981,7 @@ static int make_train_args(StepArgs *a, OpnetIO *io, BwdArgs *bw, const float *b
     io->state_f4 = (long)((W.state_end - W.state) / 16);
     memset(bw, 0, sizeof(*bw));
     bw->B = B; bw->T = T; bw->RB = RB; bw->H1 = H1; bw->H2 = H2;
+    bw->rb0 = 0; bw->rb1 = RB;
     bw->xp = a->xp; bw->h1all = a->h1buf; bw->c1all = a->c1; bw->h2all = a->h2buf; bw->c2all = a->c2;
     bw->x2all = a->x2buf; bw->psave = a->psave; bw->g1 = a->g1save; bw->g2 = a->g2save;
     bw->dyp = (const float4 *)(w + W.dyp);
@@ -1431,6 +1439,8 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
     hipStream_t st = (hipStream_t)stream;
     const int RB = a.RB;
     char *w = (char *)workspace;
+    // (33 .. 64 clips as one 4-clip persistent launch per row block, one after the other: measured 2.30 ms against 2.19 for the
+    // two chains of fused steps below - not adopted)
     const bool x4_bwd = !mlp && x4_use(B, T, H1, H2) && env_int("OPNET_XCD4_BWD", 1) != 0;
     if (!x4_bwd)        // (the 4-clip persistent form packs dy in its own initialisation launch)
         opnet_pack_dy<<<256, 256, 0, st>>>((const float4 *)dy, (float4 *)(w + W.dyp), (float *)(w + W.dcz),
@@ -1443,6 +1453,15 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
     // leave most of the chip idle (measured per step, fused / split: B=96 6.72 / 7.17 ms, B=128 7.79 / 7.92, B=256 12.97 / 12.38).
     const char *mode = getenv("OPNET_BWD_MODE");          // "fused" / "split": measurement override
     const bool fused = mode ? strcmp(mode, "fused") == 0 : RB <= 4;
+    // From 3 row blocks on a launch's time grows with the row blocks (6.3 us at 2, 11.4 at 4, 12.6 + 5.3 for the pair at 8) while it
+    // keeps a fifth of the matrix pipe busy (at 8 row blocks: 2.2 us of launch, 6 of fragment loads, 2.5 of MFMAs, 1.6 of epilogue,
+    // one after the other): slices of the batch as separate chains on separate streams overlap instead (measured
+    // 96 / 128 / 192 / 256 / 384 clips: 2 / 2 / 3 / 2-4 / 2 slices best).
+    int nsl = env_int("OPNET_BWD_SLICES", -1);
+    if (nsl < 0) nsl = RB < 2 ? 1 : (RB == 5 || RB == 6) ? 3 : RB > 12 ? 4 : 2;
+    if (nsl > BWD_MAX_SLICES) nsl = BWD_MAX_SLICES;
+    if (nsl > RB) nsl = RB;
+    const bool sliced = !mode && !mlp && !x4_bwd && nsl > 1 && (RB + nsl - 1) / nsl <= 4 * OPNET_MAX_GY;
     if (x4_bwd) {
         // small batch on a whole device: the 4-clip persistent reverse recurrence (opnet_xcd4_kernels.hip)
         Xcd4BArgs x;
@@ -1458,6 +1477,37 @@ static int train_backward_impl(const float *dy, const float *packed, void *works
         HIP_TRY(hipEventRecord(g_xcd_done[dev], st));
     } else if (int rc = mlp ? OPNET_OK : train_chain_layouts(packed, st)) {      // (the mlp image is always packed eagerly)
         return rc;
+    } else if (sliced) {
+        // slices of the batch side by side: S launch chains of the fused step, each over its own row blocks on its own stream
+        // (every buffer of the recurrence is indexed by row block, so the chains share nothing but the weights)
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(g_xcd_mu);
+        BwdSide &sd = g_bwd_side[dev & 63];
+        for (int i = 0; i < nsl - 1; ++i) {
+            if (!sd.s[i]) HIP_TRY(hipStreamCreateWithFlags(&sd.s[i], hipStreamNonBlocking));
+            if (!sd.join[i]) HIP_TRY(hipEventCreateWithFlags(&sd.join[i], hipEventDisableTiming));
+        }
+        if (!sd.fork) HIP_TRY(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(sd.fork, st));
+        BwdArgs sl[BWD_MAX_SLICES];
+        hipStream_t ss[BWD_MAX_SLICES];
+        for (int i = 0; i < nsl; ++i) {
+            sl[i] = bw;
+            sl[i].rb0 = (int)((long)RB * i / nsl);
+            sl[i].rb1 = (int)((long)RB * (i + 1) / nsl);
+            ss[i] = i == 0 ? st : sd.s[i - 1];
+            if (i) HIP_TRY(hipStreamWaitEvent(ss[i], sd.fork, 0));
+        }
+        for (int n = 0; n <= T + 1; ++n)
+            for (int i = 0; i < nsl; ++i) {
+                const int nrb = sl[i].rb1 - sl[i].rb0;
+                opnet_bwd_fused<<<dim3(2 * (H2 / 16 + H1 / 16 + 1), nrb < OPNET_MAX_GY ? nrb : OPNET_MAX_GY, 1), FUSED_THREADS, 0, ss[i]>>>(sl[i], n);
+            }
+        for (int i = 1; i < nsl; ++i) {
+            HIP_TRY(hipEventRecord(sd.join[i - 1], ss[i]));
+            HIP_TRY(hipStreamWaitEvent(st, sd.join[i - 1], 0));
+        }
     } else if (fused) {
         const dim3 gfused(2 * (H2 / 16 + H1 / 16 + 1), RB < OPNET_MAX_GY ? RB : OPNET_MAX_GY, 1);
         for (int n = 0; n <= T + 1; ++n) opnet_bwd_fused<<<gfused, FUSED_THREADS, 0, st>>>(bw, n);

@@ -23,6 +23,7 @@
 
 struct BwdArgs {
     int B, T, RB, H1, H2;
+    int rb0, rb1;           // opnet_bwd_fused works on row blocks [rb0, rb1): one launch chain per slice of the batch, side by side
     int mlp;                // OPNetLstmMlp: no video LSTM - g2 holds (d hidden, 0, 0, 0), filled by opnet_mlp_dhid
     // saved by the training forward
     const float4 *xp;       // [T][RB][24][32]
@@ -414,7 +415,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) opnet_bwd_fused(const BwdArgs a
         if (t < 0 || a.mlp) return;
         const int tile = bx >> 1, hf = bx & 1;
         const int u = tile * 16 + row, clip = hf * 16 + cl;
-        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+        for (int rb = a.rb0 + blockIdx.y; rb < a.rb1; rb += gridDim.y) {
             // the cell backward's operands are fetched before the product so their latency hides under it
             const long e = ((long)rb * H2 + u) * 32 + clip;
             const long ge = (((long)t * a.RB + rb) * H2 + u) * 32 + clip;
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) opnet_bwd_fused(const BwdArgs a
                 a.g2[ge] = cell_backward(dh, dcc, gs, c_t, c_p, &dco);
                 a.dc2[e] = dco;
             }
-            if (rb + (int)gridDim.y < a.RB) __syncthreads();
+            if (rb + (int)gridDim.y < a.rb1) __syncthreads();
         }
     } else if (bx < n2 + 2) {
         // ---------------- d frames_boxes = W_ih2^T da2_t, then einsum / softmax backward, t = T-n ----------------
@@ -453,7 +454,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) opnet_bwd_fused(const BwdArgs a
         // thread (slot o = tid >> 4, clip c = tid & 15) of the first 256 owns one logit gradient; its operands are
         // fetched before the product (the serial 16-thread version of this epilogue was the tail of the launch)
         const int o = (tid >> 4) & 15, c = hf * 16 + cl;
-        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+        for (int rb = a.rb0 + blockIdx.y; rb < a.rb1; rb += gridDim.y) {
             float xv[OPNET_FEATS_], pv = 0.f;
             if (owner && o < OPNET_SLOTS_) {
                 const float *xs = (const float *)(a.xp + ((long)t * a.RB + rb) * (OPNET_KXQ * 32));
@@ -486,7 +487,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) opnet_bwd_fused(const BwdArgs a
                 float *dst = (float *)(a.dlall + ((long)t * a.RB + rb) * 128);
                 dst[((o >> 2) * 32 + c) * 4 + (o & 3)] = o < OPNET_SLOTS_ ? pv * (dp - dots[cl]) : 0.f;
             }
-            if (rb + (int)gridDim.y < a.RB) __syncthreads();
+            if (rb + (int)gridDim.y < a.rb1) __syncthreads();
         }
     } else {
         // ---------------- LSTM1 at t = T+1-n ----------------
@@ -495,7 +496,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) opnet_bwd_fused(const BwdArgs a
         const int b1 = bx - n2 - 2;
         const int tile = b1 >> 1, hf = b1 & 1;
         const int u = tile * 16 + row, clip = hf * 16 + cl;
-        for (int rb = blockIdx.y; rb < a.RB; rb += gridDim.y) {
+        for (int rb = a.rb0 + blockIdx.y; rb < a.rb1; rb += gridDim.y) {
             const long e = ((long)rb * H1 + u) * 32 + clip;
             const long ge = (((long)t * a.RB + rb) * H1 + u) * 32 + clip;
             float4 dlv[4], gs;
@@ -531,7 +532,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) opnet_bwd_fused(const BwdArgs a
                 a.g1[ge] = cell_backward(dh, dcc, gs, c_t, c_p, &dco);
                 a.dc1[e] = dco;
             }
-            if (rb + (int)gridDim.y < a.RB) __syncthreads();
+            if (rb + (int)gridDim.y < a.rb1) __syncthreads();
         }
     }
 }

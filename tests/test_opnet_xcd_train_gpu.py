@@ -45,3 +45,17 @@ def test_persistent_16_clip_training_forward_matches_the_launch_chain(monkeypatc
         assert np.abs(g[k] - g_ref[k]).max() <= 1e-4 * max(1e-3, np.abs(g_ref[k]).max()), k
     l2, y2, lg2, g2 = _step(B, T)
     assert np.array_equal(y2, y) and all(np.array_equal(g2[k], g[k]) for k in g), "run to run"
+
+
+@pytest.mark.parametrize("B,T", [(72, 6), (128, 5), (200, 5), (256, 4), (400, 3)])
+def test_sliced_reverse_recurrence_is_bit_identical_to_one_chain(monkeypatch, B, T):
+    """three row blocks and more: the reverse recurrence as up to four launch chains over slices of the batch on separate streams
+    (the same fused step kernel on row blocks [rb0, rb1)) - every gradient bit for bit as from ONE chain of fused steps"""
+    monkeypatch.setenv("OPNET_BWD_MODE", "fused")           # one chain, fused steps
+    _, _, _, g_ref = _step(B, T)
+    monkeypatch.delenv("OPNET_BWD_MODE")
+    for slices in ("-1", "2", "4"):
+        monkeypatch.setenv("OPNET_BWD_SLICES", slices)
+        _, _, _, g = _step(B, T)
+        for k in g_ref:
+            assert np.array_equal(g[k], g_ref[k]), (slices, k)
