@@ -12,7 +12,7 @@ static void gemm_nt(const float *X, long XS, const float *Wt, long WS, const flo
 {
     // a SHORT sequence (one clip: S = 300 rows = 3 tiles of 128) leaves a dense product with a handful of workgroups walking K alone:
     // the inference path's 32 x 32 tiles with K split over the workgroup's waves (gemm_bias_act_ks) - 35 -> ~10 us a launch
-    if (!R && XS == K && WS == K && YS == N && (K & 63) == 0 && ((M + 63) / 64) * ((N + 63) / 64) < 256 && env_int("OPSEQ_GEMM_KS", 1)) {
+    if (!R && XS == K && WS == K && YS == N && (K & 15) == 0 && ((M + 63) / 64) * ((N + 63) / 64) < 256 && env_int("OPSEQ_GEMM_KS", 1)) {
         gemm_bias_act_ks<<<dim3((unsigned)((M + 31) / 32), (N + 31) / 32, 1), 256, 0, st>>>(X, Wt, bias, Y, (int)M, N, K, relu);
         return;
     }
@@ -120,7 +120,14 @@ static int attn_sweep_split(long W, long ntiles, int zmax)
 {
     const int forced = env_int("OPSEQ_ATTN_ZS", 0);
     if (forced > 0) return forced < zmax ? forced : (zmax < 1 ? 1 : zmax);
-    if (W >= 8 * 256 || ntiles < 64) return 1;
+    if (W >= 8 * 256) return 1;
+    if (ntiles < 64) {
+        // a short sequence (one clip: 10 workgroups sweeping 19 steps on a 256-CU device): up to zmax slices of >= 4 steps
+        int z = (int)(ntiles / 4);
+        if (z > zmax) z = zmax;
+        if (W > 0 && z > 256 / W) z = (int)(256 / W);
+        return z < 1 ? 1 : z;
+    }
     int best = 1;
     double best_cost = (double)((W + 255) / 256);
     for (int z = 2; z <= zmax && ntiles / z >= 32; ++z) {
@@ -430,13 +437,22 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
     long nb_cap = ((S + 63) / 64) * (wide_ / E);
     if (nb_cap > 256) nb_cap = 256;                  // (enc_colsum_final walks the workgroups' partial sums one by one)
     const int ln_rows = (int)(((S + nb_cap - 1) / nb_cap + 3) / 4 * 4);
-    const int nb_ln = (int)((S + ln_rows - 1) / ln_rows), nb_cs = (int)((S + 63) / 64);
+    const int cs_rows = 64;
+    const int nb_ln = (int)((S + ln_rows - 1) / ln_rows), nb_cs = (int)((S + cs_rows - 1) / cs_rows);
     auto colsum = [&](const float *X, long ld, int N, float *out) {
-        enc_colsum_part<<<dim3((N + 255) / 256, nb_cs, 1), 256, 0, st>>>(X, ld, part, (int)S, N, 64);
+        if (S < 4096) {         // a short sequence: one launch, a workgroup per 64 columns
+            enc_colsum_small<<<(N + 63) / 64, 256, 0, st>>>(X, ld, out, (int)S, N);
+            return;
+        }
+        enc_colsum_part<<<dim3((N + 255) / 256, nb_cs, 1), 256, 0, st>>>(X, ld, part, (int)S, N, cs_rows);
         enc_colsum_final<<<dim3((N + 255) / 256, 1, 1), 256, 0, st>>>(part, out, out, nb_cs, N);
     };
     // dW[n][k] = sum_s A[s][n] B[s][k]  (A [S][N], B [S][K])
     auto gemm_tn = [&](const float *A, long lda, int N, const float *B, long ldb, int K, float *dW) {
+        if (S <= 1024 && env_int("OPSEQ_GEMM_TN", 1)) {       // a short sequence: straight from the row-major operands (no transposes)
+            gemm_tn_ks<<<dim3((N + 31) / 32, (K + 31) / 32, 1), 256, 0, st>>>(A, lda, B, ldb, dW, (int)S, N, K);
+            return;
+        }
         transpose_to(A, lda, tA, Sp, S, N, st);
         transpose_to(B, ldb, tB, Sp, S, K, st);
         gemm_nt_ks(tA, Sp, tB, Sp, dW, N, K, (int)Sp, sc + SC.wgp, st);

@@ -265,6 +265,7 @@ __global__ void __launch_bounds__(256) enc_colsum_final(const float *__restrict_
     if (e >= E) return;
     const int j = blockIdx.y;
     float s = 0.f;
+#pragma unroll 8
     for (int b = 0; b < nblocks; ++b) s += part[((long)b * gridDim.y + j) * E + e];
     (j == 0 ? out0 : out1)[e] = s;
 }
@@ -279,6 +280,23 @@ __global__ void __launch_bounds__(256) enc_colsum_part(const float *__restrict__
     float s = 0.f;
     for (int r = r0; r < r1; ++r) s += X[(long)r * ld + n];
     part[(long)blockIdx.y * N + n] = s;
+}
+
+// the column sums of a SHORT X [rows][N] in one launch: a workgroup per 64 columns, its four waves take rows w, w + 4, ... and
+// meet in LDS (fixed order)
+__global__ void __launch_bounds__(256) enc_colsum_small(const float *__restrict__ X, long ld, float *__restrict__ out, int rows, int N)
+{
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (n < N) {
+#pragma unroll 8
+        for (int r = w; r < rows; r += 4) s += X[(long)r * ld + n];
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && n < N) out[n] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 // out[row][k] = P[row][k] * attention-dropout multiplier (the operand of P V and of dV = P^T dO when p > 0)

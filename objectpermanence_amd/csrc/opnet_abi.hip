@@ -2684,7 +2684,11 @@ extern "C" int opseq_lstm_stack_train_backward_f32(const float *dy, const float 
         c.N = 1; c.H = 1; c.W = B * T; c.Cin = 4 * H; c.Cout = KX; c.KH = 1; c.KW = 1; c.stride = 1; c.pad = 0;
         c.OH = 1; c.OW = B * T; c.KP = 4 * H; c.relu = 0;
         const int M = B * T;
-        launch_conv_tiled(c, M, st);
+        // a short sequence (one clip: 3 x 2 tiles of 128 walking K = 4H alone, 160 us): 32 x 32 tiles, K split over the waves
+        if (((M + 63) / 64) * ((KX + 63) / 64) < 256 && ((4 * H) & 15) == 0)
+            gemm_bias_act_ks<<<dim3((M + 31) / 32, (KX + 31) / 32, 1), 256, 0, st>>>(rows, packed + TP.wih0_t, nullptr, dx0, M, KX, 4 * H, 0);
+        else
+            launch_conv_tiled(c, M, st);
     }
     HIP_TRY(hipGetLastError());
     return OPNET_OK;

@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(256) gemm_bias_act(const float *__restrict__ A
 // The same product for SMALL M (one clip: S = 300 tokens - config 3): a workgroup owns a 32 x 32 output tile and its four
 // waves split K, so that linear2 (K = 2048, N = 256) is 80 workgroups of 32 hexadecets a wave instead of 20 workgroups whose
 // waves each walk 128 dependent load -> MFMA rounds (measured 28 us per call on average over the encoder's eight GEMMs at
-// S = 300: 222 us of a 0.96 ms forward).  Partials meet in LDS and are summed in fixed wave order (deterministic).  K % 64 == 0.
+// S = 300: 222 us of a 0.96 ms forward).  Partials meet in LDS and are summed in fixed wave order (deterministic).  K % 16 == 0.
 __global__ void __launch_bounds__(256) gemm_bias_act_ks(const float *__restrict__ A, const float *__restrict__ W,
                                                         const float *__restrict__ bias, float *__restrict__ C,
                                                         int M, int N, int K, int act)
@@ -468,20 +468,21 @@ __global__ void __launch_bounds__(256) gemm_bias_act_ks(const float *__restrict_
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
     const int i = lane & 15, kk = lane >> 4;
-    const int kq = K >> 2;                                     // K quarter of this wave: hexadecets [w * K/64, (w + 1) * K/64)
+    // this wave's share of K: hexadecets [w * (K / 16) / 4, (w + 1) * (K / 16) / 4) - a quarter of K when K % 64 == 0
+    const int nh16 = K >> 4, q0 = (w * nh16) >> 2, q1 = ((w + 1) * nh16) >> 2;
     const float4 *a_row[2], *w_row[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const int m = min(m0 + f * 16 + i, M - 1), nn = min(n0 + f * 16 + i, N - 1);
-        a_row[f] = (const float4 *)(A + (long)m * K + (long)w * kq) + kk;
-        w_row[f] = (const float4 *)(W + (long)nn * K + (long)w * kq) + kk;
+        a_row[f] = (const float4 *)(A + (long)m * K + (long)q0 * 16) + kk;
+        w_row[f] = (const float4 *)(W + (long)nn * K + (long)q0 * 16) + kk;
     }
     f32x4 acc[2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nhex = K >> 6;
+    const int nhex = q1 - q0;
 #pragma unroll 4
     for (int q = 0; q < nhex; ++q) {
         const float4 av0 = a_row[0][q * 4], av1 = a_row[1][q * 4];
@@ -517,6 +518,71 @@ __global__ void __launch_bounds__(256) gemm_bias_act_ks(const float *__restrict_
                 if (act == 1) o = fmaxf(o, 0.f);
                 C[(long)m * N + nn] = o;
             }
+        }
+    }
+}
+
+// The token-contracting product of a SHORT sequence, without transposed copies of its operands:
+//   C[n][k] = sum_s A[s * lda + n] B[s * ldb + k]      (dW = dY^T X of a linear layer: A = dY [S][N], B = X [S][K])
+// 32 x 32 output tiles, the sequence split over the workgroup's four waves in steps of 16 rows; a lane's operands are scalars
+// (16 lanes read 64 consecutive bytes of a row), rows beyond S count as zeros.  Partials meet in LDS, fixed wave order.
+__global__ void __launch_bounds__(256) gemm_tn_ks(const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
+                                                  float *__restrict__ C, int S, int N, int K)
+{
+    __shared__ __attribute__((aligned(16))) float4 red[4][4][64];      // [wave][fragment][lane]
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int i = lane & 15, kk = lane >> 4;
+    const int nch = (S + 15) >> 4, c0 = (w * nch) >> 2, c1 = ((w + 1) * nch) >> 2;
+    const float *ap[2], *bp[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        ap[f] = A + min(n0 + f * 16 + i, N - 1);
+        bp[f] = B + min(k0 + f * 16 + i, K - 1);
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int c = c0; c < c1; ++c) {
+        float ae[2][4], be[2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int srow = c * 16 + kk * 4 + e;
+            const bool in = srow < S;
+            const long r = in ? srow : 0;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const float av = ap[f][r * lda], bv = bp[f][r * ldb];
+                ae[f][e] = in ? av : 0.f;
+                be[f][e] = in ? bv : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[x][e], be[y][e], acc[x][y], 0, 0, 0);
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) red[w][x * 2 + y][lane] = make_float4(acc[x][y][0], acc[x][y][1], acc[x][y][2], acc[x][y][3]);
+    __syncthreads();
+    const int x = w >> 1, y = w & 1;
+    const float4 p0 = red[0][w][lane], p1 = red[1][w][lane], p2 = red[2][w][lane], p3 = red[3][w][lane];
+    const float v[4] = {((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                        ((p0.w + p1.w) + p2.w) + p3.w};
+    const int kc = k0 + y * 16 + i;
+    if (kc < K) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + x * 16 + kk * 4 + r;
+            if (n < N) C[(long)n * K + kc] = v[r];
         }
     }
 }

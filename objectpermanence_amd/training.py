@@ -76,7 +76,9 @@ def train_step(model_name: str, model: torch.nn.Module, optimizer: torch.optim.O
         guard_word = model.launch_guard() if hasattr(model, "launch_guard") else None
     else:
         loss = bucket.flat.new_zeros(())
-    bucket.collect(fill_missing=distributed)
+    if distributed or n_local == 0:
+        bucket.collect(fill_missing=distributed)       # (one process: the optimiser reads the gradients where autograd left them -
+                                                       # 37 copies into the bucket a step for transformer_lstm otherwise)
     # device-side guards of the optimiser step (optim.FusedAdam): an aborted persistent launch (its gradients are NaN) or a
     # non-finite loss must not reach the weights; the host learns of it at its next sync point (step_aborted below)
     abort_ptr = guard_word.data_ptr() if guard_word is not None else None
