@@ -445,7 +445,7 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
             return;
         }
         enc_colsum_part<<<dim3((N + 255) / 256, nb_cs, 1), 256, 0, st>>>(X, ld, part, (int)S, N, cs_rows);
-        enc_colsum_final<<<dim3((N + 255) / 256, 1, 1), 256, 0, st>>>(part, out, out, nb_cs, N);
+        enc_colsum_final<<<dim3((N + 63) / 64, 1, 1), 256, 0, st>>>(part, out, out, nb_cs, N);
     };
     // dW[n][k] = sum_s A[s][n] B[s][k]  (A [S][N], B [S][K])
     auto gemm_tn = [&](const float *A, long lda, int N, const float *B, long ldb, int K, float *dW) {
@@ -465,7 +465,7 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
 
     // ---- norm2, dropout2, linear2, ReLU/dropout, linear1 ----
     enc_ln_bwd<<<nb_ln, 256, 0, st>>>(dz_out, sv + SV.u2, (const float2 *)(sv + SV.st2), n2_w, nullptr, e1, part, (int)S, E, ln_rows);
-    enc_colsum_final<<<dim3((E + 255) / 256, 2, 1), 256, 0, st>>>(part, g_n2_w, g_n2_b, nb_ln, E);
+    enc_colsum_final<<<dim3((E + 63) / 64, 2, 1), 256, 0, st>>>(part, g_n2_w, g_n2_b, nb_ln, E);
     enc_dropout_copy<<<ew_grid((long)S * E), 256, 0, st>>>(e1, e0, (long)S * E, D.at(3u), D.thresh, D.inv_keep);   // d f
     colsum(e0, E, E, g_l2_b);
     gemm_tn(e0, E, E, hid, ffn, ffn, g_l2_w);                                               // [E][ffn]
@@ -476,7 +476,7 @@ extern "C" int opseq_encoder_layer_train_backward_f32(const float *dz_out, float
     gemm_nt_small(t0, ffn, sc + SC.wt_l1, ffn, nullptr, e1, e2, S, E, ffn, 0, sc + SC.wgp, wgp_floats, st);   // d x1 = d pre W1 + d u2
     // ---- norm1, dropout1, out_proj ----
     enc_ln_bwd<<<nb_ln, 256, 0, st>>>(e2, sv + SV.u1, (const float2 *)(sv + SV.st1), n1_w, nullptr, e1, part, (int)S, E, ln_rows);
-    enc_colsum_final<<<dim3((E + 255) / 256, 2, 1), 256, 0, st>>>(part, g_n1_w, g_n1_b, nb_ln, E);
+    enc_colsum_final<<<dim3((E + 63) / 64, 2, 1), 256, 0, st>>>(part, g_n1_w, g_n1_b, nb_ln, E);
     enc_dropout_copy<<<ew_grid((long)S * E), 256, 0, st>>>(e1, e0, (long)S * E, D.at(1u), D.thresh, D.inv_keep);   // d proj
     colsum(e0, E, E, g_out_b);
     gemm_tn(e0, E, E, att, E, E, g_out_w);
