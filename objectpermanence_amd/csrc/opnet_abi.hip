@@ -3074,18 +3074,21 @@ extern "C" int opdet_conv2d_ws_f32(const float *x, const float *w, const float *
 }
 
 // ---- Winograd F(2 x 2, 3 x 3) for stride-1 3 x 3 convs (csrc/wino_kernels.hip) ------------------------------------------------
-// workspace: the 16 position planes of the transformed input and of the products for a chunk of images; a pass whose planes exceed
-// OPDET_WINO_WS_MB (default 1024) runs in chunks of whole images
-static int wino_chunk_images(int N, int H, int W, int Cin, int Cout)
+// workspace: the 16 position planes of the transformed input and of the products for a chunk of TILES (a tile = 2 x 2 output pixels
+// of one image; any contiguous range of the pass's tiles is a chunk: the input is only read, the output written tile by tile); a
+// pass whose planes exceed OPDET_WINO_WS_MB runs in chunks
+static long wino_chunk_tiles(int N, int H, int W, int Cin, int Cout)
 {
-    const size_t per = (size_t)16 * ((H + 1) / 2) * ((W + 1) / 2) * (size_t)(Cin + Cout) * 4;
-    const size_t cap = (size_t)env_int("OPDET_WINO_WS_MB", 1024) << 20;
-    long n = (long)(cap / (per ? per : 1));
+    const long tiles = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+    const size_t per = (size_t)16 * (size_t)(Cin + Cout) * 4;                 // bytes of the planes per tile
+    const size_t cap = (size_t)env_int("OPDET_WINO_WS_MB", 256) << 20;
+    long n = (long)(cap / per);
     // (one GEMM batch addresses a position plane through a 2 GiB buffer descriptor)
-    const long lim_x = ((1L << 31) - 1) / ((long)((H + 1) / 2) * ((W + 1) / 2) * (Cin > Cout ? Cin : Cout) * 4);
+    const long lim_x = ((1L << 31) - 1) / ((long)(Cin > Cout ? Cin : Cout) * 4);
     if (n > lim_x) n = lim_x;
-    if (n > N) n = N;
-    return n < 1 ? 1 : (int)n;
+    n &= ~127L;                                                                // whole 128-row GEMM tiles
+    if (n < 128) n = 128;
+    return n > tiles ? tiles : n;
 }
 static int check_wino(int N, int H, int W, int Cin, int Cout)
 {
@@ -3107,8 +3110,7 @@ extern "C" int opdet_wino_weights_f32(const float *w, float *u, int Cin, int Cou
 extern "C" size_t opdet_conv2d_wino_workspace_bytes(int N, int H, int W, int Cin, int Cout)
 {
     if (check_wino(N, H, W, Cin, Cout)) return 0;
-    const int nc = wino_chunk_images(N, H, W, Cin, Cout);
-    return (size_t)16 * nc * ((H + 1) / 2) * ((W + 1) / 2) * (size_t)(Cin + Cout) * 4;
+    return (size_t)16 * wino_chunk_tiles(N, H, W, Cin, Cout) * (size_t)(Cin + Cout) * 4;
 }
 /* y [N, H, W, Cout] = act(conv3x3(x [N, H, W, Cin], stride 1, pad 1) + bias) through Winograd F(2 x 2, 3 x 3): u from opdet_wino_weights_f32 */
 extern "C" int opdet_conv2d_wino_f32(const float *x, const float *u, const float *bias, float *y, int N, int H, int W, int Cin, int Cout,
@@ -3120,20 +3122,18 @@ extern "C" int opdet_conv2d_wino_f32(const float *x, const float *u, const float
         return fail(OPNET_EINVAL, "x / u / y / bias / workspace must be 16-byte aligned");
     if (workspace_bytes < opdet_conv2d_wino_workspace_bytes(N, H, W, Cin, Cout)) return fail(OPNET_EWORKSPACE, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    const int nc = wino_chunk_images(N, H, W, Cin, Cout);
-    const long tiles_img = (long)((H + 1) / 2) * ((W + 1) / 2);
-    float *V = (float *)workspace, *Mm = V + (size_t)16 * nc * tiles_img * Cin;
-    for (int n0 = 0; n0 < N; n0 += nc) {
-        const int nimg = N - n0 < nc ? N - n0 : nc;
-        const long NT = nimg * tiles_img;
+    const long tiles = (long)N * ((H + 1) / 2) * ((W + 1) / 2), ct = wino_chunk_tiles(N, H, W, Cin, Cout);
+    float *V = (float *)workspace, *Mm = V + (size_t)16 * ct * Cin;
+    for (long t0 = 0; t0 < tiles; t0 += ct) {
+        const long NT = tiles - t0 < ct ? tiles - t0 : ct;
         const long ni = NT * (Cin / 4), no = NT * (Cout / 4);
-        wino_input<<<(unsigned)((ni + 255) / 256 > 16384 ? 16384 : (ni + 255) / 256), 256, 0, st>>>(x, V, n0, nimg, H, W, Cin);
+        wino_input<<<(unsigned)((ni + 255) / 256 > 16384 ? 16384 : (ni + 255) / 256), 256, 0, st>>>(x, V, t0, NT, H, W, Cin);
         ConvArgs g = {};
         g.X = V; g.Wt = u; g.Y = Mm;
         g.N = 1; g.H = 1; g.W = (int)NT; g.Cin = Cin; g.Cout = Cout; g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0; g.OH = 1; g.OW = (int)NT; g.KP = Cin;
         g.bsx = NT * Cin; g.bsw = (long)Cout * Cin; g.bsy = NT * Cout;
         conv2d_nhwc_glds<64, 3><<<dim3((unsigned)((NT + 127) / 128), (Cout + 63) / 64, 16), 256, 0, st>>>(g);
-        wino_output<<<(unsigned)((no + 255) / 256 > 16384 ? 16384 : (no + 255) / 256), 256, 0, st>>>(Mm, bias, y, n0, nimg, H, W, Cout, relu);
+        wino_output<<<(unsigned)((no + 255) / 256 > 16384 ? 16384 : (no + 255) / 256), 256, 0, st>>>(Mm, bias, y, t0, NT, H, W, Cout, relu);
     }
     HIP_TRY(hipGetLastError());
     return OPNET_OK;

@@ -45,17 +45,17 @@ __global__ void __launch_bounds__(256) wino_weights(const float *__restrict__ w,
     }
 }
 
-// images [n0, n0 + nimg) of X [N][H][W][C] -> V [16][NT][C], NT = nimg x TH x TW, TH = ceil(H / 2); one thread per (tile, channel quad);
-// pixels outside the image (the conv's zero padding, the odd row / column of an odd-sized map) read as zero
-__global__ void __launch_bounds__(256) wino_input(const float *__restrict__ X, float *__restrict__ V, int n0, int nimg, int H, int W, int C)
+// tiles [t0, t0 + NT) (tile = (image, ty, tx), TH = ceil(H / 2) x TW per image) of X [N][H][W][C] -> V [16][NT][C]; one thread per
+// (tile, channel quad); pixels outside the image (the conv's zero padding, the odd row / column of an odd-sized map) read as zero
+__global__ void __launch_bounds__(256) wino_input(const float *__restrict__ X, float *__restrict__ V, long t0, long NT, int H, int W, int C)
 {
     const int C4 = C >> 2, TH = (H + 1) >> 1, TW = (W + 1) >> 1;
-    const long NT = (long)nimg * TH * TW, n = NT * C4;
+    const long n = NT * C4;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
         const int c4 = (int)(idx % C4);
-        const long tile = idx / C4;
-        const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), img = n0 + (int)(tile / ((long)TW * TH));
+        const long tile = idx / C4, gt = t0 + tile;
+        const int tx = (int)(gt % TW), ty = (int)((gt / TW) % TH), img = (int)(gt / ((long)TW * TH));
         float4 d[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -81,16 +81,16 @@ __global__ void __launch_bounds__(256) wino_input(const float *__restrict__ X, f
     }
 }
 
-// M [16][NT][Co] -> images [n0, n0 + nimg) of Y [N][H][W][Co] = act(A^T M A + bias)
-__global__ void __launch_bounds__(256) wino_output(const float *__restrict__ M, const float *__restrict__ bias, float *__restrict__ Y, int n0,
-                                                   int nimg, int H, int W, int Co, int relu)
+// M [16][NT][Co] -> tiles [t0, t0 + NT) of Y [N][H][W][Co] = act(A^T M A + bias)
+__global__ void __launch_bounds__(256) wino_output(const float *__restrict__ M, const float *__restrict__ bias, float *__restrict__ Y, long t0,
+                                                   long NT, int H, int W, int Co, int relu)
 {
     const int C4 = Co >> 2, TH = (H + 1) >> 1, TW = (W + 1) >> 1;
-    const long NT = (long)nimg * TH * TW, n = NT * C4;
+    const long n = NT * C4;
     for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
         const int c4 = (int)(idx % C4);
-        const long tile = idx / C4;
-        const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), img = n0 + (int)(tile / ((long)TW * TH));
+        const long tile = idx / C4, gt = t0 + tile;
+        const int tx = (int)(gt % TW), ty = (int)((gt / TW) % TH), img = (int)(gt / ((long)TW * TH));
         float4 m[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
