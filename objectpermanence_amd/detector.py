@@ -84,8 +84,13 @@ class _Conv:
         n, h, w, c = x.shape
         st = _stream(x.device)
         if self._u is None or self._u.device != x.device:
-            self._u = torch.empty(int(lib.opdet_wino_weights_bytes(c, self.cout)) // 4, dtype=torch.float32, device=x.device)
-            _lib.check(lib.opdet_wino_weights_f32(self.w.data_ptr(), self._u.data_ptr(), c, self.cout, self.kp, st), "opdet_wino_weights_f32")
+            u = torch.empty(int(lib.opdet_wino_weights_bytes(c, self.cout)) // 4, dtype=torch.float32, device=x.device)
+            _lib.check(lib.opdet_wino_weights_f32(self.w.data_ptr(), u.data_ptr(), c, self.cout, self.kp, st), "opdet_wino_weights_f32")
+            # the transformed weights are shared by every stream that runs this conv, with no event between them: they are complete
+            # before they are published (once per weight set; without the wait the second pass in flight - on another stream - of a
+            # fresh detector multiplied by weights that the first pass's stream had not transformed yet)
+            torch.cuda.current_stream(x.device).synchronize()
+            self._u = u
         y = torch.empty((n, h, w, self.cout), dtype=torch.float32, device=x.device)
         key = ("wino", n, h, w)
         nws = self._ws_bytes.get(key)

@@ -71,6 +71,25 @@ def test_conv2d_winograd_matches_torch_and_the_direct_conv(monkeypatch, cin, cou
     assert (y - y_direct).abs().max().item() <= 1e-5 * max(1.0, y_direct.abs().max().item())
 
 
+def test_winograd_weights_of_a_fresh_conv_are_complete_before_another_stream_uses_them():
+    """the first Winograd call of a conv transforms its weights on the calling stream; a second pass in flight on ANOTHER stream must
+    not multiply by them before that has happened (seen as differing detections of the second pass of a fresh detector)"""
+    from objectpermanence_amd.detector import _Conv
+    sd = {"w": synth.synth_tensor("wfw", (256, 256, 3, 3), 0.03), "b": synth.synth_tensor("wfb", (256,), 0.2)}
+    x = _nhwc(torch.from_numpy(synth.synth_tensor("wfx", (2, 256, 40, 48), 1.0))).cuda()
+    ref = _Conv(sd, "w", bias="b", stride=1, pad=1)(x, relu=True).clone()
+    torch.cuda.synchronize()
+    conv = _Conv(sd, "w", bias="b", stride=1, pad=1)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(sa):
+        torch.cuda._sleep(200_000_000)              # ~0.1 s of queue ahead of the weight transform
+        ya = conv(x, relu=True)
+    with torch.cuda.stream(sb):
+        yb = conv(x, relu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, ref) and torch.equal(yb, ref)
+
+
 def test_winograd_workspaces_are_bounded_over_streams():
     """one workspace per stream the convs are enqueued on, at most OPDET_WINO_WS_STREAMS (4) of them kept: a session that
     goes through many streams does not hold a workspace for each"""
