@@ -83,6 +83,11 @@ static const size_t kGemmSplitMax = 16;
 static void gemm_nt_small(const float *X, long XS, const float *Wt, long WS, const float *bias, const float *R, float *Y, long M, int N,
                           int K, int relu, float *part, size_t part_floats, hipStream_t st)
 {
+    // a handful of tiles: the 32 x 32 K-split tile kernel with the epilogue inside (no partials, no reduce launch: 21 -> 9 us)
+    if (XS == K && WS == K && (K & 15) == 0 && ((M + 63) / 64) * ((N + 63) / 64) < 64 && env_int("OPSEQ_GEMM_KS", 1)) {
+        gemm_bias_act_ks<<<dim3((unsigned)((M + 31) / 32), (N + 31) / 32, 1), 256, 0, st>>>(X, Wt, bias, Y, (int)M, N, K, relu, R);
+        return;
+    }
     const long tiles = ((M + 127) / 128) * ((N + 63) / 64);
     int ks = (N & 3) || tiles >= 128 ? 1 : gemm_split_slices(M, N, K);
     while (ks > 1 && (size_t)ks * M * N > part_floats) --ks;

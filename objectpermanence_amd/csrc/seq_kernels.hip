@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(256) gemm_bias_act(const float *__restrict__ A
 // S = 300: 222 us of a 0.96 ms forward).  Partials meet in LDS and are summed in fixed wave order (deterministic).  K % 16 == 0.
 __global__ void __launch_bounds__(256) gemm_bias_act_ks(const float *__restrict__ A, const float *__restrict__ W,
                                                         const float *__restrict__ bias, float *__restrict__ C,
-                                                        int M, int N, int K, int act)
+                                                        int M, int N, int K, int act, const float *__restrict__ R = nullptr)
 {
     __shared__ __attribute__((aligned(16))) float4 red[4][4][64];      // [wave][fragment][lane]
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -515,6 +515,7 @@ __global__ void __launch_bounds__(256) gemm_bias_act_ks(const float *__restrict_
             const int m = m0 + x * 16 + kk * 4 + r;
             if (m < M) {
                 float o = v[r] + b;
+                if (R) o += R[(long)m * N + nn];          // (a residual [M][N], added before the activation)
                 if (act == 1) o = fmaxf(o, 0.f);
                 C[(long)m * N + nn] = o;
             }
