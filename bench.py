@@ -60,7 +60,7 @@ STATE_BYTES_PER_CLIP = 12_672  # per clip per time step: x_t + h,c read + h,c wr
 
 def _committed_pmc(stem):
     """the newest committed profiles/r<N>_<stem>.json (rocprofv3 --pmc passes reduced by tools/pmc_reduce.py / pmc_traffic.py)"""
-    for rnd in (5, 4, 3):
+    for rnd in (6, 5, 4, 3):
         path = os.path.join(REPO, "profiles", f"r{rnd}_{stem}.json")
         try:
             with open(path) as f:

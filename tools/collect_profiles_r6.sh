@@ -32,7 +32,7 @@ python tools/pmc_reduce.py mfma $O/pmc_mfma_tt32 > $O/mfma_util_transformer_trai
 python tools/pmc_reduce.py mfma $O/pmc_mfma_tt1 > $O/mfma_util_transformer_train_b1.json 2>&1
 python tools/pmc_reduce.py mfma $O/pmc_mfma_sibtrain > $O/mfma_util_siblings_train.json 2>&1
 python tools/pmc_reduce.py mfma $O/pmc_mfma > $O/mfma_util_bench.json 2>&1
-python tools/pmc_reduce.py shapes $O/pmc_fetch $O/pmc_write 160,400,640 profiles/r5_pmc_traffic.json > $O/pmc_traffic.json 2>&1
+python tools/pmc_reduce.py shapes $O/pmc_fetch $O/pmc_write 160,400,640,1024 profiles/r5_pmc_traffic.json > $O/pmc_traffic.json 2>&1
 python tools/pmc_reduce.py traffic $O/pmc_fetch_tt32 $O/pmc_write_tt32 attention_bwd > $O/pmc_traffic_attention_bwd.json 2>&1
 python tools/pmc_reduce.py traffic $O/pmc_fetch_tt32 $O/pmc_write_tt32 attention_train_fwd > $O/pmc_traffic_attention_train_fwd.json 2>&1
 # the bench lines themselves (no profiler attached)

@@ -57,7 +57,9 @@ def shapes(fdir, wdir, cands, merge=None):
                 out[short(r.get("Kernel_Name", ""))].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         return {k: [v for _, v in sorted(vs)] for k, vs in out.items()}
     F, W = series(fdir, "FETCH_SIZE"), series(wdir, "WRITE_SIZE")
-    fwd = "opnet_xcd_forward<true>"
+    # the inference instantiation with the in-launch output head: "opnet_xcd_forward<true>" until round 5, "<true, false>" since the
+    # kernel has a TRAIN template parameter
+    fwd = next((k for k in ("opnet_xcd_forward<true, false>", "opnet_xcd_forward<true>") if k in F), "opnet_xcd_forward<true, false>")
     if fwd not in F or len(F[fwd]) != len(W.get(fwd, [])):
         raise SystemExit("the two passes do not hold the same launches of " + fwd)
     compulsory = lambda n: n * 130800 + 8 * 5.68e6      # boxes read + logits + y = 130.8 KB per clip, weights once per XCD
@@ -82,7 +84,7 @@ def shapes(fdir, wdir, cands, merge=None):
                 rec["compulsory_bytes"] = int(compulsory(n))
                 rec["over_compulsory"] = round(rec["bytes_per_launch"] / compulsory(n), 3)
                 rec["note"] += "; compulsory = 130.8 KB per clip (boxes read, logits, y) + the weights once per XCD"
-            out.setdefault(kern.replace("<true>", ""), {})[str(n)] = rec
+            out.setdefault(kern.replace("<true, false>", "").replace("<true>", ""), {})[str(n)] = rec
     if merge and os.path.exists(merge):
         old = json.load(open(merge))
         for k, v in old.items():
