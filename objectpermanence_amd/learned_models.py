@@ -689,7 +689,9 @@ class _LstmStackRunner:
         # ... and its throughput form (csrc/seq_xcdt_kernels.hip): "auto" = batches of at least XCDT_MIN_BATCH clips, "1" = every
         # supported batch, "0" = never
         self.use_xcdt = os.environ.get("OPSEQ_XCDT", "auto")
-        self.XCDT_MIN_BATCH = int(os.environ.get("OPSEQ_XCDT_MIN_BATCH", 80 if layers == 1 else 40))
+        # the first batch the 4-clip form needs one more round for (it carries 32 clips a round with one layer, 16 with two): measured
+        # (tools/xcdt_threshold_probe.py) 65 clips 1.43 -> 1.20 ms, two layers 33 clips 3.21 -> 3.03 ms; at 64 / 32 the 4-clip form wins
+        self.XCDT_MIN_BATCH = int(os.environ.get("OPSEQ_XCDT_MIN_BATCH", 65 if layers == 1 else 33))
         self._tpacked: Dict[int, Tuple[tuple, torch.Tensor]] = {}
         self._tws: Dict[tuple, torch.Tensor] = {}
         self.xcdt_launches = 0
