@@ -38,8 +38,9 @@ extern "C" {
 #define OPNET_FEATS 6
 
 /* bumped whenever entry points are added or a signature changes; the Python mirror refuses a library of another version
- * (objectpermanence_amd/_lib.py) instead of failing later on a missing symbol.  4 = round 4. */
-#define OPNET_HIP_ABI_VERSION 8
+ * (objectpermanence_amd/_lib.py) instead of failing later on a missing symbol.  4 = round 4; 8 = the Winograd entry points (opdet_wino_*);
+ * 9 = opseq_slot_embed_bwd_workspace_bytes / opseq_slot_embed_relu_bwd_ws_f32. */
+#define OPNET_HIP_ABI_VERSION 9
 int opnet_hip_abi_version(void);
 const char *opnet_last_error(void);
 
@@ -320,6 +321,11 @@ int opseq_lstm_stack_train_backward_f32(const float *dy, const float *packed, vo
 /* gradient of boxes_linear.weight [F,5] given the saved forward output and its gradient */
 int opseq_slot_embed_relu_bwd_f32(const float *x, const float *out, const float *dout, float *dW, long ntok,
                                   int nslots_out, int F, void *stream);
+/* the same with a caller workspace (opseq_slot_embed_bwd_workspace_bytes): rows of out / dout read coalesced, per-block partial sums
+ * added in block order (deterministic) - 0.59 -> 0.08 ms at 9 600 tokens x 15 slots x 256 features */
+size_t opseq_slot_embed_bwd_workspace_bytes(long ntok, int nslots_out, int F);
+int opseq_slot_embed_relu_bwd_ws_f32(const float *x, const float *out, const float *dout, float *dW, long ntok,
+                                     int nslots_out, int F, void *workspace, size_t workspace_bytes, void *stream);
 /* relu(boxes_linear(x)) (:138,:178): x [ntok,15,5], W [F,5] -> out [ntok, nslots_out, F];
  * nslots_out = 15 (all slots) or 1 (slot 0 only - the live path of TransformerLstm). */
 int opseq_slot_embed_relu_f32(const float *x, const float *W, float *out, long ntok, int nslots_out, int F,

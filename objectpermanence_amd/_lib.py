@@ -13,7 +13,7 @@ from . import build as _build
 _LIB = None
 
 OPNET_OK = 0
-ABI_VERSION = 8                            # include/opnet_hip.h OPNET_HIP_ABI_VERSION
+ABI_VERSION = 9                            # include/opnet_hip.h OPNET_HIP_ABI_VERSION
 NO_OFFSET = ctypes.c_size_t(-1).value      # opnet_*_status_offset: "this shape never runs a persistent kernel"
 
 
@@ -180,6 +180,10 @@ def _declare(lib):
                                                         fp, fp, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.opseq_slot_embed_relu_bwd_f32.restype = c_int
     lib.opseq_slot_embed_relu_bwd_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_int, c_int, c_void_p]
+    lib.opseq_slot_embed_bwd_workspace_bytes.restype = c_size_t
+    lib.opseq_slot_embed_bwd_workspace_bytes.argtypes = [ctypes.c_long, c_int, c_int]
+    lib.opseq_slot_embed_relu_bwd_ws_f32.restype = c_int
+    lib.opseq_slot_embed_relu_bwd_ws_f32.argtypes = [fp, fp, fp, fp, ctypes.c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]
     lib.opseq_slot_embed_relu_f32.restype = c_int
     lib.opseq_slot_embed_relu_f32.argtypes = [fp, fp, fp, ctypes.c_long, c_int, c_int, c_void_p]
     lib.opseq_encoder_workspace_bytes.restype = c_size_t
@@ -305,7 +309,7 @@ EXPORTS = [
     "opseq_xcd_status_offset", "opseq_xcd_pack_weights_f32", "opseq_xcd_forward_f32", "opseq_lstm_stack_train_status_offset", "opseq_xcd_set_trace",
     "opseq_xcdt_supported", "opseq_xcdt_enable", "opseq_xcdt_max_batch", "opseq_xcdt_packed_bytes", "opseq_xcdt_workspace_bytes",
     "opseq_xcdt_status_offset", "opseq_xcdt_pack_weights_f32", "opseq_xcdt_forward_f32", "opseq_xcdt_set_trace",
-    "opseq_slot_embed_relu_f32", "opseq_slot_embed_relu_bwd_f32",
+    "opseq_slot_embed_relu_f32", "opseq_slot_embed_relu_bwd_f32", "opseq_slot_embed_bwd_workspace_bytes", "opseq_slot_embed_relu_bwd_ws_f32",
     "opseq_lstm_stack_train_packed_bytes", "opseq_lstm_stack_train_workspace_bytes",
     "opseq_lstm_stack_train_pack_weights_f32", "opseq_lstm_stack_train_forward_f32",
     "opseq_lstm_stack_train_backward_f32",

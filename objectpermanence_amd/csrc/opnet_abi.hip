@@ -2707,6 +2707,31 @@ extern "C" int opseq_slot_embed_relu_f32(const float *x, const float *W, float *
     return OPNET_OK;
 }
 
+static int slot_embed_bwd_blocks(long nrows)
+{
+    long nb = (nrows + 63) / 64;                        // >= 64 rows a workgroup
+    return (int)(nb > 1024 ? 1024 : nb < 1 ? 1 : nb);
+}
+extern "C" size_t opseq_slot_embed_bwd_workspace_bytes(long ntok, int nslots_out, int F)
+{
+    if (ntok <= 0 || F <= 0 || (nslots_out != 1 && nslots_out != 15)) return 0;
+    return (size_t)slot_embed_bwd_blocks(ntok * nslots_out) * F * 5 * sizeof(float);
+}
+extern "C" int opseq_slot_embed_relu_bwd_ws_f32(const float *x, const float *out, const float *dout, float *dW, long ntok,
+                                                int nslots_out, int F, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!x || !out || !dout || !dW || !workspace) return fail(OPNET_EINVAL, "null pointer");
+    if (ntok <= 0 || F <= 0 || (nslots_out != 1 && nslots_out != 15)) return fail(OPNET_ESHAPE, "bad shape");
+    if (workspace_bytes < opseq_slot_embed_bwd_workspace_bytes(ntok, nslots_out, F)) return fail(OPNET_EWORKSPACE, "workspace too small");
+    const long nrows = ntok * nslots_out;
+    const int nb = slot_embed_bwd_blocks(nrows);
+    const long rpb = (nrows + nb - 1) / nb;
+    slot_embed_relu_bwd_part<<<nb, 256, 0, (hipStream_t)stream>>>(x, out, dout, (float *)workspace, nrows, nslots_out, F, rpb);
+    slot_embed_bwd_final<<<(F * 5 + 255) / 256, 256, 0, (hipStream_t)stream>>>((const float *)workspace, dW, nb, F);
+    HIP_TRY(hipGetLastError());
+    return OPNET_OK;
+}
+
 extern "C" int opseq_slot_embed_relu_bwd_f32(const float *x, const float *out, const float *dout, float *dW, long ntok,
                                              int nslots_out, int F, void *stream)
 {

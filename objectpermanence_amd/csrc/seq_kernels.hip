@@ -395,6 +395,39 @@ __global__ void __launch_bounds__(256) slot_embed_relu_bwd(const float *__restri
     if (threadIdx.x < 5) dW[f * 5 + threadIdx.x] = red[threadIdx.x][0];
 }
 
+// the same gradient with the rows of out / dout read as they lie (thread = feature: 1 KB per row and array at F = 256; slot_embed_relu_bwd
+// walks a feature's column with a stride of F floats): workgroup b adds up rows [b * rpb, (b + 1) * rpb) into part[b][f][5]
+// (the row's five inputs are the same for every thread), slot_embed_bwd_final adds the workgroups' partials in order
+__global__ void __launch_bounds__(256) slot_embed_relu_bwd_part(const float *__restrict__ x, const float *__restrict__ out,
+                                                                const float *__restrict__ dout, float *__restrict__ part,
+                                                                long nrows, int nslots_out, int F, long rpb)
+{
+    const long r0 = blockIdx.x * rpb, r1 = min(nrows, r0 + rpb);
+    for (int f = threadIdx.x; f < F; f += 256) {
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (long r = r0; r < r1; ++r) {
+            const long tok = r / nslots_out;
+            const int slot = (int)(r - tok * nslots_out);
+            const float *xi = x + (tok * 15 + slot) * 5;
+            const long o = r * F + f;
+            const float g = out[o] > 0.f ? dout[o] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[k] = fmaf(g, xi[k], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) part[((long)blockIdx.x * F + f) * 5 + k] = acc[k];
+    }
+}
+__global__ void __launch_bounds__(256) slot_embed_bwd_final(const float *__restrict__ part, float *__restrict__ dW, int nblocks, int F)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;         // (f, k)
+    if (i >= F * 5) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < nblocks; ++b) s += part[(long)b * F * 5 + i];
+    dW[i] = s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C[M][N] = act(A[M][K] * W[N][K]^T + bias[N])   (row-major fp32; K % 16 == 0)
 // ------------------------------------------------------------------------------------------------

@@ -660,8 +660,11 @@ class _SlotEmbedFunction(torch.autograd.Function):
         dW = torch.empty((F, 5), dtype=torch.float32, device=x.device)
         dout = dout.contiguous().float()
         with torch.cuda.device(x.device):
-            _lib.check(lib.opseq_slot_embed_relu_bwd_f32(x.data_ptr(), out.data_ptr(), dout.data_ptr(), dW.data_ptr(), ntok,
-                                                         nslots_out, F, _stream_ptr(x.device)), "opseq_slot_embed_relu_bwd_f32")
+            nws = int(lib.opseq_slot_embed_bwd_workspace_bytes(ntok, nslots_out, F))
+            ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)      # per-workgroup partial sums (<= 5 MB)
+            _lib.check(lib.opseq_slot_embed_relu_bwd_ws_f32(x.data_ptr(), out.data_ptr(), dout.data_ptr(), dW.data_ptr(), ntok,
+                                                            nslots_out, F, ws.data_ptr(), ws.numel(), _stream_ptr(x.device)),
+                       "opseq_slot_embed_relu_bwd_ws_f32")
         return None, dW, None
 
 

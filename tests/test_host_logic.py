@@ -43,7 +43,7 @@ def test_persistent_forward_workspace_is_rings_not_histories(monkeypatch):
 def test_size_queries_and_validation_without_gpu():
     lib = _lib()
     from objectpermanence_amd import _lib as binding
-    assert lib.opnet_hip_abi_version() == binding.ABI_VERSION == 8
+    assert lib.opnet_hip_abi_version() == binding.ABI_VERSION == 9
     w = lib.opnet_workspace_bytes(32, 300, 256, 512)
     assert w > 32 * 300 * 96 * 4 and lib.opnet_workspace_bytes(64, 300, 256, 512) > w
     assert lib.opnet_workspace_bytes(33, 300, 256, 512) == lib.opnet_workspace_bytes(64, 300, 256, 512)

@@ -308,3 +308,38 @@ def test_transformer_train_mode_with_the_references_dropout_masks(golden_dir, ta
     m.dropout = 0.0
     loss0 = l1_mean(m(torch.from_numpy(x).cuda()), torch.from_numpy(labels).cuda())
     assert abs(float(loss0) - float(g[pre + "loss"])) > 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ntok,nslots,F", [(300, 1, 256), (1234, 15, 256), (77, 15, 40), (9600, 15, 256)])
+def test_slot_embed_weight_gradient_with_workspace_matches_torch_and_the_column_walk(ntok, nslots, F):
+    """opseq_slot_embed_relu_bwd_ws_f32 (rows read as they lie, per-workgroup partial sums added in order) against torch's fp64
+    gradient of relu(x W^T) and against opseq_slot_embed_relu_bwd_f32 (one workgroup per feature, strided reads); run to run bit-identical"""
+    import torch
+    from objectpermanence_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(ntok + F)
+    x = torch.rand((ntok, 15, 5), generator=g)
+    W = (torch.rand((F, 5), generator=g) - 0.5)
+    dout = torch.randn((ntok, nslots, F), generator=g)
+    xd, Wd, dd = x.cuda(), W.cuda(), dout.cuda()
+    out = torch.empty((ntok, nslots * F), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.opseq_slot_embed_relu_f32(xd.data_ptr(), Wd.data_ptr(), out.data_ptr(), ntok, nslots, F, st), "fwd")
+    ws = torch.empty(int(lib.opseq_slot_embed_bwd_workspace_bytes(ntok, nslots, F)), dtype=torch.uint8, device="cuda")
+    got = [torch.empty((F, 5), device="cuda") for _ in range(3)]
+    for k in (0, 1):
+        _lib.check(lib.opseq_slot_embed_relu_bwd_ws_f32(xd.data_ptr(), out.data_ptr(), dd.data_ptr(), got[k].data_ptr(), ntok, nslots, F,
+                                                        ws.data_ptr(), ws.numel(), st), "bwd ws")
+    _lib.check(lib.opseq_slot_embed_relu_bwd_f32(xd.data_ptr(), out.data_ptr(), dd.data_ptr(), got[2].data_ptr(), ntok, nslots, F, st), "bwd")
+    torch.cuda.synchronize()
+    W64 = W.double().requires_grad_(True)
+    ref_out = torch.relu(x[:, :nslots].double() @ W64.t())
+    (ref_out * dout.double()).sum().backward()
+    ref = W64.grad
+    scale = float(ref.abs().max())
+    assert torch.equal(got[0], got[1])
+    assert (got[0].cpu().double() - ref).abs().max() <= 2e-5 * scale
+    assert (got[0] - got[2]).abs().max().item() <= 2e-5 * scale
+    assert lib.opseq_slot_embed_relu_bwd_ws_f32(xd.data_ptr(), out.data_ptr(), dd.data_ptr(), got[0].data_ptr(), ntok, nslots, F,
+                                                ws.data_ptr(), 16, st) == -3          # OPNET_EWORKSPACE
