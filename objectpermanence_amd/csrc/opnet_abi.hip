@@ -1340,7 +1340,8 @@ extern "C" int opnet_train_forward_f32(const float *boxes, const float *packed, 
 // wave job fits ONE round of the SIMDs and big (4 units of work per step) and small (1) end together.  `partial`: WG2_MAX_WAVES x
 // WG2_PART_F floats of workspace.  false = not applicable (OPNET_WGRAD2=0, or a slice beyond a buffer descriptor's 2 GiB): the caller
 // runs opnet_wgrad.
-static bool wgrad_wave_tiles(const WgradArgs *jobs, int njobs, int T, int RB, int B, float *partial, const unsigned *abort, hipStream_t st)
+static bool wgrad_wave_tiles(const WgradArgs *jobs, int njobs, int T, int RB, int B, float *partial, const unsigned *abort, hipStream_t st,
+                             int max_waves = WG2_MAX_WAVES)
 {
     if (env_int("OPNET_WGRAD2", 1) == 0 || njobs < 1 || njobs > OPNET_WGRAD_JOBS || !partial) return false;
     Wg2Batch tb;
@@ -1360,18 +1361,25 @@ static bool wgrad_wave_tiles(const WgradArgs *jobs, int njobs, int T, int RB, in
         J.tiles_n = (J.g.NQ + tq - 1) / tq;
         (J.big ? nb : ns) += J.tiles_m * J.tiles_n;
     }
+    // slices per big / small tile: the wave jobs run in rounds of WG2_MAX_WAVES (one wave per SIMD), a round lasts as long as its
+    // longest job (a big tile's step is 4 units of work) - the plan with the smallest rounds x length that the partial buffer holds.
+    // With few tiles that is one round of many slices (OPNet: 80 big tiles, 12 slices); with many (a 3840-wide W_ih0: 672 big tiles)
+    // one slice each would leave a third of the SIMDs idle for the whole launch, three slices run two full rounds of a third the length.
     const long nit = (long)T * RB;
     long best = -1;
     int sb_best = 1, ss_best = 1;
     for (int ss = 1; ss <= 32; ++ss) {
-        const long left = WG2_MAX_WAVES - (long)ns * ss;
-        if (left < (nb ? nb : 0) || (!nb && left < 0)) break;
-        long sb = nb ? left / nb : 1;
-        if (sb > nit) sb = nit;
-        if (sb < 1) break;
-        const long cost_b = nb ? (nit + sb - 1) / sb * 4 : 0, cost_s = ns ? (nit + ss - 1) / ss : 0;
-        const long cost = cost_b > cost_s ? cost_b : cost_s;
-        if (best < 0 || cost < best) { best = cost; sb_best = (int)sb; ss_best = ss; }
+        if ((long)ns * ss > max_waves || ss > nit) break;
+        for (int sb = 1; sb <= 32; ++sb) {
+            const long nw_ = (long)ns * ss + (long)nb * sb;
+            if (nw_ > max_waves || sb > nit) break;
+            const long cost_b = nb ? (nit + sb - 1) / sb * 4 : 0, cost_s = ns ? (nit + ss - 1) / ss : 0;
+            const long rounds = (nw_ + WG2_MAX_WAVES - 1) / WG2_MAX_WAVES;
+            const long cost = rounds * (cost_b > cost_s ? cost_b : cost_s);
+            // (ties: the most slices of the big tiles for the same small-tile slices - what the one-round planner of rounds 3-5 chose)
+            if (best < 0 || cost < best || (cost == best && ss == ss_best)) { best = cost; sb_best = sb; ss_best = ss; }
+            if (!nb) break;
+        }
         if (!ns) break;
     }
     if (best < 0) return false;
@@ -1390,7 +1398,7 @@ static bool wgrad_wave_tiles(const WgradArgs *jobs, int njobs, int T, int RB, in
         J.wave_begin = nw;
         nw += J.slices * J.tiles_m * J.tiles_n;
     }
-    if (nw > WG2_MAX_WAVES) return false;
+    if (nw > max_waves) return false;
     tb.njobs = njobs; tb.nwaves = nw;
     tb.partial = partial;
     tb.abort = abort;
@@ -2322,6 +2330,18 @@ struct StackTrainWs {
 };
 static bool seqx_train_shape(int B, int L, int KX, int H) { return seqx_dims(L, KX, H) && B <= opseq_xcd_max_batch(L); }
 
+// wave jobs the stack's weight-gradient launch may plan (the capacity of its partial-tile buffer): one round of the SIMDs, or two when
+// the products have so many 128 x 128 tiles (a wide layer-0 input: 480 of them at KX = 3840) that one round could not even hold two
+// time slices per tile
+static int stack_wgrad_max_waves(int L, int KX, int H)
+{
+    const int tm = (H + 31) / 32;                                   // 4H rows = H m-quads
+    const int kxq = ((KX + 15) / 16) * 4;                           // input quads (padded to 16)
+    long big = (long)(2 * L - 1) * tm * ((H / 4 + 31) / 32);       // W_hh of every layer, W_ih of the upper layers
+    if (H >= 32 && kxq >= 17) big += (long)tm * ((kxq + 31) / 32);  // W_ih0
+    return big * 2 > WG2_MAX_WAVES ? 2 * WG2_MAX_WAVES : WG2_MAX_WAVES;
+}
+
 static StackTrainWs stack_train_ws_layout(int B, int T, int L, int KX, int H)
 {
     const size_t RB = (B + 31) / 32, KXP = (size_t)((KX + 15) / 16) * 16, TT = T;
@@ -2346,7 +2366,7 @@ static StackTrainWs stack_train_ws_layout(int B, int T, int L, int KX, int H)
     W.dcz_end = o;
     W.darows = o; o += (size_t)B * TT * 4 * H * 4;      // da0 as rows, for the input-gradient GEMM
     o = align_up(o, 4096);
-    W.wgpart = o; o += (size_t)WG2_MAX_WAVES * WG2_PART_F * 4;     // partial tiles of the weight-gradient waves (64 MB)
+    W.wgpart = o; o += (size_t)stack_wgrad_max_waves(L, KX, H) * WG2_PART_F * 4;     // partial tiles of the weight-gradient waves (64 / 128 MB)
     W.sx_status = o;
     for (int l = 0; l < 2; ++l) W.sx_hl[l] = W.sx_hc[l] = o;
     if (seqx_train_shape(B, L, KX, H)) {
@@ -2670,7 +2690,7 @@ extern "C" int opseq_lstm_stack_train_backward_f32(const float *dy, const float 
         }
         wb.abort = sxb_status;    // (null on the launch chain: nothing can give up there)
         const int nj = (int)(jobs.size() - j0 < OPNET_WGRAD_JOBS ? jobs.size() - j0 : OPNET_WGRAD_JOBS);
-        if (!wgrad_wave_tiles(wb.job, nj, T, RB, B, (float *)(w + W.wgpart), sxb_status, st))
+        if (!wgrad_wave_tiles(wb.job, nj, T, RB, B, (float *)(w + W.wgpart), sxb_status, st, stack_wgrad_max_waves(L, KX, H)))
             opnet_wgrad<<<ntiles, 256, 0, st>>>(wb);
     }
     if (dx0) {
