@@ -2729,7 +2729,7 @@ extern "C" int opseq_slot_embed_relu_f32(const float *x, const float *W, float *
 
 static int slot_embed_bwd_blocks(long nrows)
 {
-    long nb = (nrows + 63) / 64;                        // >= 64 rows a workgroup
+    long nb = (nrows + 15) / 16;                        // >= 16 rows a workgroup
     return (int)(nb > 1024 ? 1024 : nb < 1 ? 1 : nb);
 }
 extern "C" size_t opseq_slot_embed_bwd_workspace_bytes(long ntok, int nslots_out, int F)
@@ -2747,7 +2747,7 @@ extern "C" int opseq_slot_embed_relu_bwd_ws_f32(const float *x, const float *out
     const int nb = slot_embed_bwd_blocks(nrows);
     const long rpb = (nrows + nb - 1) / nb;
     slot_embed_relu_bwd_part<<<nb, 256, 0, (hipStream_t)stream>>>(x, out, dout, (float *)workspace, nrows, nslots_out, F, rpb);
-    slot_embed_bwd_final<<<(F * 5 + 255) / 256, 256, 0, (hipStream_t)stream>>>((const float *)workspace, dW, nb, F);
+    slot_embed_bwd_final<<<(F * 5 + 63) / 64, 256, 0, (hipStream_t)stream>>>((const float *)workspace, dW, nb, F);
     HIP_TRY(hipGetLastError());
     return OPNET_OK;
 }

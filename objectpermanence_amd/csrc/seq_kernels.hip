@@ -405,14 +405,17 @@ __global__ void __launch_bounds__(256) slot_embed_relu_bwd_part(const float *__r
     const long r0 = blockIdx.x * rpb, r1 = min(nrows, r0 + rpb);
     for (int f = threadIdx.x; f < F; f += 256) {
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        long tok = r0 / nslots_out;
+        int slot = (int)(r0 - tok * nslots_out);
+        const float *po = out + r0 * F + f, *pd = dout + r0 * F + f;
+#pragma unroll 4
         for (long r = r0; r < r1; ++r) {
-            const long tok = r / nslots_out;
-            const int slot = (int)(r - tok * nslots_out);
             const float *xi = x + (tok * 15 + slot) * 5;
-            const long o = r * F + f;
-            const float g = out[o] > 0.f ? dout[o] : 0.f;
+            const float g = *po > 0.f ? *pd : 0.f;
 #pragma unroll
             for (int k = 0; k < 5; ++k) acc[k] = fmaf(g, xi[k], acc[k]);
+            po += F; pd += F;
+            if (++slot == nslots_out) { slot = 0; ++tok; }
         }
 #pragma unroll
         for (int k = 0; k < 5; ++k) part[((long)blockIdx.x * F + f) * 5 + k] = acc[k];
@@ -420,12 +423,17 @@ __global__ void __launch_bounds__(256) slot_embed_relu_bwd_part(const float *__r
 }
 __global__ void __launch_bounds__(256) slot_embed_bwd_final(const float *__restrict__ part, float *__restrict__ dW, int nblocks, int F)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;         // (f, k)
-    if (i >= F * 5) return;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;                 // (f, k); wave w adds the workgroups w, w + 4, ..., the four meet in LDS
     float s = 0.f;
+    if (i < F * 5) {
 #pragma unroll 8
-    for (int b = 0; b < nblocks; ++b) s += part[(long)b * F * 5 + i];
-    dW[i] = s;
+        for (int b = w; b < nblocks; b += 4) s += part[(long)b * F * 5 + i];
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < F * 5) dW[i] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 // ------------------------------------------------------------------------------------------------
