@@ -22,7 +22,11 @@ static void gemm_nt(const float *X, long XS, const float *Wt, long WS, const flo
     c.OH = 1; c.OW = (int)M; c.KP = K; c.relu = relu;
     c.XS = (int)XS; c.WS = (int)WS; c.YS = (int)YS;
     const unsigned gx = (unsigned)((M + 127) / 128);
-    if (N > 64) conv2d_nhwc_glds<128, 3><<<dim3(gx, (N + 127) / 128, 1), 256, 0, st>>>(c);
+    // 128 x 128 tiles need well over one round of the chip's resident workgroups (3 a CU = 768) to even out: below ~1 300 of them the
+    // 64-wide tile (twice the workgroups, half the work each) balances better - measured on the training step: 16 clips (608 tiles in
+    // the FFN products) 6.50 -> 6.10 ms, 8 clips 4.04 -> 3.99, 32 clips (1 200 tiles) 14.65 -> 14.52
+    const bool wide = N > 64 && (long)gx * ((N + 127) / 128) >= env_int("OPSEQ_GEMM_WIDE_MIN_TILES", 1300);
+    if (wide) conv2d_nhwc_glds<128, 3><<<dim3(gx, (N + 127) / 128, 1), 256, 0, st>>>(c);
     else conv2d_nhwc_glds<64, 3><<<dim3(gx, (N + 63) / 64, 1), 256, 0, st>>>(c);
 }
 
