@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(256) enc_colsum_part(const float *__restrict__
     if (n >= N) return;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float s = 0.f;
+#pragma unroll 8
     for (int r = r0; r < r1; ++r) s += X[(long)r * ld + n];
     part[(long)blockIdx.y * N + n] = s;
 }
